@@ -1,0 +1,43 @@
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    g = {k: z[k] for k in z.files}
+    g["meta"] = json.loads(str(g["meta"]))
+    return g
+
+
+def spec_from_meta(meta, g):
+    """Build an oracle Spec from a fixture's meta block."""
+    from oracle.muygps_oracle import Spec
+
+    ls = meta["length_scale"]
+    ls = np.asarray(ls, dtype=np.float64) if isinstance(ls, list) else float(ls)
+    noise = g["noise_table"] if meta.get("hetero") else float(meta["noise"])
+    return Spec(kernel=meta["kernel"], metric=meta["metric"], length_scale=ls, noise=noise)
+
+
+@pytest.fixture(params=golden_names())
+def golden(request):
+    return load_golden(request.param)

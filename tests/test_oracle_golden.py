@@ -1,0 +1,131 @@
+"""Pin the numpy oracle to the real reference through the committed fixtures.
+
+The fixtures in tests/golden/ were produced by importing /root/reference (see
+tests/golden/make_golden.py); here every stage of the oracle must reproduce
+them to fp64 round-off.  CPU only.
+"""
+
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import muygps_oracle as orc
+from tests.conftest import GOLDEN_DIR, spec_from_meta
+
+RTOL = 1e-10
+ATOL = 1e-12
+
+
+def close(a, b, rtol=RTOL, atol=ATOL):
+    np.testing.assert_allclose(np.asarray(a), np.asarray(b), rtol=rtol, atol=atol)
+
+
+def test_tensors_and_kernels(golden):
+    g, meta = golden, golden["meta"]
+    spec = spec_from_meta(meta, g)
+    X, bi, ni = g["features"], g["batch_idx"], g["nn_idx"]
+    cd = orc.crosswise_tensor(X, X, bi, ni)
+    pd = orc.pairwise_tensor(X, ni)
+    if spec.anisotropic:
+        if "crosswise" in g:
+            close(cd, g["crosswise"])
+        if "pairwise" in g:
+            close(pd, g["pairwise"])
+    else:
+        if "crosswise" in g:
+            close(orc.metric_reduce(cd, spec.metric), g["crosswise"])
+        if "pairwise" in g:
+            close(orc.metric_reduce(pd, spec.metric), g["pairwise"])
+    Kc, Kin = orc.kernel_tensors(spec, cd, pd)
+    close(Kc, g["Kcross"])
+    if "Kin" in g:
+        close(Kin, g["Kin"])
+    if "Kin_perturbed" in g:
+        close(orc.perturb(spec, Kin, ni), g["Kin_perturbed"])
+    close(g["targets"][bi], g["batch_targets"])
+    close(g["targets"][ni], g["batch_nn_targets"])
+
+
+def test_posterior_and_scale(golden):
+    g, meta = golden, golden["meta"]
+    spec = spec_from_meta(meta, g)
+    X, y, bi, ni = g["features"], g["targets"], g["batch_idx"], g["nn_idx"]
+    mean, var = orc.posterior_mean_var(spec, X, X, bi, ni, y)
+    close(mean, g["mean"], rtol=1e-8, atol=1e-10)
+    close(var, g["var_unscaled"], rtol=1e-8, atol=1e-10)
+    s = np.atleast_1d(orc.sigma_sq(spec, X, ni, y))
+    close(s, g["sigma_sq"], rtol=1e-9)
+    if "var_scaled" in g:
+        close(s[0] * var, g["var_scaled"], rtol=1e-8, atol=1e-10)
+    mc, vc = orc.posterior_mean_var_chunked(spec, X, X, bi, ni, y, chunk=5)
+    close(mc, mean)
+    close(vc, var)
+
+
+def test_losses(golden):
+    g = golden
+    if "lool" not in g:
+        pytest.skip("multi-response fixture: only mse is defined")
+    mean, var, y, s = g["mean"], g["var_unscaled"], g["batch_targets"], float(g["sigma_sq"][0])
+    close(orc.lool_fn(mean, y, var, s), g["lool"], rtol=1e-9)
+    close(orc.mse_fn(mean, y), g["mse"], rtol=1e-9)
+    close(orc.looph_fn(mean, y, var, s), g["looph"], rtol=1e-9)
+    close(orc.pseudo_huber_fn(mean, y), g["huber"], rtol=1e-9)
+
+
+def test_mse_multiresponse(golden):
+    g = golden
+    close(orc.mse_fn(g["mean"], g["batch_targets"]), g["mse"], rtol=1e-9)
+
+
+def test_objective_probes(golden):
+    g, meta = golden, golden["meta"]
+    if "probe_values" not in g:
+        pytest.skip("no probes in this fixture")
+    X, y, bi, ni = g["features"], g["targets"], g["batch_idx"], g["nn_idx"]
+    for j, probe in enumerate(meta["probes"]):
+        spec = spec_from_meta(meta, g)
+        if "length_scale" in probe:
+            spec.length_scale = probe["length_scale"]
+        elif "length_scale0" in probe:
+            spec.length_scale = np.array([probe[f"length_scale{i}"] for i in range(meta["d"])])
+        # App. B 3b: sigma_sq keeps the STORED noise even when `noise` is a free kwarg
+        spec_mv = spec_from_meta(meta, g)
+        spec_mv.length_scale = spec.length_scale
+        if "noise" in probe:
+            spec_mv.noise = probe["noise"]
+        mean, var = orc.posterior_mean_var(spec_mv, X, X, bi, ni, y)
+        s = orc.sigma_sq(spec, X, ni, y)
+        yb = y[bi]
+        vals = [
+            -orc.lool_fn(mean, yb, var, s), -orc.mse_fn(mean, yb),
+            -orc.looph_fn(mean, yb, var, s), -orc.pseudo_huber_fn(mean, yb),
+        ]
+        close(vals, g["probe_values"][:, j], rtol=1e-8)
+
+
+def test_chunk_sizes_rule():
+    with open(os.path.join(GOLDEN_DIR, "chunk_sizes.json")) as f:
+        rule = json.load(f)
+    for key, sizes in rule.items():
+        n, p = (int(t) for t in key.split("_"))
+        assert orc.chunk_sizes(n, p) == sizes
+        assert sum(sizes) == n
+
+
+def test_kernels_against_sklearn():
+    """Known-answer pin used by the reference itself (tests/kernels.py:325-526)."""
+    from sklearn.gaussian_process.kernels import RBF, Matern
+
+    rng = np.random.default_rng(7)
+    X = rng.normal(size=(40, 3))
+    D = orc.pairwise_tensor(X, np.arange(40)[None, :])[0]
+    ell = 1.7
+    close(orc.rbf_fn(orc.isotropy(orc.F2(D), ell, "F2")), RBF(length_scale=ell)(X), rtol=1e-9)
+    for name, nu in (("matern05", 0.5), ("matern15", 1.5), ("matern25", 2.5), ("maternInf", np.inf)):
+        K = orc.KERNELS[name](orc.isotropy(orc.l2(D), ell, "l2"))
+        close(K, Matern(length_scale=ell, nu=nu)(X), rtol=1e-9)
+    ells = np.array([0.5, 1.5, 2.5])
+    close(orc.matern_15_fn(orc.anisotropy(D, ells, "l2")), Matern(length_scale=ells, nu=1.5)(X), rtol=1e-9)
