@@ -1,0 +1,173 @@
+/*
+ * muygpys_hip.h -- C ABI of the MI355X-native MuyGPyS local-GP hot path.
+ *
+ * The reference (LLNL/MuyGPyS 0.9.0) is pure Python and has no FFI; its
+ * "interface for this path" is the set of free functions each backend module
+ * exports (src/MuyGPyS/_src/<family>/{numpy,torch,jax,mpi}.py), resolved by
+ * _collect_implementation (src/MuyGPyS/_src/util.py:9-32).  Every entry point
+ * below names the reference function(s) it replaces; the Python binding a
+ * maintainer would add is shown in INTEGRATION.md and implemented in
+ * muygpys_amd/_src/<family>/hip.py via ctypes.
+ *
+ * Conventions
+ *   - all data pointers are DEVICE pointers on the current HIP device, row-major,
+ *     contiguous; indices are int64 (reference: itype = int64,
+ *     _src/math/numpy.py:92-94); T is float (_f32) or double (_f64)
+ *     (MUYGPYS_FTYPE, _src/config.py:254-261).
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  Entry
+ *     points only enqueue work; they never synchronise, allocate or free.
+ *   - return value: 0 on success, a negative MGP_E* code on bad arguments, or
+ *     -(1000 + hipError_t) when the HIP runtime reports an error.  Nothing throws.
+ *   - inputs are never written; outputs never alias inputs.
+ *   - non-SPD neighbourhoods (non-positive Cholesky pivot; the reference's LU
+ *     would raise numpy.linalg.LinAlgError only for an exactly singular matrix)
+ *     produce NaN outputs and are counted in `*info` (device int32, may be NULL).
+ */
+#ifndef MUYGPYS_HIP_H
+#define MUYGPYS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* kernel ids -- _src/gp/kernels/numpy.py:12-31 */
+enum mgp_kernel {
+  MGP_KERNEL_RBF = 0,        /* exp(-x/2),  x = F2 / l^2             :12-13 */
+  MGP_KERNEL_MATERN_05 = 1,  /* exp(-r),    r = l2 / l               :16-17 */
+  MGP_KERNEL_MATERN_15 = 2,  /* (1+s3 r) exp(-s3 r)                  :20-22 */
+  MGP_KERNEL_MATERN_25 = 3,  /* (1+s5 r+5r^2/3) exp(-s5 r)           :25-27 */
+  MGP_KERNEL_MATERN_INF = 4  /* exp(-r^2/2)                          :30-31 */
+};
+
+/* metric ids -- _src/gp/tensors/numpy.py:89-94, gp/deformation/metric.py:237-265 */
+enum mgp_metric { MGP_METRIC_L2 = 0, MGP_METRIC_F2 = 1 };
+
+/* noise model -- _src/gp/noise/numpy.py:9-14 (homoscedastic), :56-67 (heteroscedastic) */
+enum mgp_noise_mode {
+  MGP_NOISE_SCALAR = 0,  /* eps * I, eps = noise_scalar                               */
+  MGP_NOISE_TABLE = 1,   /* diag(noise_dev[nn_idx[b, :]]): per-training-point table    */
+  MGP_NOISE_BATCH = 2    /* diag(noise_dev[b, :]): already gathered (b,k) tensor       */
+};
+
+enum mgp_status {
+  MGP_OK = 0,
+  MGP_EINVAL = -1,       /* null pointer / negative size / unknown enum      */
+  MGP_EUNSUPPORTED = -2, /* shape outside what the kernels were built for    */
+  MGP_EHIP = -1000       /* -(1000 + hipError_t)                             */
+};
+
+const char* mgp_version(void);
+/* Largest nn_count the fused / solve kernels accept for a given float width and
+ * feature/response count (LDS-resident factorisation). */
+int mgp_max_nn_count(int elem_size, int response_count);
+
+/* ---------------------------------------------------------------------------
+ * Fused hot path.  Replaces, in one launch and without materialising anything:
+ *   T1 _crosswise_tensor + T2 _pairwise_tensor   _src/gp/tensors/numpy.py:47-69
+ *   T3 _F2 / _l2                                 :89-94
+ *   T4 target / noise gathers                    gp/muygps.py:474,543,545
+ *   D1 Isotropy.__call__ / D2 Anisotropy.__call__ gp/deformation/isotropy.py:60-89,
+ *                                                 anisotropy.py:43-70
+ *   K1/K2 kernel functions                       _src/gp/kernels/numpy.py:12-31
+ *   N1/N2 perturb                                _src/gp/noise/numpy.py:9-14,56-67
+ *   S1 _muygps_posterior_mean                    _src/gp/muygps/numpy.py:17-41
+ *   S2 _muygps_diagonal_variance (Kout = 1)      :44-67
+ *   S3 _analytic_scale_optim_unnormalized terms  _src/optimize/scale/numpy.py:9-15
+ *
+ *   feat_q   (n_q, d)   query table (rows selected by batch_idx)
+ *   feat_nn  (n_nn, d)  neighbour table (rows selected by nn_idx)
+ *   batch_idx (b)       may be NULL = identity (row i of feat_q)
+ *   nn_idx   (b, k)
+ *   targets  (n_nn, R)  neighbour responses (rows selected by nn_idx)
+ *   length_scale (ls_count) device; ls_count == 1 Isotropy, == d Anisotropy
+ *   mean (b, R), var (b) [unscaled: 1 - c^T K^-1 c], ykinvy (b, R) or NULL
+ *   [y_r^T K^-1 y_r per neighbourhood], info device int32 or NULL.
+ * ------------------------------------------------------------------------- */
+int mgp_posterior_f32(const float* feat_q, const float* feat_nn, int d,
+                      const int64_t* batch_idx, const int64_t* nn_idx, int64_t b, int k,
+                      const float* targets, int R,
+                      int noise_mode, double noise_scalar, const float* noise_dev,
+                      int kernel_id, int metric_id, const float* length_scale, int ls_count,
+                      float* mean, float* var, float* ykinvy, int* info, void* stream);
+int mgp_posterior_f64(const double* feat_q, const double* feat_nn, int d,
+                      const int64_t* batch_idx, const int64_t* nn_idx, int64_t b, int k,
+                      const double* targets, int R,
+                      int noise_mode, double noise_scalar, const double* noise_dev,
+                      int kernel_id, int metric_id, const double* length_scale, int ls_count,
+                      double* mean, double* var, double* ykinvy, int* info, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Materialising per-function kernels (API parity with the backend modules).
+ * ------------------------------------------------------------------------- */
+
+/* T1 _crosswise_tensor, _src/gp/tensors/numpy.py:47-58: out (b,k,d) = q - x_nn */
+int mgp_crosswise_diffs_f32(const float* feat_q, const float* feat_nn, int d, const int64_t* batch_idx,
+                            const int64_t* nn_idx, int64_t b, int k, float* out, void* stream);
+int mgp_crosswise_diffs_f64(const double* feat_q, const double* feat_nn, int d, const int64_t* batch_idx,
+                            const int64_t* nn_idx, int64_t b, int k, double* out, void* stream);
+/* T2 _pairwise_tensor, :61-69: out (b,k,k,d)[b,i,j,:] = x[nn[b,i]] - x[nn[b,j]] */
+int mgp_pairwise_diffs_f32(const float* feat, int d, const int64_t* nn_idx, int64_t b, int k, float* out,
+                           void* stream);
+int mgp_pairwise_diffs_f64(const double* feat, int d, const int64_t* nn_idx, int64_t b, int k, double* out,
+                           void* stream);
+/* T1+T3 fused: out (b,k) = metric(q - x_nn); T2+T3 fused: out (b,k,k).  What
+ * Isotropy.crosswise_tensor / pairwise_tensor return (isotropy.py:92-161). */
+int mgp_crosswise_dists_f32(const float* feat_q, const float* feat_nn, int d, const int64_t* batch_idx,
+                            const int64_t* nn_idx, int64_t b, int k, int metric_id, float* out, void* stream);
+int mgp_crosswise_dists_f64(const double* feat_q, const double* feat_nn, int d, const int64_t* batch_idx,
+                            const int64_t* nn_idx, int64_t b, int k, int metric_id, double* out, void* stream);
+int mgp_pairwise_dists_f32(const float* feat, int d, const int64_t* nn_idx, int64_t b, int k, int metric_id,
+                           float* out, void* stream);
+int mgp_pairwise_dists_f64(const double* feat, int d, const int64_t* nn_idx, int64_t b, int k, int metric_id,
+                           double* out, void* stream);
+/* T3 _F2/_l2 (:89-94) with the optional Anisotropy division (anisotropy.py:70):
+ * out[n] = metric(diffs[n,:] / length_scale[:]); length_scale NULL = no division. */
+int mgp_reduce_diffs_f32(const float* diffs, int64_t n, int d, const float* length_scale, int metric_id,
+                         float* out, void* stream);
+int mgp_reduce_diffs_f64(const double* diffs, int64_t n, int d, const double* length_scale, int metric_id,
+                         double* out, void* stream);
+/* D1 + K1/K2: out[i] = kernel(in[i] * in_scale).  in_scale = 1/l (l2) or 1/l^2 (F2)
+ * (metric.py:241,264); _src/gp/kernels/numpy.py:12-31. */
+int mgp_kernel_apply_f32(const float* in, int64_t n, int kernel_id, double in_scale, float* out, void* stream);
+int mgp_kernel_apply_f64(const double* in, int64_t n, int kernel_id, double in_scale, double* out, void* stream);
+/* N1/N2 perturb, _src/gp/noise/numpy.py:9-14,56-67: out = Kin + diag(noise). noise_dev
+ * is (b,k) when noise_mode == MGP_NOISE_BATCH. */
+int mgp_perturb_f32(const float* Kin, int64_t b, int k, int noise_mode, double noise_scalar,
+                    const float* noise_dev, float* out, void* stream);
+int mgp_perturb_f64(const double* Kin, int64_t b, int k, int noise_mode, double noise_scalar,
+                    const double* noise_dev, double* out, void* stream);
+/* S1/S2/S3 + fast-mean precompute on a materialised (already perturbed) Kin (b,k,k):
+ *   mean (b,R)   = Kcross^T Kin^-1 Y           _src/gp/muygps/numpy.py:17-41
+ *   var (b)      = kout - Kcross^T Kin^-1 Kcross   :44-67
+ *   ykinvy (b,R) = y_r^T Kin^-1 y_r            _src/optimize/scale/numpy.py:9-15
+ *   coeffs (b,k,R) = Kin^-1 Y                  _src/gp/muygps/numpy.py:88-95
+ * Any of Kcross / Y and the outputs that need them may be NULL. */
+int mgp_solve_f32(const float* Kin, const float* Kcross, const float* Y, int64_t b, int k, int R, double kout,
+                  float* mean, float* var, float* ykinvy, float* coeffs, int* info, void* stream);
+int mgp_solve_f64(const double* Kin, const double* Kcross, const double* Y, int64_t b, int k, int R, double kout,
+                  double* mean, double* var, double* ykinvy, double* coeffs, int* info, void* stream);
+
+/* L1/L2 loss sums in fp64, _src/optimize/loss/numpy.py:22-117.  For n residuals
+ * r = pred - target and variances v (may be NULL), with s = *scale_dev (device
+ * double, NULL = 1) writes
+ *   out[0] = sum r^2                      (mse numerator, :22-31)
+ *   out[1] = sum r^2 / (s v) + log(s v)   (lool, :34-61)
+ *   out[2] = sum huber_delta^2 (sqrt(1 + (r/huber_delta)^2) - 1)            (:64-72)
+ *   out[3] = sum 2 looph_delta^2 (sqrt(1 + r^2/(looph_delta^2 s v)) - 1) + log(s v)  (:75-117)
+ *   out[4] = sum r^2 / v,  out[5] = sum log v   (separable lool pieces for a single allreduce)
+ * `out` is a device double[6], overwritten (not accumulated). */
+int mgp_loss_sums_f32(const float* pred, const float* target, const float* var, int64_t n,
+                      const double* scale_dev, double huber_delta, double looph_delta, double* out, void* stream);
+int mgp_loss_sums_f64(const double* pred, const double* target, const double* var, int64_t n,
+                      const double* scale_dev, double huber_delta, double looph_delta, double* out, void* stream);
+/* Column sums in fp64: out[r] = sum_i x[i, r]  (x is (n, R)); used for
+ * sum_b y^T K^-1 y (scale/numpy.py:9-15).  out is a device double[R]. */
+int mgp_column_sums_f32(const float* x, int64_t n, int R, double* out, void* stream);
+int mgp_column_sums_f64(const double* x, int64_t n, int R, double* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUYGPYS_HIP_H */

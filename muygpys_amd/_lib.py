@@ -1,0 +1,123 @@
+"""ctypes binding of libmuygpys_hip.so (the C ABI in include/muygpys_hip.h).
+
+The product path has no CPU fallback: if the library is missing or a call fails this
+module raises.  torch is imported first so that the library's libamdhip64 dependency
+resolves to the HIP runtime torch already loaded (one runtime per process; device
+pointers and streams are then interchangeable).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+import torch  # noqa: F401  (must precede the dlopen below)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libmuygpys_hip.so")
+HEADER = os.path.join(HERE, "..", "include", "muygpys_hip.h")
+
+KERNEL_IDS = {"rbf": 0, "matern05": 1, "matern15": 2, "matern25": 3, "maternInf": 4}
+METRIC_IDS = {"l2": 0, "F2": 1}
+NOISE_SCALAR, NOISE_TABLE, NOISE_BATCH = 0, 1, 2
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def _status_message(rc: int) -> str:
+    if rc == -1:
+        return "MGP_EINVAL (null pointer / bad size / unknown enum)"
+    if rc == -2:
+        return "MGP_EUNSUPPORTED (shape outside what the kernels were built for)"
+    if rc <= -1000:
+        return f"HIP runtime error {-rc - 1000}"
+    return f"status {rc}"
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise HipLibraryError(f"{what} failed: {_status_message(rc)}")
+
+
+_p = C.c_void_p
+_i = C.c_int
+_l = C.c_int64
+_d = C.c_double
+
+_SIGS = {
+    "posterior": [_p, _p, _i, _p, _p, _l, _i, _p, _i, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p],
+    "crosswise_diffs": [_p, _p, _i, _p, _p, _l, _i, _p, _p],
+    "pairwise_diffs": [_p, _i, _p, _l, _i, _p, _p],
+    "crosswise_dists": [_p, _p, _i, _p, _p, _l, _i, _i, _p, _p],
+    "pairwise_dists": [_p, _i, _p, _l, _i, _i, _p, _p],
+    "reduce_diffs": [_p, _l, _i, _p, _i, _p, _p],
+    "kernel_apply": [_p, _l, _i, _d, _p, _p],
+    "perturb": [_p, _l, _i, _i, _d, _p, _p, _p],
+    "solve": [_p, _p, _p, _l, _i, _i, _d, _p, _p, _p, _p, _p, _p],
+    "loss_sums": [_p, _p, _p, _l, _p, _d, _d, _p, _p],
+    "column_sums": [_p, _l, _i, _p, _p],
+}
+
+
+def exported_names_from_header():
+    """Every function the public header declares (used by the CPU symbol test)."""
+    with open(HEADER) as f:
+        text = f.read()
+    return sorted(set(re.findall(r"\b(mgp_[a-z0-9_]+)\s*\(", text)))
+
+
+def load():
+    """dlopen the library (once) and attach argtypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the hip backend)"
+        )
+    lib = C.CDLL(LIB_PATH)
+    lib.mgp_version.restype = C.c_char_p
+    lib.mgp_max_nn_count.argtypes = [_i, _i]
+    lib.mgp_max_nn_count.restype = _i
+    lib.mgp_debug_force_generic.argtypes = [_i]
+    lib.mgp_debug_force_generic.restype = None
+    for base, sig in _SIGS.items():
+        for suf in ("f32", "f64"):
+            fn = getattr(lib, f"mgp_{base}_{suf}")
+            fn.argtypes = sig
+            fn.restype = _i
+    _lib = lib
+    return lib
+
+
+def suffix(dtype) -> str:
+    if dtype == torch.float32:
+        return "f32"
+    if dtype == torch.float64:
+        return "f64"
+    raise TypeError(f"hip backend supports float32/float64 tensors, got {dtype}")
+
+
+def fn(base: str, dtype):
+    return getattr(load(), f"mgp_{base}_{suffix(dtype)}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not (isinstance(t, torch.Tensor) and t.is_cuda):
+            raise TypeError("hip backend functions take torch tensors on a ROCm device ('cuda')")

@@ -1,0 +1,59 @@
+// Argument blocks + launcher declarations shared by the translation units.
+#pragma once
+
+#include "mgp_device.h"
+
+namespace mgp {
+
+struct FusedArgs {
+  const void* feat_q;
+  const void* feat_nn;
+  const int64_t* batch_idx;
+  const int64_t* nn_idx;
+  const void* targets;
+  const void* noise_dev;
+  const void* length_scale;
+  void* mean;
+  void* var;
+  void* ykinvy;
+  int* info;
+  int64_t b;
+  double noise_scalar;
+  int d, k, R, noise_mode, kernel_id, metric_id, ls_count, dc;
+};
+
+struct SolveArgs {
+  const void* Kin;
+  const void* Kcross;
+  const void* Y;
+  void* mean;
+  void* var;
+  void* ykinvy;
+  void* coeffs;
+  int* info;
+  int64_t b;
+  double kout;
+  int k, R;
+};
+
+template <typename T> int launch_fused_generic(const FusedArgs&, hipStream_t);
+template <typename T> int launch_solve_generic(const SolveArgs&, hipStream_t);
+// register-resident wave-per-neighbourhood kernels; MGP_EUNSUPPORTED when the shape is not covered
+template <typename T> int launch_fused_wave(const FusedArgs&, hipStream_t);
+int max_nn_count(int elem_size, int R);
+
+template <typename T>
+int launch_crosswise_diffs(const T*, const T*, int, const int64_t*, const int64_t*, int64_t, int, T*, hipStream_t);
+template <typename T> int launch_pairwise_diffs(const T*, int, const int64_t*, int64_t, int, T*, hipStream_t);
+template <typename T>
+int launch_crosswise_dists(const T*, const T*, int, const int64_t*, const int64_t*, int64_t, int, int, T*,
+                           hipStream_t);
+template <typename T> int launch_pairwise_dists(const T*, int, const int64_t*, int64_t, int, int, T*, hipStream_t);
+template <typename T> int launch_reduce_diffs(const T*, int64_t, int, const T*, int, T*, hipStream_t);
+template <typename T> int launch_kernel_apply(const T*, int64_t, int, double, T*, hipStream_t);
+template <typename T> int launch_perturb(const T*, int64_t, int, int, double, const T*, T*, hipStream_t);
+template <typename T>
+int launch_loss_sums(const T*, const T*, const T*, int64_t, const double*, double, double, double*, hipStream_t);
+template <typename T> int launch_column_sums(const T*, int64_t, int, double*, hipStream_t);
+
+}  // namespace mgp

@@ -1,0 +1,118 @@
+// extern "C" boundary: argument validation + dispatch to the kernels.  See
+// include/muygpys_hip.h for the contract and the reference functions each entry replaces.
+#include "mgp_args.h"
+
+namespace mgp {
+
+static bool valid_kernel(int id) { return id >= MGP_KERNEL_RBF && id <= MGP_KERNEL_MATERN_INF; }
+static bool valid_metric(int id) { return id == MGP_METRIC_L2 || id == MGP_METRIC_F2; }
+
+// 0 = let the dispatcher choose; 1 = force the generic LDS kernel (tests / A-B timing)
+static int g_force_generic = 0;
+
+template <typename T>
+int posterior(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t* ni, int64_t b, int k, const T* tg,
+              int R, int noise_mode, double eps, const T* nd, int kernel_id, int metric_id, const T* ls,
+              int ls_count, T* mean, T* var, T* yk, int* info, void* stream) {
+  if (b < 0 || k < 1 || d < 1 || R < 1) return MGP_EINVAL;
+  if (!fq || !fn || !ni || !tg || !ls || !mean || !var) return MGP_EINVAL;
+  if (!valid_kernel(kernel_id) || !valid_metric(metric_id)) return MGP_EINVAL;
+  if (noise_mode < MGP_NOISE_SCALAR || noise_mode > MGP_NOISE_BATCH) return MGP_EINVAL;
+  if (noise_mode != MGP_NOISE_SCALAR && !nd) return MGP_EINVAL;
+  if (ls_count != 1 && ls_count != d) return MGP_EINVAL;
+  if (b == 0) return MGP_OK;
+  FusedArgs a{fq, fn, bi, ni, tg, nd, ls, mean, var, yk, info, b, eps, d, k, R, noise_mode, kernel_id, metric_id,
+              ls_count, 0};
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (!g_force_generic) {
+    const int rc = launch_fused_wave<T>(a, s);
+    if (rc != MGP_EUNSUPPORTED) return rc;
+  }
+  return launch_fused_generic<T>(a, s);
+}
+
+template <typename T>
+int solve(const T* Kin, const T* Kc, const T* Y, int64_t b, int k, int R, double kout, T* mean, T* var, T* yk,
+          T* coeffs, int* info, void* stream) {
+  if (b < 0 || k < 1 || R < 0 || !Kin) return MGP_EINVAL;
+  if (R > 0 && !Y) return MGP_EINVAL;
+  if ((mean || var) && !Kc) return MGP_EINVAL;
+  if ((mean || yk || coeffs) && R == 0) return MGP_EINVAL;
+  if (b == 0) return MGP_OK;
+  SolveArgs a{Kin, Kc, Y, mean, var, yk, coeffs, info, b, kout, k, R};
+  return launch_solve_generic<T>(a, static_cast<hipStream_t>(stream));
+}
+}  // namespace mgp
+
+using namespace mgp;
+#define S_(x) static_cast<hipStream_t>(x)
+
+extern "C" {
+
+const char* mgp_version(void) { return "muygpys_amd-hip 0.1 (gfx950)"; }
+int mgp_max_nn_count(int elem_size, int R) { return max_nn_count(elem_size, R); }
+/* test hook, not part of the public header: force the generic LDS kernel */
+void mgp_debug_force_generic(int on) { g_force_generic = on; }
+
+int mgp_posterior_f32(const float* fq, const float* fn, int d, const int64_t* bi, const int64_t* ni, int64_t b, int k,
+                      const float* tg, int R, int nm, double eps, const float* nd, int kid, int mid, const float* ls,
+                      int lsc, float* mean, float* var, float* yk, int* info, void* st) {
+  return posterior<float>(fq, fn, d, bi, ni, b, k, tg, R, nm, eps, nd, kid, mid, ls, lsc, mean, var, yk, info, st);
+}
+int mgp_posterior_f64(const double* fq, const double* fn, int d, const int64_t* bi, const int64_t* ni, int64_t b,
+                      int k, const double* tg, int R, int nm, double eps, const double* nd, int kid, int mid,
+                      const double* ls, int lsc, double* mean, double* var, double* yk, int* info, void* st) {
+  return posterior<double>(fq, fn, d, bi, ni, b, k, tg, R, nm, eps, nd, kid, mid, ls, lsc, mean, var, yk, info, st);
+}
+
+#define MGP_DEFINE(SUF, T)                                                                                           \
+  int mgp_crosswise_diffs_##SUF(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t* ni, int64_t b,    \
+                                int k, T* out, void* st) {                                                           \
+    if (!fq || !fn || !ni || !out || b < 0 || k < 1 || d < 1) return MGP_EINVAL;                                     \
+    return launch_crosswise_diffs<T>(fq, fn, d, bi, ni, b, k, out, S_(st));                                          \
+  }                                                                                                                  \
+  int mgp_pairwise_diffs_##SUF(const T* f, int d, const int64_t* ni, int64_t b, int k, T* out, void* st) {           \
+    if (!f || !ni || !out || b < 0 || k < 1 || d < 1) return MGP_EINVAL;                                             \
+    return launch_pairwise_diffs<T>(f, d, ni, b, k, out, S_(st));                                                    \
+  }                                                                                                                  \
+  int mgp_crosswise_dists_##SUF(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t* ni, int64_t b,    \
+                                int k, int mid, T* out, void* st) {                                                  \
+    if (!fq || !fn || !ni || !out || b < 0 || k < 1 || d < 1 || !valid_metric(mid)) return MGP_EINVAL;               \
+    return launch_crosswise_dists<T>(fq, fn, d, bi, ni, b, k, mid, out, S_(st));                                     \
+  }                                                                                                                  \
+  int mgp_pairwise_dists_##SUF(const T* f, int d, const int64_t* ni, int64_t b, int k, int mid, T* out, void* st) {  \
+    if (!f || !ni || !out || b < 0 || k < 1 || d < 1 || !valid_metric(mid)) return MGP_EINVAL;                       \
+    return launch_pairwise_dists<T>(f, d, ni, b, k, mid, out, S_(st));                                               \
+  }                                                                                                                  \
+  int mgp_reduce_diffs_##SUF(const T* diffs, int64_t n, int d, const T* ls, int mid, T* out, void* st) {             \
+    if (!diffs || !out || n < 0 || d < 1 || !valid_metric(mid)) return MGP_EINVAL;                                   \
+    return launch_reduce_diffs<T>(diffs, n, d, ls, mid, out, S_(st));                                                \
+  }                                                                                                                  \
+  int mgp_kernel_apply_##SUF(const T* in, int64_t n, int kid, double scale, T* out, void* st) {                      \
+    if (!in || !out || n < 0 || !valid_kernel(kid)) return MGP_EINVAL;                                               \
+    return launch_kernel_apply<T>(in, n, kid, scale, out, S_(st));                                                   \
+  }                                                                                                                  \
+  int mgp_perturb_##SUF(const T* Kin, int64_t b, int k, int nm, double eps, const T* nd, T* out, void* st) {         \
+    if (!Kin || !out || b < 0 || k < 1) return MGP_EINVAL;                                                           \
+    if (nm != MGP_NOISE_SCALAR && nm != MGP_NOISE_BATCH) return MGP_EINVAL;                                          \
+    if (nm == MGP_NOISE_BATCH && !nd) return MGP_EINVAL;                                                             \
+    return launch_perturb<T>(Kin, b, k, nm, eps, nd, out, S_(st));                                                   \
+  }                                                                                                                  \
+  int mgp_solve_##SUF(const T* Kin, const T* Kc, const T* Y, int64_t b, int k, int R, double kout, T* mean, T* var,  \
+                      T* yk, T* coeffs, int* info, void* st) {                                                       \
+    return solve<T>(Kin, Kc, Y, b, k, R, kout, mean, var, yk, coeffs, info, st);                                     \
+  }                                                                                                                  \
+  int mgp_loss_sums_##SUF(const T* pred, const T* target, const T* var, int64_t n, const double* scale_dev,          \
+                          double hd, double ld, double* out, void* st) {                                             \
+    if (!pred || !target || !out || n < 0 || !(hd > 0) || !(ld > 0)) return MGP_EINVAL;                              \
+    return launch_loss_sums<T>(pred, target, var, n, scale_dev, hd, ld, out, S_(st));                                \
+  }                                                                                                                  \
+  int mgp_column_sums_##SUF(const T* x, int64_t n, int R, double* out, void* st) {                                   \
+    if (!x || !out || n < 0 || R < 0) return MGP_EINVAL;                                                             \
+    return launch_column_sums<T>(x, n, R, out, S_(st));                                                              \
+  }
+
+MGP_DEFINE(f32, float)
+MGP_DEFINE(f64, double)
+
+}  // extern "C"

@@ -1,0 +1,72 @@
+// Shared device helpers for the gfx950 kernels of the MuyGPyS local-GP hot path.
+// Wave size is 64 on CDNA4; every cross-lane idiom below is written for that.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/muygpys_hip.h"
+
+#define MGP_WAVE 64
+
+#define MGP_HIP_CHECK_LAUNCH()                              \
+  do {                                                      \
+    hipError_t e__ = hipGetLastError();                     \
+    if (e__ != hipSuccess) return -(1000 + (int)e__);       \
+  } while (0)
+
+namespace mgp {
+
+template <typename T> struct num;
+template <> struct num<float> {
+  static __device__ __forceinline__ float exp(float x) { return expf(x); }
+  static __device__ __forceinline__ float sqrt(float x) { return sqrtf(x); }
+  static __device__ __forceinline__ float rsqrt(float x) { return 1.0f / sqrtf(x); }
+  static __device__ __forceinline__ float nan() { return __builtin_nanf(""); }
+};
+template <> struct num<double> {
+  static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
+  static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+  static __device__ __forceinline__ double rsqrt(double x) { return 1.0 / ::sqrt(x); }
+  static __device__ __forceinline__ double nan() { return __builtin_nan(""); }
+};
+
+// acc = sum_d (diff)^2 [anisotropic: sum_d (diff / l_d)^2].  Returns the kernel's
+// argument: Isotropy l2: sqrt(acc)/l; F2: acc/l^2 (gp/deformation/metric.py:241,264);
+// Anisotropy: sqrt(acc) / acc (anisotropy.py:70).  post_scale = 1/l or 1/l^2 or 1.
+template <typename T>
+__device__ __forceinline__ T metric_arg(T acc, int metric_id, T post_scale) {
+  return (metric_id == MGP_METRIC_L2 ? num<T>::sqrt(acc) : acc) * post_scale;
+}
+
+// _src/gp/kernels/numpy.py:12-31
+template <typename T>
+__device__ __forceinline__ T kernel_eval(int kernel_id, T x) {
+  switch (kernel_id) {
+    case MGP_KERNEL_RBF:
+      return num<T>::exp(-x * T(0.5));
+    case MGP_KERNEL_MATERN_05:
+      return num<T>::exp(-x);
+    case MGP_KERNEL_MATERN_15: {
+      T t = x * T(1.7320508075688772935);
+      return (T(1) + t) * num<T>::exp(-t);
+    }
+    case MGP_KERNEL_MATERN_25: {
+      T t = x * T(2.2360679774997896964);
+      return (T(1) + t + t * t * T(1.0 / 3.0)) * num<T>::exp(-t);
+    }
+    default:  // MGP_KERNEL_MATERN_INF
+      return num<T>::exp(-x * x * T(0.5));
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__host__ __device__ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace mgp

@@ -1,0 +1,270 @@
+// Materialising per-function kernels: the HIP counterparts of the reference's backend
+// functions when a caller insists on the intermediate tensors (API parity).  All are
+// HBM-bound elementwise / gather kernels: one output element (or one feature chunk) per
+// lane, consecutive lanes on consecutive addresses.
+#include "mgp_device.h"
+
+namespace mgp {
+
+static const int kBlock = 256;
+
+static inline int grid_1d(int64_t n) {
+  int64_t g = ceil_div(n, kBlock);
+  const int64_t cap = 256LL * 32;  // 256 CUs x 32 resident waves; grid-stride beyond
+  return (int)(g < cap ? (g < 1 ? 1 : g) : cap);
+}
+
+// T1: out[b,j,:] = q[batch_idx[b],:] - x[nn_idx[b,j],:]      _src/gp/tensors/numpy.py:47-58
+template <typename T>
+__global__ void crosswise_diffs_kernel(const T* fq, const T* fn, int d, const int64_t* bidx, const int64_t* nidx,
+                                       int64_t b, int k, T* out) {
+  const int64_t n = b * k * (int64_t)d;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = t / d;
+    const int c = (int)(t - row * d);
+    const int64_t bi = row / k;
+    const int64_t q = bidx ? bidx[bi] : bi;
+    out[t] = fq[q * d + c] - fn[nidx[row] * d + c];
+  }
+}
+
+// T2: out[b,i,j,:] = x[nn[b,i],:] - x[nn[b,j],:]              _src/gp/tensors/numpy.py:61-69
+template <typename T>
+__global__ void pairwise_diffs_kernel(const T* f, int d, const int64_t* nidx, int64_t b, int k, T* out) {
+  const int64_t n = b * k * (int64_t)k * d;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pr = t / d;
+    const int c = (int)(t - pr * d);
+    const int64_t bi = pr / ((int64_t)k * k);
+    const int ij = (int)(pr - bi * k * k);
+    const int i = ij / k, j = ij - i * k;
+    out[t] = f[nidx[bi * k + i] * d + c] - f[nidx[bi * k + j] * d + c];
+  }
+}
+
+// T1+T3: out[b,j] = metric(q - x_j)
+template <typename T>
+__global__ void crosswise_dists_kernel(const T* fq, const T* fn, int d, const int64_t* bidx, const int64_t* nidx,
+                                       int64_t b, int k, int metric_id, T* out) {
+  const int64_t n = b * k;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t bi = t / k;
+    const T* q = fq + (bidx ? bidx[bi] : bi) * d;
+    const T* x = fn + nidx[t] * d;
+    T acc = T(0);
+    for (int c = 0; c < d; ++c) {
+      const T df = q[c] - x[c];
+      acc += df * df;
+    }
+    out[t] = metric_id == MGP_METRIC_L2 ? num<T>::sqrt(acc) : acc;
+  }
+}
+
+// T2+T3: out[b,i,j] = metric(x_i - x_j)
+template <typename T>
+__global__ void pairwise_dists_kernel(const T* f, int d, const int64_t* nidx, int64_t b, int k, int metric_id,
+                                      T* out) {
+  const int64_t n = b * k * (int64_t)k;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t bi = t / ((int64_t)k * k);
+    const int ij = (int)(t - bi * k * k);
+    const int i = ij / k, j = ij - i * k;
+    const T* xi = f + nidx[bi * k + i] * d;
+    const T* xj = f + nidx[bi * k + j] * d;
+    T acc = T(0);
+    for (int c = 0; c < d; ++c) {
+      const T df = xi[c] - xj[c];
+      acc += df * df;
+    }
+    out[t] = metric_id == MGP_METRIC_L2 ? num<T>::sqrt(acc) : acc;
+  }
+}
+
+// T3 (+D2): out[n] = metric(diffs[n,:] / ls[:])
+template <typename T>
+__global__ void reduce_diffs_kernel(const T* diffs, int64_t n, int d, const T* ls, int metric_id, T* out) {
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+    const T* x = diffs + t * d;
+    T acc = T(0);
+    for (int c = 0; c < d; ++c) {
+      const T df = ls ? x[c] / ls[c] : x[c];
+      acc += df * df;
+    }
+    out[t] = metric_id == MGP_METRIC_L2 ? num<T>::sqrt(acc) : acc;
+  }
+}
+
+// D1 + K1/K2
+template <typename T>
+__global__ void kernel_apply_kernel(const T* in, int64_t n, int kernel_id, T in_scale, T* out) {
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+    out[t] = kernel_eval<T>(kernel_id, in[t] * in_scale);
+}
+
+// N1/N2
+template <typename T>
+__global__ void perturb_kernel(const T* Kin, int64_t b, int k, int noise_mode, T noise_scalar, const T* noise_dev,
+                               T* out) {
+  const int64_t n = b * k * (int64_t)k;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t bi = t / ((int64_t)k * k);
+    const int ij = (int)(t - bi * k * k);
+    const int i = ij / k, j = ij - i * k;
+    T v = Kin[t];
+    if (i == j) v += noise_mode == MGP_NOISE_SCALAR ? noise_scalar : noise_dev[bi * k + i];
+    out[t] = v;
+  }
+}
+
+// ---- fp64 reductions (single workgroup finishes; inputs are O(b) scalars) ----------------
+
+template <int N>
+__device__ inline void block_reduce_store(double (&v)[N], double* out) {
+  __shared__ double red[N][kBlock / MGP_WAVE];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const double s = wave_sum(v[i]);
+    if (lane == 0) red[i][w] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < N) {
+    double s = 0;
+    for (int j = 0; j < kBlock / MGP_WAVE; ++j) s += red[threadIdx.x][j];
+    atomicAdd(out + threadIdx.x, s);
+  }
+  __syncthreads();
+}
+
+// _src/optimize/loss/numpy.py:22-117 in one pass
+template <typename T>
+__global__ void loss_sums_kernel(const T* pred, const T* target, const T* var, int64_t n, const double* scale_dev,
+                                 double hd, double ld, double* out) {
+  const double s = scale_dev ? *scale_dev : 1.0;
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+    const double r = (double)pred[t] - (double)target[t];
+    const double r2 = r * r;
+    acc[0] += r2;
+    acc[2] += hd * hd * (::sqrt(1.0 + (r / hd) * (r / hd)) - 1.0);
+    if (var) {
+      const double v = (double)var[t];
+      const double sv = s * v;
+      acc[1] += r2 / sv + ::log(sv);
+      acc[3] += 2.0 * ld * ld * (::sqrt(1.0 + r2 / (ld * ld * sv)) - 1.0) + ::log(sv);
+      acc[4] += r2 / v;
+      acc[5] += ::log(v);
+    }
+  }
+  block_reduce_store<6>(acc, out);
+}
+
+template <typename T>
+__global__ void column_sums_kernel(const T* x, int64_t n, int R, double* out) {
+  // one column at a time (R is small); rows strided over the whole grid
+  for (int r = 0; r < R; ++r) {
+    double acc[1] = {0};
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+      acc[0] += (double)x[t * R + r];
+    block_reduce_store<1>(acc, out + r);
+  }
+}
+
+template <typename T>
+int launch_crosswise_diffs(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t* ni, int64_t b, int k,
+                           T* out, hipStream_t s) {
+  if (b * k * (int64_t)d == 0) return MGP_OK;
+  hipLaunchKernelGGL(crosswise_diffs_kernel<T>, dim3(grid_1d(b * k * d)), dim3(kBlock), 0, s, fq, fn, d, bi, ni, b,
+                     k, out);
+  MGP_HIP_CHECK_LAUNCH();
+  return MGP_OK;
+}
+template <typename T>
+int launch_pairwise_diffs(const T* f, int d, const int64_t* ni, int64_t b, int k, T* out, hipStream_t s) {
+  if (b * k * (int64_t)d == 0) return MGP_OK;
+  hipLaunchKernelGGL(pairwise_diffs_kernel<T>, dim3(grid_1d(b * k * k * d)), dim3(kBlock), 0, s, f, d, ni, b, k,
+                     out);
+  MGP_HIP_CHECK_LAUNCH();
+  return MGP_OK;
+}
+template <typename T>
+int launch_crosswise_dists(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t* ni, int64_t b, int k,
+                           int metric, T* out, hipStream_t s) {
+  if (b * k == 0) return MGP_OK;
+  hipLaunchKernelGGL(crosswise_dists_kernel<T>, dim3(grid_1d(b * k)), dim3(kBlock), 0, s, fq, fn, d, bi, ni, b, k,
+                     metric, out);
+  MGP_HIP_CHECK_LAUNCH();
+  return MGP_OK;
+}
+template <typename T>
+int launch_pairwise_dists(const T* f, int d, const int64_t* ni, int64_t b, int k, int metric, T* out,
+                          hipStream_t s) {
+  if (b * k == 0) return MGP_OK;
+  hipLaunchKernelGGL(pairwise_dists_kernel<T>, dim3(grid_1d(b * k * k)), dim3(kBlock), 0, s, f, d, ni, b, k, metric,
+                     out);
+  MGP_HIP_CHECK_LAUNCH();
+  return MGP_OK;
+}
+template <typename T>
+int launch_reduce_diffs(const T* diffs, int64_t n, int d, const T* ls, int metric, T* out, hipStream_t s) {
+  if (n == 0) return MGP_OK;
+  hipLaunchKernelGGL(reduce_diffs_kernel<T>, dim3(grid_1d(n)), dim3(kBlock), 0, s, diffs, n, d, ls, metric, out);
+  MGP_HIP_CHECK_LAUNCH();
+  return MGP_OK;
+}
+template <typename T>
+int launch_kernel_apply(const T* in, int64_t n, int kernel_id, double scale, T* out, hipStream_t s) {
+  if (n == 0) return MGP_OK;
+  hipLaunchKernelGGL(kernel_apply_kernel<T>, dim3(grid_1d(n)), dim3(kBlock), 0, s, in, n, kernel_id, (T)scale, out);
+  MGP_HIP_CHECK_LAUNCH();
+  return MGP_OK;
+}
+template <typename T>
+int launch_perturb(const T* Kin, int64_t b, int k, int mode, double eps, const T* nd, T* out, hipStream_t s) {
+  if (b * k == 0) return MGP_OK;
+  hipLaunchKernelGGL(perturb_kernel<T>, dim3(grid_1d(b * k * k)), dim3(kBlock), 0, s, Kin, b, k, mode, (T)eps, nd,
+                     out);
+  MGP_HIP_CHECK_LAUNCH();
+  return MGP_OK;
+}
+template <typename T>
+int launch_loss_sums(const T* pred, const T* target, const T* var, int64_t n, const double* scale_dev, double hd,
+                     double ld, double* out, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(out, 0, 6 * sizeof(double), s);
+  if (e != hipSuccess) return -(1000 + (int)e);
+  if (n == 0) return MGP_OK;
+  int g = grid_1d(n);
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(loss_sums_kernel<T>, dim3(g), dim3(kBlock), 0, s, pred, target, var, n, scale_dev, hd, ld, out);
+  MGP_HIP_CHECK_LAUNCH();
+  return MGP_OK;
+}
+template <typename T>
+int launch_column_sums(const T* x, int64_t n, int R, double* out, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(out, 0, (size_t)R * sizeof(double), s);
+  if (e != hipSuccess) return -(1000 + (int)e);
+  if (n == 0 || R == 0) return MGP_OK;
+  int g = grid_1d(n);
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(column_sums_kernel<T>, dim3(g), dim3(kBlock), 0, s, x, n, R, out);
+  MGP_HIP_CHECK_LAUNCH();
+  return MGP_OK;
+}
+
+#define MGP_INSTANTIATE(T)                                                                                         \
+  template int launch_crosswise_diffs<T>(const T*, const T*, int, const int64_t*, const int64_t*, int64_t, int, T*, \
+                                         hipStream_t);                                                             \
+  template int launch_pairwise_diffs<T>(const T*, int, const int64_t*, int64_t, int, T*, hipStream_t);             \
+  template int launch_crosswise_dists<T>(const T*, const T*, int, const int64_t*, const int64_t*, int64_t, int, int, \
+                                         T*, hipStream_t);                                                         \
+  template int launch_pairwise_dists<T>(const T*, int, const int64_t*, int64_t, int, int, T*, hipStream_t);        \
+  template int launch_reduce_diffs<T>(const T*, int64_t, int, const T*, int, T*, hipStream_t);                     \
+  template int launch_kernel_apply<T>(const T*, int64_t, int, double, T*, hipStream_t);                            \
+  template int launch_perturb<T>(const T*, int64_t, int, int, double, const T*, T*, hipStream_t);                  \
+  template int launch_loss_sums<T>(const T*, const T*, const T*, int64_t, const double*, double, double, double*,  \
+                                   hipStream_t);                                                                   \
+  template int launch_column_sums<T>(const T*, int64_t, int, double*, hipStream_t);
+MGP_INSTANTIATE(float)
+MGP_INSTANTIATE(double)
+
+}  // namespace mgp
