@@ -98,7 +98,7 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--kernel", default="matern15")
     ap.add_argument("--knn", action="store_true", help="exact GPU kNN neighbourhoods instead of random rows")
-    ap.add_argument("--cpu-sample", type=int, default=4096, help="0 disables the CPU baseline leg")
+    ap.add_argument("--cpu-sample", type=int, default=65536, help="0 disables the CPU baseline leg")
     ap.add_argument("--force-generic", action="store_true", help="time the generic LDS kernel")
     args = ap.parse_args()
 
