@@ -87,6 +87,8 @@ def load():
     lib.mgp_max_nn_count.restype = _i
     lib.mgp_debug_force_generic.argtypes = [_i]
     lib.mgp_debug_force_generic.restype = None
+    lib.mgp_debug_set_phase_mask.argtypes = [_i]
+    lib.mgp_debug_set_phase_mask.restype = None
     for base, sig in _SIGS.items():
         for suf in ("f32", "f64"):
             fn = getattr(lib, f"mgp_{base}_{suf}")
