@@ -10,6 +10,7 @@ static bool valid_metric(int id) { return id == MGP_METRIC_L2 || id == MGP_METRI
 // 0 = let the dispatcher choose; 1 = force the generic LDS kernel (tests / A-B timing)
 static int g_force_generic = 0;
 extern int g_phase_mask;  // mgp_fused_wave.hip (timing ablations only)
+extern int g_grid_per_cu;
 
 template <typename T>
 int posterior(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t* ni, int64_t b, int k, const T* tg,
@@ -55,6 +56,7 @@ int mgp_max_nn_count(int elem_size, int R) { return max_nn_count(elem_size, R); 
 /* test hook, not part of the public header: force the generic LDS kernel */
 void mgp_debug_force_generic(int on) { g_force_generic = on; }
 void mgp_debug_set_phase_mask(int mask) { mgp::g_phase_mask = mask; }
+void mgp_debug_set_grid_per_cu(int n) { mgp::g_grid_per_cu = n; }
 
 int mgp_posterior_f32(const float* fq, const float* fn, int d, const int64_t* bi, const int64_t* ni, int64_t b, int k,
                       const float* tg, int R, int nm, double eps, const float* nd, int kid, int mid, const float* ls,
