@@ -11,6 +11,7 @@ static bool valid_metric(int id) { return id == MGP_METRIC_L2 || id == MGP_METRI
 static int g_force_generic = 0;
 extern int g_phase_mask;  // mgp_fused_wave.hip (timing ablations only)
 extern int g_grid_per_cu;
+extern int g_lds_pad;
 
 template <typename T>
 int posterior(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t* ni, int64_t b, int k, const T* tg,
@@ -57,6 +58,7 @@ int mgp_max_nn_count(int elem_size, int R) { return max_nn_count(elem_size, R); 
 void mgp_debug_force_generic(int on) { g_force_generic = on; }
 void mgp_debug_set_phase_mask(int mask) { mgp::g_phase_mask = mask; }
 void mgp_debug_set_grid_per_cu(int n) { mgp::g_grid_per_cu = n; }
+void mgp_debug_set_lds_pad(int n) { mgp::g_lds_pad = n; }
 
 int mgp_posterior_f32(const float* fq, const float* fn, int d, const int64_t* bi, const int64_t* ni, int64_t b, int k,
                       const float* tg, int R, int nm, double eps, const float* nd, int kid, int mid, const float* ls,

@@ -8,12 +8,14 @@
 //     slot q             the query point            (features gathered by batch_idx)
 //     slot q+1 .. NP-1   the R response rows        (no features)
 //
+// Phase 0  indices (prefetched one task ahead), responses and nugget of the neighbours.
 // Phase 1  gather: the (k+1) feature rows are staged once in LDS with coalesced 16-byte
-//          loads (consecutive lanes walk a row; rows padded to an odd number of 16-B slots
-//          so that ds_read_b128 of a column of rows is bank-conflict free).
+//          loads (d/4 consecutive lanes walk one row, all loads of a task in flight together;
+//          rows padded to an odd number of 16-B slots so that ds_read_b128 of a column of
+//          rows is bank-conflict free).
 // Phase 2  distances, difference form sum((x-y)^2) (never the Gram trick: fp32 parity),
 //          each unordered pair ONCE: lane i accumulates d(i, (i+s) mod NP) for s = 1..NP/2
-//          in registers (packed-f32 FMAs), reading the partner row from LDS.
+//          in registers (v_pk_add_f32 / v_pk_fma_f32), reading the partner row from LDS.
 // Phase 3  kernel function + nugget, exchanged through a small LDS matrix so that lane i
 //          ends up holding row i of the augmented system
 //                [ K+eps  .   . ]
@@ -22,12 +24,15 @@
 //          in NP registers.
 // Phase 4  right-looking Cholesky, row per lane, all in registers: step j broadcasts
 //          column j through a 64-entry LDS buffer (one ds_write_b32, a few uniform
-//          ds_read_b128), then a chain of FMAs on the trailing registers.  After k steps
-//          the Schur complement of the (query, responses) block holds
+//          ds_read_b128), then packed FMAs on the trailing registers.  After k steps the
+//          Schur complement of the (query, responses) block holds
 //          var = S[q][q],  mean_r = -S[q+1+r][q],  y_r^T K^-1 y_r = -S[q+1+r][q+1+r].
 //
-// No inter-wave communication, no barriers that wait on other waves (one wave per
-// workgroup: __syncthreads() is a compiler/wait-count fence only).
+// No inter-wave communication, no barrier that waits on another wave (one wave per
+// workgroup: __syncthreads() is a compiler / wait-count fence only).  The kernel is
+// VALU-issue bound, so the code below spends its effort on instruction
+// count: packed f32 math, compile-time shapes for the headline configuration
+// (KFIX/RFIX/DFIX), and a grid sized to exactly the resident capacity.
 #include "mgp_args.h"
 
 namespace mgp {
@@ -71,15 +76,9 @@ __device__ __forceinline__ void accum(double& a, const v16<double>::type& df) {
 __device__ __forceinline__ float acc_total(const v16<float>::acc& a) { return a.x + a.y; }
 __device__ __forceinline__ double acc_total(const double& a) { return a; }
 
-__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
-
-__device__ __forceinline__ float fast_rcp(float p) {
-  float r = __builtin_amdgcn_rcpf(p);
-  const float e = __builtin_fmaf(-p, r, 1.0f);
-  return __builtin_fmaf(e, r, r);
-}
-__device__ __forceinline__ double fast_rcp(double p) {
+// 1/p for the pivot: v_rcp_f32 is 1 ulp (as good as the FMAs it feeds); f64 needs refining
+__device__ __forceinline__ float pivot_rcp(float p) { return __builtin_amdgcn_rcpf(p); }
+__device__ __forceinline__ double pivot_rcp(double p) {
   double r = __builtin_amdgcn_rcp(p);
   double e = __builtin_fma(-p, r, 1.0);
   r = __builtin_fma(e, r, r);
@@ -131,7 +130,8 @@ struct WaveGeom {
   int mask;      // debug: phases to execute (bit0 gather, 1 distances, 2 kernel+exchange, 3 factor)
 };
 
-template <typename T, int NP, int KFIX>  // KFIX > 0: nn_count known at compile time
+// KFIX / RFIX / DFIX > 0: nn_count / response_count / feature_count known at compile time
+template <typename T, int NP, int KFIX, int RFIX, int DFIX>
 __global__ __launch_bounds__(64, (sizeof(T) == 4 ? (NP == 32 ? 3 : 2) : (NP == 32 ? 2 : 1)))
 void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   constexpr int NH = 64 / NP;     // neighbourhoods per wave
@@ -139,17 +139,23 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   constexpr int E = v16<T>::N;    // elements per 16 bytes
   constexpr int CH = 2 * E;       // feature chunk per inner iteration (two 16-B reads per row)
   constexpr int KS = NP + E;      // row stride of the exchange matrix: NP/E + 1 (odd) 16-B slots
+  constexpr int DPADFIX = (DFIX + CH - 1) / CH * CH;
+  constexpr int DSTFIX = DFIX > 0 ? (DPADFIX < 64 ? DPADFIX : 64) : CH;
   using V = typename v16<T>::type;
   using ACC = typename v16<T>::acc;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int k = KFIX > 0 ? KFIX : a.k;
-  const int d = a.d, R = a.R, q = g.q, xs = g.xs;
+  const int R = RFIX > 0 ? RFIX : a.R;
+  const int d = DFIX > 0 ? DFIX : a.d;
+  const int q = RFIX > 0 ? NP - 1 - RFIX : g.q;
+  const int dst = DFIX > 0 ? DSTFIX : g.dst;
+  const int xs = DFIX > 0 ? DSTFIX + E : g.xs;
   const int tile_elems = NH * NP * (xs > KS ? xs : KS);
   T* tile = reinterpret_cast<T*>(smem);               // feature tile, later the exchange matrix
   T* colbuf = tile + tile_elems;                      // 64 entries
-  T* ilbuf = colbuf + 64;                             // g.dst entries (Anisotropy)
-  int64_t* idxbuf = reinterpret_cast<int64_t*>(ilbuf + g.dst + (g.dst & 1));  // 64 entries
+  T* ilbuf = colbuf + 64;                             // dst entries (Anisotropy)
+  int64_t* idxbuf = reinterpret_cast<int64_t*>(ilbuf + dst + (dst & 1));  // 64 entries
 
   const T* feat_q = static_cast<const T*>(a.feat_q);
   const T* feat_nn = static_cast<const T*>(a.feat_nn);
@@ -162,6 +168,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     const T l = ls[0];
     post_scale = a.metric_id == MGP_METRIC_L2 ? T(1) / l : T(1) / (l * l);
   }
+  const bool nopad = k == q;  // every slot below q is a real neighbour
 
   // XCD-aware task order: workgroups b and b+8 share an XCD (round-robin dispatch), so give
   // each XCD one contiguous eighth of the neighbourhoods -> neighbouring neighbourhoods
@@ -174,12 +181,13 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   const int64_t t_step = gridDim.x >> 3;
 
   // Index prefetch: the (dependent) index load of task t+1 is issued at the top of task t.
+  // The row of the index tensor is addressed as uniform 64-bit base + 32-bit lane offset.
   auto load_index = [&](int64_t task, int h, int i) -> int64_t {
-    int64_t nb = task * NH + h;
-    if (nb >= a.b) nb = a.b - 1;
+    const int64_t nb0 = task * NH;                       // uniform
+    const int hh = (NH > 1 && nb0 + h >= a.b) ? 0 : h;   // odd tail: replay the first half
     int64_t v = 0;
-    if (i < k) v = a.nn_idx[nb * k + i];
-    else if (i == q) v = a.batch_idx ? a.batch_idx[nb] : nb;
+    if (i < k) v = (a.nn_idx + nb0 * k)[hh * k + i];
+    else if (i == q) v = a.batch_idx ? (a.batch_idx + nb0)[hh] : nb0 + hh;
     return v;
   };
   const int64_t task0 = xcd * per_xcd + (blockIdx.x >> 3);
@@ -197,9 +205,9 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     T* Kh = tile + h * NP * KS;
     T* colh = colbuf + h * NP;
     int64_t* idxh = idxbuf + h * NP;
-    const int64_t nb_raw = task * NH + h;
-    const bool live = nb_raw < a.b;
-    const int64_t nb = live ? nb_raw : a.b - 1;
+    const int64_t nb0 = task * NH;
+    const bool live = nb0 + h < a.b;
+    const int hh = live ? h : 0;
 
     // ---- phase 0: indices, responses, nugget -------------------------------------------
     const int64_t myidx = next_idx;
@@ -211,40 +219,55 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       myy0 = targets[myidx * (int64_t)R];
       if (a.noise_mode == MGP_NOISE_SCALAR) myeps = (T)a.noise_scalar;
       else if (a.noise_mode == MGP_NOISE_TABLE) myeps = noise_dev[myidx];
-      else myeps = noise_dev[nb * k + i];
+      else myeps = (noise_dev + nb0 * k)[hh * k + i];
     }
 
     ACC acc[NS];
 
     // ---- phases 1+2: stage features, accumulate squared distances ---------------------
-    for (int d0 = 0; d0 < d; d0 += g.dst) {
-      const int w = min(g.dst, d - d0);
+    for (int d0 = 0; d0 < d; d0 += dst) {
+      const int w = min(dst, d - d0);
       const int wp = (w + CH - 1) / CH * CH;
       __syncthreads();
       if (!(g.mask & 1)) {
-      } else if (g.vec_ok) {
+      } else if (DFIX > 0 || g.vec_ok) {
+        // c16p consecutive lanes walk one row; rpr rows per round; all rounds of a task in flight
         const int c16 = w / E, c16p = wp / E;
-        const unsigned magic = (1u << 20) / (unsigned)c16p + 1u;
-        constexpr int U = 10;  // 16-byte loads in flight per lane (a whole d=40 fp32 row set)
-        for (int t0 = i; t0 < NP * c16p; t0 += U * NP) {
+        const int rpr = NP / c16p;
+        const int sub = DFIX > 0 ? i / c16p : (int)(((unsigned)i * ((1u << 16) / (unsigned)c16p + 1u)) >> 16);
+        const int c = i - sub * c16p;
+        const bool lane_on = sub < rpr;
+        constexpr int RPRFIX = NP / (DSTFIX / E);
+        constexpr int U = (KFIX > 0 && DFIX > 0) ? (KFIX + RPRFIX - 1) / RPRFIX : 6;
+        const int64_t* idxl = idxh + sub;
+        T* xdst = Xh + sub * xs + c * E;
+        for (int r0 = 0; r0 < k; r0 += U * rpr) {
           V v[U];
-          int dst_off[U];
 #pragma unroll
           for (int u = 0; u < U; ++u) {
-            const int t = t0 + u * NP;
-            const int row = (int)(((unsigned)t * magic) >> 20);
-            const int c = t - row * c16p;
-            dst_off[u] = t < NP * c16p ? row * xs + c * E : -1;
+            const int row = r0 + u * rpr + sub;
             v[u] = V(0);
-            if (t < NP * c16p && c < c16 && (row < k || row == q)) {
-              const T* src = (row < k ? feat_nn : feat_q) + idxh[row] + d0 + c * E;
-              v[u] = *reinterpret_cast<const V*>(src);
-            }
+            if (lane_on && row < k && c < c16)
+              v[u] = *reinterpret_cast<const V*>(feat_nn + idxl[r0 + u * rpr] + d0 + c * E);
           }
 #pragma unroll
-          for (int u = 0; u < U; ++u)
-            if (dst_off[u] >= 0) *reinterpret_cast<V*>(Xh + dst_off[u]) = v[u];
+          for (int u = 0; u < U; ++u) {
+            const int row = r0 + u * rpr + sub;
+            if (lane_on && row < k) *reinterpret_cast<V*>(xdst + (r0 + u * rpr) * xs) = v[u];
+          }
         }
+        // the query row, and zero rows for the padding slots (their distances are masked later,
+        // zeros only keep them finite)
+        if (i < c16p) {
+          V vq = V(0);
+          if (i < c16) vq = *reinterpret_cast<const V*>(feat_q + idxh[q] + d0 + i * E);
+          *reinterpret_cast<V*>(Xh + q * xs + i * E) = vq;
+        }
+        if (!nopad)
+          for (int t = i; t < (q - k) * c16p; t += NP) {
+            const int row = k + t / c16p;
+            *reinterpret_cast<V*>(Xh + row * xs + (t % c16p) * E) = V(0);
+          }
       } else {
         const unsigned magic = (1u << 20) / (unsigned)wp + 1u;
         for (int t = i; t < NP * wp; t += NP) {
@@ -264,28 +287,35 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         for (int s = 0; s < NS; ++s) acc[s] = ACC(0);
       }
       const T* xown = Xh + i * xs;
-      for (int c0 = 0; c0 < ((g.mask & 2) ? wp : 0); c0 += CH) {
-        const V own0 = *reinterpret_cast<const V*>(xown + c0);
-        const V own1 = *reinterpret_cast<const V*>(xown + c0 + E);
+      if (g.mask & 2) {
         if (aniso) {
-          const V il0 = *reinterpret_cast<const V*>(ilbuf + c0);
-          const V il1 = *reinterpret_cast<const V*>(ilbuf + c0 + E);
+          for (int c0 = 0; c0 < wp; c0 += CH) {
+            const V own0 = *reinterpret_cast<const V*>(xown + c0);
+            const V own1 = *reinterpret_cast<const V*>(xown + c0 + E);
+            const V il0 = *reinterpret_cast<const V*>(ilbuf + c0);
+            const V il1 = *reinterpret_cast<const V*>(ilbuf + c0 + E);
 #pragma unroll
-          for (int s = 1; s <= NS; ++s) {
-            const T* xo = Xh + ((i + s) & (NP - 1)) * xs + c0;
-            const V o0 = *reinterpret_cast<const V*>(xo);
-            const V o1 = *reinterpret_cast<const V*>(xo + E);
-            accum(acc[s - 1], vsub(own0, o0) * il0);
-            accum(acc[s - 1], vsub(own1, o1) * il1);
+            for (int s = 1; s <= NS; ++s) {
+              const T* xo = Xh + ((i + s) & (NP - 1)) * xs + c0;
+              const V o0 = *reinterpret_cast<const V*>(xo);
+              const V o1 = *reinterpret_cast<const V*>(xo + E);
+              accum(acc[s - 1], vsub(own0, o0) * il0);
+              accum(acc[s - 1], vsub(own1, o1) * il1);
+            }
           }
         } else {
 #pragma unroll
-          for (int s = 1; s <= NS; ++s) {
-            const T* xo = Xh + ((i + s) & (NP - 1)) * xs + c0;
-            const V o0 = *reinterpret_cast<const V*>(xo);
-            const V o1 = *reinterpret_cast<const V*>(xo + E);
-            accum(acc[s - 1], vsub(own0, o0));
-            accum(acc[s - 1], vsub(own1, o1));
+          for (int c0 = 0; c0 < (DFIX > 0 ? DSTFIX : wp); c0 += CH) {
+            const V own0 = *reinterpret_cast<const V*>(xown + c0);
+            const V own1 = *reinterpret_cast<const V*>(xown + c0 + E);
+#pragma unroll
+            for (int s = 1; s <= NS; ++s) {
+              const T* xo = Xh + ((i + s) & (NP - 1)) * xs + c0;
+              const V o0 = *reinterpret_cast<const V*>(xo);
+              const V o1 = *reinterpret_cast<const V*>(xo + E);
+              accum(acc[s - 1], vsub(own0, o0));
+              accum(acc[s - 1], vsub(own1, o1));
+            }
           }
         }
       }
@@ -299,14 +329,25 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       int i3 = i;
       asm volatile("" : "+v"(i3));
       T* Kh3 = tile + (NH == 1 ? 0 : (lane / NP) * NP * KS);
-      if (g.mask & 4)
+      if (g.mask & 4) {
+        if (nopad) {
 #pragma unroll
-      for (int s = 1; s <= NS; ++s) {
-        const int c = (i3 + s) & (NP - 1);
-        const int hi = max(i3, c), lo = min(i3, c);
-        const bool valid = lo < k && (hi < k || hi == q);
-        const T kv = cov_from_sqdist<T>(acc_total(acc[s - 1]), a.kernel_id, a.metric_id, post_scale);
-        if (hi <= q) Kh3[hi * KS + lo] = valid ? kv : T(0);
+          for (int s = 1; s <= NS; ++s) {
+            const int c = (i3 + s) & (NP - 1);
+            const int hi = max(i3, c), lo = min(i3, c);
+            const T kv = cov_from_sqdist<T>(acc_total(acc[s - 1]), a.kernel_id, a.metric_id, post_scale);
+            if (hi <= q) Kh3[hi * KS + lo] = kv;
+          }
+        } else {
+#pragma unroll
+          for (int s = 1; s <= NS; ++s) {
+            const int c = (i3 + s) & (NP - 1);
+            const int hi = max(i3, c), lo = min(i3, c);
+            const bool valid = lo < k && (hi < k || hi == q);
+            const T kv = cov_from_sqdist<T>(acc_total(acc[s - 1]), a.kernel_id, a.metric_id, post_scale);
+            if (hi <= q) Kh3[hi * KS + lo] = valid ? kv : T(0);
+          }
+        }
       }
       Kh3[i3 * KS + i3] = i3 < k ? T(1) + myeps : (i3 <= q ? T(1) : T(0));
       Kh3[(q + 1) * KS + i3] = myy0;
@@ -331,28 +372,44 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         for (int c4 = j / E; c4 < NP / E; ++c4) col[c4] = *reinterpret_cast<const V*>(colh + c4 * E);
         const T p = col[j / E][j % E];
         bad = bad || !(p > T(0));
-        const V nt = V(-ajj * fast_rcp(p));
+        const V nt = V(-ajj * pivot_rcp(p));
 #pragma unroll
         for (int c4 = j / E; c4 < NP / E; ++c4) A[c4] = col[c4] * nt + A[c4];
       }
     }
 
     // ---- phase 5: Schur block -> outputs ----------------------------------------------
-    __syncthreads();
+    T* mean = static_cast<T*>(a.mean);
+    T* var = static_cast<T*>(a.var);
+    T* yk = static_cast<T*>(a.ykinvy);
+    const int64_t nb = nb0 + h;
+    if (RFIX == 1) {
+      // q = NP-2 and the response row NP-1 are compile-time: the Schur block sits in fixed registers
+      constexpr int QF = NP - 2, YF = NP - 1;
+      const T sq = A[QF / E][QF % E], sy = A[YF / E][YF % E];
+      if (live) {
+        if (i == QF) {
+          var[nb] = bad ? num<T>::nan() : sq;
+          if (bad && a.info) atomicAdd(a.info, 1);
+        } else if (i == YF) {
+          mean[nb] = bad ? num<T>::nan() : -sq;
+          if (yk) yk[nb] = bad ? num<T>::nan() : -sy;
+        }
+      }
+    } else {
+      __syncthreads();
 #pragma unroll
-    for (int c4 = 0; c4 < NP / E; ++c4) *reinterpret_cast<V*>(Kh + i * KS + c4 * E) = A[c4];
-    __syncthreads();
-    if (live) {
-      T* mean = static_cast<T*>(a.mean);
-      T* var = static_cast<T*>(a.var);
-      T* yk = static_cast<T*>(a.ykinvy);
-      if (i == q) {
-        var[nb] = bad ? num<T>::nan() : Kh[q * KS + q];
-        if (bad && a.info) atomicAdd(a.info, 1);
-      } else if (i > q) {
-        const int r = i - q - 1;
-        mean[nb * R + r] = bad ? num<T>::nan() : -Kh[i * KS + q];
-        if (yk) yk[nb * R + r] = bad ? num<T>::nan() : -Kh[i * KS + i];
+      for (int c4 = 0; c4 < NP / E; ++c4) *reinterpret_cast<V*>(Kh + i * KS + c4 * E) = A[c4];
+      __syncthreads();
+      if (live) {
+        if (i == q) {
+          var[nb] = bad ? num<T>::nan() : Kh[q * KS + q];
+          if (bad && a.info) atomicAdd(a.info, 1);
+        } else if (i > q) {
+          const int r = i - q - 1;
+          mean[nb * R + r] = bad ? num<T>::nan() : -Kh[i * KS + q];
+          if (yk) yk[nb * R + r] = bad ? num<T>::nan() : -Kh[i * KS + i];
+        }
       }
     }
   }
@@ -360,8 +417,9 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 
 int g_phase_mask = 0xF;
 int g_grid_per_cu = 0;  // debug override of resident workgroups per CU
+int g_lds_pad = 0;      // debug: extra dynamic LDS bytes per workgroup
 
-template <typename T, int NP, int KFIX>
+template <typename T, int NP, int KFIX, int RFIX, int DFIX>
 static int launch_np(const FusedArgs& a, hipStream_t stream) {
   constexpr int NH = 64 / NP;
   constexpr int E = v16<T>::N;
@@ -375,10 +433,11 @@ static int launch_np(const FusedArgs& a, hipStream_t stream) {
   g.xs = g.dst + E;  // dst/E is even -> dst/E + 1 slots: odd
   const uintptr_t align = (uintptr_t)a.feat_q | (uintptr_t)a.feat_nn;
   g.vec_ok = (a.d % E == 0) && (align % 16 == 0);
+  if (DFIX > 0 && !g.vec_ok) return MGP_EUNSUPPORTED;
   g.ntasks = (a.b + NH - 1) / NH;
   const int rowmax = g.xs > KS ? g.xs : KS;
   size_t lds = ((size_t)NH * NP * rowmax + 64 + g.dst + (g.dst & 1)) * sizeof(T) + 64 * sizeof(int64_t);
-  lds = (lds + 15) & ~(size_t)15;
+  lds = ((lds + 15) & ~(size_t)15) + (size_t)g_lds_pad;
   // Persistent grid = exactly the resident capacity: every workgroup owns a fixed share of the
   // tasks, so one workgroup more than fits runs as a second, nearly empty round (measured: 13
   // instead of 12 per CU costs 40 %).  Residency comes from the occupancy query for this kernel
@@ -389,11 +448,14 @@ static int launch_np(const FusedArgs& a, hipStream_t stream) {
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MGP_EHIP;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        &n, reinterpret_cast<const void*>(&fused_wave_kernel<T, NP, KFIX>), 64, lds);
+        &n, reinterpret_cast<const void*>(&fused_wave_kernel<T, NP, KFIX, RFIX, DFIX>), 64, lds);
     if (e != hipSuccess) return -(1000 + (int)e);
     if (n < 1) return MGP_EUNSUPPORTED;
     cached_lds = (int)lds;
-    cached_per_cu = n;
+    // the occupancy query over-reports for LDS-bound shapes: measured on gfx950, LDS is handed out
+    // in 1280-byte granules of the CU's 160 KiB (13 x 12192 B is refused, 12 x 12704 B fits)
+    const int by_lds = (int)((160 * 1024) / (((lds + 1279) / 1280) * 1280));
+    cached_per_cu = n < by_lds ? n : by_lds;
     cached_cus = prop.multiProcessorCount;
   }
   int per_cu = cached_per_cu;
@@ -401,7 +463,8 @@ static int launch_np(const FusedArgs& a, hipStream_t stream) {
   int64_t grid = (int64_t)cached_cus * per_cu / 8 * 8;
   if (grid < 8) grid = 8;
   if (grid > g.ntasks) grid = (g.ntasks + 7) / 8 * 8;
-  hipLaunchKernelGGL((fused_wave_kernel<T, NP, KFIX>), dim3((unsigned)grid), dim3(64), lds, stream, a, g);
+  hipLaunchKernelGGL((fused_wave_kernel<T, NP, KFIX, RFIX, DFIX>), dim3((unsigned)grid), dim3(64), lds, stream, a,
+                     g);
   MGP_HIP_CHECK_LAUNCH();
   return MGP_OK;
 }
@@ -409,9 +472,12 @@ static int launch_np(const FusedArgs& a, hipStream_t stream) {
 template <typename T>
 int launch_fused_wave(const FusedArgs& a, hipStream_t stream) {
   const int rows = a.k + 1 + a.R;
-  if (a.k == 30 && a.R == 1) return launch_np<T, 32, 30>(a, stream);  // BASELINE configs 2/3
-  if (rows <= 32) return launch_np<T, 32, 0>(a, stream);
-  if (rows <= 64) return launch_np<T, 64, 0>(a, stream);
+  if constexpr (sizeof(T) == 4) if (a.k == 30 && a.R == 1 && a.d == 40) {  // BASELINE configs 2/3, all shapes static
+    const int rc = launch_np<T, 32, 30, 1, 40>(a, stream);
+    if (rc != MGP_EUNSUPPORTED) return rc;
+  }
+  if (rows <= 32) return launch_np<T, 32, 0, 0, 0>(a, stream);
+  if (rows <= 64) return launch_np<T, 64, 0, 0, 0>(a, stream);
   return MGP_EUNSUPPORTED;
 }
 

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--generic", default="0")
     ap.add_argument("--aniso", type=int, default=0)
     ap.add_argument("--grids", default="0")
+    ap.add_argument("--ldspad", type=int, default=0)
     args = ap.parse_args()
     dev = torch.device("cuda")
     td = torch.float32 if args.dtype == "f32" else torch.float64
@@ -40,6 +41,7 @@ def main():
     mean = torch.empty((args.b, 1), device=dev, dtype=td)
     var = torch.empty((args.b,), device=dev, dtype=td)
     lib = _lib.load()
+    lib.mgp_debug_set_lds_pad(args.ldspad)
     variants = [(int(m), int(g), int(pc)) for g in args.generic.split(",") for m in args.masks.split(",")
                 for pc in args.grids.split(",")]
     times = {v: [] for v in variants}
