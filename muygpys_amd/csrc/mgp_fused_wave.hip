@@ -121,6 +121,13 @@ __device__ __forceinline__ T cov_from_sqdist(T acc, int kernel_id, int metric_id
   }
 }
 
+// 16 bytes per lane straight from global memory into LDS (no VGPR round trip): the LDS
+// destination is the wave-uniform pointer + lane * 16, the global source is per lane.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 struct WaveGeom {
   int q;         // query slot
   int dst;       // feature stage width (elements, multiple of the chunk)
@@ -190,9 +197,62 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     else if (i == q) v = a.batch_idx ? (a.batch_idx + nb0)[hh] : nb0 + hh;
     return v;
   };
+  // Start-up skew: all resident waves run the same phase sequence with the same durations, so
+  // without it they stay in lockstep (everyone gathers, then everyone computes) and the memory
+  // system and the VALUs take turns instead of overlapping.  A one-off pseudo-random delay of
+  // up to about one task spreads the phases; it persists because every task takes equally long.
+  if (g.mask & 16) {
+    const unsigned slots = ((blockIdx.x >> 3) * 2654435761u) >> 27;  // 0..31, differs between co-resident waves
+    for (unsigned n = 0; n < slots; ++n) __builtin_amdgcn_s_sleep(16);  // 16 x 64 cycles each
+  }
+
   const int64_t task0 = xcd * per_xcd + (blockIdx.x >> 3);
   int64_t next_idx = 0;
   if (task0 < t_end) next_idx = load_index(task0, NH == 1 ? 0 : (int)threadIdx.x / NP, threadIdx.x & (NP - 1));
+
+  // Software-pipelined gather (static shapes, one feature stage): the feature tile of task
+  // t+1 is requested right before the factorisation of task t -- by then the tile region of
+  // LDS is free (row i of the system sits in registers) -- with direct global->LDS loads, so it
+  // costs no registers and its latency hides behind the Cholesky.  One load instruction fills
+  // 64 consecutive 16-byte slots of the tile (SPR slots per row, the last one padding).
+  constexpr bool PIPE = KFIX > 0 && DFIX > 0 && DFIX <= 64;
+  constexpr int SPR = DSTFIX / E + 1;                       // 16-byte slots per staged row
+  constexpr int C16V = DFIX / E;                            // ... of which hold data
+  constexpr int NGL = PIPE ? (NH * NP * SPR + 63) / 64 : 1;  // direct-to-LDS loads per task
+  static_assert(!PIPE || (NH * NP * SPR) % 64 == 0, "tile must be a whole number of 1-KiB pieces");
+  T pre_y = T(0), pre_eps = T(0);
+  auto pipe_issue = [&](int64_t task_n, int64_t idx_n, int lane_) {
+    const int h = NH == 1 ? 0 : lane_ / NP;
+    const int i = lane_ & (NP - 1);
+    idxbuf[lane_] = idx_n * (int64_t)d;  // slots without a feature row hold 0: any valid row will do
+    __syncthreads();
+    if (g.mask & 1) {
+#pragma unroll
+      for (int n = 0; n < NGL; ++n) {
+        const int sigma = 64 * n + lane_;
+        const int row = sigma / SPR;            // 0 .. NH*NP-1 (both halves)
+        int c = sigma - row * SPR;
+        c = c < C16V ? c : C16V - 1;            // padding slot: re-read the last data slot
+        const T* base = (row & (NP - 1)) == q ? feat_q : feat_nn;
+        glds16(base + idxbuf[row] + c * E, reinterpret_cast<char*>(tile) + n * 1024);
+      }
+    }
+    pre_y = T(0);
+    pre_eps = T(0);
+    if (i < k) {
+      const int64_t nb0 = task_n * NH;
+      const int hh = (NH > 1 && nb0 + h >= a.b) ? 0 : h;
+      pre_y = targets[idx_n * (int64_t)R];
+      if (a.noise_mode == MGP_NOISE_SCALAR) pre_eps = (T)a.noise_scalar;
+      else if (a.noise_mode == MGP_NOISE_TABLE) pre_eps = noise_dev[idx_n];
+      else pre_eps = (noise_dev + nb0 * k)[hh * k + i];
+    }
+  };
+  if (PIPE && task0 < t_end) {
+    pipe_issue(task0, next_idx, threadIdx.x);
+    if (task0 + t_step < t_end)
+      next_idx = load_index(task0 + t_step, NH == 1 ? 0 : (int)threadIdx.x / NP, threadIdx.x & (NP - 1));
+  }
 
   for (int64_t task = task0; task < t_end; task += t_step) {
     // The lane id is made opaque per task: otherwise LICM hoists every per-lane address, mask
@@ -210,16 +270,24 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     const int hh = live ? h : 0;
 
     // ---- phase 0: indices, responses, nugget -------------------------------------------
-    const int64_t myidx = next_idx;
-    if (task + t_step < t_end) next_idx = load_index(task + t_step, h, i);
-    __syncthreads();  // previous task's LDS reads are complete
-    idxh[i] = myidx * (int64_t)d;  // element offset of the row
+    int64_t myidx = 0;
     T myeps = T(0), myy0 = T(0);
-    if (i < k) {
-      myy0 = targets[myidx * (int64_t)R];
-      if (a.noise_mode == MGP_NOISE_SCALAR) myeps = (T)a.noise_scalar;
-      else if (a.noise_mode == MGP_NOISE_TABLE) myeps = noise_dev[myidx];
-      else myeps = (noise_dev + nb0 * k)[hh * k + i];
+    if (PIPE) {
+      // the tile of this task was requested during the previous task's factorisation; the
+      // barrier at the top of the stage loop below waits for it (vmcnt) before anyone reads it
+      myy0 = pre_y;
+      myeps = pre_eps;
+    } else {
+      myidx = next_idx;
+      if (task + t_step < t_end) next_idx = load_index(task + t_step, h, i);
+      __syncthreads();  // previous task's LDS reads are complete
+      idxh[i] = myidx * (int64_t)d;  // element offset of the row
+      if (i < k) {
+        myy0 = targets[myidx * (int64_t)R];
+        if (a.noise_mode == MGP_NOISE_SCALAR) myeps = (T)a.noise_scalar;
+        else if (a.noise_mode == MGP_NOISE_TABLE) myeps = noise_dev[myidx];
+        else myeps = (noise_dev + nb0 * k)[hh * k + i];
+      }
     }
 
     ACC acc[NS];
@@ -229,7 +297,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       const int w = min(dst, d - d0);
       const int wp = (w + CH - 1) / CH * CH;
       __syncthreads();
-      if (!(g.mask & 1)) {
+      if (PIPE || !(g.mask & 1)) {
       } else if (DFIX > 0 || g.vec_ok) {
         // c16p consecutive lanes walk one row; rpr rows per round; all rounds of a task in flight
         const int c16 = w / E, c16p = wp / E;
@@ -357,6 +425,13 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     V A[NP / E];
 #pragma unroll
     for (int c4 = 0; c4 < NP / E; ++c4) A[c4] = *reinterpret_cast<const V*>(Kh + i * KS + c4 * E);
+
+    // the next task's rows are requested now: their latency hides behind the factorisation, and
+    // the registers they land in are not live during the (register-hungry) distance phase
+    if (PIPE && task + t_step < t_end) {
+      pipe_issue(task + t_step, next_idx, lane);
+      if (task + 2 * t_step < t_end) next_idx = load_index(task + 2 * t_step, h, i);
+    }
 
     // ---- phase 4: Cholesky, row per lane, column broadcast through LDS ----------------
     // Whole 16-byte groups are updated from the pivot's group on: entries of columns <= j
