@@ -103,7 +103,7 @@ __device__ __forceinline__ double sqrt_fast(double x) { return ::sqrt(x); }
 template <typename T>
 __device__ __forceinline__ T cov_from_sqdist(T acc, int kernel_id, int metric_id, T post_scale) {
   const T x = (metric_id == MGP_METRIC_L2 ? sqrt_fast(acc) : acc) * post_scale;
-  switch (kernel_id) {
+  switch (kernel_id) {  // callers pass compile-time ids (see KERNEL_DISPATCH): no branch survives
     case MGP_KERNEL_RBF:
       return exp_neg(x * T(0.5));
     case MGP_KERNEL_MATERN_05:
@@ -126,6 +126,25 @@ __device__ __forceinline__ T cov_from_sqdist(T acc, int kernel_id, int metric_id
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// Call f(ic<KID>, ic<MID>) with kernel id and metric id as compile-time constants: the uniform
+// switch is taken once per task instead of once per matrix entry.
+template <int V> struct ic { static constexpr int value = V; };
+template <int MID, typename F>
+__device__ __forceinline__ void kernel_dispatch_m(int kernel_id, F&& f) {
+  switch (kernel_id) {
+    case MGP_KERNEL_RBF: f(ic<MGP_KERNEL_RBF>{}, ic<MID>{}); break;
+    case MGP_KERNEL_MATERN_05: f(ic<MGP_KERNEL_MATERN_05>{}, ic<MID>{}); break;
+    case MGP_KERNEL_MATERN_15: f(ic<MGP_KERNEL_MATERN_15>{}, ic<MID>{}); break;
+    case MGP_KERNEL_MATERN_25: f(ic<MGP_KERNEL_MATERN_25>{}, ic<MID>{}); break;
+    default: f(ic<MGP_KERNEL_MATERN_INF>{}, ic<MID>{}); break;
+  }
+}
+template <typename F>
+__device__ __forceinline__ void kernel_dispatch(int kernel_id, int metric_id, F&& f) {
+  if (metric_id == MGP_METRIC_L2) kernel_dispatch_m<MGP_METRIC_L2>(kernel_id, f);
+  else kernel_dispatch_m<MGP_METRIC_F2>(kernel_id, f);
 }
 
 struct WaveGeom {
@@ -161,7 +180,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   const int tile_elems = NH * NP * (xs > KS ? xs : KS);
   T* tile = reinterpret_cast<T*>(smem);               // feature tile, later the exchange matrix
   T* colbuf = tile + tile_elems;                      // 64 entries
-  T* ilbuf = colbuf + 64;                             // dst entries (Anisotropy)
+  T* ilbuf = colbuf + 64;                              // dst entries (Anisotropy)
   int64_t* idxbuf = reinterpret_cast<int64_t*>(ilbuf + dst + (dst & 1));  // 64 entries
 
   const T* feat_q = static_cast<const T*>(a.feat_q);
@@ -189,22 +208,25 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 
   // Index prefetch: the (dependent) index load of task t+1 is issued at the top of task t.
   // The row of the index tensor is addressed as uniform 64-bit base + 32-bit lane offset.
+  // Branch-free on purpose: ONE load instruction per call whatever the slot, so that the value
+  // can stay in flight across the task (loads under divergent branches that write the same
+  // register make the compiler wait for the first before issuing the second).  Slots without
+  // an index read a valid dummy element and are zeroed when the value is consumed.
   auto load_index = [&](int64_t task, int h, int i) -> int64_t {
     const int64_t nb0 = task * NH;                       // uniform
     const int hh = (NH > 1 && nb0 + h >= a.b) ? 0 : h;   // odd tail: replay the first half
-    int64_t v = 0;
-    if (i < k) v = (a.nn_idx + nb0 * k)[hh * k + i];
-    else if (i == q) v = a.batch_idx ? (a.batch_idx + nb0)[hh] : nb0 + hh;
-    return v;
+    const int64_t* row = a.nn_idx + nb0 * k;
+    const int64_t* p = row + (hh * k + (i < k ? i : 0));
+    if (a.batch_idx != nullptr && i == q) p = a.batch_idx + nb0 + hh;
+    return *p;
   };
-  // Start-up skew: all resident waves run the same phase sequence with the same durations, so
-  // without it they stay in lockstep (everyone gathers, then everyone computes) and the memory
-  // system and the VALUs take turns instead of overlapping.  A one-off pseudo-random delay of
-  // up to about one task spreads the phases; it persists because every task takes equally long.
-  if (g.mask & 16) {
-    const unsigned slots = ((blockIdx.x >> 3) * 2654435761u) >> 27;  // 0..31, differs between co-resident waves
-    for (unsigned n = 0; n < slots; ++n) __builtin_amdgcn_s_sleep(16);  // 16 x 64 cycles each
-  }
+  auto fix_index = [&](int64_t raw, int64_t task, int h, int i) -> int64_t {
+    const int64_t nb0 = task * NH;
+    const int hh = (NH > 1 && nb0 + h >= a.b) ? 0 : h;
+    if (i < k) return raw;
+    if (i == q) return a.batch_idx != nullptr ? raw : nb0 + hh;
+    return 0;
+  };
 
   const int64_t task0 = xcd * per_xcd + (blockIdx.x >> 3);
   int64_t next_idx = 0;
@@ -237,19 +259,20 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         glds16(base + idxbuf[row] + c * E, reinterpret_cast<char*>(tile) + n * 1024);
       }
     }
-    pre_y = T(0);
-    pre_eps = T(0);
-    if (i < k) {
+    // response and nugget of the slot's row: unconditional single loads (idx_n is 0, a valid
+    // row, for slots without one; the values are masked where they are consumed)
+    pre_y = targets[idx_n * (int64_t)R];
+    pre_eps = (T)a.noise_scalar;
+    if (a.noise_mode != MGP_NOISE_SCALAR) {
       const int64_t nb0 = task_n * NH;
       const int hh = (NH > 1 && nb0 + h >= a.b) ? 0 : h;
-      pre_y = targets[idx_n * (int64_t)R];
-      if (a.noise_mode == MGP_NOISE_SCALAR) pre_eps = (T)a.noise_scalar;
-      else if (a.noise_mode == MGP_NOISE_TABLE) pre_eps = noise_dev[idx_n];
-      else pre_eps = (noise_dev + nb0 * k)[hh * k + i];
+      const T* pn = a.noise_mode == MGP_NOISE_TABLE ? noise_dev + idx_n : noise_dev + nb0 * k + (hh * k + (i < k ? i : 0));
+      pre_eps = *pn;
     }
   };
   if (PIPE && task0 < t_end) {
-    pipe_issue(task0, next_idx, threadIdx.x);
+    pipe_issue(task0, fix_index(next_idx, task0, NH == 1 ? 0 : (int)threadIdx.x / NP, threadIdx.x & (NP - 1)),
+               threadIdx.x);
     if (task0 + t_step < t_end)
       next_idx = load_index(task0 + t_step, NH == 1 ? 0 : (int)threadIdx.x / NP, threadIdx.x & (NP - 1));
   }
@@ -275,10 +298,10 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     if (PIPE) {
       // the tile of this task was requested during the previous task's factorisation; the
       // barrier at the top of the stage loop below waits for it (vmcnt) before anyone reads it
-      myy0 = pre_y;
+      myy0 = i < k ? pre_y : T(0);
       myeps = pre_eps;
     } else {
-      myidx = next_idx;
+      myidx = fix_index(next_idx, task, h, i);
       if (task + t_step < t_end) next_idx = load_index(task + t_step, h, i);
       __syncthreads();  // previous task's LDS reads are complete
       idxh[i] = myidx * (int64_t)d;  // element offset of the row
@@ -398,24 +421,27 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       asm volatile("" : "+v"(i3));
       T* Kh3 = tile + (NH == 1 ? 0 : (lane / NP) * NP * KS);
       if (g.mask & 4) {
-        if (nopad) {
+        kernel_dispatch(a.kernel_id, a.metric_id, [&](auto kid, auto mid) {
+          constexpr int KID = decltype(kid)::value, MID = decltype(mid)::value;
+          if (nopad) {
 #pragma unroll
-          for (int s = 1; s <= NS; ++s) {
-            const int c = (i3 + s) & (NP - 1);
-            const int hi = max(i3, c), lo = min(i3, c);
-            const T kv = cov_from_sqdist<T>(acc_total(acc[s - 1]), a.kernel_id, a.metric_id, post_scale);
-            if (hi <= q) Kh3[hi * KS + lo] = kv;
-          }
-        } else {
+            for (int s = 1; s <= NS; ++s) {
+              const int c = (i3 + s) & (NP - 1);
+              const int hi = max(i3, c), lo = min(i3, c);
+              const T kv = cov_from_sqdist<T>(acc_total(acc[s - 1]), KID, MID, post_scale);
+              if (hi <= q) Kh3[hi * KS + lo] = kv;
+            }
+          } else {
 #pragma unroll
-          for (int s = 1; s <= NS; ++s) {
-            const int c = (i3 + s) & (NP - 1);
-            const int hi = max(i3, c), lo = min(i3, c);
-            const bool valid = lo < k && (hi < k || hi == q);
-            const T kv = cov_from_sqdist<T>(acc_total(acc[s - 1]), a.kernel_id, a.metric_id, post_scale);
-            if (hi <= q) Kh3[hi * KS + lo] = valid ? kv : T(0);
+            for (int s = 1; s <= NS; ++s) {
+              const int c = (i3 + s) & (NP - 1);
+              const int hi = max(i3, c), lo = min(i3, c);
+              const bool valid = lo < k && (hi < k || hi == q);
+              const T kv = cov_from_sqdist<T>(acc_total(acc[s - 1]), KID, MID, post_scale);
+              if (hi <= q) Kh3[hi * KS + lo] = valid ? kv : T(0);
+            }
           }
-        }
+        });
       }
       Kh3[i3 * KS + i3] = i3 < k ? T(1) + myeps : (i3 <= q ? T(1) : T(0));
       Kh3[(q + 1) * KS + i3] = myy0;
@@ -429,7 +455,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     // the next task's rows are requested now: their latency hides behind the factorisation, and
     // the registers they land in are not live during the (register-hungry) distance phase
     if (PIPE && task + t_step < t_end) {
-      pipe_issue(task + t_step, next_idx, lane);
+      pipe_issue(task + t_step, fix_index(next_idx, task + t_step, h, i), lane);
       if (task + 2 * t_step < t_end) next_idx = load_index(task + 2 * t_step, h, i);
     }
 
