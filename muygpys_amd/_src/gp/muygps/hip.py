@@ -1,0 +1,68 @@
+"""hip implementation of the solve family (reference: src/MuyGPyS/_src/gp/muygps/numpy.py).
+
+All of these go through ``mgp_solve_*``: one LDS-resident Cholesky of the (already perturbed)
+``Kin`` per neighbourhood instead of the reference's LU ``linalg.solve``.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from muygpys_amd import _lib
+
+
+def _solve(Kin, Kcross, Y, kout=1.0, want=("mean",)):
+    _lib.require_cuda(Kin, Kcross, Y)
+    if Kin.ndim != 3 or Kin.shape[1] != Kin.shape[2]:
+        raise ValueError(f"Kin must have shape (batch, nn, nn); got {tuple(Kin.shape)}")
+    K = Kin.contiguous()
+    b, k, _ = K.shape
+    dev, dt = K.device, K.dtype
+    Kc = None if Kcross is None else Kcross.to(dt).reshape(b, k).contiguous()
+    Yc = None if Y is None else Y.to(dt).reshape(b, k, -1).contiguous()
+    R = 0 if Yc is None else Yc.shape[2]
+    mean = torch.empty((b, R), device=dev, dtype=dt) if "mean" in want else None
+    var = torch.empty((b,), device=dev, dtype=dt) if "var" in want else None
+    yk = torch.empty((b, R), device=dev, dtype=dt) if "ykinvy" in want else None
+    co = torch.empty((b, k, R), device=dev, dtype=dt) if "coeffs" in want else None
+    info = torch.zeros(1, device=dev, dtype=torch.int32)
+    rc = _lib.fn("solve", dt)(
+        _lib.ptr(K), _lib.ptr(Kc), _lib.ptr(Yc), b, k, R, float(kout), _lib.ptr(mean), _lib.ptr(var),
+        _lib.ptr(yk), _lib.ptr(co), _lib.ptr(info), _lib.stream_ptr(),
+    )
+    _lib.check(rc, "mgp_solve")
+    return mean, var, yk, co
+
+
+def _muygps_posterior_mean(Kin, Kcross, nn_targets, **kwargs):
+    """numpy.py:17-41: Kcross^T Kin^-1 Y -> (b,) for (b,k) targets, (b,R) for (b,k,R)."""
+    mean, _, _, _ = _solve(Kin, Kcross, nn_targets, want=("mean",))
+    b = Kin.shape[0]
+    return mean.reshape((b,) + tuple(nn_targets.shape[2:]))
+
+
+def _muygps_diagonal_variance(Kin, Kcross, Kout, batch_size: int = 1, **kwargs):
+    """numpy.py:44-67: Kout - Kcross^T Kin^-1 Kcross -> (b,)."""
+    kout = float(Kout) if not isinstance(Kout, torch.Tensor) else float(Kout.reshape(-1)[0].item())
+    _, var, _, _ = _solve(Kin, Kcross, None, kout=kout, want=("var",))
+    return var
+
+
+def _muygps_fast_posterior_mean_precompute(Kin, train_nn_targets_fast, **kwargs):
+    """numpy.py:88-95: coefficients Kin^-1 Y, squeezed."""
+    Y = train_nn_targets_fast if train_nn_targets_fast.ndim == 3 else train_nn_targets_fast[:, :, None]
+    _, _, _, co = _solve(Kin, None, Y, want=("coeffs",))
+    return torch.squeeze(co)
+
+
+def _muygps_fast_posterior_mean(Kcross, coeffs_tensor, **kwargs):
+    """numpy.py:70-77: einsum('ij,ijk->ik')."""
+    _lib.require_cuda(Kcross, coeffs_tensor)
+    C = coeffs_tensor if coeffs_tensor.ndim == 3 else coeffs_tensor[:, :, None]
+    return torch.squeeze(torch.einsum("ij,ijk->ik", Kcross, C))
+
+
+def _mmuygps_fast_posterior_mean(Kcross, coeffs_tensor, **kwargs):
+    """numpy.py:80-85."""
+    _lib.require_cuda(Kcross, coeffs_tensor)
+    return torch.einsum("ijk,ijk->ik", Kcross, coeffs_tensor)
