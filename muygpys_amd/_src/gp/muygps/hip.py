@@ -58,7 +58,7 @@ def _muygps_fast_posterior_mean_precompute(Kin, train_nn_targets_fast, **kwargs)
 def _muygps_fast_posterior_mean(Kcross, coeffs_tensor, **kwargs):
     """numpy.py:70-77: einsum('ij,ijk->ik')."""
     _lib.require_cuda(Kcross, coeffs_tensor)
-    C = coeffs_tensor if coeffs_tensor.ndim == 3 else coeffs_tensor[:, :, None]
+    C = torch.atleast_3d(coeffs_tensor)  # (k,) -> (1,k,1), (b,k) -> (b,k,1), like np.atleast_3d
     return torch.squeeze(torch.einsum("ij,ijk->ik", Kcross, C))
 
 

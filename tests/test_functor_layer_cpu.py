@@ -1,0 +1,234 @@
+"""CPU: the host logic of the functor layer (closure plumbing, keyword routing, hyper-parameter
+rules, objective assembly, optimiser drivers) with the numpy ORACLE injected through the
+reference's own ``_backend_*`` seams -- no GPU, no hip kernel.  The same objects with their
+default (hip) backends are exercised on the GPU in tests/test_gpu_functor_layer.py."""
+
+import numpy as np
+import pytest
+
+from oracle import muygps_oracle as orc
+from tests.conftest import load_golden
+
+
+def numpy_metric(name):
+    from muygpys_amd.gp.deformation import MetricFn
+
+    return MetricFn(
+        differences_metric_fn=orc.l2 if name == "l2" else orc.F2,
+        crosswise_differences_fn=orc.crosswise_tensor,
+        pairwise_diffferences_fn=orc.pairwise_tensor,
+        apply_length_scale_fn=(lambda x, y: x / y) if name == "l2" else (lambda x, y: x / y**2),
+    )
+
+
+def numpy_model(meta, g, bounds=None, noise_bounds="fixed"):
+    """A muygpys_amd MuyGPS whose every backend callable is the numpy oracle."""
+    from muygpys_amd.gp import MuyGPS
+    from muygpys_amd.gp.deformation import Anisotropy, Isotropy
+    from muygpys_amd.gp.hyperparameter import AnalyticScale, Parameter, VectorParameter
+    from muygpys_amd.gp.kernels import RBF, Matern
+    from muygpys_amd.gp.noise import HeteroscedasticNoise, HomoscedasticNoise
+
+    bounds = bounds or {}
+
+    def P(name, val):
+        return Parameter(val, bounds[name]) if name in bounds else Parameter(val)
+
+    metric = numpy_metric(meta["metric"])
+    ls = meta["length_scale"]
+    if isinstance(ls, list):
+        deformation = Anisotropy(metric, VectorParameter(*[P(f"length_scale{i}", v) for i, v in enumerate(ls)]))
+    else:
+        deformation = Isotropy(metric, P("length_scale", ls))
+    kfns = dict(
+        _backend_05_fn=lambda d, **kw: orc.matern_05_fn(d), _backend_15_fn=lambda d, **kw: orc.matern_15_fn(d),
+        _backend_25_fn=lambda d, **kw: orc.matern_25_fn(d), _backend_inf_fn=lambda d, **kw: orc.matern_inf_fn(d),
+    )
+    if meta["kernel"] == "rbf":
+        kernel = RBF(deformation=deformation, _backend_fn=lambda d, **kw: orc.rbf_fn(d))
+    else:
+        nu = {"matern05": 0.5, "matern15": 1.5, "matern25": 2.5, "maternInf": np.inf}[meta["kernel"]]
+        kernel = Matern(smoothness=Parameter(nu), deformation=deformation, **kfns)
+    if meta.get("hetero"):
+        noise = HeteroscedasticNoise(
+            g["noise_table"][g["nn_idx"]], _backend_fn=orc.heteroscedastic_perturb
+        )
+    else:
+        noise = HomoscedasticNoise(meta["noise"], noise_bounds, _backend_fn=orc.homoscedastic_perturb)
+    return MuyGPS(
+        kernel=kernel, noise=noise,
+        scale=AnalyticScale(_backend_fn=lambda K, y, **kw: orc.analytic_scale_optim(K, y)),
+        _backend_mean_fn=lambda K, Kc, y, **kw: orc.posterior_mean(K, Kc, y),
+        _backend_var_fn=lambda K, Kc, Kout, **kw: orc.diagonal_variance(K, Kc, Kout),
+        _backend_fast_mean_fn=lambda Kc, c, **kw: orc.fast_posterior_mean(Kc, c),
+        _backend_fast_precompute_fn=lambda K, y, **kw: orc.fast_posterior_mean_precompute(K, y),
+    )
+
+
+def close(a, b, rtol=1e-9, atol=1e-11):
+    np.testing.assert_allclose(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64), rtol=rtol, atol=atol)
+
+
+def test_call_sequence_matches_reference(golden):
+    """make_train_tensors -> kernel -> posterior_mean / posterior_variance / optimize_scale,
+    in the reference's order, reproduces the reference's numbers (fixtures)."""
+    g, meta = golden, golden["meta"]
+    m = numpy_model(meta, g)
+    cross, pair, y_b, y_nn = m.make_train_tensors(
+        g["batch_idx"], g["nn_idx"], g["features"], g["targets"], materialize=True
+    )
+    if "crosswise" in g:
+        close(cross, g["crosswise"])
+    if "pairwise" in g:
+        close(pair, g["pairwise"])
+    close(y_b, g["batch_targets"])
+    close(y_nn, g["batch_nn_targets"])
+    Kin, Kc = m.kernel(pair), m.kernel(cross)
+    close(Kc, g["Kcross"])
+    if "Kin" in g:
+        close(Kin, g["Kin"])
+    close(m.posterior_mean(Kin, Kc, y_nn), g["mean"], rtol=1e-8, atol=1e-10)
+    close(m.get_opt_var_fn()(Kin, Kc), g["var_unscaled"], rtol=1e-8, atol=1e-10)
+    assert not m.scale.trained
+    if meta["R"] == 1:
+        m = m.optimize_scale(pair, y_nn)
+        assert m.scale.trained
+        close(m.scale(), g["sigma_sq"][0], rtol=1e-9)
+        # public variance is pre-multiplied by sigma^2, the objective's is not (variance.py:40-41)
+        close(m.posterior_variance(Kin, Kc), g["var_scaled"], rtol=1e-8, atol=1e-10)
+        close(m.get_opt_var_fn()(Kin, Kc), g["var_unscaled"], rtol=1e-8, atol=1e-10)
+
+
+def test_objective_probes_match_reference(golden):
+    from muygpys_amd.optimize import L_BFGS_B_optimize
+    from muygpys_amd.optimize.loss import looph_fn, lool_fn, mse_fn, pseudo_huber_fn
+
+    g, meta = golden, golden["meta"]
+    if "probe_values" not in g:
+        pytest.skip("no probes in this fixture")
+    probes = meta["probes"]
+    bounds = {k: (1e-6, 1e6) for p in probes for k in p if k != "noise"}
+    noise_bounds = (1e-8, 1e2) if any("noise" in p for p in probes) and not meta.get("hetero") else "fixed"
+    m = numpy_model(meta, g, bounds=bounds, noise_bounds=noise_bounds)
+    cross, pair, y_b, y_nn = m.make_train_tensors(
+        g["batch_idx"], g["nn_idx"], g["features"], g["targets"], materialize=True
+    )
+    for row, lfn in enumerate((lool_fn, mse_fn, looph_fn, pseudo_huber_fn)):
+        if lfn in (lool_fn, looph_fn):
+            # these call the backend loss: inject the oracle's
+            from muygpys_amd.optimize.loss import LossFn, make_var_predict_and_loss_fn
+
+            lfn = LossFn(orc.lool_fn if row == 0 else orc.looph_fn, make_var_predict_and_loss_fn)
+        else:
+            from muygpys_amd.optimize.loss import LossFn, make_raw_predict_and_loss_fn
+
+            lfn = LossFn(orc.mse_fn if row == 1 else orc.pseudo_huber_fn, make_raw_predict_and_loss_fn)
+        obj = L_BFGS_B_optimize.make_obj_fn(m, y_b, y_nn, cross, pair, loss_fn=lfn)
+        vals = [float(obj(**p)) for p in probes]
+        close(vals, g["probe_values"][row], rtol=1e-8)
+
+
+def test_parameter_rules():
+    """Bounds / value validation of gp/hyperparameter/scalar.py (tests/kernels.py:136-300)."""
+    from muygpys_amd.gp.hyperparameter import Parameter
+
+    p = Parameter(1.0)
+    assert p.fixed() and p() == 1.0 and p.get_bounds() == (0.0, 0.0)
+    q = Parameter(0.5, (0.1, 2.0))
+    assert not q.fixed() and q.get_bounds() == (0.1, 2.0)
+    for bad_bounds in ("free", 3.0, (1.0,), (1.0, 2.0, 3.0), ("a", 2.0), (2.0, 1.0)):
+        with pytest.raises(ValueError):
+            Parameter(1.0, bad_bounds)
+    for bad_val in ([1.0, 2.0], np.array([1.0, 2.0])):
+        with pytest.raises(ValueError):
+            Parameter(bad_val, (0.1, 3.0))
+    with pytest.raises(ValueError):
+        Parameter(5.0, (0.1, 2.0))
+    with pytest.raises(ValueError):
+        Parameter(0.01, (0.1, 2.0))
+    with pytest.raises(ValueError):
+        Parameter("sample")  # fixed bounds cannot be sampled
+    with pytest.raises(ValueError):
+        Parameter("gaussian", (0.1, 2.0))
+    np.random.seed(0)
+    for mode in ("sample", "log_sample"):
+        for _ in range(20):
+            v = Parameter(mode, (0.1, 2.0))()
+            assert 0.1 <= v <= 2.0
+
+
+def test_noise_and_scale_rules():
+    from muygpys_amd.gp.hyperparameter import AnalyticScale, FixedScale
+    from muygpys_amd.gp.noise import HeteroscedasticNoise, HomoscedasticNoise, NullNoise
+
+    with pytest.raises(ValueError):
+        HomoscedasticNoise(1e-3, (-1.0, 1.0))
+    with pytest.raises(ValueError):
+        HeteroscedasticNoise(np.array([[1e-3, -1e-3]]), _backend_fn=orc.heteroscedastic_perturb)
+    assert HeteroscedasticNoise(np.ones((2, 3)), _backend_fn=orc.heteroscedastic_perturb).fixed()
+    K = np.ones((2, 3, 3))
+    assert NullNoise().perturb(K) is K
+    n = HomoscedasticNoise(0.25, _backend_fn=orc.homoscedastic_perturb)
+    close(n.perturb(K)[0], np.ones((3, 3)) + 0.25 * np.eye(3))
+    close(n.perturb(K, noise=0.5)[1], np.ones((3, 3)) + 0.5 * np.eye(3))
+    close(n.perturb_fn(lambda Kin: Kin)(K, noise=2.0)[0], np.ones((3, 3)) + 2.0 * np.eye(3))
+    for bad in (0.0, -1.0, [1.0, 2.0]):
+        with pytest.raises(ValueError):
+            FixedScale(bad)
+    s = AnalyticScale(_backend_fn=lambda K, y, **kw: 3.0)
+    assert s() == 1.0 and not s.trained
+    s._set(2.5)
+    assert s() == 2.5 and s.trained
+    assert s.scale_fn(lambda x: x)(2.0) == 5.0
+
+
+def test_anisotropy_shape_check_and_keyword_routing():
+    g = load_golden("m15_aniso_l2_k8_d4")
+    m = numpy_model(g["meta"], g, bounds={f"length_scale{i}": (0.1, 10.0) for i in range(4)})
+    names, x0, bounds = m.get_opt_params()
+    assert names == [f"length_scale{i}" for i in range(4)]
+    close(x0, g["meta"]["length_scale"])
+    cross, pair, _, _ = m.make_train_tensors(g["batch_idx"], g["nn_idx"], g["features"], g["targets"], materialize=True)
+    with pytest.raises(ValueError):
+        m.kernel(pair[..., :3])
+    # keywords may arrive in any order; elements are matched by index
+    a = m.kernel(cross, length_scale0=0.5, length_scale1=2.0, length_scale2=3.0, length_scale3=0.9)
+    b = m.kernel(cross, length_scale3=0.9, length_scale2=3.0, length_scale1=2.0, length_scale0=0.5)
+    close(a, b)
+    close(a, orc.matern_15_fn(orc.anisotropy(cross, [0.5, 2.0, 3.0, 0.9], "l2")))
+
+
+def test_matern_selects_closed_forms_only_for_fixed_smoothness():
+    from muygpys_amd.gp.hyperparameter import Parameter
+    from muygpys_amd.gp.kernels import Matern
+    from muygpys_amd.gp.kernels.kernel_fn import _set_matern_fn
+    from muygpys_amd.gp.hyperparameter import NamedParam
+
+    tags = dict(_backend_05_fn="05", _backend_15_fn="15", _backend_25_fn="25", _backend_inf_fn="inf", _backend_gen_fn="gen")
+    for nu, tag in ((0.5, "05"), (1.5, "15"), (2.5, "25"), (np.inf, "inf"), (0.42, "gen")):
+        assert _set_matern_fn(NamedParam("smoothness", Parameter(nu)), **tags) == tag
+    assert _set_matern_fn(NamedParam("smoothness", Parameter(1.5, (0.1, 3.0))), **tags) == "gen"
+    assert Matern(smoothness=Parameter(1.5)).Kout() == 1.0
+
+
+def test_lbfgsb_and_bayes_drivers_recover_length_scale():
+    """Behavioural check of the outer loops (the Bayes-opt restatement is parity-unpinned, see
+    _src/optimize/chassis/hip.py): both drivers improve the LOOCV objective over its starting point
+    and stay inside the bounds."""
+    from muygpys_amd.optimize import Bayes_optimize, L_BFGS_B_optimize
+    from muygpys_amd.optimize.loss import LossFn, make_var_predict_and_loss_fn
+
+    g = load_golden("m15_iso_knn_k30_d40_c2")
+    meta = dict(g["meta"])
+    meta["length_scale"] = 1.5  # deliberately poor start
+    m = numpy_model(meta, g, bounds={"length_scale": (0.5, 20.0)})
+    cross, pair, y_b, y_nn = m.make_train_tensors(g["batch_idx"], g["nn_idx"], g["features"], g["targets"], materialize=True)
+    lfn = LossFn(orc.lool_fn, make_var_predict_and_loss_fn)
+    obj = L_BFGS_B_optimize.make_obj_fn(m, y_b, y_nn, cross, pair, loss_fn=lfn)
+    start = float(obj(length_scale=1.5))
+    for driver, kw in ((L_BFGS_B_optimize, {}), (Bayes_optimize, dict(init_points=3, n_iter=6, random_state=1))):
+        new = driver(m, y_b, y_nn, cross, pair, loss_fn=lfn, **kw)
+        ls = new.kernel.deformation.length_scale()
+        assert 0.5 <= ls <= 20.0
+        assert float(obj(length_scale=ls)) >= start
+        assert m.kernel.deformation.length_scale() == 1.5, "the input model must not be modified"
