@@ -26,12 +26,11 @@ class ScaleFn:
         self._trained = False
 
     def _check_positive_float(self, val):
-        if isinstance(val, Sequence) or (hasattr(val, "__len__") and len(val) != 1):
+        size = getattr(val, "numel", None)
+        size = size() if callable(size) else getattr(val, "size", None)
+        if isinstance(val, Sequence) or (size is not None and int(size) != 1):
             raise ValueError(f"Scale parameter must be scalar, not {val}.")
-        if hasattr(val, "item"):
-            fval = float(val.item()) if hasattr(val, "numel") or np.ndim(val) else float(val)
-        else:
-            fval = float(val)
+        fval = float(val.reshape(-1)[0]) if size is not None else float(val)
         if fval <= 0.0:
             raise ValueError(f"Scale parameter must be positive, not {val}.")
         return fval
