@@ -18,12 +18,12 @@ int posterior(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t*
               int R, int noise_mode, double eps, const T* nd, int kernel_id, int metric_id, const T* ls,
               int ls_count, T* mean, T* var, T* yk, int* info, void* stream) {
   if (b < 0 || k < 1 || d < 1 || R < 1) return MGP_EINVAL;
+  if (b == 0) return MGP_OK;  // empty shard: nothing to read or write (outputs may be NULL)
   if (!fq || !fn || !ni || !tg || !ls || !mean || !var) return MGP_EINVAL;
   if (!valid_kernel(kernel_id) || !valid_metric(metric_id)) return MGP_EINVAL;
   if (noise_mode < MGP_NOISE_SCALAR || noise_mode > MGP_NOISE_BATCH) return MGP_EINVAL;
   if (noise_mode != MGP_NOISE_SCALAR && !nd) return MGP_EINVAL;
   if (ls_count != 1 && ls_count != d) return MGP_EINVAL;
-  if (b == 0) return MGP_OK;
   FusedArgs a{fq, fn, bi, ni, tg, nd, ls, mean, var, yk, info, b, eps, d, k, R, noise_mode, kernel_id, metric_id,
               ls_count, 0};
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -37,7 +37,9 @@ int posterior(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t*
 template <typename T>
 int solve(const T* Kin, const T* Kc, const T* Y, int64_t b, int k, int R, double kout, T* mean, T* var, T* yk,
           T* coeffs, int* info, void* stream) {
-  if (b < 0 || k < 1 || R < 0 || !Kin) return MGP_EINVAL;
+  if (b < 0 || k < 1 || R < 0) return MGP_EINVAL;
+  if (b == 0) return MGP_OK;
+  if (!Kin) return MGP_EINVAL;
   if (R > 0 && !Y) return MGP_EINVAL;
   if ((mean || var) && !Kc) return MGP_EINVAL;
   if ((mean || yk || coeffs) && R == 0) return MGP_EINVAL;

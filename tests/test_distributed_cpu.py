@@ -1,0 +1,104 @@
+"""CPU, world_size 2 over gloo: the sharding rule and the single-all-reduce LOOCV objective
+(muygpys_amd/distributed.py) reproduce the serial value.  The per-rank partial sums are
+computed by the numpy oracle here (injected ``local_fn``); on GPUs the same combine code runs
+over RCCL with the fused HIP kernel producing the partials (tests/test_gpu_distributed.py).
+Counterpart of the reference's tests/backend/mpi_correctness.py:1103-1134,1243-1378."""
+
+import json
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def oracle_local_partials(spec, features, targets, batch_indices, nn_indices):
+    from oracle import muygps_oracle as orc
+
+    X, y = features.numpy(), targets.numpy()
+    bi, ni = batch_indices.numpy(), nn_indices.numpy()
+    out = torch.zeros(5, dtype=torch.float64)
+    if len(bi) == 0:
+        return out, torch.zeros(0, dtype=torch.float64), torch.zeros(0, dtype=torch.float64)
+    ospec = orc.Spec(spec.kernel, spec.metric, spec.length_scale, spec.noise)
+    mean, var = orc.posterior_mean_var(ospec, X, X, bi, ni, y)
+    r2 = (mean - y[bi]) ** 2
+    b, k = ni.shape
+    out[0], out[1], out[2], out[3] = (r2 / var).sum(), np.log(var).sum(), r2.sum(), b
+    out[4] = orc.sigma_sq(ospec, X, ni, y) * b * k
+    return out, torch.from_numpy(mean), torch.from_numpy(var)
+
+
+def _worker(rank, world, port, fixture, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from muygpys_amd import distributed as D
+        from muygpys_amd.fused import KernelSpec
+        from tests.conftest import load_golden
+
+        g = load_golden(fixture)
+        meta = g["meta"]
+        spec = KernelSpec(meta["kernel"], meta["metric"], meta["length_scale"], meta["noise"])
+        X, y = torch.from_numpy(g["features"]), torch.from_numpy(g["targets"])
+        bi, ni = torch.from_numpy(g["batch_idx"]), torch.from_numpy(g["nn_idx"])
+        res = D.sharded_loocv(spec, X, y, bi, ni, loss="lool", local_fn=oracle_local_partials)
+        lo, hi = D.shard_bounds(len(bi), rank, world)
+        q.put((rank, res["lool"], res["sigma_sq"], res["mse"], res["count"], lo, hi, res["mean"].numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fixture", ["m15_iso_l2_k10_d8", "m15_iso_b1_k3_d2"])  # 32 rows; 1 row (one rank idle)
+def test_two_rank_objective_equals_serial(fixture):
+    from tests.conftest import load_golden
+
+    g = load_golden(fixture)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, fixture, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    b = len(g["batch_idx"])
+    means = []
+    for rank, lool, sig, mse, count, lo, hi, mean in got:
+        np.testing.assert_allclose(lool, g["lool"], rtol=1e-9)
+        np.testing.assert_allclose(sig, g["sigma_sq"][0], rtol=1e-9)
+        np.testing.assert_allclose(mse, g["mse"], rtol=1e-9)
+        assert count == b
+        means.append(mean)
+    # shards concatenate in rank order to the serial result; remainder goes to the LAST rank
+    assert (got[0][5], got[0][6], got[1][5], got[1][6]) == (0, b // 2, b // 2, b)
+    np.testing.assert_allclose(np.concatenate(means), g["mean"], rtol=1e-9, atol=1e-12)
+
+
+def test_chunk_rule_matches_reference_fixture():
+    from muygpys_amd import distributed as D
+    from tests.conftest import GOLDEN_DIR
+
+    with open(os.path.join(GOLDEN_DIR, "chunk_sizes.json")) as f:
+        rule = json.load(f)
+    for key, sizes in rule.items():
+        n, p = (int(t) for t in key.split("_"))
+        assert D.chunk_sizes(n, p) == sizes
+        bounds = [D.shard_bounds(n, r, p) for r in range(p)]
+        assert bounds[0][0] == 0 and bounds[-1][1] == n
+        assert all(bounds[i][1] == bounds[i + 1][0] for i in range(p - 1))
