@@ -28,6 +28,18 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r01_wave_pmc_traffic.json")
+
+
+def measured_traffic(b: int, k: int, d: int, dtype: str):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
+    collected separately, gfx950 correction applied; see profiles/r01_wave_pmc_traffic.json).
+    The counters were taken on the headline shape; scaled by neighbourhood count, else null."""
+    if not (k == 30 and d == 40 and dtype == "f32" and os.path.exists(TRAFFIC_JSON)):
+        return None
+    with open(TRAFFIC_JSON) as f:
+        t = json.load(f)
+    return t["hbm_bytes_per_launch_corrected"] / t["neighbourhoods_per_launch"] * b
 
 
 def algorithmic_bytes(k: int, d: int, R: int, s: int) -> int:
@@ -196,8 +208,10 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "algorithmic_bytes_per_neighbourhood": B, "kernel_ms": avg_ms,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(b, k, d, args.dtype),
+                "kernel": "mgp::fused_wave_kernel" if not args.force_generic else "mgp::fused_generic_kernel",
+                "algorithmic_bytes_per_neighbourhood": B, "algorithmic_bytes_per_launch": B * b,
+                "kernel_ms": avg_ms,
             },
         }
         if args.cpu_sample > 0:

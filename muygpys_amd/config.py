@@ -13,6 +13,7 @@ from __future__ import annotations
 import os
 
 _BACKENDS = ("hip",)
+_REFERENCE_BACKENDS = ("numpy", "jax", "torch", "mpi")
 _FTYPES = ("64", "32")
 
 
@@ -30,7 +31,10 @@ class _State:
 class _Config:
     def __init__(self):
         self.state = _State()
-        self.update("muygpys_backend", os.environ.get("MUYGPYS_BACKEND", "hip"))
+        env_backend = os.environ.get("MUYGPYS_BACKEND", "hip")
+        # numpy/jax/torch/mpi select one of the REFERENCE package's backends (this package may be
+        # loaded next to it, see integration.py); they are not a request addressed to this package
+        self.update("muygpys_backend", "hip" if env_backend in _REFERENCE_BACKENDS else env_backend)
         self.update("muygpys_ftype", os.environ.get("MUYGPYS_FTYPE", "64"))
 
     def update(self, name: str, value) -> None:

@@ -1,0 +1,59 @@
+"""Install the hip backend into an importable LLNL/MuyGPyS (the reference package itself).
+
+MuyGPyS resolves its backend once, at import of each family module, through
+``MuyGPyS._src.util._collect_implementation(package, *names)`` -> ``import package.<backend>``
+(src/MuyGPyS/_src/util.py:9-32), and accepts only numpy/jax/torch/mpi
+(_src/config.py:223).  ``install()`` makes ``hip`` a fifth backend WITHOUT editing the
+reference tree:
+
+    import MuyGPyS                      # config only; no family module is bound yet
+    import muygpys_amd.integration as hip_backend
+    hip_backend.install()               # before the first `import MuyGPyS.gp ...`
+    from MuyGPyS.gp import MuyGPS       # now backed by the HIP kernels
+
+What a maintainer would commit instead is shown in INTEGRATION.md: eight three-line
+``hip.py`` files and one ``elif`` in util.py.
+
+With the reference's own functor layer the per-function (materialising) kernels run; the fused
+single-launch path is reached through this package's functor layer (``muygpys_amd.gp``), which
+hands lazy handles to the same calls.
+"""
+
+from __future__ import annotations
+
+import importlib
+import sys
+
+FAMILIES = (
+    "math", "gp.tensors", "gp.kernels", "gp.muygps", "gp.noise", "optimize.loss", "optimize.scale", "optimize.chassis",
+)
+
+
+def install(package: str = "MuyGPyS", require_device: bool = True) -> None:
+    ref = importlib.import_module(package)
+    bound = [m for m in sys.modules if m.startswith(f"{package}._src.") and m.split(".")[-1] in
+             ("tensors", "kernels", "muygps", "noise", "loss", "scale", "chassis")]
+    if bound:
+        raise RuntimeError(
+            f"install() must run before the backend families are imported; already bound: {sorted(bound)}"
+        )
+    from muygpys_amd.config import config as hip_config
+
+    if require_device:
+        hip_config.require_device()
+    # 1. the family modules MuyGPyS will look for
+    for fam in FAMILIES:
+        sys.modules[f"{package}._src.{fam}.hip"] = importlib.import_module(f"muygpys_amd._src.{fam}.hip")
+    # 2. the resolver learns the fifth name
+    util = importlib.import_module(f"{package}._src.util")
+    original = util._collect_implementation
+
+    def _collect_implementation(pkg, *funcs):
+        if ref.config.state.backend == "hip":
+            return util._collect_functions(pkg + ".hip", *funcs)
+        return original(pkg, *funcs)
+
+    util._collect_implementation = _collect_implementation
+    # 3. select it (the enum validator only knows the four stock names, so set the state mirror)
+    ref.config.state.backend = "hip"
+    ref.config.state.ftype = hip_config.state.ftype
