@@ -83,7 +83,7 @@ def cpu_baseline(k: int, d: int, sample: int, seed: int):
     timed on this box's host cores on a bounded sample of the same workload."""
     from oracle import muygps_oracle as orc  # checker/baseline only -- never on the product path
 
-    n = 20000
+    n = max(20000, sample)
     X, y = synth(n, d, seed)
     X, y = X.astype(np.float64), y.astype(np.float64)
     bi, ni = random_neighbors(n, sample, k, seed + 1)
@@ -110,7 +110,7 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--kernel", default="matern15")
     ap.add_argument("--knn", action="store_true", help="exact GPU kNN neighbourhoods instead of random rows")
-    ap.add_argument("--cpu-sample", type=int, default=65536, help="0 disables the CPU baseline leg")
+    ap.add_argument("--cpu-sample", type=int, default=131072, help="0 disables the CPU baseline leg")
     ap.add_argument("--force-generic", action="store_true", help="time the generic LDS kernel")
     args = ap.parse_args()
 
