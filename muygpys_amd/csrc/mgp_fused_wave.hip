@@ -179,9 +179,16 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   const int xs = DFIX > 0 ? DSTFIX + E : g.xs;
   const int tile_elems = NH * NP * (xs > KS ? xs : KS);
   T* tile = reinterpret_cast<T*>(smem);               // feature tile, later the exchange matrix
+  // Plain kernels: [tile][colbuf 64][ilbuf dst][idxbuf 64 x int64].  Pipelined kernels keep LDS
+  // at tile + 256 bytes (9 allocation granules of 1280 B -> 14 workgroups per CU): the 32-bit row
+  // indices live in the column buffer (only read while the gather is issued, before the
+  // factorisation writes there) and the inverse length scales in the tile row of the last slot
+  // (a response slot: it has no features, and its distances are never used).
+  constexpr bool PIPE_ = KFIX > 0 && DFIX > 0 && DFIX <= 64;
   T* colbuf = tile + tile_elems;                      // 64 entries
-  T* ilbuf = colbuf + 64;                              // dst entries (Anisotropy)
-  int64_t* idxbuf = reinterpret_cast<int64_t*>(ilbuf + dst + (dst & 1));  // 64 entries
+  T* ilbuf = PIPE_ ? tile + (NP - 1) * xs : colbuf + 64;  // dst entries (Anisotropy)
+  int64_t* idxbuf = reinterpret_cast<int64_t*>(ilbuf + dst + (dst & 1));  // 64 entries (plain kernels)
+  int* idxbuf32 = reinterpret_cast<int*>(colbuf);                           // 64 entries (pipelined)
 
   const T* feat_q = static_cast<const T*>(a.feat_q);
   const T* feat_nn = static_cast<const T*>(a.feat_nn);
@@ -246,7 +253,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   auto pipe_issue = [&](int64_t task_n, int64_t idx_n, int lane_) {
     const int h = NH == 1 ? 0 : lane_ / NP;
     const int i = lane_ & (NP - 1);
-    idxbuf[lane_] = idx_n * (int64_t)d;  // slots without a feature row hold 0: any valid row will do
+    idxbuf32[lane_] = (int)idx_n;  // row number (< 2^31); slots without a feature row hold 0: a valid row
     __syncthreads();
     if (g.mask & 1) {
 #pragma unroll
@@ -256,7 +263,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         int c = sigma - row * SPR;
         c = c < C16V ? c : C16V - 1;            // padding slot: re-read the last data slot
         const T* base = (row & (NP - 1)) == q ? feat_q : feat_nn;
-        glds16(base + idxbuf[row] + c * E, reinterpret_cast<char*>(tile) + n * 1024);
+        glds16(base + (int64_t)idxbuf32[row] * d + c * E, reinterpret_cast<char*>(tile) + n * 1024);
       }
     }
     // response and nugget of the slot's row: unconditional single loads (idx_n is 0, a valid
@@ -537,7 +544,9 @@ static int launch_np(const FusedArgs& a, hipStream_t stream) {
   if (DFIX > 0 && !g.vec_ok) return MGP_EUNSUPPORTED;
   g.ntasks = (a.b + NH - 1) / NH;
   const int rowmax = g.xs > KS ? g.xs : KS;
-  size_t lds = ((size_t)NH * NP * rowmax + 64 + g.dst + (g.dst & 1)) * sizeof(T) + 64 * sizeof(int64_t);
+  constexpr bool PIPE = KFIX > 0 && DFIX > 0 && DFIX <= 64;
+  size_t lds = PIPE ? ((size_t)NH * NP * rowmax + 64) * sizeof(T)
+                    : ((size_t)NH * NP * rowmax + 64 + g.dst + (g.dst & 1)) * sizeof(T) + 64 * sizeof(int64_t);
   lds = ((lds + 15) & ~(size_t)15) + (size_t)g_lds_pad;
   // Persistent grid = exactly the resident capacity: every workgroup owns a fixed share of the
   // tasks, so one workgroup more than fits runs as a second, nearly empty round (measured: 13
