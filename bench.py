@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--knn", action="store_true", help="exact GPU kNN neighbourhoods instead of random rows")
     ap.add_argument("--cpu-sample", type=int, default=131072, help="0 disables the CPU baseline leg")
     ap.add_argument("--force-generic", action="store_true", help="time the generic LDS kernel")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for self-tests)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="self-test only: every rank uses cuda:0 (exercises the N>1 logic on a 1-GPU box with gloo)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -123,8 +126,13 @@ def main():
 
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.one_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device: the hip path has no CPU fallback")
     dev = torch.device("cuda", local_rank)
@@ -174,7 +182,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     non_spd = int(info.item())

@@ -27,6 +27,9 @@ def main():
     ap.add_argument("--masks", default="15")
     ap.add_argument("--generic", default="0")
     ap.add_argument("--aniso", type=int, default=0)
+    ap.add_argument("--R", type=int, default=1)
+    ap.add_argument("--kernel", default="matern15")
+    ap.add_argument("--metric", default="l2")
     ap.add_argument("--grids", default="0")
     ap.add_argument("--ldspad", type=int, default=0)
     args = ap.parse_args()
@@ -34,11 +37,13 @@ def main():
     td = torch.float32 if args.dtype == "f32" else torch.float64
     X, y = synth(args.n, args.d, 20241008)
     Xd, yd = torch.from_numpy(X).to(dev, td), torch.from_numpy(y).to(dev, td)
+    if args.R > 1:
+        yd = yd[:, None].repeat(1, args.R).contiguous() * torch.linspace(0.5, 1.5, args.R, device=dev, dtype=td)
     bi, ni = random_neighbors(args.n, args.b, args.k, 1)
     bi, ni = torch.from_numpy(bi).to(dev), torch.from_numpy(ni).to(dev)
     ls = [5.0] * args.d if args.aniso else 5.0
-    spec = KernelSpec("matern15", "l2", ls, 1e-3)
-    mean = torch.empty((args.b, 1), device=dev, dtype=td)
+    spec = KernelSpec(args.kernel, args.metric, ls, 1e-3)
+    mean = torch.empty((args.b, args.R), device=dev, dtype=td)
     var = torch.empty((args.b,), device=dev, dtype=td)
     lib = _lib.load()
     lib.mgp_debug_set_lds_pad(args.ldspad)
