@@ -67,15 +67,10 @@ def random_neighbors(n: int, b: int, k: int, seed: int):
 
 
 def knn_neighbors(Xd: torch.Tensor, bi: torch.Tensor, k: int, chunk: int = 2048):
-    """Exact brute-force kNN on the GPU (self excluded), squared-l2 like neighbors.py:246-250."""
-    sq = (Xd * Xd).sum(1)
-    out = torch.empty((bi.numel(), k), dtype=torch.int64, device=Xd.device)
-    for s in range(0, bi.numel(), chunk):
-        q = Xd[bi[s:s + chunk]]
-        d2 = sq[None, :] - 2.0 * (q @ Xd.T) + (q * q).sum(1)[:, None]
-        d2[torch.arange(q.shape[0], device=Xd.device), bi[s:s + chunk]] = float("inf")
-        out[s:s + chunk] = d2.topk(k, dim=1, largest=False).indices
-    return out
+    """Exact brute-force kNN on the GPU (self excluded), muygpys_amd/neighbors.py."""
+    from muygpys_amd.neighbors import NN_Wrapper
+
+    return NN_Wrapper(Xd, k, chunk=chunk).get_batch_nns(bi)[0]
 
 
 def cpu_baseline(k: int, d: int, sample: int, seed: int):
