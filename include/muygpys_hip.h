@@ -149,6 +149,25 @@ int mgp_solve_f32(const float* Kin, const float* Kcross, const float* Y, int64_t
 int mgp_solve_f64(const double* Kin, const double* Kcross, const double* Y, int64_t b, int k, int R, double kout,
                   double* mean, double* var, double* ykinvy, double* coeffs, int* info, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Fused fast posterior mean (prediction from precomputed coefficients).  Replaces
+ *   _crosswise_tensor + metric + kernel + _muygps_fast_posterior_mean
+ *   (_src/gp/tensors/numpy.py:47-58,89-94, _src/gp/kernels/numpy.py:12-31,
+ *    _src/gp/muygps/numpy.py:70-77) as chained by examples/fast_posterior_mean.py:317-400:
+ *   mean[t, r] = sum_j kernel(dist(q_t, x_{nn_idx[t, j]})) * coeffs[coeff_row[t], j, r]
+ * coeffs (n_train, k, R) = mgp_solve_* `coeffs` output of the self-including neighbourhoods
+ * (_muygps_fast_posterior_mean_precompute, numpy.py:88-95); coeff_row (b) = the closest
+ * training point of each test point; nn_idx (b, k) = that point's neighbourhood.
+ * ------------------------------------------------------------------------- */
+int mgp_fast_posterior_mean_f32(const float* feat_q, const float* feat_nn, int d, const int64_t* batch_idx,
+                                const int64_t* nn_idx, int64_t b, int k, const float* coeffs,
+                                const int64_t* coeff_row, int R, int kernel_id, int metric_id,
+                                const float* length_scale, int ls_count, float* mean, void* stream);
+int mgp_fast_posterior_mean_f64(const double* feat_q, const double* feat_nn, int d, const int64_t* batch_idx,
+                                const int64_t* nn_idx, int64_t b, int k, const double* coeffs,
+                                const int64_t* coeff_row, int R, int kernel_id, int metric_id,
+                                const double* length_scale, int ls_count, double* mean, void* stream);
+
 /* L1/L2 loss sums in fp64, _src/optimize/loss/numpy.py:22-117.  For n residuals
  * r = pred - target and variances v (may be NULL), with s = *scale_dev (device
  * double, NULL = 1) writes

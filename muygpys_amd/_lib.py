@@ -61,6 +61,7 @@ _SIGS = {
     "solve": [_p, _p, _p, _l, _i, _i, _d, _p, _p, _p, _p, _p, _p],
     "loss_sums": [_p, _p, _p, _l, _p, _d, _d, _p, _p],
     "column_sums": [_p, _l, _i, _p, _p],
+    "fast_posterior_mean": [_p, _p, _i, _p, _p, _l, _i, _p, _p, _i, _i, _i, _p, _i, _p, _p],
 }
 
 

@@ -55,5 +55,8 @@ template <typename T> int launch_perturb(const T*, int64_t, int, int, double, co
 template <typename T>
 int launch_loss_sums(const T*, const T*, const T*, int64_t, const double*, double, double, double*, hipStream_t);
 template <typename T> int launch_column_sums(const T*, int64_t, int, double*, hipStream_t);
+template <typename T>
+int launch_fast_mean(const void*, const void*, int, const int64_t*, const int64_t*, int64_t, int, const void*,
+                     const int64_t*, int, int, int, const void*, int, void*, hipStream_t);
 
 }  // namespace mgp

@@ -120,6 +120,19 @@ int mgp_posterior_f64(const double* fq, const double* fn, int d, const int64_t* 
     return launch_column_sums<T>(x, n, R, out, S_(st));                                                              \
   }
 
+#define MGP_DEFINE_FAST(SUF, T)                                                                                     \
+  int mgp_fast_posterior_mean_##SUF(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t* ni, int64_t b, \
+                                    int k, const T* coeffs, const int64_t* crow, int R, int kid, int mid,            \
+                                    const T* ls, int lsc, T* mean, void* st) {                                       \
+    if (b < 0 || k < 1 || d < 1 || R < 1) return MGP_EINVAL;                                                         \
+    if (b == 0) return MGP_OK;                                                                                       \
+    if (!fq || !fn || !ni || !coeffs || !crow || !ls || !mean) return MGP_EINVAL;                                    \
+    if (!valid_kernel(kid) || !valid_metric(mid) || (lsc != 1 && lsc != d)) return MGP_EINVAL;                       \
+    return launch_fast_mean<T>(fq, fn, d, bi, ni, b, k, coeffs, crow, R, kid, mid, ls, lsc, mean, S_(st));           \
+  }
+MGP_DEFINE_FAST(f32, float)
+MGP_DEFINE_FAST(f64, double)
+
 MGP_DEFINE(f32, float)
 MGP_DEFINE(f64, double)
 

@@ -134,3 +134,82 @@ def posterior_mean_var(
     if want_ykinvy:
         return mean_out, var, (yk.reshape(b) if squeeze else yk)
     return mean_out, var
+
+
+def fast_posterior_mean(
+    spec: KernelSpec,
+    test_features: torch.Tensor,
+    train_features: torch.Tensor,
+    test_indices: Optional[torch.Tensor],
+    closest_set: torch.Tensor,
+    coeffs: torch.Tensor,
+    closest_neighbor: torch.Tensor,
+    out: Optional[torch.Tensor] = None,
+):
+    """Prediction from precomputed coefficients, fused (``mgp_fast_posterior_mean_*``).
+
+    ``closest_set (b, k)`` is the self-including neighbourhood of each test point's closest
+    training point ``closest_neighbor (b,)`` and ``coeffs (n_train, k[, R])`` the coefficient
+    table (reference workflow: examples/fast_posterior_mean.py:373-400; maths
+    _src/gp/muygps/numpy.py:70-77).  Returns ``(b,)`` or ``(b, R)``."""
+    _lib.require_cuda(test_features, train_features, test_indices, closest_set, coeffs, closest_neighbor)
+    dtype = train_features.dtype
+    fq = (test_features[:, None] if test_features.ndim == 1 else test_features).contiguous()
+    fn = (train_features[:, None] if train_features.ndim == 1 else train_features).contiguous()
+    d = fn.shape[1]
+    ni = closest_set.to(torch.int64).contiguous()
+    b, k = ni.shape
+    bi = None if test_indices is None else test_indices.to(torch.int64).contiguous()
+    squeeze = coeffs.ndim == 2
+    co = (coeffs[:, :, None] if squeeze else coeffs).to(dtype).contiguous()
+    if co.shape[1] != k:
+        raise ValueError(f"coefficient rows hold {co.shape[1]} entries but the neighbourhoods have {k}")
+    R = co.shape[2]
+    crow = closest_neighbor.to(torch.int64).contiguous()
+    ls = _length_scale_tensor(spec.length_scale, d, fn)
+    mean = out if out is not None else torch.empty((b, R), device=fn.device, dtype=dtype)
+    rc = _lib.fn("fast_posterior_mean", dtype)(
+        _lib.ptr(fq), _lib.ptr(fn), d, _lib.ptr(bi), _lib.ptr(ni), b, k, _lib.ptr(co), _lib.ptr(crow), R,
+        spec.kernel_id(), spec.metric_id(), _lib.ptr(ls), ls.numel(), _lib.ptr(mean), _lib.stream_ptr(),
+    )
+    _lib.check(rc, "mgp_fast_posterior_mean")
+    return mean.reshape(b) if squeeze else mean
+
+
+def fast_coefficients(spec: KernelSpec, train_features: torch.Tensor, train_targets: torch.Tensor,
+                      train_nn_indices: torch.Tensor, chunk: int = 262144) -> torch.Tensor:
+    """Coefficient table ``C_i = (K_i + eps)^-1 y_i`` over the self-including neighbourhoods
+    ``[i, nn[i][:-1]]`` (_fast_nn_update + _muygps_fast_posterior_mean_precompute,
+    _src/gp/tensors/numpy.py:97-108, _src/gp/muygps/numpy.py:88-95), computed once per model in
+    row chunks through the per-function kernels.  Returns ``(n, k)`` or ``(n, k, R)`` together
+    with the updated index table ``(n, k)``."""
+    from muygpys_amd._src.gp.kernels import hip as K
+    from muygpys_amd._src.gp.muygps import hip as M
+    from muygpys_amd._src.gp.noise import hip as N
+    from muygpys_amd._src.gp.tensors import hip as T
+
+    _lib.require_cuda(train_features, train_targets, train_nn_indices)
+    nn_fast = T._fast_nn_update(train_nn_indices.to(torch.int64))
+    n, k = nn_fast.shape
+    d = 1 if train_features.ndim == 1 else train_features.shape[1]
+    squeeze = train_targets.ndim == 1
+    R = 1 if squeeze else train_targets.shape[1]
+    out = torch.empty((n, k, R), device=train_features.device, dtype=train_features.dtype)
+    aniso = not isinstance(spec.length_scale, (int, float)) and len(spec.length_scale) > 1
+    for s in range(0, n, chunk):
+        idx = nn_fast[s:s + chunk].contiguous()
+        if aniso:
+            ls = _length_scale_tensor(spec.length_scale, d, train_features)
+            dist = T._reduce(T._pairwise_tensor(train_features, idx), spec.metric_id(), ls)
+            Kin = K._apply(dist, spec.kernel, 1.0)
+        else:
+            ell = float(spec.length_scale if isinstance(spec.length_scale, (int, float)) else spec.length_scale[0])
+            scale = 1.0 / ell if spec.metric == "l2" else 1.0 / ell**2
+            Kin = K._apply(T._pairwise_distances(train_features, idx, spec.metric), spec.kernel, scale)
+        if isinstance(spec.noise, torch.Tensor) and spec.noise.ndim >= 1:
+            Kin = N._heteroscedastic_perturb(Kin, spec.noise[idx] if spec.noise.ndim == 1 else spec.noise[s:s + chunk])
+        else:
+            Kin = N._homoscedastic_perturb(Kin, float(spec.noise))
+        Y = train_targets[idx].reshape(idx.shape[0], k, R)
+        out[s:s + chunk] = M._solve(Kin, None, Y, want=("coeffs",))[3]
+    return (out.reshape(n, k) if squeeze else out), nn_fast
