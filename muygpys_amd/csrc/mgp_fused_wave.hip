@@ -428,27 +428,24 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       asm volatile("" : "+v"(i3));
       T* Kh3 = tile + (NH == 1 ? 0 : (lane / NP) * NP * KS);
       if (g.mask & 4) {
+        // All NS covariances first (independent chains the scheduler can interleave), then the
+        // stores -- unconditional: an entry whose row is a response slot (hi > q) goes to the
+        // unused padding column of the last row instead of being branched around.
+        T kv[NS];
         kernel_dispatch(a.kernel_id, a.metric_id, [&](auto kid, auto mid) {
           constexpr int KID = decltype(kid)::value, MID = decltype(mid)::value;
-          if (nopad) {
 #pragma unroll
-            for (int s = 1; s <= NS; ++s) {
-              const int c = (i3 + s) & (NP - 1);
-              const int hi = max(i3, c), lo = min(i3, c);
-              const T kv = cov_from_sqdist<T>(acc_total(acc[s - 1]), KID, MID, post_scale);
-              if (hi <= q) Kh3[hi * KS + lo] = kv;
-            }
-          } else {
-#pragma unroll
-            for (int s = 1; s <= NS; ++s) {
-              const int c = (i3 + s) & (NP - 1);
-              const int hi = max(i3, c), lo = min(i3, c);
-              const bool valid = lo < k && (hi < k || hi == q);
-              const T kv = cov_from_sqdist<T>(acc_total(acc[s - 1]), KID, MID, post_scale);
-              if (hi <= q) Kh3[hi * KS + lo] = valid ? kv : T(0);
-            }
-          }
+          for (int s = 1; s <= NS; ++s) kv[s - 1] = cov_from_sqdist<T>(acc_total(acc[s - 1]), KID, MID, post_scale);
         });
+        const int dump = (NP - 1) * KS + NP;  // columns NP .. KS-1 of a row are padding
+#pragma unroll
+        for (int s = 1; s <= NS; ++s) {
+          const int c = (i3 + s) & (NP - 1);
+          const int hi = max(i3, c), lo = min(i3, c);
+          T v = kv[s - 1];
+          if (!nopad) v = (lo < k && (hi < k || hi == q)) ? v : T(0);
+          Kh3[hi <= q ? hi * KS + lo : dump] = v;
+        }
       }
       Kh3[i3 * KS + i3] = i3 < k ? T(1) + myeps : (i3 <= q ? T(1) : T(0));
       Kh3[(q + 1) * KS + i3] = myy0;
