@@ -158,7 +158,7 @@ struct WaveGeom {
 
 // KFIX / RFIX / DFIX > 0: nn_count / response_count / feature_count known at compile time
 template <typename T, int NP, int KFIX, int RFIX, int DFIX>
-__global__ __launch_bounds__(64, (sizeof(T) == 4 ? (NP == 32 ? 3 : 2) : (NP == 32 ? 2 : 1)))
+__global__ __launch_bounds__(64, (sizeof(T) == 4 ? (NP == 32 ? 3 : 2) : (NP == 32 ? 2 : 2)))
 void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   constexpr int NH = 64 / NP;     // neighbourhoods per wave
   constexpr int NS = NP / 2;      // cyclic offsets
@@ -472,14 +472,30 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       if (j < k && (g.mask & 8)) {
         const T ajj = A[j / E][j % E];
         colh[i] = ajj;
-        V col[NP / E];
+        if constexpr (sizeof(T) == 8) {
+          // fp64: the pivot first (one group), then the trailing groups streamed: load, FMA,
+          // next -- no full copy of the column is held, which keeps the 128-register rows of
+          // the big shapes out of the spill zone (2 waves/SIMD instead of 1)
+          const V cp = *reinterpret_cast<const V*>(colh + (j / E) * E);
+          const T p = cp[j % E];
+          bad = bad || !(p > T(0));
+          const V nt = V(-ajj * pivot_rcp(p));
+          A[j / E] = cp * nt + A[j / E];
 #pragma unroll
-        for (int c4 = j / E; c4 < NP / E; ++c4) col[c4] = *reinterpret_cast<const V*>(colh + c4 * E);
-        const T p = col[j / E][j % E];
-        bad = bad || !(p > T(0));
-        const V nt = V(-ajj * pivot_rcp(p));
+          for (int c4 = j / E + 1; c4 < NP / E; ++c4) {
+            const V cv = *reinterpret_cast<const V*>(colh + c4 * E);
+            A[c4] = cv * nt + A[c4];
+          }
+        } else {
+          V col[NP / E];
 #pragma unroll
-        for (int c4 = j / E; c4 < NP / E; ++c4) A[c4] = col[c4] * nt + A[c4];
+          for (int c4 = j / E; c4 < NP / E; ++c4) col[c4] = *reinterpret_cast<const V*>(colh + c4 * E);
+          const T p = col[j / E][j % E];
+          bad = bad || !(p > T(0));
+          const V nt = V(-ajj * pivot_rcp(p));
+#pragma unroll
+          for (int c4 = j / E; c4 < NP / E; ++c4) A[c4] = col[c4] * nt + A[c4];
+        }
       }
     }
 
