@@ -124,3 +124,20 @@ def require_cuda(*tensors):
     for t in tensors:
         if t is not None and not (isinstance(t, torch.Tensor) and t.is_cuda):
             raise TypeError("hip backend functions take torch tensors on a ROCm device ('cuda')")
+
+
+def raise_if_not_spd(info, what: str) -> None:
+    """Reference behaviour for an unsolvable local system: numpy.linalg.LinAlgError from
+    ``linalg.solve`` (_src/gp/muygps/numpy.py:37).  ``info`` is the device counter the kernels
+    increment per neighbourhood with a non-positive Cholesky pivot."""
+    from muygpys_amd.config import config
+
+    if info is None or not config.state.check_spd:
+        return
+    bad = int(info.item())
+    if bad:
+        import numpy as np
+
+        raise np.linalg.LinAlgError(
+            f"{what}: {bad} neighbourhood(s) are not positive definite (singular or indefinite K + noise)"
+        )

@@ -31,6 +31,7 @@ def _solve(Kin, Kcross, Y, kout=1.0, want=("mean",)):
         _lib.ptr(yk), _lib.ptr(co), _lib.ptr(info), _lib.stream_ptr(),
     )
     _lib.check(rc, "mgp_solve")
+    _lib.raise_if_not_spd(info, "mgp_solve")
     return mean, var, yk, co
 
 

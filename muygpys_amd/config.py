@@ -22,6 +22,10 @@ class _State:
         self.backend = "hip"
         self.ftype = "64"
         self.hip_enabled = None  # resolved lazily: a visible ROCm device
+        # raise numpy.linalg.LinAlgError (like the reference's linalg.solve on a singular system)
+        # when a neighbourhood is not positive definite; costs one device sync per solve call,
+        # MUYGPYS_HIP_CHECK_SPD=0 turns it off (outputs of such neighbourhoods are then NaN)
+        self.check_spd = os.environ.get("MUYGPYS_HIP_CHECK_SPD", "1") != "0"
 
     def low_precision(self) -> bool:
         """config.state.low_precision(), config.py:53."""

@@ -80,6 +80,9 @@ def _fused(Kin: lazy.LazyCov, Kcross: lazy.LazyCov, nn_targets: lazy.LazyTargets
         hit = posterior_mean_var(
             spec, c.data, a.nn_data, c.data_indices, a.nn_indices, nn_targets.targets, want_ykinvy=True, info=info
         ) + (info,)
+        from muygpys_amd import _lib
+
+        _lib.raise_if_not_spd(info, "fused posterior")
         Kin.cache.clear()  # one evaluation at a time: hyper-parameters changed -> old entries are dead
         Kin.cache[key] = hit
     return hit

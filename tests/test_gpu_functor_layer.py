@@ -125,3 +125,23 @@ def test_lbfgsb_on_gpu_improves_objective():
     new = L_BFGS_B_optimize(m, y_b, y_nn, cross, pair)
     ls = new.kernel.deformation.length_scale()
     assert 0.5 <= ls <= 20.0 and float(obj(length_scale=ls)) >= float(obj(length_scale=1.5))
+
+
+def test_singular_neighbourhood_raises_linalgerror():
+    """Reference behaviour: linalg.solve raises numpy.linalg.LinAlgError on a singular system."""
+    from muygpys_amd.gp import MuyGPS
+    from muygpys_amd.gp.deformation import F2, Isotropy
+    from muygpys_amd.gp.hyperparameter import Parameter
+    from muygpys_amd.gp.kernels import RBF
+    from muygpys_amd.gp.noise import HomoscedasticNoise
+
+    X = torch.randn(50, 4, device="cuda", dtype=torch.float64)
+    y = torch.randn(50, device="cuda", dtype=torch.float64)
+    ni = torch.tensor([[1, 1, 2, 3], [4, 5, 6, 7]], device="cuda")  # duplicate neighbour, zero nugget
+    bi = torch.tensor([0, 8], device="cuda")
+    m = MuyGPS(kernel=RBF(deformation=Isotropy(F2, length_scale=Parameter(1.0))), noise=HomoscedasticNoise(0.0))
+    for materialize in (False, True):
+        cross, pair, y_nn = m.make_predict_tensors(bi, ni, None, X, y, materialize=materialize)
+        Kin, Kc = m.kernel(pair), m.kernel(cross)
+        with pytest.raises(np.linalg.LinAlgError):
+            m.posterior_mean(Kin, Kc, y_nn)
