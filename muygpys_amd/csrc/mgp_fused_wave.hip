@@ -596,6 +596,8 @@ template <typename T>
 int launch_fused_wave(const FusedArgs& a, hipStream_t stream) {
   const int rows = a.k + 1 + a.R;
   if constexpr (sizeof(T) == 4) if (a.k == 30 && a.R == 1 && a.d == 40) {  // BASELINE configs 2/3, all shapes static
+    const int rc2 = launch_fused_wave2_f32(a, stream);
+    if (rc2 != MGP_EUNSUPPORTED) return rc2;
     const int rc = launch_np<T, 32, 30, 1, 40>(a, stream);
     if (rc != MGP_EUNSUPPORTED) return rc;
   }

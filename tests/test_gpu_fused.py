@@ -85,3 +85,37 @@ def test_non_spd_is_flagged():
     assert int(info.item()) == 1
     assert torch.isnan(mean[0]) and torch.isnan(var[0])
     assert torch.isfinite(mean[1]) and torch.isfinite(var[1])
+
+
+@pytest.mark.parametrize("name", ["m15_iso_knn_k30_d40_c2", "m25_iso_l2_k30_d40"])
+def test_two_rows_per_lane_variant_matches_golden(name):
+    """The opt-in two-rows-per-lane kernel (mgp_fused_wave2.hip) on the headline shape."""
+    from muygpys_amd import _lib
+    from muygpys_amd.fused import posterior_mean_var
+    from tests.conftest import load_golden
+
+    g = load_golden(name)
+    meta = g["meta"]
+    td = torch.float32
+    X, y = to_dev(g["features"], td), to_dev(g["targets"], td)
+    bi, ni = to_dev(g["batch_idx"]), to_dev(g["nn_idx"])
+    lib = _lib.load()
+    lib.mgp_debug_enable_wave2(1)
+    try:
+        for kernel in ("matern15", "rbf", "matern05", "matern25", "maternInf"):
+            metric = "F2" if kernel == "rbf" else "l2"
+            from muygpys_amd.fused import KernelSpec
+            from oracle import muygps_oracle as orc
+
+            spec = KernelSpec(kernel, metric, 5.0, 1e-3)
+            mean, var, yk = posterior_mean_var(spec, X, X, bi, ni, y, want_ykinvy=True)
+            torch.cuda.synchronize()
+            m_ref, v_ref = orc.posterior_mean_var(orc.Spec(kernel, metric, 5.0, 1e-3), g["features"], g["features"],
+                                                   g["batch_idx"], g["nn_idx"], g["targets"])
+            assert_close(mean.cpu().numpy(), m_ref, RTOL["float32"], f"mean {kernel}")
+            assert_close(var.cpu().numpy(), v_ref, RTOL["float32"], f"var {kernel}")
+            s_ref = orc.sigma_sq(orc.Spec(kernel, metric, 5.0, 1e-3), g["features"], g["nn_idx"], g["targets"])
+            b, k = g["nn_idx"].shape
+            assert_close([float(yk.double().sum() / (b * k))], [s_ref], RTOL["float32"], f"sigma_sq {kernel}")
+    finally:
+        lib.mgp_debug_enable_wave2(0)

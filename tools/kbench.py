@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--metric", default="l2")
     ap.add_argument("--grids", default="0")
     ap.add_argument("--ldspad", type=int, default=0)
+    ap.add_argument("--wave2", default="1")
     args = ap.parse_args()
     dev = torch.device("cuda")
     td = torch.float32 if args.dtype == "f32" else torch.float64
@@ -47,14 +48,15 @@ def main():
     var = torch.empty((args.b,), device=dev, dtype=td)
     lib = _lib.load()
     lib.mgp_debug_set_lds_pad(args.ldspad)
-    variants = [(int(m), int(g), int(pc)) for g in args.generic.split(",") for m in args.masks.split(",")
-                for pc in args.grids.split(",")]
+    variants = [(int(m), int(g), int(pc), int(w2)) for g in args.generic.split(",") for m in args.masks.split(",")
+                for pc in args.grids.split(",") for w2 in args.wave2.split(",")]
     times = {v: [] for v in variants}
     for r in range(args.rounds + 1):
         for v in variants:
             lib.mgp_debug_set_phase_mask(v[0])
             lib.mgp_debug_force_generic(v[1])
             lib.mgp_debug_set_grid_per_cu(v[2])
+            lib.mgp_debug_enable_wave2(v[3])
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             posterior_mean_var(spec, Xd, Xd, bi, ni, yd, out_mean=mean, out_var=var)
@@ -64,7 +66,7 @@ def main():
                 times[v].append(e0.elapsed_time(e1))
     for v in variants:
         t = np.array(times[v])
-        print(f"mask={v[0]:2d} generic={v[1]} grid/cu={v[2]:2d} median {np.median(t):8.3f} ms  min {t.min():8.3f} ms  "
+        print(f"mask={v[0]:2d} generic={v[1]} grid/cu={v[2]:2d} wave2={v[3]} median {np.median(t):8.3f} ms  min {t.min():8.3f} ms  "
               f"-> {args.b / np.median(t) / 1e3:8.1f} M nbhd/s")
 
 
