@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--grids", default="0")
     ap.add_argument("--ldspad", type=int, default=0)
     ap.add_argument("--wave2", default="1")
+    ap.add_argument("--hot-rows", type=int, default=0, help="restrict neighbour rows to the first N (cache-resident gather)")
     args = ap.parse_args()
     dev = torch.device("cuda")
     td = torch.float32 if args.dtype == "f32" else torch.float64
@@ -42,6 +43,9 @@ def main():
         yd = yd[:, None].repeat(1, args.R).contiguous() * torch.linspace(0.5, 1.5, args.R, device=dev, dtype=td)
     bi, ni = random_neighbors(args.n, args.b, args.k, 1)
     bi, ni = torch.from_numpy(bi).to(dev), torch.from_numpy(ni).to(dev)
+    if args.hot_rows:
+        ni = ni % args.hot_rows
+        bi = bi % args.hot_rows + args.hot_rows
     ls = [5.0] * args.d if args.aniso else 5.0
     spec = KernelSpec(args.kernel, args.metric, ls, 1e-3)
     mean = torch.empty((args.b, args.R), device=dev, dtype=td)
