@@ -119,3 +119,42 @@ def test_two_rows_per_lane_variant_matches_golden(name):
             assert_close([float(yk.double().sum() / (b * k))], [s_ref], RTOL["float32"], f"sigma_sq {kernel}")
     finally:
         lib.mgp_debug_enable_wave2(0)
+
+
+@pytest.mark.parametrize("mode", ["aniso", "hetero_table", "hetero_batch", "no_batch_idx", "odd_batch"])
+def test_static_headline_shape_variants(mode):
+    """The compile-time-shape instantiation (k=30, d=40, R=1, fp32) with the run-time options it
+    still has to honour: per-feature length scales, both heteroscedastic layouts, identity batch
+    indices, an odd number of neighbourhoods (half-empty last wave)."""
+    from muygpys_amd.fused import KernelSpec, posterior_mean_var
+
+    rng = np.random.default_rng(99)
+    N, d, k, b = 3000, 40, 30, 257
+    X = rng.normal(size=(N, d))
+    y = np.sin(X[:, :3].sum(1)) + 0.1 * rng.normal(size=N)
+    bi = rng.choice(N, size=b, replace=False)
+    ni = np.stack([rng.choice(np.delete(np.arange(N), i), size=k, replace=False) for i in bi])
+    ls, noise_o, noise_d = 5.0, 1e-3, 1e-3
+    Q, bi_o, bi_d = X, bi, to_dev(bi)
+    if mode == "aniso":
+        ls = list(rng.uniform(3.0, 8.0, size=d))
+    elif mode == "hetero_table":
+        noise_o = 10.0 ** rng.uniform(-4, -2, size=N)
+        noise_d = to_dev(noise_o, torch.float32)
+    elif mode == "hetero_batch":
+        table = 10.0 ** rng.uniform(-4, -2, size=N)
+        noise_o = table
+        noise_d = to_dev(table[ni], torch.float32)
+    elif mode == "no_batch_idx":
+        Q = X[bi]
+        bi_o, bi_d = np.arange(b), None
+    ospec = orc.Spec("matern15", "l2", np.asarray(ls) if isinstance(ls, list) else ls, noise_o)
+    m_ref, v_ref = orc.posterior_mean_var(ospec, Q, X, bi_o, ni, y)
+    spec = KernelSpec("matern15", "l2", ls, noise_d)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    mean, var = posterior_mean_var(spec, to_dev(Q, torch.float32), to_dev(X, torch.float32), bi_d, to_dev(ni),
+                                   to_dev(y, torch.float32), info=info)
+    torch.cuda.synchronize()
+    assert int(info.item()) == 0
+    assert_close(mean.cpu().numpy(), m_ref, RTOL["float32"], f"mean ({mode})")
+    assert_close(var.cpu().numpy(), v_ref, RTOL["float32"], f"var ({mode})")
