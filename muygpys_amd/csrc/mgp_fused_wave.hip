@@ -188,7 +188,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   T* colbuf = tile + tile_elems;                      // 64 entries
   T* ilbuf = PIPE_ ? tile + (NP - 1) * xs : colbuf + 64;  // dst entries (Anisotropy)
   int64_t* idxbuf = reinterpret_cast<int64_t*>(ilbuf + dst + (dst & 1));  // 64 entries (plain kernels)
-  int* idxbuf32 = reinterpret_cast<int*>(colbuf);                           // 64 entries (pipelined)
+  const T** rowaddr = reinterpret_cast<const T**>(colbuf);  // 64 row pointers (pipelined; overlays colbuf + 256 B)
 
   const T* feat_q = static_cast<const T*>(a.feat_q);
   const T* feat_nn = static_cast<const T*>(a.feat_nn);
@@ -253,18 +253,23 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   auto pipe_issue = [&](int64_t task_n, int64_t idx_n, int lane_) {
     const int h = NH == 1 ? 0 : lane_ / NP;
     const int i = lane_ & (NP - 1);
-    idxbuf32[lane_] = (int)idx_n;  // row number (< 2^31); slots without a feature row hold 0: a valid row
+    // pointer to this slot's feature row; slots without one (idx_n = 0) point at row 0 -- any
+    // valid row will do, their tile rows are never used
+    rowaddr[lane_] = (i == q ? feat_q : feat_nn) + idx_n * (int64_t)d;
     __syncthreads();
     if (g.mask & 1) {
+      // 16-byte slot sigma = 64 n + lane of the tile: row = sigma / SPR, column = sigma % SPR
+      // (unsigned 32-bit arithmetic throughout; the padding slot re-reads the last data slot)
+      const T* src[NGL];
 #pragma unroll
       for (int n = 0; n < NGL; ++n) {
-        const int sigma = 64 * n + lane_;
-        const int row = sigma / SPR;            // 0 .. NH*NP-1 (both halves)
-        int c = sigma - row * SPR;
-        c = c < C16V ? c : C16V - 1;            // padding slot: re-read the last data slot
-        const T* base = (row & (NP - 1)) == q ? feat_q : feat_nn;
-        glds16(base + (int64_t)idxbuf32[row] * d + c * E, reinterpret_cast<char*>(tile) + n * 1024);
+        const unsigned sigma = 64u * n + (unsigned)lane_;
+        const unsigned row = (sigma * ((1u << 16) / SPR + 1u)) >> 16;
+        const unsigned c = min(sigma - row * SPR, (unsigned)(C16V - 1));
+        src[n] = rowaddr[row] + c * E;
       }
+#pragma unroll
+      for (int n = 0; n < NGL; ++n) glds16(src[n], reinterpret_cast<char*>(tile) + n * 1024);
     }
     // response and nugget of the slot's row: unconditional single loads (idx_n is 0, a valid
     // row, for slots without one; the values are masked where they are consumed)
@@ -558,7 +563,7 @@ static int launch_np(const FusedArgs& a, hipStream_t stream) {
   g.ntasks = (a.b + NH - 1) / NH;
   const int rowmax = g.xs > KS ? g.xs : KS;
   constexpr bool PIPE = KFIX > 0 && DFIX > 0 && DFIX <= 64;
-  size_t lds = PIPE ? ((size_t)NH * NP * rowmax + 64) * sizeof(T)
+  size_t lds = PIPE ? (size_t)NH * NP * rowmax * sizeof(T) + 64 * sizeof(void*)
                     : ((size_t)NH * NP * rowmax + 64 + g.dst + (g.dst & 1)) * sizeof(T) + 64 * sizeof(int64_t);
   lds = ((lds + 15) & ~(size_t)15) + (size_t)g_lds_pad;
   // Persistent grid = exactly the resident capacity: every workgroup owns a fixed share of the
