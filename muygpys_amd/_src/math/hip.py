@@ -51,7 +51,10 @@ itype = int64
 
 
 def _device():
-    return torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+    """The current ROCm device; there is no host fallback (ValueError without a device, like an
+    unavailable backend in the reference, _src/config.py:230-243)."""
+    config.require_device()
+    return torch.device("cuda", torch.cuda.current_device())
 
 
 def _typed(dtype, fn):

@@ -52,3 +52,15 @@ def test_device_is_required_not_emulated():
 
     with pytest.raises(TypeError):
         T._F2(torch.zeros((3, 2)))
+
+
+def test_math_facade_has_no_host_fallback():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a device is visible")
+    import muygpys_amd._src.math as mm
+
+    for ctor in (lambda: mm.ones((2, 2)), lambda: mm.array([1.0, 2.0]), lambda: mm.arange(3)):
+        with pytest.raises(ValueError):
+            ctor()
