@@ -1,18 +1,16 @@
-from muygpys_amd._src.util import _collect_implementation
+"""Kernel family: elementwise covariance functions (reference name list: _src/gp/kernels/__init__.py:8-23)."""
 
-(
-    _rbf_fn,
-    _matern_05_fn,
-    _matern_15_fn,
-    _matern_25_fn,
-    _matern_inf_fn,
-    _matern_gen_fn,
-) = _collect_implementation(
-    "muygpys_amd._src.gp.kernels",
-    "_rbf_fn",
-    "_matern_05_fn",
-    "_matern_15_fn",
-    "_matern_25_fn",
-    "_matern_inf_fn",
-    "_matern_gen_fn",
+from muygpys_amd._src.util import export_backend
+
+__all__ = export_backend(
+    __name__,
+    globals(),
+    """
+    _rbf_fn
+    _matern_05_fn
+    _matern_15_fn
+    _matern_25_fn
+    _matern_inf_fn
+    _matern_gen_fn
+    """,
 )

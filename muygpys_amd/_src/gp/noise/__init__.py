@@ -1,12 +1,13 @@
-from muygpys_amd._src.util import _collect_implementation
+"""Noise family: nugget perturbations (reference name list: _src/gp/noise/__init__.py:8-15)."""
 
-(
-    _homoscedastic_perturb,
-    _heteroscedastic_perturb,
-    _shear_perturb33,
-) = _collect_implementation(
-    "muygpys_amd._src.gp.noise",
-    "_homoscedastic_perturb",
-    "_heteroscedastic_perturb",
-    "_shear_perturb33",
+from muygpys_amd._src.util import export_backend
+
+__all__ = export_backend(
+    __name__,
+    globals(),
+    """
+    _homoscedastic_perturb
+    _heteroscedastic_perturb
+    _shear_perturb33
+    """,
 )

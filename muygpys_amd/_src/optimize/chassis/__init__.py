@@ -1,10 +1,12 @@
-from muygpys_amd._src.util import _collect_implementation
+"""Outer optimiser drivers (reference name list: _src/optimize/chassis/__init__.py:8-15)."""
 
-(
-    _scipy_optimize,
-    _bayes_opt_optimize,
-) = _collect_implementation(
-    "muygpys_amd._src.optimize.chassis",
-    "_scipy_optimize",
-    "_bayes_opt_optimize",
+from muygpys_amd._src.util import export_backend
+
+__all__ = export_backend(
+    __name__,
+    globals(),
+    """
+    _scipy_optimize
+    _bayes_opt_optimize
+    """,
 )

@@ -1,10 +1,12 @@
-from muygpys_amd._src.util import _collect_implementation
+"""Analytic sigma^2 family (reference name list: _src/optimize/scale/__init__.py:8-15)."""
 
-(
-    _analytic_scale_optim,
-    _analytic_scale_optim_unnormalized,
-) = _collect_implementation(
-    "muygpys_amd._src.optimize.scale",
-    "_analytic_scale_optim",
-    "_analytic_scale_optim_unnormalized",
+from muygpys_amd._src.util import export_backend
+
+__all__ = export_backend(
+    __name__,
+    globals(),
+    """
+    _analytic_scale_optim
+    _analytic_scale_optim_unnormalized
+    """,
 )

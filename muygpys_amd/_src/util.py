@@ -18,6 +18,17 @@ def _collect_functions(package, *funcs):
     return tuple(getattr(__import__(package, fromlist=[f]), f) for f in funcs)
 
 
+def export_backend(module_name: str, namespace: dict, names: str):
+    """Bind the space-separated backend function ``names`` of family ``module_name`` into
+    ``namespace`` (a family package's globals) from its ``<backend>`` submodule, and return them
+    as the package's ``__all__``.  One call per family ``__init__`` replaces the reference's
+    hand-written tuple assignment around ``_collect_implementation``."""
+    wanted = names.split()
+    for name, fn in zip(wanted, _collect_implementation(module_name, *wanted)):
+        namespace[name] = fn
+    return wanted
+
+
 def auto_str(klass):
     """Same contract as util.py:35-45: print public members."""
 
