@@ -606,6 +606,10 @@ int launch_fused_wave(const FusedArgs& a, hipStream_t stream) {
     const int rc = launch_np<T, 32, 30, 1, 40>(a, stream);
     if (rc != MGP_EUNSUPPORTED) return rc;
   }
+  if (a.k == 50 && a.R == 1 && a.d == 8) {  // BASELINE config 4 shape, all shapes static
+    const int rc = launch_np<T, 64, 50, 1, 8>(a, stream);
+    if (rc != MGP_EUNSUPPORTED) return rc;
+  }
   if (rows <= 32) return launch_np<T, 32, 0, 0, 0>(a, stream);
   if (rows <= 64) return launch_np<T, 64, 0, 0, 0>(a, stream);
   return MGP_EUNSUPPORTED;
