@@ -88,6 +88,8 @@ def load():
     lib.mgp_max_nn_count.restype = _i
     lib.mgp_debug_force_generic.argtypes = [_i]
     lib.mgp_debug_force_generic.restype = None
+    lib.mgp_debug_prefer_rhs.argtypes = [_i]
+    lib.mgp_debug_prefer_rhs.restype = None
     lib.mgp_debug_enable_wave2.argtypes = [_i]
     lib.mgp_debug_enable_wave2.restype = None
     lib.mgp_debug_set_phase_mask.argtypes = [_i]

@@ -40,6 +40,8 @@ template <typename T> int launch_fused_generic(const FusedArgs&, hipStream_t);
 template <typename T> int launch_solve_generic(const SolveArgs&, hipStream_t);
 // register-resident wave-per-neighbourhood kernels; MGP_EUNSUPPORTED when the shape is not covered
 template <typename T> int launch_fused_wave(const FusedArgs&, hipStream_t);
+// k <= 64 with up to 16 responses carried as right-hand-side columns (mgp_fused_rhs.hip)
+template <typename T> int launch_fused_rhs(const FusedArgs&, hipStream_t);
 int launch_fused_wave2_f32(const FusedArgs&, hipStream_t);  // two rows per lane, static headline shape
 int max_nn_count(int elem_size, int R);
 

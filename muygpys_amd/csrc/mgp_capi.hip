@@ -9,6 +9,7 @@ static bool valid_metric(int id) { return id == MGP_METRIC_L2 || id == MGP_METRI
 
 // 0 = let the dispatcher choose; 1 = force the generic LDS kernel (tests / A-B timing)
 static int g_force_generic = 0;
+static int g_prefer_rhs = 0;  // tests: try the rhs-columns kernel before the row form
 extern int g_phase_mask;  // mgp_fused_wave.hip (timing ablations only)
 extern int g_grid_per_cu;
 extern int g_lds_pad;
@@ -29,7 +30,9 @@ int posterior(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t*
               ls_count, 0};
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (!g_force_generic) {
-    const int rc = launch_fused_wave<T>(a, s);
+    int rc = g_prefer_rhs ? launch_fused_rhs<T>(a, s) : launch_fused_wave<T>(a, s);
+    if (rc != MGP_EUNSUPPORTED) return rc;
+    rc = g_prefer_rhs ? launch_fused_wave<T>(a, s) : launch_fused_rhs<T>(a, s);
     if (rc != MGP_EUNSUPPORTED) return rc;
   }
   return launch_fused_generic<T>(a, s);
@@ -59,6 +62,7 @@ const char* mgp_version(void) { return "muygpys_amd-hip 0.1 (gfx950)"; }
 int mgp_max_nn_count(int elem_size, int R) { return max_nn_count(elem_size, R); }
 /* test hook, not part of the public header: force the generic LDS kernel */
 void mgp_debug_force_generic(int on) { g_force_generic = on; }
+void mgp_debug_prefer_rhs(int on) { g_prefer_rhs = on; }
 void mgp_debug_set_phase_mask(int mask) { mgp::g_phase_mask = mask; }
 void mgp_debug_set_grid_per_cu(int n) { mgp::g_grid_per_cu = n; }
 void mgp_debug_set_lds_pad(int n) { mgp::g_lds_pad = n; }

@@ -1,0 +1,302 @@
+// Register-resident fused kernel, "right-hand sides as columns" form: nn_count up to 64 with
+// any number of responses (BASELINE config 5: k = 64, R = 16).
+//
+// mgp_fused_wave.hip appends the query and the R responses as extra ROWS of the local system,
+// which needs k + 1 + R lanes.  Here all 64 lanes are neighbour rows and the cross-covariance
+// c and the responses Y are carried as 1 + R extra COLUMNS, i.e. 1 + R registers per lane
+// (lane i holds c_i and Y[i][:]).  Elimination step j (LDL^T, right-looking, row per lane):
+//
+//     all lanes post A_i[j]            -> column broadcast (as in the row form)
+//     lane j posts its 1+R rhs values  -> rhs broadcast
+//     lane i > j:  t = A_i[j] / d_j;   A_i[c] -= t A_c[j] (c > j);   rhs_i[:] -= t rhs_j[:]
+//
+// After k steps lane j holds u_j = (L^-1 c)_j and (L^-1 y_r)_j, and with its pivot d_j
+//     var = Kout - sum_j u_j^2 / d_j,  mean_r = sum_j u_j uy_jr / d_j,  y_r^T K^-1 y_r = sum_j uy_jr^2 / d_j
+// are cross-lane sums.  Same maths as SURVEY.md sec. 8a rows S1-S3
+// (_src/gp/muygps/numpy.py:17-67, _src/optimize/scale/numpy.py:9-15), one factorisation.
+//
+// One wave (= one workgroup) per neighbourhood; phases 0-3 as in mgp_fused_wave.hip (register
+// staged row-walking gather; cyclic difference-form distances among the k rows plus one
+// crosswise distance per lane; covariances exchanged through LDS into row-per-lane registers).
+#include "mgp_wave_common.h"
+
+namespace mgp {
+
+struct RhsGeom {
+  int dst, xs, vec_ok;
+  int64_t ntasks;
+};
+
+template <typename T, int RC>  // RC: compiled number of response columns (run-time R <= RC)
+__global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel(FusedArgs a, RhsGeom g) {
+  constexpr int NP = 64;
+  constexpr int NS = NP / 2;
+  constexpr int E = v16<T>::N;
+  constexpr int CH = 2 * E;
+  constexpr int KS = NP + E;
+  constexpr int NR = 1 + RC;                       // rhs columns: cross-covariance + responses
+  constexpr int NRV = (NR + E - 1) / E;            // ... in 16-byte groups
+  using V = typename v16<T>::type;
+  using ACC = typename v16<T>::acc;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int k = a.k, d = a.d, R = a.R, xs = g.xs, dst = g.dst;
+  const int rows_x = NP + 1;                       // tile rows: 64 slots + the query
+  const int tile_elems = rows_x * xs > NP * KS ? rows_x * xs : NP * KS;
+  T* tile = reinterpret_cast<T*>(smem);            // feature tile, later the exchange matrix
+  T* colbuf = tile + tile_elems;                   // 64
+  T* rhsbuf = colbuf + 64;                         // NRV * E
+  T* ilbuf = rhsbuf + NRV * E;                     // dst
+  int64_t* idxbuf = reinterpret_cast<int64_t*>(ilbuf + dst + (dst & 1));  // 65
+
+  const T* feat_q = static_cast<const T*>(a.feat_q);
+  const T* feat_nn = static_cast<const T*>(a.feat_nn);
+  const T* targets = static_cast<const T*>(a.targets);
+  const T* noise_dev = static_cast<const T*>(a.noise_dev);
+  const T* ls = static_cast<const T*>(a.length_scale);
+  const bool aniso = a.ls_count > 1;
+  T post_scale = T(1);
+  if (!aniso) {
+    const T l = ls[0];
+    post_scale = a.metric_id == MGP_METRIC_L2 ? T(1) / l : T(1) / (l * l);
+  }
+
+  for (int64_t nb = blockIdx.x; nb < g.ntasks; nb += gridDim.x) {
+    int i = threadIdx.x;
+    asm volatile("" : "+v"(i));  // keep per-lane addresses out of LICM (register pressure)
+
+    // ---- indices, nugget, responses ------------------------------------------------------
+    int64_t myidx = 0;
+    if (i < k) myidx = a.nn_idx[nb * k + i];
+    const int64_t qidx = a.batch_idx ? a.batch_idx[nb] : nb;
+    __syncthreads();
+    idxbuf[i] = myidx * (int64_t)d;
+    if (i == 0) idxbuf[NP] = qidx * (int64_t)d;
+    T myeps = T(0);
+    T rhs[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) rhs[r] = T(0);
+    if (i < k) {
+      if (a.noise_mode == MGP_NOISE_SCALAR) myeps = (T)a.noise_scalar;
+      else if (a.noise_mode == MGP_NOISE_TABLE) myeps = noise_dev[myidx];
+      else myeps = noise_dev[nb * k + i];
+#pragma unroll
+      for (int r = 0; r < RC; ++r)
+        if (r < R) rhs[1 + r] = targets[myidx * (int64_t)R + r];
+    }
+
+    // ---- gather + distances (pairwise: cyclic scheme; crosswise: lane i vs the query) ------
+    ACC acc[NS];
+    ACC accq = ACC(0);
+    for (int d0 = 0; d0 < d; d0 += dst) {
+      const int w = min(dst, d - d0);
+      const int wp = (w + CH - 1) / CH * CH;
+      __syncthreads();
+      if (g.vec_ok) {
+        const int c16 = w / E, c16p = wp / E;
+        const int rpr = NP / c16p;
+        const int sub = (int)(((unsigned)i * ((1u << 16) / (unsigned)c16p + 1u)) >> 16);
+        const int c = i - sub * c16p;
+        const bool lane_on = sub < rpr;
+        constexpr int U = 6;
+        for (int r0 = 0; r0 <= k; r0 += U * rpr) {  // row k of this loop is the query (tile row NP)
+          V v[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int row = r0 + u * rpr + sub;
+            v[u] = V(0);
+            if (lane_on && row <= k && c < c16)
+              v[u] = *reinterpret_cast<const V*>((row < k ? feat_nn : feat_q) + idxbuf[row < k ? row : NP] + d0 + c * E);
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int row = r0 + u * rpr + sub;
+            if (lane_on && row <= k) *reinterpret_cast<V*>(tile + (row < k ? row : NP) * xs + c * E) = v[u];
+          }
+        }
+        for (int t = i; t < (NP - k) * c16p; t += NP)  // zero rows for the unused slots
+          *reinterpret_cast<V*>(tile + (k + t / c16p) * xs + (t % c16p) * E) = V(0);
+      } else {
+        const unsigned magic = (1u << 20) / (unsigned)wp + 1u;
+        for (int t = i; t < rows_x * wp; t += NP) {
+          const int row = (int)(((unsigned)t * magic) >> 20);
+          const int c = t - row * wp;
+          T v = T(0);
+          if (c < w && (row < k || row == NP)) v = ((row < k ? feat_nn : feat_q) + idxbuf[row] + d0)[c];
+          tile[row * xs + c] = v;
+        }
+      }
+      if (aniso)
+        for (int c = i; c < wp; c += 64) ilbuf[c] = c < w ? T(1) / ls[d0 + c] : T(0);
+      __syncthreads();
+      if (d0 == 0) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s] = ACC(0);
+      }
+      const T* xown = tile + i * xs;
+      const T* xq = tile + NP * xs;
+      for (int c0 = 0; c0 < wp; c0 += CH) {
+        const V own0 = *reinterpret_cast<const V*>(xown + c0);
+        const V own1 = *reinterpret_cast<const V*>(xown + c0 + E);
+        V il0 = V(1), il1 = V(1);
+        if (aniso) {
+          il0 = *reinterpret_cast<const V*>(ilbuf + c0);
+          il1 = *reinterpret_cast<const V*>(ilbuf + c0 + E);
+        }
+        const V q0 = *reinterpret_cast<const V*>(xq + c0), q1 = *reinterpret_cast<const V*>(xq + c0 + E);
+        if (aniso) {
+          accum(accq, vsub(own0, q0) * il0);
+          accum(accq, vsub(own1, q1) * il1);
+#pragma unroll
+          for (int s = 1; s <= NS; ++s) {
+            const T* xo = tile + ((i + s) & (NP - 1)) * xs + c0;
+            accum(acc[s - 1], vsub(own0, *reinterpret_cast<const V*>(xo)) * il0);
+            accum(acc[s - 1], vsub(own1, *reinterpret_cast<const V*>(xo + E)) * il1);
+          }
+        } else {
+          accum(accq, vsub(own0, q0));
+          accum(accq, vsub(own1, q1));
+#pragma unroll
+          for (int s = 1; s <= NS; ++s) {
+            const T* xo = tile + ((i + s) & (NP - 1)) * xs + c0;
+            accum(acc[s - 1], vsub(own0, *reinterpret_cast<const V*>(xo)));
+            accum(acc[s - 1], vsub(own1, *reinterpret_cast<const V*>(xo + E)));
+          }
+        }
+      }
+    }
+
+    // ---- covariances -> exchange matrix -> row per lane; cross-covariance stays in the lane ----
+    __syncthreads();
+    {
+      T kv[NS];
+      T kq = T(0);
+      kernel_dispatch(a.kernel_id, a.metric_id, [&](auto kid, auto mid) {
+        constexpr int KID = decltype(kid)::value, MID = decltype(mid)::value;
+#pragma unroll
+        for (int s = 1; s <= NS; ++s) kv[s - 1] = cov_from_sqdist<T>(acc_total(acc[s - 1]), KID, MID, post_scale);
+        kq = cov_from_sqdist<T>(acc_total(accq), KID, MID, post_scale);
+      });
+#pragma unroll
+      for (int s = 1; s <= NS; ++s) {
+        const int c = (i + s) & (NP - 1);
+        const int hi = max(i, c), lo = min(i, c);
+        tile[hi * KS + lo] = hi < k ? kv[s - 1] : T(0);  // unused slots: identity rows
+      }
+      tile[i * KS + i] = i < k ? T(1) + myeps : T(1);
+      rhs[0] = i < k ? kq : T(0);
+    }
+    __syncthreads();
+    V A[NP / E];
+#pragma unroll
+    for (int c4 = 0; c4 < NP / E; ++c4) A[c4] = *reinterpret_cast<const V*>(tile + i * KS + c4 * E);
+
+    // ---- elimination with rhs columns ----------------------------------------------------------
+    bool bad = false;
+    T mypiv = T(1);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      if (j < k) {
+        const T ajj = A[j / E][j % E];
+        colbuf[i] = ajj;
+        if (i == j) {
+#pragma unroll
+          for (int r = 0; r < NR; ++r) rhsbuf[r] = rhs[r];
+        }
+        const V cp = *reinterpret_cast<const V*>(colbuf + (j / E) * E);
+        const T p = cp[j % E];
+        bad = bad || !(p > T(0));
+        if (i == j) mypiv = p;
+        const T t = i > j ? ajj * pivot_rcp(p) : T(0);  // rows <= j are finished: leave them alone
+        const V nt = V(-t);
+        A[j / E] = cp * nt + A[j / E];
+#pragma unroll
+        for (int c4 = j / E + 1; c4 < NP / E; ++c4) {
+          const V cv = *reinterpret_cast<const V*>(colbuf + c4 * E);
+          A[c4] = cv * nt + A[c4];
+        }
+#pragma unroll
+        for (int r4 = 0; r4 < NRV; ++r4) {
+          const V rv = *reinterpret_cast<const V*>(rhsbuf + r4 * E);
+#pragma unroll
+          for (int e = 0; e < E; ++e)
+            if (r4 * E + e < NR) rhs[r4 * E + e] = fma_t(-t, rv[e], rhs[r4 * E + e]);
+        }
+      }
+    }
+
+    // ---- outputs: cross-lane sums over the k rows ---------------------------------------------
+    const T inv_d = i < k ? pivot_rcp(mypiv) : T(0);
+    const T u = rhs[0];
+    T* mean = static_cast<T*>(a.mean);
+    T* var = static_cast<T*>(a.var);
+    T* yk = static_cast<T*>(a.ykinvy);
+    const T sv = wave_sum(u * u * inv_d);
+    if (i == 0) {
+      var[nb] = bad ? num<T>::nan() : T(1) - sv;
+      if (bad && a.info) atomicAdd(a.info, 1);
+    }
+#pragma unroll
+    for (int r = 0; r < RC; ++r) {
+      if (r < R) {
+        const T sm = wave_sum(u * rhs[1 + r] * inv_d);
+        if (i == 0) mean[nb * R + r] = bad ? num<T>::nan() : sm;
+        if (yk) {
+          const T sy = wave_sum(rhs[1 + r] * rhs[1 + r] * inv_d);
+          if (i == 0) yk[nb * R + r] = bad ? num<T>::nan() : sy;
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int RC>
+static int launch_rhs(const FusedArgs& a, hipStream_t stream) {
+  constexpr int NP = 64;
+  constexpr int E = v16<T>::N;
+  constexpr int CH = 2 * E;
+  constexpr int KS = NP + E;
+  constexpr int NRV = (1 + RC + E - 1) / E;
+  RhsGeom g;
+  const int dpad = (a.d + CH - 1) / CH * CH;
+  g.dst = dpad < 64 ? dpad : 64;
+  g.xs = g.dst + E;
+  const uintptr_t align = (uintptr_t)a.feat_q | (uintptr_t)a.feat_nn;
+  g.vec_ok = (a.d % E == 0) && (align % 16 == 0);
+  g.ntasks = a.b;
+  const size_t tile_elems = (size_t)((NP + 1) * g.xs > NP * KS ? (NP + 1) * g.xs : NP * KS);
+  size_t lds = (tile_elems + 64 + NRV * E + g.dst + (g.dst & 1)) * sizeof(T) + 66 * sizeof(int64_t);
+  lds = (lds + 15) & ~(size_t)15;
+  static int cached_lds = -1, cached_per_cu = 0, cached_cus = 0;
+  if (cached_lds != (int)lds) {
+    int dev = 0, n = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MGP_EHIP;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        &n, reinterpret_cast<const void*>(&fused_rhs_kernel<T, RC>), 64, lds);
+    if (e != hipSuccess) return -(1000 + (int)e);
+    const int by_lds = (int)((160 * 1024) / (((lds + 1279) / 1280) * 1280));
+    cached_per_cu = n < by_lds ? n : by_lds;
+    cached_cus = prop.multiProcessorCount;
+    cached_lds = (int)lds;
+    if (cached_per_cu < 1) return MGP_EUNSUPPORTED;
+  }
+  int64_t grid = (int64_t)cached_cus * cached_per_cu;
+  if (grid > g.ntasks) grid = g.ntasks;
+  hipLaunchKernelGGL((fused_rhs_kernel<T, RC>), dim3((unsigned)grid), dim3(64), lds, stream, a, g);
+  MGP_HIP_CHECK_LAUNCH();
+  return MGP_OK;
+}
+
+template <typename T>
+int launch_fused_rhs(const FusedArgs& a, hipStream_t stream) {
+  if (a.k > 64) return MGP_EUNSUPPORTED;
+  if (a.R <= 4) return launch_rhs<T, 4>(a, stream);
+  if (a.R <= 16) return launch_rhs<T, 16>(a, stream);
+  return MGP_EUNSUPPORTED;
+}
+
+template int launch_fused_rhs<float>(const FusedArgs&, hipStream_t);
+template int launch_fused_rhs<double>(const FusedArgs&, hipStream_t);
+
+}  // namespace mgp

@@ -1,0 +1,123 @@
+// Device helpers shared by the register-resident wave kernels (mgp_fused_wave.hip,
+// mgp_fused_rhs.hip): 16-byte vector types, packed-f32 difference/accumulate, fast exp / sqrt /
+// reciprocal, squared distance -> covariance, direct-to-LDS load, compile-time kernel dispatch.
+#pragma once
+
+#include "mgp_args.h"
+
+namespace mgp {
+
+template <typename T> struct v16;
+template <> struct v16<float> {
+  typedef float type __attribute__((ext_vector_type(4)));
+  typedef float acc __attribute__((ext_vector_type(2)));
+  static constexpr int N = 4;
+};
+template <> struct v16<double> {
+  typedef double type __attribute__((ext_vector_type(2)));
+  typedef double acc;
+  static constexpr int N = 2;
+};
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+// packed subtract in ONE instruction (hipcc lowers a <2 x float> fsub to two v_sub_f32)
+__device__ __forceinline__ f2 pk_sub(f2 x, f2 y) {
+  f2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+__device__ __forceinline__ v16<float>::type vsub(const v16<float>::type& x, const v16<float>::type& y) {
+  v16<float>::type r;
+  r.xy = pk_sub(x.xy, y.xy);
+  r.zw = pk_sub(x.zw, y.zw);
+  return r;
+}
+__device__ __forceinline__ v16<double>::type vsub(const v16<double>::type& x, const v16<double>::type& y) {
+  return x - y;
+}
+__device__ __forceinline__ void accum(v16<float>::acc& a, const v16<float>::type& df) {
+  a = df.xy * df.xy + a;  // v_pk_fma_f32
+  a = df.zw * df.zw + a;
+}
+__device__ __forceinline__ void accum(double& a, const v16<double>::type& df) {
+  a = __builtin_fma(df.x, df.x, a);
+  a = __builtin_fma(df.y, df.y, a);
+}
+__device__ __forceinline__ float acc_total(const v16<float>::acc& a) { return a.x + a.y; }
+__device__ __forceinline__ double acc_total(const double& a) { return a; }
+
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// 1/p for the pivot: v_rcp_f32 is 1 ulp (as good as the FMAs it feeds); f64 needs refining
+__device__ __forceinline__ float pivot_rcp(float p) { return __builtin_amdgcn_rcpf(p); }
+__device__ __forceinline__ double pivot_rcp(double p) {
+  double r = __builtin_amdgcn_rcp(p);
+  double e = __builtin_fma(-p, r, 1.0);
+  r = __builtin_fma(e, r, r);
+  e = __builtin_fma(-p, r, 1.0);
+  return __builtin_fma(e, r, r);
+}
+
+// e^{-t} (t >= 0) on v_exp_f32 with a two-term log2(e) so that the argument's rounding
+// error does not scale with t: ~2 ulp, 6 instructions (libm expf is ~25).
+__device__ __forceinline__ float exp_neg(float t) {
+  const float hi = -t * 1.44269502162933349609375f;
+  const float lo = __builtin_fmaf(-t, 1.44269502162933349609375f, -hi) - t * 1.925963033500011e-08f;
+  const float e = __builtin_amdgcn_exp2f(hi);
+  return __builtin_fmaf(e * lo, 0.693147180559945f, e);
+}
+__device__ __forceinline__ double exp_neg(double t) { return ::exp(-t); }
+__device__ __forceinline__ float sqrt_fast(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ double sqrt_fast(double x) { return ::sqrt(x); }
+
+// squared distance -> covariance; same formulas as kernel_eval/metric_arg in mgp_device.h
+// (_src/gp/kernels/numpy.py:12-31, gp/deformation/metric.py:241,264)
+template <typename T>
+__device__ __forceinline__ T cov_from_sqdist(T acc, int kernel_id, int metric_id, T post_scale) {
+  const T x = (metric_id == MGP_METRIC_L2 ? sqrt_fast(acc) : acc) * post_scale;
+  switch (kernel_id) {  // callers pass compile-time ids (see KERNEL_DISPATCH): no branch survives
+    case MGP_KERNEL_RBF:
+      return exp_neg(x * T(0.5));
+    case MGP_KERNEL_MATERN_05:
+      return exp_neg(x);
+    case MGP_KERNEL_MATERN_15: {
+      const T t = x * T(1.7320508075688772935);
+      return (T(1) + t) * exp_neg(t);
+    }
+    case MGP_KERNEL_MATERN_25: {
+      const T t = x * T(2.2360679774997896964);
+      return (T(1) + t + t * t * T(1.0 / 3.0)) * exp_neg(t);
+    }
+    default:
+      return exp_neg(x * x * T(0.5));
+  }
+}
+
+// 16 bytes per lane straight from global memory into LDS (no VGPR round trip): the LDS
+// destination is the wave-uniform pointer + lane * 16, the global source is per lane.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// Call f(ic<KID>, ic<MID>) with kernel id and metric id as compile-time constants: the uniform
+// switch is taken once per task instead of once per matrix entry.
+template <int V> struct ic { static constexpr int value = V; };
+template <int MID, typename F>
+__device__ __forceinline__ void kernel_dispatch_m(int kernel_id, F&& f) {
+  switch (kernel_id) {
+    case MGP_KERNEL_RBF: f(ic<MGP_KERNEL_RBF>{}, ic<MID>{}); break;
+    case MGP_KERNEL_MATERN_05: f(ic<MGP_KERNEL_MATERN_05>{}, ic<MID>{}); break;
+    case MGP_KERNEL_MATERN_15: f(ic<MGP_KERNEL_MATERN_15>{}, ic<MID>{}); break;
+    case MGP_KERNEL_MATERN_25: f(ic<MGP_KERNEL_MATERN_25>{}, ic<MID>{}); break;
+    default: f(ic<MGP_KERNEL_MATERN_INF>{}, ic<MID>{}); break;
+  }
+}
+template <typename F>
+__device__ __forceinline__ void kernel_dispatch(int kernel_id, int metric_id, F&& f) {
+  if (metric_id == MGP_METRIC_L2) kernel_dispatch_m<MGP_METRIC_L2>(kernel_id, f);
+  else kernel_dispatch_m<MGP_METRIC_F2>(kernel_id, f);
+}
+
+}  // namespace mgp

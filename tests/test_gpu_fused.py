@@ -158,3 +158,35 @@ def test_static_headline_shape_variants(mode):
     assert int(info.item()) == 0
     assert_close(mean.cpu().numpy(), m_ref, RTOL["float32"], f"mean ({mode})")
     assert_close(var.cpu().numpy(), v_ref, RTOL["float32"], f"var ({mode})")
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_rhs_columns_kernel_matches_golden(golden, dtype):
+    """The right-hand-sides-as-columns kernel (mgp_fused_rhs.hip: k <= 64, R <= 16) on every
+    fixture it covers, forced ahead of the row form."""
+    from muygpys_amd import _lib
+    from muygpys_amd.fused import posterior_mean_var
+
+    g, meta = golden, golden["meta"]
+    if meta["k"] > 64 or meta["R"] > 16:
+        pytest.skip("outside the kernel's range")
+    if dtype == "float32" and meta["d"] < 10 and meta["noise"] < 1e-4 and not meta.get("hetero"):
+        pytest.skip("fp32 at tiny nugget / low d is ill-conditioned (reference skips it too)")
+    td = getattr(torch, dtype)
+    X, y = to_dev(g["features"], td), to_dev(g["targets"], td)
+    bi, ni = to_dev(g["batch_idx"]), to_dev(g["nn_idx"])
+    lib = _lib.load()
+    lib.mgp_debug_prefer_rhs(1)
+    try:
+        info = torch.zeros(1, dtype=torch.int32, device="cuda")
+        mean, var, yk = posterior_mean_var(_kspec(meta, g, td), X, X, bi, ni, y, want_ykinvy=True, info=info)
+        torch.cuda.synchronize()
+    finally:
+        lib.mgp_debug_prefer_rhs(0)
+    assert int(info.item()) == 0
+    rtol = RTOL[dtype]
+    assert_close(mean.cpu().numpy(), g["mean"], rtol, "mean")
+    assert_close(var.cpu().numpy(), g["var_unscaled"], rtol, "var")
+    b, k = g["nn_idx"].shape
+    sig = yk.double().sum(dim=0).cpu().numpy().reshape(-1) / (b * k)
+    assert_close(sig, g["sigma_sq"], rtol, "sigma_sq")

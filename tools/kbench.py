@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--grids", default="0")
     ap.add_argument("--ldspad", type=int, default=0)
     ap.add_argument("--wave2", default="1")
+    ap.add_argument("--prefer-rhs", type=int, default=0)
     ap.add_argument("--hot-rows", type=int, default=0, help="restrict neighbour rows to the first N (cache-resident gather)")
     args = ap.parse_args()
     dev = torch.device("cuda")
@@ -52,6 +53,7 @@ def main():
     var = torch.empty((args.b,), device=dev, dtype=td)
     lib = _lib.load()
     lib.mgp_debug_set_lds_pad(args.ldspad)
+    lib.mgp_debug_prefer_rhs(args.prefer_rhs)
     variants = [(int(m), int(g), int(pc), int(w2)) for g in args.generic.split(",") for m in args.masks.split(",")
                 for pc in args.grids.split(",") for w2 in args.wave2.split(",")]
     times = {v: [] for v in variants}
