@@ -99,6 +99,49 @@ int mgp_posterior_f64(const double* feat_q, const double* feat_nn, int d,
                       double* mean, double* var, double* ykinvy, int* info, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * Backward pass of the fused hot path (vector-Jacobian product).  Replaces what
+ * torch autograd derives for the reference's torch backend when a deep-kernel
+ * model trains through MuyGPs_layer (torch/muygps_layer.py:129-164,
+ * torch/multivariate_muygps_layer.py:117-154; loss.sum().backward() at
+ * examples/muygps_torch.py:425-437): the cotangents of
+ *   mean (b,R) = Kcross K^-1 Y   and   var (b) = 1 - Kcross K^-1 Kcross
+ * with respect to the feature tables, the neighbour responses, the length
+ * scale(s) and the noise diagonal, without materialising any (b,k,k,d) tensor.
+ *
+ *   forward arguments: as mgp_posterior_*.
+ *   grad_mean (b, R) / grad_var (b): upstream cotangents; either may be NULL (= 0).
+ *   grad_feat_q  (n_q, d)  and  grad_feat_nn (n_nn, d): ACCUMULATED into with
+ *       atomic adds (caller zero-fills; the two may be the same buffer when the
+ *       query and neighbour tables are the same tensor, as in LOOCV training).
+ *   grad_targets (n_nn, R): accumulated likewise.
+ *   grad_ls (b, ls_count): per-neighbourhood partials of d/d length_scale
+ *       (sum over b on the caller's side, mgp_column_sums_*).
+ *   grad_noise (b, k): cotangent of each neighbourhood's noise diagonal (sum
+ *       everything for a homoscedastic eps; scatter by nn_idx for a table).
+ *   Any grad_* output may be NULL (skipped).  Pairs at zero distance contribute
+ *   no distance gradient (torch.norm's subgradient, _src/gp/tensors/torch.py:85-86).
+ *   Non-SPD neighbourhoods leave their cotangents untouched and count in *info.
+ * ------------------------------------------------------------------------- */
+int mgp_posterior_backward_f32(const float* feat_q, const float* feat_nn, int d,
+                               const int64_t* batch_idx, const int64_t* nn_idx, int64_t b, int k,
+                               const float* targets, int R,
+                               int noise_mode, double noise_scalar, const float* noise_dev,
+                               int kernel_id, int metric_id, const float* length_scale, int ls_count,
+                               const float* grad_mean, const float* grad_var,
+                               float* grad_feat_q, float* grad_feat_nn, float* grad_targets,
+                               float* grad_ls, float* grad_noise, int* info, void* stream);
+int mgp_posterior_backward_f64(const double* feat_q, const double* feat_nn, int d,
+                               const int64_t* batch_idx, const int64_t* nn_idx, int64_t b, int k,
+                               const double* targets, int R,
+                               int noise_mode, double noise_scalar, const double* noise_dev,
+                               int kernel_id, int metric_id, const double* length_scale, int ls_count,
+                               const double* grad_mean, const double* grad_var,
+                               double* grad_feat_q, double* grad_feat_nn, double* grad_targets,
+                               double* grad_ls, double* grad_noise, int* info, void* stream);
+/* Largest nn_count the backward kernel accepts (two LDS-resident k x k triangles). */
+int mgp_max_nn_count_backward(int elem_size);
+
+/* ---------------------------------------------------------------------------
  * Materialising per-function kernels (API parity with the backend modules).
  * ------------------------------------------------------------------------- */
 

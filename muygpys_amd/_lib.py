@@ -61,6 +61,8 @@ _SIGS = {
     "solve": [_p, _p, _p, _l, _i, _i, _d, _p, _p, _p, _p, _p, _p],
     "loss_sums": [_p, _p, _p, _l, _p, _d, _d, _p, _p],
     "column_sums": [_p, _l, _i, _p, _p],
+    "posterior_backward": [_p, _p, _i, _p, _p, _l, _i, _p, _i, _i, _d, _p, _i, _i, _p, _i,
+                           _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "fast_posterior_mean": [_p, _p, _i, _p, _p, _l, _i, _p, _p, _i, _i, _i, _p, _i, _p, _p],
 }
 
@@ -86,6 +88,8 @@ def load():
     lib.mgp_version.restype = C.c_char_p
     lib.mgp_max_nn_count.argtypes = [_i, _i]
     lib.mgp_max_nn_count.restype = _i
+    lib.mgp_max_nn_count_backward.argtypes = [_i]
+    lib.mgp_max_nn_count_backward.restype = _i
     lib.mgp_debug_force_generic.argtypes = [_i]
     lib.mgp_debug_force_generic.restype = None
     lib.mgp_debug_prefer_rhs.argtypes = [_i]

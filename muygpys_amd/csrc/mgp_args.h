@@ -36,6 +36,20 @@ struct SolveArgs {
   int k, R;
 };
 
+// Vector-Jacobian product of the fused path (mgp_backward.hip); every grad_* may be NULL.
+struct BackwardArgs {
+  FusedArgs f;             // forward inputs (mean/var/ykinvy unused)
+  const void* grad_mean;   // (b, R) upstream
+  const void* grad_var;    // (b)    upstream
+  void* grad_feat_q;       // (n_q, d)   += (atomic)
+  void* grad_feat_nn;      // (n_nn, d)  += (atomic)
+  void* grad_targets;      // (n_nn, R)  += (atomic)
+  void* grad_ls;           // (b, ls_count) per-neighbourhood partials
+  void* grad_noise;        // (b, k) per-neighbourhood diagonal cotangent
+};
+template <typename T> int launch_backward(const BackwardArgs&, hipStream_t);
+int max_nn_count_backward(int elem_size);
+
 template <typename T> int launch_fused_generic(const FusedArgs&, hipStream_t);
 template <typename T> int launch_solve_generic(const SolveArgs&, hipStream_t);
 // register-resident wave-per-neighbourhood kernels; MGP_EUNSUPPORTED when the shape is not covered

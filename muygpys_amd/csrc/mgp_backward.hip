@@ -1,0 +1,259 @@
+// Backward pass (vector-Jacobian product) of the fused local-GP path.
+//
+// The reference gets these gradients from torch autograd over its torch backend
+// (torch/muygps_layer.py:129-164 builds crosswise/pairwise tensors -> kernel -> posterior mean
+// and variance; examples/muygps_torch.py:425-437 calls loss.sum().backward()), which keeps every
+// (b,k,k,d) intermediate alive for the backward sweep.  Here one workgroup recomputes the local
+// system of a neighbourhood in LDS and contracts the cotangents analytically:
+//
+//   mean_r = c^T K^-1 y_r,  var = 1 - c^T K^-1 c,   a = K^-1 c,   w = K^-1 (Y gm)
+//   dL = dc . (w - 2 gv a) + sum_ij dK_ij (gv a_i a_j - a_i w_j) + sum_r gm_r a . dy_r
+//
+// so two solves (rows k and k+1 of the augmented factor, then a back-substitution) serve any
+// response count.  K_ij = kappa(x(acc_ij)) with acc = sum_d ((x_i - x_j) / l_d)^2; the chain through
+// kappa and the metric is applied per pair, and the per-point feature cotangents leave with one
+// atomic add per (point, feature).
+#include "mgp_args.h"
+#include "mgp_lds_factor.h"
+
+namespace mgp {
+
+__device__ __forceinline__ void tri_decode(int p, int& row, int& col) {
+  int a_ = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
+  while (a_ * (a_ - 1) / 2 > p) --a_;
+  while ((a_ + 1) * a_ / 2 <= p) ++a_;
+  row = a_;
+  col = p - a_ * (a_ - 1) / 2;
+}
+
+// dynamic LDS carve:
+// [idx (k+1) i64][S (k+2)*SP][Q (k+1)*SP][X (k+1)*(dc+1)][il dc][lacc dc][piv k][red 2][flag]
+template <typename T>
+__global__ void backward_kernel(BackwardArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const FusedArgs& a = g.f;
+  const int k = a.k, d = a.d, R = a.R, dc = a.dc;
+  const int rows = k + 2;
+  const int SP = lds_row_stride(k);
+  const int XP = dc + 1;
+  int64_t* idx = reinterpret_cast<int64_t*>(smem);
+  T* S = reinterpret_cast<T*>(idx + (k + 1));
+  T* Q = S + rows * SP;
+  T* X = Q + (k + 1) * SP;
+  T* il = X + (k + 1) * XP;
+  T* lacc = il + dc;
+  T* piv = lacc + dc;
+  T* red = piv + k;
+  int* flag = reinterpret_cast<int*>(red + 2);
+
+  const T* feat_q = static_cast<const T*>(a.feat_q);
+  const T* feat_nn = static_cast<const T*>(a.feat_nn);
+  const T* targets = static_cast<const T*>(a.targets);
+  const T* noise_dev = static_cast<const T*>(a.noise_dev);
+  const T* ls = static_cast<const T*>(a.length_scale);
+  const T* gmean = static_cast<const T*>(g.grad_mean);
+  const T* gvar = static_cast<const T*>(g.grad_var);
+  T* gq = static_cast<T*>(g.grad_feat_q);
+  T* gnn = static_cast<T*>(g.grad_feat_nn);
+  T* gtg = static_cast<T*>(g.grad_targets);
+  T* gls = static_cast<T*>(g.grad_ls);
+  T* gnz = static_cast<T*>(g.grad_noise);
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const bool aniso = a.ls_count > 1;
+  const bool l2 = a.metric_id == MGP_METRIC_L2;
+  const int npairs = (k + 1) * k / 2;
+
+  T post_scale = T(1), inv_l = T(1);
+  if (!aniso) {
+    inv_l = T(1) / ls[0];
+    post_scale = l2 ? inv_l : inv_l * inv_l;
+  }
+
+  for (int64_t nb = blockIdx.x; nb < a.b; nb += gridDim.x) {
+    __syncthreads();
+    for (int r = tid; r <= k; r += NT)
+      idx[r] = r < k ? a.nn_idx[nb * k + r] : (a.batch_idx ? a.batch_idx[nb] : nb);
+    if (tid == 0) red[0] = T(0);
+    __syncthreads();
+
+    // ---- forward recomputation: acc (kept in Q), covariances (S), combined right-hand side ----
+    for (int d0 = 0; d0 < d; d0 += dc) {
+      const int w = min(dc, d - d0);
+      for (int t = tid; t < (k + 1) * w; t += NT) {
+        const int r = t / w, c = t - r * w;
+        X[r * XP + c] = ((r < k ? feat_nn : feat_q) + idx[r] * (int64_t)d + d0)[c];
+      }
+      if (aniso)
+        for (int c = tid; c < w; c += NT) il[c] = T(1) / ls[d0 + c];
+      __syncthreads();
+      for (int p = tid; p < npairs; p += NT) {
+        int a_, c_;
+        tri_decode(p, a_, c_);
+        const T* xa = X + a_ * XP;
+        const T* xc = X + c_ * XP;
+        T acc = T(0);
+        for (int j = 0; j < w; ++j) {
+          T df = xa[j] - xc[j];
+          if (aniso) df *= il[j];
+          acc += df * df;
+        }
+        T* dst = Q + a_ * SP + c_;
+        *dst = d0 == 0 ? acc : *dst + acc;
+      }
+      __syncthreads();
+    }
+    for (int p = tid; p < npairs; p += NT) {
+      int a_, c_;
+      tri_decode(p, a_, c_);
+      S[a_ * SP + c_] = kernel_eval<T>(a.kernel_id, metric_arg<T>(Q[a_ * SP + c_], a.metric_id, post_scale));
+    }
+    for (int r = tid; r < k; r += NT) {
+      T eps;
+      if (a.noise_mode == MGP_NOISE_SCALAR) eps = (T)a.noise_scalar;
+      else if (a.noise_mode == MGP_NOISE_TABLE) eps = noise_dev[idx[r]];
+      else eps = noise_dev[nb * k + r];
+      S[r * SP + r] = T(1) + eps;
+      T yt = T(0);
+      if (gmean)
+        for (int q = 0; q < R; ++q) yt += gmean[nb * R + q] * targets[idx[r] * (int64_t)R + q];
+      S[(k + 1) * SP + r] = yt;
+    }
+    __syncthreads();
+    const bool bad = factor_augmented_lds<T>(S, SP, k, rows, piv, flag, tid, NT);
+    if (bad) {
+      if (tid == 0 && a.info) atomicAdd(a.info, 1);
+      continue;  // cotangents of a non-SPD neighbourhood are left untouched
+    }
+    // ---- back-substitution L^T [a w] = [z zy], both vectors at once, column oriented ----
+    T* av = S + k * SP;
+    T* wv = S + (k + 1) * SP;
+    for (int j = k - 1; j >= 0; --j) {
+      if (tid < 2) S[(k + tid) * SP + j] *= piv[j];
+      __syncthreads();
+      const T aj = av[j], wj = wv[j];
+      const T* Lj = S + j * SP;
+      for (int m = tid; m < j; m += NT) {
+        const T l = Lj[m];
+        av[m] -= l * aj;
+        wv[m] -= l * wj;
+      }
+      __syncthreads();
+    }
+    const T gv = gvar ? gvar[nb] : T(0);
+
+    // ---- cotangent of every pair's acc (overwrites Q), isotropic length-scale partial ----
+    T liso = T(0);
+    for (int p = tid; p < npairs; p += NT) {
+      int a_, c_;
+      tri_decode(p, a_, c_);
+      T gK;
+      if (a_ < k) gK = T(2) * gv * av[a_] * av[c_] - (av[a_] * wv[c_] + av[c_] * wv[a_]);
+      else gK = wv[c_] - T(2) * gv * av[c_];
+      const T acc = Q[a_ * SP + c_];
+      const T x = metric_arg<T>(acc, a.metric_id, post_scale);
+      const T kp = kernel_deriv<T>(a.kernel_id, x);
+      T dk_dacc;
+      if (l2) dk_dacc = x > T(0) ? kp * post_scale * post_scale / (T(2) * x) : T(0);
+      else dk_dacc = kp * post_scale;
+      Q[a_ * SP + c_] = gK * dk_dacc;
+      liso += gK * kp * x;
+    }
+    if (gls && !aniso) {
+      liso = wave_sum(liso);
+      if ((tid & 63) == 0) atomicAdd(&red[0], liso);
+    }
+    if (gnz)
+      for (int r = tid; r < k; r += NT) gnz[nb * k + r] = gv * av[r] * av[r] - av[r] * wv[r];
+    if (gtg && gmean)
+      for (int t = tid; t < k * R; t += NT) {
+        const int c = t / R, r = t - c * R;
+        unsafeAtomicAdd(gtg + idx[c] * (int64_t)R + r, gmean[nb * R + r] * av[c]);
+      }
+    __syncthreads();
+    if (gls && !aniso && tid == 0) gls[nb] = -(l2 ? T(1) : T(2)) * inv_l * red[0];  // dx/dl = -x/l | -2x/l
+
+    // ---- per-point feature cotangents (and anisotropic length-scale partials) ----
+    if (!gq && !gnn && !(gls && aniso)) continue;
+    for (int d0 = 0; d0 < d; d0 += dc) {
+      const int w = min(dc, d - d0);
+      __syncthreads();
+      for (int t = tid; t < (k + 1) * w; t += NT) {
+        const int r = t / w, c = t - r * w;
+        X[r * XP + c] = ((r < k ? feat_nn : feat_q) + idx[r] * (int64_t)d + d0)[c];
+      }
+      for (int c = tid; c < w; c += NT) {
+        il[c] = aniso ? T(1) / ls[d0 + c] : T(1);
+        lacc[c] = T(0);
+      }
+      __syncthreads();
+      for (int t = tid; t < (k + 1) * w; t += NT) {
+        const int i = t / w, c = t - i * w;
+        const T xi = X[i * XP + c];
+        T s = T(0), s2 = T(0);
+        for (int j = 0; j < i; ++j) {
+          const T q = Q[i * SP + j];
+          const T df = xi - X[j * XP + c];
+          s += q * df;
+          s2 += q * df * df;
+        }
+        for (int j = i + 1; j <= k; ++j) s += Q[j * SP + i] * (xi - X[j * XP + c]);
+        const T gx = T(2) * s * il[c] * il[c];
+        if (i < k) {
+          if (gnn) unsafeAtomicAdd(gnn + idx[i] * (int64_t)d + d0 + c, gx);
+        } else if (gq) {
+          unsafeAtomicAdd(gq + idx[k] * (int64_t)d + d0 + c, gx);
+        }
+        if (gls && aniso) atomicAdd(&lacc[c], s2);
+      }
+      __syncthreads();
+      if (gls && aniso)
+        for (int c = tid; c < w; c += NT)
+          gls[nb * (int64_t)a.ls_count + d0 + c] = T(-2) * il[c] * il[c] * il[c] * lacc[c];
+    }
+  }
+}
+
+static const size_t kMaxLdsBwd = 160 * 1024;
+
+template <typename T>
+static size_t backward_lds_bytes(int k, int dc) {
+  const int SP = lds_row_stride(k);
+  size_t n = (size_t)(k + 1) * sizeof(int64_t);
+  n += ((size_t)(k + 2) * SP + (size_t)(k + 1) * SP + (size_t)(k + 1) * (dc + 1) + 2 * (size_t)dc + k + 2) *
+           sizeof(T) + 16;
+  return (n + 15) & ~(size_t)15;
+}
+
+template <typename T>
+int launch_backward(const BackwardArgs& in, hipStream_t stream) {
+  BackwardArgs g = in;
+  int dc = g.f.d < 64 ? g.f.d : 64;
+  while (dc > 4 && backward_lds_bytes<T>(g.f.k, dc) > kMaxLdsBwd) dc /= 2;
+  const size_t lds = backward_lds_bytes<T>(g.f.k, dc);
+  if (lds > kMaxLdsBwd) return MGP_EUNSUPPORTED;
+  g.f.dc = dc;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&backward_kernel<T>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return -(1000 + (int)e);
+  }
+  int per_cu = (int)(kMaxLdsBwd / lds);
+  per_cu = per_cu < 1 ? 1 : (per_cu > 16 ? 16 : per_cu);
+  const int64_t full = 256LL * per_cu;
+  const int threads = g.f.k + 2 <= 64 ? 64 : (g.f.k + 2 <= 128 ? 128 : 256);
+  hipLaunchKernelGGL(backward_kernel<T>, dim3((unsigned)(g.f.b < full ? g.f.b : full)), dim3(threads), lds, stream, g);
+  MGP_HIP_CHECK_LAUNCH();
+  return MGP_OK;
+}
+
+template int launch_backward<float>(const BackwardArgs&, hipStream_t);
+template int launch_backward<double>(const BackwardArgs&, hipStream_t);
+
+int max_nn_count_backward(int elem_size) {
+  int k = 1;
+  while ((elem_size == 4 ? backward_lds_bytes<float>(k + 1, 4) : backward_lds_bytes<double>(k + 1, 4)) <= kMaxLdsBwd)
+    ++k;
+  return k;
+}
+
+}  // namespace mgp

@@ -39,6 +39,25 @@ int posterior(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t*
 }
 
 template <typename T>
+int posterior_backward(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t* ni, int64_t b, int k,
+                       const T* tg, int R, int noise_mode, double eps, const T* nd, int kernel_id, int metric_id,
+                       const T* ls, int ls_count, const T* gmean, const T* gvar, T* gfq, T* gfn, T* gtg, T* gls,
+                       T* gnz, int* info, void* stream) {
+  if (b < 0 || k < 1 || d < 1 || R < 1) return MGP_EINVAL;
+  if (b == 0) return MGP_OK;
+  if (!fq || !fn || !ni || !tg || !ls) return MGP_EINVAL;
+  if (!gmean && !gvar) return MGP_EINVAL;
+  if (!valid_kernel(kernel_id) || !valid_metric(metric_id)) return MGP_EINVAL;
+  if (noise_mode < MGP_NOISE_SCALAR || noise_mode > MGP_NOISE_BATCH) return MGP_EINVAL;
+  if (noise_mode != MGP_NOISE_SCALAR && !nd) return MGP_EINVAL;
+  if (ls_count != 1 && ls_count != d) return MGP_EINVAL;
+  BackwardArgs g{{fq, fn, bi, ni, tg, nd, ls, nullptr, nullptr, nullptr, info, b, eps, d, k, R, noise_mode, kernel_id,
+                  metric_id, ls_count, 0},
+                 gmean, gvar, gfq, gfn, gtg, gls, gnz};
+  return launch_backward<T>(g, static_cast<hipStream_t>(stream));
+}
+
+template <typename T>
 int solve(const T* Kin, const T* Kc, const T* Y, int64_t b, int k, int R, double kout, T* mean, T* var, T* yk,
           T* coeffs, int* info, void* stream) {
   if (b < 0 || k < 1 || R < 0) return MGP_EINVAL;
@@ -78,6 +97,18 @@ int mgp_posterior_f64(const double* fq, const double* fn, int d, const int64_t* 
                       const double* ls, int lsc, double* mean, double* var, double* yk, int* info, void* st) {
   return posterior<double>(fq, fn, d, bi, ni, b, k, tg, R, nm, eps, nd, kid, mid, ls, lsc, mean, var, yk, info, st);
 }
+
+#define MGP_DEFINE_BWD(SUF, T)                                                                                      \
+  int mgp_posterior_backward_##SUF(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t* ni, int64_t b, \
+                                   int k, const T* tg, int R, int nm, double eps, const T* nd, int kid, int mid,     \
+                                   const T* ls, int lsc, const T* gmean, const T* gvar, T* gfq, T* gfn, T* gtg,     \
+                                   T* gls, T* gnz, int* info, void* st) {                                            \
+    return posterior_backward<T>(fq, fn, d, bi, ni, b, k, tg, R, nm, eps, nd, kid, mid, ls, lsc, gmean, gvar, gfq,  \
+                                 gfn, gtg, gls, gnz, info, st);                                                      \
+  }
+MGP_DEFINE_BWD(f32, float)
+MGP_DEFINE_BWD(f64, double)
+int mgp_max_nn_count_backward(int elem_size) { return max_nn_count_backward(elem_size); }
 
 #define MGP_DEFINE(SUF, T)                                                                                           \
   int mgp_crosswise_diffs_##SUF(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t* ni, int64_t b,    \

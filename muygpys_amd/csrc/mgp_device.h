@@ -60,6 +60,25 @@ __device__ __forceinline__ T kernel_eval(int kernel_id, T x) {
   }
 }
 
+// d kernel_eval / d x (the kernel's own argument), for the backward pass.
+template <typename T>
+__device__ __forceinline__ T kernel_deriv(int kernel_id, T x) {
+  switch (kernel_id) {
+    case MGP_KERNEL_RBF:
+      return T(-0.5) * num<T>::exp(-x * T(0.5));
+    case MGP_KERNEL_MATERN_05:
+      return -num<T>::exp(-x);
+    case MGP_KERNEL_MATERN_15:
+      return T(-3) * x * num<T>::exp(-x * T(1.7320508075688772935));
+    case MGP_KERNEL_MATERN_25: {
+      T t = x * T(2.2360679774997896964);
+      return T(-5.0 / 3.0) * x * (T(1) + t) * num<T>::exp(-t);
+    }
+    default:  // MGP_KERNEL_MATERN_INF
+      return -x * num<T>::exp(-x * x * T(0.5));
+  }
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll

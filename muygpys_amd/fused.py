@@ -70,6 +70,10 @@ def _noise_args(noise, b: int, k: int, like: torch.Tensor):
         _lib.require_cuda(noise)
         nz = noise.to(dtype=like.dtype).contiguous()
         if nz.ndim == 1:
+            if nz.shape[0] != like.shape[0]:
+                raise ValueError(
+                    f"per-training-point noise table holds {nz.shape[0]} entries for {like.shape[0]} training points"
+                )
             return _lib.NOISE_TABLE, 0.0, nz
         if nz.shape != (b, k):
             raise ValueError(f"heteroscedastic noise tensor must have shape {(b, k)}, got {tuple(nz.shape)}")

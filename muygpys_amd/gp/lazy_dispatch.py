@@ -63,15 +63,35 @@ def _noise_key(noise):
     return ("scalar", float(noise))
 
 
-def _fused(Kin: lazy.LazyCov, Kcross: lazy.LazyCov, nn_targets: lazy.LazyTargets):
+def _wants_grad(*xs) -> bool:
+    return torch.is_grad_enabled() and any(isinstance(x, torch.Tensor) and x.requires_grad for x in xs)
+
+
+def _fused(Kin: lazy.LazyCov, Kcross: lazy.LazyCov, nn_targets: lazy.LazyTargets, differentiable=None):
     """(mean, var_unscaled_with_Kout_1, ykinvy) of a lazy triple, computed once per
-    (noise, Kcross, targets) and cached on the shared Kin cache."""
+    (noise, Kcross, targets) and cached on the shared Kin cache.
+
+    When a feature table, the targets, or a tensor-valued length scale / noise requires grad
+    (deep-kernel training through MuyGPs_layer, torch/muygps_layer.py:129-164) the launch goes
+    through :mod:`muygpys_amd.autograd`, whose backward is the HIP vector-Jacobian kernel; that
+    entry carries no ``ykinvy`` (the scale is a constant of the layer, as in the reference)."""
     from muygpys_amd.fused import KernelSpec, posterior_mean_var
 
-    key = (_noise_key(Kin.noise), id(Kcross.diffs), id(nn_targets.targets))
+    a, c = Kin.diffs, Kcross.diffs
+    if differentiable is None:
+        differentiable = _wants_grad(a.nn_data, c.data, nn_targets.targets, a.length_scale, Kin.noise)
+    key = (_noise_key(Kin.noise), id(Kcross.diffs), id(nn_targets.targets), bool(differentiable))
     hit = Kin.cache.get(key)
+    if hit is None and differentiable:
+        from muygpys_amd.autograd import posterior
+
+        spec = KernelSpec(
+            kernel=Kin.kernel, metric=a.metric, length_scale=a.length_scale,
+            noise=0.0 if Kin.noise is None else Kin.noise,
+        )
+        hit = posterior(spec, c.data, a.nn_data, c.data_indices, a.nn_indices, nn_targets.targets) + (None, None)
+        Kin.cache[key] = hit
     if hit is None:
-        a, c = Kin.diffs, Kcross.diffs
         spec = KernelSpec(
             kernel=Kin.kernel, metric=a.metric, length_scale=a.length_scale,
             noise=0.0 if Kin.noise is None else Kin.noise,
@@ -124,7 +144,7 @@ def analytic_scale_optim(Kin, nn_targets, batch_dim_count: int = 1, **kwargs):
             raise ValueError(f"cannot reshape array of size {b * k * nn_targets.targets.shape[1]} into shape ({b},{k},1)")
         nk = _noise_key(Kin.noise)
         for key, hit in Kin.cache.items():
-            if key[0] == nk and key[2] == id(nn_targets.targets):
+            if key[0] == nk and key[2] == id(nn_targets.targets) and hit[2] is not None:
                 return _scale_from_ykinvy(hit[2], Kin)
         # no sibling launch yet (MuyGPS.optimize_scale has no crosswise tensor): run the fused
         # kernel with neighbour 0 standing in as the query -- its mean/variance outputs are
@@ -136,7 +156,7 @@ def analytic_scale_optim(Kin, nn_targets, batch_dim_count: int = 1, **kwargs):
                                a.nn_indices[:, 0].contiguous(), a.length_scale),
                 Kin.kernel,
             )
-            return _scale_from_ykinvy(_fused(Kin, stand_in, nn_targets)[2], Kin)
+            return _scale_from_ykinvy(_fused(Kin, stand_in, nn_targets, differentiable=False)[2], Kin)
     return _S._analytic_scale_optim(lazy.force(Kin), lazy.force(nn_targets), batch_dim_count=batch_dim_count, **kwargs)
 
 

@@ -418,3 +418,101 @@ def loocv_objective(spec, train_features, batch_indices, nn_indices, train_targe
     if loss == "huber":
         return -pseudo_huber_fn(mean, y)
     raise ValueError(loss)
+
+
+# --------------------------------------------------------------------------
+# Backward pass: what torch autograd computes over the reference's torch backend
+# (torch/muygps_layer.py:129-164 -> loss.sum().backward(), examples/muygps_torch.py:425-437).
+# Restated as an explicit reverse sweep over the SAME operation sequence as
+# posterior_mean_var above (each forward op's adjoint, last to first), with the dense
+# (b,k,k,d) intermediates materialised like autograd keeps them.
+# Parity pin: tests/golden/grad_*.npz (generator tests/golden/make_golden_grad.py).
+# --------------------------------------------------------------------------
+
+KERNEL_DERIVS = {
+    # d kernel / d (its argument)
+    "rbf": lambda s: -0.5 * np.exp(-s / 2.0),
+    "matern05": lambda r: -np.exp(-r),
+    "matern15": lambda r: -3.0 * r * np.exp(-np.sqrt(3) * r),
+    "matern25": lambda r: -(5.0 / 3.0) * r * (1.0 + np.sqrt(5) * r) * np.exp(-np.sqrt(5) * r),
+    "maternInf": lambda r: -r * np.exp(-(r**2) / 2.0),
+}
+
+
+def _metric_adjoint(diffs, reduced, g_reduced, metric):
+    """Adjoint of _l2 / _F2 (_src/gp/tensors/torch.py:81-86); torch.norm's subgradient at 0 is 0."""
+    if metric == "F2":
+        return 2.0 * g_reduced[..., None] * diffs
+    safe = np.where(reduced > 0, reduced, 1.0)
+    return np.where(reduced[..., None] > 0, g_reduced[..., None] * diffs / safe[..., None], 0.0)
+
+
+def _kernel_adjoint(spec, diffs, g_K):
+    """Adjoint of kernel_tensors for one difference tensor: returns (g_diffs, g_length_scale)."""
+    dfn = KERNEL_DERIVS[spec.kernel]
+    if spec.anisotropic:
+        ls = np.asarray(spec.length_scale, dtype=diffs.dtype)
+        scaled = diffs / ls
+        arg = metric_reduce(scaled, spec.metric)
+        g_scaled = _metric_adjoint(scaled, arg, g_K * dfn(arg), spec.metric)
+        g_ls = -(g_scaled * diffs / ls**2).reshape(-1, ls.shape[0]).sum(axis=0)
+        return g_scaled / ls, g_ls
+    ell = float(spec.length_scale)
+    p = 1 if spec.metric == "l2" else 2
+    dist = metric_reduce(diffs, spec.metric)
+    g_arg = g_K * dfn(dist / ell**p)
+    g_ls = np.array([-(p * g_arg * dist / ell ** (p + 1)).sum()])
+    return _metric_adjoint(diffs, dist, g_arg / ell**p, spec.metric), g_ls
+
+
+def posterior_vjp(spec, test_features, train_features, batch_indices, nn_indices, train_targets,
+                  grad_mean, grad_var):
+    """Cotangents of (mean, var) = posterior_mean_var(...) contracted with (grad_mean, grad_var).
+
+    Returns a dict: ``test_features`` (n_q,d), ``train_features`` (n,d), ``targets`` (n,R),
+    ``length_scale`` (1,) or (d,), ``noise`` (scalar, or (n,) for a heteroscedastic table).
+    When the query table IS the training table (LOOCV) add the first two.
+    """
+    tg = train_targets if train_targets.ndim == 2 else train_targets[:, None]
+    gm = grad_mean if grad_mean.ndim == 2 else grad_mean[:, None]
+    b, k = nn_indices.shape
+    cd = crosswise_tensor(test_features, train_features, batch_indices, nn_indices)
+    pd = pairwise_tensor(train_features, nn_indices)
+    Kc, Kin0 = kernel_tensors(spec, cd, pd)
+    Kin = perturb(spec, Kin0, nn_indices)
+    Y = tg[nn_indices]                                   # (b,k,R)
+    A = np.linalg.solve(Kin, Kc[..., None])[..., 0]      # F = Kin^-1 Kcross, (b,k)
+
+    # mean = F^T Y ; var = 1 - F^T Kcross
+    g_A = np.einsum("br,bkr->bk", gm, Y) - grad_var[:, None] * Kc
+    g_Y = A[:, :, None] * gm[:, None, :]
+    g_Kc = -grad_var[:, None] * A
+    # F = solve(Kin, Kcross):  g_Kcross += Kin^-T g_F ;  g_Kin = -(Kin^-T g_F) F^T
+    t = np.linalg.solve(np.swapaxes(Kin, -1, -2), g_A[..., None])[..., 0]
+    g_Kc = g_Kc + t
+    g_Kin = -t[:, :, None] * A[:, None, :]
+    # perturb: Kin = Kin0 + diag(noise)
+    g_diag = np.einsum("bii->bi", g_Kin)
+    if spec.heteroscedastic:
+        g_noise = np.zeros_like(np.asarray(spec.noise, dtype=g_diag.dtype))
+        np.add.at(g_noise, nn_indices, g_diag)
+    else:
+        g_noise = g_diag.sum()
+    g_cd, g_ls_c = _kernel_adjoint(spec, cd, g_Kc)
+    g_pd, g_ls_p = _kernel_adjoint(spec, pd, g_Kin)
+    # crosswise[b,i] = q[batch[b]] - x[nn[b,i]] ; pairwise[b,i,j] = x[nn[b,i]] - x[nn[b,j]]
+    g_q = np.zeros_like(test_features, dtype=g_cd.dtype)
+    g_x = np.zeros_like(train_features, dtype=g_cd.dtype)
+    np.add.at(g_q, batch_indices, g_cd.sum(axis=1))
+    np.add.at(g_x, nn_indices, -g_cd)
+    np.add.at(g_x, nn_indices, g_pd.sum(axis=2))
+    np.add.at(g_x, nn_indices, -g_pd.sum(axis=1))
+    g_t = np.zeros_like(tg, dtype=g_Y.dtype)
+    np.add.at(g_t, nn_indices, g_Y)
+    return {
+        "test_features": g_q,
+        "train_features": g_x,
+        "targets": g_t if train_targets.ndim == 2 else g_t[:, 0],
+        "length_scale": g_ls_c + g_ls_p,
+        "noise": g_noise,
+    }

@@ -17,8 +17,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-def golden_names():
+def _npz_names():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def golden_names():
+    """Forward-path fixtures (tests/golden/make_golden.py)."""
+    return [n for n in _npz_names() if not n.startswith("grad_")]
+
+
+def grad_golden_names():
+    """Gradient fixtures from the reference's torch backend + autograd (make_golden_grad.py)."""
+    return [n for n in _npz_names() if n.startswith("grad_")]
 
 
 def load_golden(name):
@@ -40,4 +50,19 @@ def spec_from_meta(meta, g):
 
 @pytest.fixture(params=golden_names())
 def golden(request):
+    return load_golden(request.param)
+
+
+def grad_spec(meta, g):
+    """Oracle Spec + query table of a gradient fixture."""
+    from oracle.muygps_oracle import Spec
+
+    ls = np.asarray(meta["ls"], dtype=np.float64) if isinstance(meta["ls"], list) else float(meta["ls"])
+    noise = g["noise_table"] if meta["hetero"] else float(meta["eps"])
+    xq = g["test_features"] if meta["separate_test"] else g["features"]
+    return Spec(kernel=meta["kernel"], metric=meta["metric"], length_scale=ls, noise=noise), xq
+
+
+@pytest.fixture(params=grad_golden_names())
+def grad_golden(request):
     return load_golden(request.param)

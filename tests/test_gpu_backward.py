@@ -1,0 +1,264 @@
+"""GPU parity of the backward kernel (mgp_posterior_backward_*) and of the layers built on it:
+against the reference's own autograd results (tests/golden/grad_*.npz), against the oracle's
+reverse sweep on random shapes, and through a short deep-kernel training run."""
+
+import numpy as np
+import pytest
+
+from oracle import muygps_oracle as orc
+from tests.conftest import grad_spec
+from tests.util import RTOL, assert_close, to_dev
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _run(spec_o, xq_np, x_np, bi_np, ni_np, y_np, gm_np, gv_np, dtype, shared, hetero=False):
+    """Product path: autograd.posterior forward + .backward(); returns numpy grads."""
+    from muygpys_amd.autograd import posterior
+    from muygpys_amd.fused import KernelSpec
+
+    td = getattr(torch, dtype)
+    x = to_dev(x_np, td).requires_grad_(True)
+    xq = x if shared else to_dev(xq_np, td).requires_grad_(True)
+    y = to_dev(y_np, td).requires_grad_(True)
+    ls = to_dev(np.atleast_1d(spec_o.length_scale), td).requires_grad_(True)
+    if np.ndim(spec_o.noise) == 0:
+        nz = torch.tensor(float(spec_o.noise), device="cuda", dtype=td, requires_grad=True)
+    else:
+        nz = to_dev(spec_o.noise, td).requires_grad_(True)
+    spec = KernelSpec(kernel=spec_o.kernel, metric=spec_o.metric, length_scale=ls, noise=nz)
+    mean, var = posterior(spec, xq, x, to_dev(bi_np), to_dev(ni_np), y)
+    gm = to_dev(gm_np.reshape(mean.shape), td)
+    ((mean * gm).sum() + (var * to_dev(gv_np, td)).sum()).backward()
+    torch.cuda.synchronize()
+    out = dict(mean=mean.detach().cpu().numpy(), var=var.detach().cpu().numpy(), x=x.grad.cpu().numpy(),
+               y=y.grad.cpu().numpy(), ls=ls.grad.cpu().numpy(), noise=nz.grad.cpu().numpy())
+    if not shared:
+        out["xq"] = xq.grad.cpu().numpy()
+    return out
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_backward_matches_reference_autograd(grad_golden, dtype):
+    g, meta = grad_golden, grad_golden["meta"]
+    if dtype == "float32" and meta["d"] < 10 and not meta["hetero"] and float(meta["eps"]) < 1e-3:
+        pytest.skip("fp32 at tiny nugget / low d is ill-conditioned (reference skips it too, tests/gp.py:514-519)")
+    spec, xq = grad_spec(meta, g)
+    shared = not meta["separate_test"]
+    out = _run(spec, xq, g["features"], g["batch_indices"], g["nn_indices"], g["targets"], g["grad_mean"],
+               g["grad_var"], dtype, shared, meta["hetero"])
+    rtol = RTOL[dtype] * (10 if dtype == "float32" else 1)  # gradients amplify the solve's conditioning
+    assert_close(out["mean"].reshape(g["mean"].shape), g["mean"], RTOL[dtype], "mean")
+    assert_close(out["var"], g["var"], RTOL[dtype], "var")
+    assert_close(out["x"], g["g_features"], rtol, "g_features")
+    if not shared:
+        assert_close(out["xq"], g["g_test_features"], rtol, "g_test_features")
+    assert_close(out["y"].reshape(g["g_targets"].shape), g["g_targets"], rtol, "g_targets")
+    assert_close(out["ls"], g["g_length_scale"], rtol, "g_length_scale")
+    if meta["hetero"]:
+        assert_close(out["noise"], g["g_noise_table"], rtol, "g_noise_table")
+    else:
+        assert_close(out["noise"].reshape(()), g["g_noise"], rtol, "g_noise")
+
+
+CASES = [
+    # kernel, metric, aniso, d, k, R, b
+    ("matern15", "l2", False, 40, 30, 1, 700),
+    ("matern25", "l2", True, 8, 50, 1, 300),
+    ("rbf", "F2", False, 40, 64, 4, 200),
+    ("matern05", "l2", False, 5, 17, 2, 400),
+    ("maternInf", "l2", True, 70, 12, 1, 150),   # d > one LDS feature chunk
+    ("matern15", "l2", False, 3, 90, 1, 64),     # k above one wave
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"{c[0]}-{c[1]}-{'aniso' if c[2] else 'iso'}-d{c[3]}-k{c[4]}-R{c[5]}" for c in CASES])
+def test_backward_random_vs_oracle(case):
+    kernel, metric, aniso, d, k, R, b = case
+    rng = np.random.default_rng(100 + CASES.index(case))
+    n = 1500
+    X = rng.normal(size=(n, d))
+    Y = np.sin(X @ rng.normal(size=(d, R)) / np.sqrt(d)) + 0.1 * rng.normal(size=(n, R))
+    bi = rng.choice(n, size=b, replace=False)
+    ni = np.stack([rng.choice(np.setdiff1d(np.arange(n), [i]), size=k, replace=False) for i in bi])
+    # typical squared distance is 2d: a length scale near sqrt(d) keeps the kernel argument O(1)
+    ls = np.sqrt(d) * rng.uniform(0.7, 1.5, size=d) if aniso else float(np.sqrt(d))
+    spec = orc.Spec(kernel, metric, ls, 1e-2)
+    gm, gv = rng.normal(size=(b, R)), rng.normal(size=b)
+    ref = orc.posterior_vjp(spec, X, X, bi, ni, Y, gm, gv)
+    out = _run(spec, X, X, bi, ni, Y, gm, gv, "float64", True)
+    assert_close(out["x"], ref["train_features"] + ref["test_features"], 1e-5, "g_features")
+    assert_close(out["y"], ref["targets"], 1e-5, "g_targets")
+    assert_close(out["ls"], ref["length_scale"], 1e-5, "g_length_scale")
+    assert_close(out["noise"].reshape(()), ref["noise"], 1e-5, "g_noise")
+
+
+def test_backward_only_mean_or_only_var():
+    """A loss that reads only one output hands the kernel a NULL cotangent for the other."""
+    from muygpys_amd.autograd import posterior
+    from muygpys_amd.fused import KernelSpec
+
+    rng = np.random.default_rng(5)
+    n, d, k, b = 500, 6, 12, 90
+    X = rng.normal(size=(n, d))
+    Y = rng.normal(size=n)
+    bi = rng.choice(n, size=b, replace=False)
+    ni = np.stack([rng.choice(np.setdiff1d(np.arange(n), [i]), size=k, replace=False) for i in bi])
+    spec_o = orc.Spec("matern15", "l2", 2.0, 1e-2)
+    gm, gv = rng.normal(size=b), rng.normal(size=b)
+    for which in ("mean", "var"):
+        x = to_dev(X, torch.float64).requires_grad_(True)
+        mean, var = posterior(KernelSpec("matern15", "l2", 2.0, 1e-2), x, x, to_dev(bi), to_dev(ni),
+                              to_dev(Y, torch.float64))
+        if which == "mean":
+            (mean * to_dev(gm, torch.float64)).sum().backward()
+            ref = orc.posterior_vjp(spec_o, X, X, bi, ni, Y, gm, np.zeros(b))
+        else:
+            (var * to_dev(gv, torch.float64)).sum().backward()
+            ref = orc.posterior_vjp(spec_o, X, X, bi, ni, Y, np.zeros(b), gv)
+        assert_close(x.grad.cpu().numpy(), ref["train_features"] + ref["test_features"], 1e-5, which)
+
+
+def test_backward_rejects_oversized_neighbourhoods():
+    from muygpys_amd import _lib
+    from muygpys_amd.autograd import posterior
+    from muygpys_amd.fused import KernelSpec
+
+    kmax = _lib.load().mgp_max_nn_count_backward(8)
+    assert 64 <= kmax < 200
+    x = torch.randn(kmax + 50, 2, device="cuda", dtype=torch.float64, requires_grad=True)
+    ni = torch.arange(kmax + 1, device="cuda")[None, :] + 1
+    with pytest.raises(ValueError):
+        posterior(KernelSpec(), x, x, torch.zeros(1, dtype=torch.int64, device="cuda"), ni, x[:, 0].detach())
+
+
+def _toy_problem(dtype, n=600, d=12, k=16, b=200, R=2, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    X = torch.randn(n, d, generator=g, dtype=dtype)
+    W = torch.randn(d, R, generator=g, dtype=dtype) / d**0.5
+    Y = torch.sin(X @ W) + 0.05 * torch.randn(n, R, generator=g, dtype=dtype)
+    return X.cuda(), Y.cuda()
+
+
+def test_muygps_layer_trains_embedding():
+    """Deep-kernel flow of tests/torch/muygps_torch.py:42-170 in miniature: an embedding followed by
+    MuyGPs_layer, lool loss, Adam; the loss must fall and gradients must reach the embedding."""
+    from muygpys_amd.gp import MuyGPS
+    from muygpys_amd.gp.deformation import Isotropy, l2
+    from muygpys_amd.gp.hyperparameter import ScalarParam
+    from muygpys_amd.gp.kernels import Matern
+    from muygpys_amd.gp.noise import HomoscedasticNoise
+    from muygpys_amd.neighbors import NN_Wrapper
+    from muygpys_amd.torch import MuyGPs_layer
+
+    torch.manual_seed(0)
+    X, Y = _toy_problem(torch.float32)
+    n, k, b = X.shape[0], 16, 200
+    nbrs = NN_Wrapper(X, k, nn_method="exact")
+    bi = torch.randperm(n, device="cuda")[:b].sort().values
+    ni = nbrs.get_batch_nns(bi)[0]
+    model = MuyGPS(
+        kernel=Matern(smoothness=ScalarParam(1.5), deformation=Isotropy(l2, length_scale=ScalarParam(2.0))),
+        noise=HomoscedasticNoise(1e-2),
+    )
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.embedding = torch.nn.Sequential(torch.nn.Linear(12, 10), torch.nn.PReLU(1), torch.nn.Linear(10, 6))
+            self.GP_layer = MuyGPs_layer(model, bi, ni, Y[bi], Y[ni])
+
+        def forward(self, x):
+            return self.GP_layer(self.embedding(x))
+
+    net = Net().cuda()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2)
+    losses = []
+    for _ in range(25):
+        opt.zero_grad()
+        pred, var = net(X)
+        assert pred.shape == (b, 2) and var.shape == (b,)
+        loss = (((pred - Y[bi]) ** 2) / var[:, None] + torch.log(var)[:, None]).sum()
+        loss.backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.embedding.parameters())
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0] - 1e-3 * abs(losses[0]), losses
+
+
+def test_muygps_layer_gradient_equals_torch_autograd_of_dense_ops():
+    """x.grad from the layer == autograd through a dense torch restatement of the same maths
+    (cdist-free: explicit differences, torch.linalg.solve), fp64."""
+    from muygpys_amd.gp import MuyGPS
+    from muygpys_amd.gp.deformation import Isotropy, l2
+    from muygpys_amd.gp.hyperparameter import ScalarParam
+    from muygpys_amd.gp.kernels import Matern
+    from muygpys_amd.gp.noise import HomoscedasticNoise
+    from muygpys_amd.torch import MuyGPs_layer
+
+    X, Y = _toy_problem(torch.float64, n=300, d=5, k=9, b=70, R=2, seed=3)
+    n, k, b = 300, 9, 70
+    g = torch.Generator().manual_seed(1)
+    bi = torch.randperm(n, generator=g)[:b].cuda()
+    ni = torch.stack([torch.randperm(n, generator=g)[:k] for _ in range(b)]).cuda()
+    ni = torch.where(ni == bi[:, None], (ni + 1) % n, ni)
+    model = MuyGPS(
+        kernel=Matern(smoothness=ScalarParam(2.5), deformation=Isotropy(l2, length_scale=ScalarParam(1.7))),
+        noise=HomoscedasticNoise(1e-2),
+    )
+    layer = MuyGPs_layer(model, bi, ni, Y[bi], Y[ni])
+    x1 = X.clone().requires_grad_(True)
+    pred, var = layer(x1)
+    gm = torch.randn(pred.shape, dtype=torch.float64, device="cuda")
+    gv = torch.randn(var.shape, dtype=torch.float64, device="cuda")
+    ((pred * gm).sum() + (var * gv).sum()).backward()
+
+    x2 = X.clone().requires_grad_(True)
+    cd = torch.linalg.norm(x2[bi][:, None, :] - x2[ni], dim=-1) / 1.7
+    pd = torch.linalg.norm(x2[ni][:, :, None, :] - x2[ni][:, None, :, :] + 0.0, dim=-1) / 1.7
+
+    def m25(r):
+        t = r * 5**0.5
+        return (1 + t + t**2 / 3) * torch.exp(-t)
+
+    Kin = m25(pd) + 1e-2 * torch.eye(k, dtype=torch.float64, device="cuda")
+    Kc = m25(cd)
+    F = torch.linalg.solve(Kin, Kc[..., None])
+    pred2 = (F.transpose(-1, -2) @ Y[ni])[:, 0, :]
+    var2 = 1 - (F[..., 0] * Kc).sum(-1)
+    ((pred2 * gm).sum() + (var2 * gv).sum()).backward()
+    assert_close(pred.detach().cpu().numpy(), pred2.detach().cpu().numpy(), 1e-5, "pred")
+    assert_close(x1.grad.cpu().numpy(), x2.grad.cpu().numpy(), 1e-5, "x.grad")
+
+
+def test_multivariate_layer_shapes_and_grad():
+    from muygpys_amd.gp import MuyGPS
+    from muygpys_amd.gp.deformation import Isotropy, l2
+    from muygpys_amd.gp.hyperparameter import ScalarParam
+    from muygpys_amd.gp.kernels import Matern
+    from muygpys_amd.gp.noise import HomoscedasticNoise
+    from muygpys_amd.torch import MultivariateMuyGPs_layer
+
+    X, Y = _toy_problem(torch.float32, n=400, d=6, k=10, b=80, R=2, seed=2)
+    g = torch.Generator().manual_seed(4)
+    bi = torch.randperm(400, generator=g)[:80].cuda()
+    ni = torch.stack([torch.randperm(400, generator=g)[:10] for _ in range(80)]).cuda()
+    models = [
+        MuyGPS(kernel=Matern(smoothness=ScalarParam(0.5), deformation=Isotropy(l2, length_scale=ScalarParam(ell))),
+               noise=HomoscedasticNoise(1e-2))
+        for ell in (1.0, 2.5)
+    ]
+    layer = MultivariateMuyGPs_layer(models, bi, ni, Y[bi], Y[ni])
+    x = X.clone().requires_grad_(True)
+    pred, var = layer(x)
+    assert pred.shape == (80, 2) and var.shape == (80, 2)
+    (pred.sum() + var.sum()).backward()
+    assert torch.isfinite(x.grad).all() and float(x.grad.abs().sum()) > 0
+    # column r equals a single-model layer with model r
+    from muygpys_amd.torch import MuyGPs_layer
+
+    single = MuyGPs_layer(models[1], bi, ni, Y[bi][:, 1:], Y[ni][:, :, 1:])
+    p1, v1 = single(X)
+    assert_close(p1.reshape(-1).cpu().numpy(), pred[:, 1].detach().cpu().numpy(), 1e-3, "col 1 mean")
+    assert_close(v1.reshape(-1).cpu().numpy(), var[:, 1].detach().cpu().numpy(), 1e-3, "col 1 var")
