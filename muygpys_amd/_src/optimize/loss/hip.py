@@ -22,14 +22,14 @@ def _sums(predictions, targets, variances=None, scale=None, huber_delta=1.5, loo
         t = t.reshape(p.shape)
     v = None
     if variances is not None:
-        if variances.ndim != 1:
+        if variances.ndim == 3:
             raise NotImplementedError("full-covariance variances are outside the hip hot path")
         v = variances.to(p.dtype).contiguous()
         if v.numel() != p.numel():
             raise ValueError("variances must have one entry per prediction (1-D responses)")
     s = None
     if scale is not None:
-        s = (scale.detach() if isinstance(scale, torch.Tensor) else torch.tensor(float(scale)))
+        s = scale.detach() if isinstance(scale, torch.Tensor) else torch.tensor(float(scale), dtype=torch.float64)
         s = s.to(device=p.device, dtype=torch.float64).reshape(-1)[:1].contiguous()
     out = torch.empty(6, device=p.device, dtype=torch.float64)
     rc = _lib.fn("loss_sums", p.dtype)(
@@ -40,6 +40,43 @@ def _sums(predictions, targets, variances=None, scale=None, huber_delta=1.5, loo
     return out
 
 
+def _wants_grad(*xs) -> bool:
+    return torch.is_grad_enabled() and any(isinstance(x, torch.Tensor) and x.requires_grad for x in xs)
+
+
+class _LoolSum(torch.autograd.Function):
+    """sum(r^2 / (s v) + log(s v)) with the HIP reduction as forward and the closed-form elementwise
+    cotangents as backward, so a deep-kernel loop (examples/muygps_torch.py:425-437) can call
+    ``loss.backward()`` on the hip backend's own loss."""
+
+    @staticmethod
+    def forward(ctx, predictions, targets, variances, scale):
+        ctx.save_for_backward(predictions, targets, variances)
+        ctx.scale = 1.0 if scale is None else float(scale)
+        return _sums(predictions.detach(), targets, variances.detach(), scale=scale)[1].to(predictions.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        p, t, v = ctx.saved_tensors
+        r = p - t.to(p.dtype).reshape(p.shape)
+        vv = v.reshape(p.shape) * ctx.scale
+        gp = g * 2.0 * r / vv if ctx.needs_input_grad[0] else None
+        gv = (g * (1.0 / vv - (r / vv) ** 2) * ctx.scale).reshape(v.shape) if ctx.needs_input_grad[2] else None
+        return gp, None, gv, None
+
+
+class _MseMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, predictions, targets):
+        ctx.save_for_backward(predictions, targets)
+        return (_sums(predictions.detach(), targets)[0] / predictions.numel()).to(predictions.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        p, t = ctx.saved_tensors
+        return g * 2.0 * (p - t.to(p.dtype).reshape(p.shape)) / p.numel(), None
+
+
 def _cross_entropy_fn(predictions, targets, **kwargs):
     """numpy.py:12-19 calls sklearn.metrics.log_loss (classification only): out of scope."""
     raise NotImplementedError("The hip backend does not implement the cross-entropy loss.")
@@ -47,16 +84,23 @@ def _cross_entropy_fn(predictions, targets, **kwargs):
 
 def _mse_fn(predictions, targets, **kwargs):
     """numpy.py:22-31."""
+    if _wants_grad(predictions):
+        return _MseMean.apply(predictions, targets)
     return (_sums(predictions, targets)[0] / predictions.numel()).to(predictions.dtype)
 
 
 def _lool_fn_unscaled(predictions, targets, variances, **kwargs):
-    """numpy.py:34-51 (1-D variance branch)."""
+    """numpy.py:34-51 (1-D variance branch; elementwise for same-shape 2-D, torch.py:62-65)."""
+    if _wants_grad(predictions, variances):
+        return _LoolSum.apply(predictions, targets, variances, None)
     return _sums(predictions, targets, variances)[1].to(predictions.dtype)
 
 
 def _lool_fn(predictions, targets, variances, scale, **kwargs):
     """numpy.py:54-61."""
+    if _wants_grad(predictions, variances):
+        sv = float(scale.detach().reshape(-1)[0]) if isinstance(scale, torch.Tensor) else float(scale)
+        return _LoolSum.apply(predictions, targets, variances, sv)
     return _sums(predictions, targets, variances, scale=scale)[1].to(predictions.dtype)
 
 

@@ -18,6 +18,8 @@
 
 namespace mgp {
 
+int g_bwd_stage = 0;  // timing ablations only: stop every neighbourhood after stage N (0 = run all)
+
 __device__ __forceinline__ void tri_decode(int p, int& row, int& col) {
   int a_ = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
   while (a_ * (a_ - 1) / 2 > p) --a_;
@@ -29,7 +31,7 @@ __device__ __forceinline__ void tri_decode(int p, int& row, int& col) {
 // dynamic LDS carve:
 // [idx (k+1) i64][S (k+2)*SP][Q (k+1)*SP][X (k+1)*(dc+1)][il dc][lacc dc][piv k][red 2][flag]
 template <typename T>
-__global__ void backward_kernel(BackwardArgs g) {
+__global__ void backward_kernel(BackwardArgs g, int stage) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const FusedArgs& a = g.f;
   const int k = a.k, d = a.d, R = a.R, dc = a.dc;
@@ -92,10 +94,18 @@ __global__ void backward_kernel(BackwardArgs g) {
         const T* xa = X + a_ * XP;
         const T* xc = X + c_ * XP;
         T acc = T(0);
-        for (int j = 0; j < w; ++j) {
-          T df = xa[j] - xc[j];
-          if (aniso) df *= il[j];
-          acc += df * df;
+        if (aniso) {
+#pragma unroll 4
+          for (int j = 0; j < w; ++j) {
+            const T df = (xa[j] - xc[j]) * il[j];
+            acc += df * df;
+          }
+        } else {
+#pragma unroll 4
+          for (int j = 0; j < w; ++j) {
+            const T df = xa[j] - xc[j];
+            acc += df * df;
+          }
         }
         T* dst = Q + a_ * SP + c_;
         *dst = d0 == 0 ? acc : *dst + acc;
@@ -119,7 +129,9 @@ __global__ void backward_kernel(BackwardArgs g) {
       S[(k + 1) * SP + r] = yt;
     }
     __syncthreads();
+    if (stage == 1) continue;
     const bool bad = factor_augmented_lds<T>(S, SP, k, rows, piv, flag, tid, NT);
+    if (stage == 2) continue;
     if (bad) {
       if (tid == 0 && a.info) atomicAdd(a.info, 1);
       continue;  // cotangents of a non-SPD neighbourhood are left untouched
@@ -139,6 +151,7 @@ __global__ void backward_kernel(BackwardArgs g) {
       }
       __syncthreads();
     }
+    if (stage == 3) continue;
     const T gv = gvar ? gvar[nb] : T(0);
 
     // ---- cotangent of every pair's acc (overwrites Q), isotropic length-scale partial ----
@@ -155,9 +168,13 @@ __global__ void backward_kernel(BackwardArgs g) {
       T dk_dacc;
       if (l2) dk_dacc = x > T(0) ? kp * post_scale * post_scale / (T(2) * x) : T(0);
       else dk_dacc = kp * post_scale;
-      Q[a_ * SP + c_] = gK * dk_dacc;
+      const T q = gK * dk_dacc;
+      Q[a_ * SP + c_] = q;  // symmetric, zero diagonal: the per-point sweep below runs a uniform loop
+      Q[c_ * SP + a_] = q;
       liso += gK * kp * x;
     }
+    for (int r = tid; r <= k; r += NT) Q[r * SP + r] = T(0);
+    if (stage == 4) continue;
     if (gls && !aniso) {
       liso = wave_sum(liso);
       if ((tid & 63) == 0) atomicAdd(&red[0], liso);
@@ -172,6 +189,7 @@ __global__ void backward_kernel(BackwardArgs g) {
     __syncthreads();
     if (gls && !aniso && tid == 0) gls[nb] = -(l2 ? T(1) : T(2)) * inv_l * red[0];  // dx/dl = -x/l | -2x/l
 
+    if (stage == 5) continue;
     // ---- per-point feature cotangents (and anisotropic length-scale partials) ----
     if (!gq && !gnn && !(gls && aniso)) continue;
     for (int d0 = 0; d0 < d; d0 += dc) {
@@ -189,16 +207,21 @@ __global__ void backward_kernel(BackwardArgs g) {
       for (int t = tid; t < (k + 1) * w; t += NT) {
         const int i = t / w, c = t - i * w;
         const T xi = X[i * XP + c];
+        const T* qi = Q + i * SP;
+        const T* xc = X + c;
         T s = T(0), s2 = T(0);
-        for (int j = 0; j < i; ++j) {
-          const T q = Q[i * SP + j];
-          const T df = xi - X[j * XP + c];
+#pragma unroll 4
+        for (int j = 0; j <= k; ++j) {
+          const T q = qi[j];
+          const T df = xi - xc[j * XP];
           s += q * df;
           s2 += q * df * df;
         }
-        for (int j = i + 1; j <= k; ++j) s += Q[j * SP + i] * (xi - X[j * XP + c]);
+        s2 *= T(0.5);  // every pair was visited from both ends
         const T gx = T(2) * s * il[c] * il[c];
-        if (i < k) {
+        if (stage == 6) {  // ablation: plain store instead of the atomic
+          if (gnn) gnn[idx[i] * (int64_t)d + d0 + c] = gx;
+        } else if (i < k) {
           if (gnn) unsafeAtomicAdd(gnn + idx[i] * (int64_t)d + d0 + c, gx);
         } else if (gq) {
           unsafeAtomicAdd(gq + idx[k] * (int64_t)d + d0 + c, gx);
@@ -241,7 +264,7 @@ int launch_backward(const BackwardArgs& in, hipStream_t stream) {
   per_cu = per_cu < 1 ? 1 : (per_cu > 16 ? 16 : per_cu);
   const int64_t full = 256LL * per_cu;
   const int threads = g.f.k + 2 <= 64 ? 64 : (g.f.k + 2 <= 128 ? 128 : 256);
-  hipLaunchKernelGGL(backward_kernel<T>, dim3((unsigned)(g.f.b < full ? g.f.b : full)), dim3(threads), lds, stream, g);
+  hipLaunchKernelGGL(backward_kernel<T>, dim3((unsigned)(g.f.b < full ? g.f.b : full)), dim3(threads), lds, stream, g, g_bwd_stage);
   MGP_HIP_CHECK_LAUNCH();
   return MGP_OK;
 }

@@ -66,11 +66,13 @@ __global__ void fused_generic_kernel(FusedArgs a) {
         const T* xc = X + c_ * XP;
         T acc = T(0);
         if (aniso) {
+#pragma unroll 4
           for (int j = 0; j < w; ++j) {
             const T df = (xa[j] - xc[j]) * il[j];
             acc += df * df;
           }
         } else {
+#pragma unroll 4
           for (int j = 0; j < w; ++j) {
             const T df = xa[j] - xc[j];
             acc += df * df;

@@ -34,6 +34,7 @@ __device__ inline bool factor_augmented_lds(T* S, int SP, int k, int rows, T* pi
     for (int i = j + tid; i < rows; i += NT) {
       T* rowi = S + i * SP;
       T s = rowi[j];
+#pragma unroll 4
       for (int m = 0; m < j; ++m) s -= rowi[m] * rowj[m];
       if (i == j) {
         if (!(s > T(0))) *bad_flag = 1;

@@ -262,3 +262,107 @@ def test_multivariate_layer_shapes_and_grad():
     p1, v1 = single(X)
     assert_close(p1.reshape(-1).cpu().numpy(), pred[:, 1].detach().cpu().numpy(), 1e-3, "col 1 mean")
     assert_close(v1.reshape(-1).cpu().numpy(), var[:, 1].detach().cpu().numpy(), 1e-3, "col 1 var")
+
+
+def _svdk(layer_cls, gp_model, bi, ni, Y, in_dim):
+    class SVDK(torch.nn.Module):
+        """embedding -> GP layer, the shape of MuyGPyS/_test/torch_utils.py:10-93."""
+
+        def __init__(self):
+            super().__init__()
+            self.embedding = torch.nn.Sequential(
+                torch.nn.Linear(in_dim, 30), torch.nn.ELU(1), torch.nn.Linear(30, 10), torch.nn.ELU(1)
+            )
+            self.batch_indices, self.batch_nn_indices = bi, ni
+            self.batch_targets, self.batch_nn_targets = Y[bi], Y[ni]
+            self.GP_layer = layer_cls(gp_model, bi, ni, Y[bi], Y[ni])
+            self.deformation = self.GP_layer.deformation
+
+        def forward(self, x):
+            return self.GP_layer(self.embedding(x))
+
+    return SVDK().cuda()
+
+
+@pytest.mark.parametrize("multivariate", [False, True])
+def test_train_deep_kernel_flow(multivariate):
+    """tests/torch/muygps_torch.py:42-170 on the hip backend: sample a batch, train the deep kernel for
+    a few iterations with the lool loss, refresh neighbours in the embedded space, predict."""
+    from muygpys_amd.examples.muygps_torch import predict_model, train_deep_kernel_muygps, update_nearest_neighbors
+    from muygpys_amd.gp import MuyGPS
+    from muygpys_amd.gp.deformation import Isotropy, l2
+    from muygpys_amd.gp.hyperparameter import ScalarParam
+    from muygpys_amd.gp.kernels import Matern
+    from muygpys_amd.gp.noise import HomoscedasticNoise
+    from muygpys_amd.neighbors import NN_Wrapper
+    from muygpys_amd.optimize.batch import sample_batch
+    from muygpys_amd.torch import MultivariateMuyGPs_layer, MuyGPs_layer
+
+    torch.manual_seed(1)
+    train_count, test_count, feature_count, nn_count, batch_count = 1000, 100, 40, 30, 500
+    R = 2 if multivariate else 1
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(train_count + test_count, feature_count, generator=g)
+    W = torch.randn(feature_count, R, generator=g) / feature_count**0.5
+    Yall = torch.sin(X @ W) + 0.05 * torch.randn(train_count + test_count, R, generator=g)
+    Xtr, Xte, Ytr, Yte = X[:train_count].cuda(), X[train_count:].cuda(), Yall[:train_count].cuda(), Yall[train_count:].cuda()
+
+    nbrs = NN_Wrapper(Xtr, nn_count, nn_method="exact")
+    bi, ni = sample_batch(nbrs, batch_count, train_count)
+    assert bi.shape == (batch_count,) and ni.shape == (batch_count, nn_count) and ni.dtype == torch.int64
+    assert not (ni == bi[:, None]).any()
+
+    def one():
+        return MuyGPS(
+            kernel=Matern(smoothness=ScalarParam(0.5), deformation=Isotropy(l2, length_scale=ScalarParam(1.0))),
+            noise=HomoscedasticNoise(1e-3),
+        )
+
+    if multivariate:
+        model = _svdk(MultivariateMuyGPs_layer, [one(), one()], bi, ni, Ytr, feature_count)
+    else:
+        model = _svdk(MuyGPs_layer, one(), bi, ni, Ytr, feature_count)
+    before = [p.detach().clone() for p in model.embedding.parameters()]
+    nbrs2, trained = train_deep_kernel_muygps(
+        model=model, train_features=Xtr, train_responses=Ytr, batch_indices=bi, nbrs_lookup=nbrs,
+        training_iterations=10, optimizer_method=torch.optim.Adam, learning_rate=1e-3, scheduler_decay=0.95,
+        loss_function="lool", update_frequency=1,
+    )
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(before, trained.embedding.parameters()))
+    assert nbrs2.feature_count == 10 and trained.batch_nn_indices.shape == (batch_count, nn_count)
+    trained.eval()
+    pred, var = predict_model(model=trained, test_features=Xte, train_features=Xtr, train_responses=Ytr,
+                              nbrs_lookup=nbrs2, nn_count=nn_count)
+    assert pred.shape == (test_count, R)
+    assert var.shape == ((test_count, R) if multivariate else (test_count,))
+    assert torch.isfinite(pred).all() and (var > 0).all()
+    mse = float(((pred - Yte) ** 2).sum() / test_count)
+    assert mse <= 3.0  # the reference's own acceptance bar (tests/torch/muygps_torch.py:56,166-168)
+    assert mse < float((Yte**2).sum() / test_count)  # and better than predicting zero
+    nbrs3, _ = update_nearest_neighbors(trained, Xtr, Ytr, bi, nn_count)
+    assert nbrs3.train_count == train_count
+
+
+def test_differentiable_losses_match_torch_expression():
+    from muygpys_amd.optimize.loss import lool_fn, lool_fn_unscaled, mse_fn
+
+    torch.manual_seed(0)
+    p = torch.randn(300, device="cuda", dtype=torch.float64, requires_grad=True)
+    t = torch.randn(300, device="cuda", dtype=torch.float64)
+    v = (torch.rand(300, device="cuda", dtype=torch.float64) + 0.1).requires_grad_(True)
+    for fn, ref in [
+        (lambda: lool_fn_unscaled(p, t, v), lambda: ((p - t) ** 2 / v + torch.log(v)).sum()),
+        (lambda: lool_fn(p, t, v, 1.7), lambda: ((p - t) ** 2 / (1.7 * v) + torch.log(1.7 * v)).sum()),
+        (lambda: mse_fn(p, t), lambda: ((p - t) ** 2).mean()),
+    ]:
+        p.grad = v.grad = None
+        a = fn()
+        a.backward()
+        gp, gv = p.grad.clone(), None if v.grad is None else v.grad.clone()
+        p.grad = v.grad = None
+        b = ref()
+        b.backward()
+        assert_close(a.detach().cpu().numpy(), b.detach().cpu().numpy(), 1e-10, "value")
+        assert_close(gp.cpu().numpy(), p.grad.cpu().numpy(), 1e-10, "d/dpred")
+        if gv is not None:
+            assert_close(gv.cpu().numpy(), v.grad.cpu().numpy(), 1e-10, "d/dvar")
