@@ -15,7 +15,8 @@ import re
 import torch  # noqa: F401  (must precede the dlopen below)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libmuygpys_hip.so")
+# MUYGPYS_HIP_LIB points at an alternative build of the same ABI (kernel A/B experiments)
+LIB_PATH = os.environ.get("MUYGPYS_HIP_LIB") or os.path.join(HERE, "lib", "libmuygpys_hip.so")
 HEADER = os.path.join(HERE, "..", "include", "muygpys_hip.h")
 
 KERNEL_IDS = {"rbf": 0, "matern05": 1, "matern15": 2, "matern25": 3, "maternInf": 4}

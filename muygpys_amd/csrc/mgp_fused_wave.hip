@@ -14,8 +14,15 @@
 //          rows padded to an odd number of 16-B slots so that ds_read_b128 of a column of
 //          rows is bank-conflict free).
 // Phase 2  distances, difference form sum((x-y)^2) (never the Gram trick: fp32 parity),
-//          each unordered pair ONCE: lane i accumulates d(i, (i+s) mod NP) for s = 1..NP/2
-//          in registers (v_pk_add_f32 / v_pk_fma_f32), reading the partner row from LDS.
+//          each unordered pair ONCE, NP/2 pairs per lane in registers (v_pk_add_f32 /
+//          v_pk_fma_f32).  LDS read bandwidth is what this phase is short of (measured: halving
+//          the partner reads at equal VALU work saves 21 % of the kernel), so the pairs are
+//          register-blocked BA x BP (BA = 4 own rows, BP = NP/8 partner rows per lane): lane i
+//          keeps own rows i + o_j, o_0 = 0, o_j = (j+1) BP + 1, and every partner row i+p
+//          (p = 1..BP) it reads serves all of them -- pair {i+p, i+o_j} has cyclic distance
+//          p for j = 0 and o_j - p in (j BP, (j+1) BP] otherwise, so the BA x BP pairs of all
+//          lanes cover the distances 1..NP/2 exactly like the one-row scheme, with 8 instead
+//          of 17 row reads at NP = 32.
 // Phase 3  kernel function + nugget, exchanged through a small LDS matrix so that lane i
 //          ends up holding row i of the augmented system
 //                [ K+eps  .   . ]
@@ -51,7 +58,10 @@ template <typename T, int NP, int KFIX, int RFIX, int DFIX>
 __global__ __launch_bounds__(64, (sizeof(T) == 4 ? (NP == 32 ? 3 : 2) : (NP == 32 ? 2 : 2)))
 void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   constexpr int NH = 64 / NP;     // neighbourhoods per wave
-  constexpr int NS = NP / 2;      // cyclic offsets
+  constexpr int NS = NP / 2;      // pairs per lane
+  constexpr int BA = 4;           // own rows per lane        } register blocking of the pair scheme,
+  constexpr int BP = NS / BA;     // partner rows per lane    } see phase 2
+  auto own_offset = [](int j) { return j == 0 ? 0 : (j + 1) * BP + 1; };
   constexpr int E = v16<T>::N;    // elements per 16 bytes
   constexpr int CH = 2 * E;       // feature chunk per inner iteration (two 16-B reads per row)
   constexpr int KS = NP + E;      // row stride of the exchange matrix: NP/E + 1 (odd) 16-B slots
@@ -279,35 +289,50 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) acc[s] = ACC(0);
       }
-      const T* xown = Xh + i * xs;
       if (g.mask & 2) {
         if (aniso) {
           for (int c0 = 0; c0 < wp; c0 += CH) {
-            const V own0 = *reinterpret_cast<const V*>(xown + c0);
-            const V own1 = *reinterpret_cast<const V*>(xown + c0 + E);
+            V own0[BA], own1[BA];
+#pragma unroll
+            for (int j = 0; j < BA; ++j) {
+              const T* xj = Xh + ((i + own_offset(j)) & (NP - 1)) * xs + c0;
+              own0[j] = *reinterpret_cast<const V*>(xj);
+              own1[j] = *reinterpret_cast<const V*>(xj + E);
+            }
             const V il0 = *reinterpret_cast<const V*>(ilbuf + c0);
             const V il1 = *reinterpret_cast<const V*>(ilbuf + c0 + E);
 #pragma unroll
-            for (int s = 1; s <= NS; ++s) {
+            for (int s = 1; s <= BP; ++s) {
               const T* xo = Xh + ((i + s) & (NP - 1)) * xs + c0;
               const V o0 = *reinterpret_cast<const V*>(xo);
               const V o1 = *reinterpret_cast<const V*>(xo + E);
-              accum(acc[s - 1], vsub(own0, o0) * il0);
-              accum(acc[s - 1], vsub(own1, o1) * il1);
+#pragma unroll
+              for (int j = 0; j < BA; ++j) {
+                accum(acc[j * BP + s - 1], vsub(own0[j], o0) * il0);
+                accum(acc[j * BP + s - 1], vsub(own1[j], o1) * il1);
+              }
             }
           }
         } else {
 #pragma unroll
           for (int c0 = 0; c0 < (DFIX > 0 ? DSTFIX : wp); c0 += CH) {
-            const V own0 = *reinterpret_cast<const V*>(xown + c0);
-            const V own1 = *reinterpret_cast<const V*>(xown + c0 + E);
+            V own0[BA], own1[BA];
 #pragma unroll
-            for (int s = 1; s <= NS; ++s) {
+            for (int j = 0; j < BA; ++j) {
+              const T* xj = Xh + ((i + own_offset(j)) & (NP - 1)) * xs + c0;
+              own0[j] = *reinterpret_cast<const V*>(xj);
+              own1[j] = *reinterpret_cast<const V*>(xj + E);
+            }
+#pragma unroll
+            for (int s = 1; s <= BP; ++s) {
               const T* xo = Xh + ((i + s) & (NP - 1)) * xs + c0;
               const V o0 = *reinterpret_cast<const V*>(xo);
               const V o1 = *reinterpret_cast<const V*>(xo + E);
-              accum(acc[s - 1], vsub(own0, o0));
-              accum(acc[s - 1], vsub(own1, o1));
+#pragma unroll
+              for (int j = 0; j < BA; ++j) {
+                accum(acc[j * BP + s - 1], vsub(own0[j], o0));
+                accum(acc[j * BP + s - 1], vsub(own1[j], o1));
+              }
             }
           }
         }
@@ -335,8 +360,10 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         const int dump = (NP - 1) * KS + NP;  // columns NP .. KS-1 of a row are padding
 #pragma unroll
         for (int s = 1; s <= NS; ++s) {
-          const int c = (i3 + s) & (NP - 1);
-          const int hi = max(i3, c), lo = min(i3, c);
+          // pair j * BP + p - 1: (own row j, partner p)
+          const int r1 = (i3 + own_offset((s - 1) / BP)) & (NP - 1);
+          const int c = (i3 + (s - 1) % BP + 1) & (NP - 1);
+          const int hi = max(r1, c), lo = min(r1, c);
           T v = kv[s - 1];
           if (!nopad) v = (lo < k && (hi < k || hi == q)) ? v : T(0);
           Kh3[hi <= q ? hi * KS + lo : dump] = v;

@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--metric", default="l2")
     ap.add_argument("--grids", default="0")
     ap.add_argument("--ldspad", type=int, default=0)
-    ap.add_argument("--wave2", default="1")
+    ap.add_argument("--wave2", default="0")
     ap.add_argument("--prefer-rhs", type=int, default=0)
     ap.add_argument("--hot-rows", type=int, default=0, help="restrict neighbour rows to the first N (cache-resident gather)")
     args = ap.parse_args()
