@@ -31,6 +31,10 @@ template <typename T, int RC>  // RC: compiled number of response columns (run-t
 __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel(FusedArgs a, RhsGeom g) {
   constexpr int NP = 64;
   constexpr int NS = NP / 2;
+  // register blocking of the pair scheme (mgp_fused_wave.hip, phase 2): BA own rows x BP partners
+  constexpr int BA = 4;
+  constexpr int BP = NS / BA;
+  auto own_offset = [](int j) { return j == 0 ? 0 : (j + 1) * BP + 1; };
   constexpr int E = v16<T>::N;
   constexpr int CH = 2 * E;
   constexpr int KS = NP + E;
@@ -133,11 +137,15 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
 #pragma unroll
         for (int s = 0; s < NS; ++s) acc[s] = ACC(0);
       }
-      const T* xown = tile + i * xs;
       const T* xq = tile + NP * xs;
       for (int c0 = 0; c0 < wp; c0 += CH) {
-        const V own0 = *reinterpret_cast<const V*>(xown + c0);
-        const V own1 = *reinterpret_cast<const V*>(xown + c0 + E);
+        V own0[BA], own1[BA];
+#pragma unroll
+        for (int j = 0; j < BA; ++j) {
+          const T* xj = tile + ((i + own_offset(j)) & (NP - 1)) * xs + c0;
+          own0[j] = *reinterpret_cast<const V*>(xj);
+          own1[j] = *reinterpret_cast<const V*>(xj + E);
+        }
         V il0 = V(1), il1 = V(1);
         if (aniso) {
           il0 = *reinterpret_cast<const V*>(ilbuf + c0);
@@ -145,22 +153,30 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
         }
         const V q0 = *reinterpret_cast<const V*>(xq + c0), q1 = *reinterpret_cast<const V*>(xq + c0 + E);
         if (aniso) {
-          accum(accq, vsub(own0, q0) * il0);
-          accum(accq, vsub(own1, q1) * il1);
+          accum(accq, vsub(own0[0], q0) * il0);
+          accum(accq, vsub(own1[0], q1) * il1);
 #pragma unroll
-          for (int s = 1; s <= NS; ++s) {
+          for (int s = 1; s <= BP; ++s) {
             const T* xo = tile + ((i + s) & (NP - 1)) * xs + c0;
-            accum(acc[s - 1], vsub(own0, *reinterpret_cast<const V*>(xo)) * il0);
-            accum(acc[s - 1], vsub(own1, *reinterpret_cast<const V*>(xo + E)) * il1);
+            const V o0 = *reinterpret_cast<const V*>(xo), o1 = *reinterpret_cast<const V*>(xo + E);
+#pragma unroll
+            for (int j = 0; j < BA; ++j) {
+              accum(acc[j * BP + s - 1], vsub(own0[j], o0) * il0);
+              accum(acc[j * BP + s - 1], vsub(own1[j], o1) * il1);
+            }
           }
         } else {
-          accum(accq, vsub(own0, q0));
-          accum(accq, vsub(own1, q1));
+          accum(accq, vsub(own0[0], q0));
+          accum(accq, vsub(own1[0], q1));
 #pragma unroll
-          for (int s = 1; s <= NS; ++s) {
+          for (int s = 1; s <= BP; ++s) {
             const T* xo = tile + ((i + s) & (NP - 1)) * xs + c0;
-            accum(acc[s - 1], vsub(own0, *reinterpret_cast<const V*>(xo)));
-            accum(acc[s - 1], vsub(own1, *reinterpret_cast<const V*>(xo + E)));
+            const V o0 = *reinterpret_cast<const V*>(xo), o1 = *reinterpret_cast<const V*>(xo + E);
+#pragma unroll
+            for (int j = 0; j < BA; ++j) {
+              accum(acc[j * BP + s - 1], vsub(own0[j], o0));
+              accum(acc[j * BP + s - 1], vsub(own1[j], o1));
+            }
           }
         }
       }
@@ -179,8 +195,9 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
       });
 #pragma unroll
       for (int s = 1; s <= NS; ++s) {
-        const int c = (i + s) & (NP - 1);
-        const int hi = max(i, c), lo = min(i, c);
+        const int r1 = (i + own_offset((s - 1) / BP)) & (NP - 1);  // pair j * BP + p - 1: (own row j, partner p)
+        const int c = (i + (s - 1) % BP + 1) & (NP - 1);
+        const int hi = max(r1, c), lo = min(r1, c);
         tile[hi * KS + lo] = hi < k ? kv[s - 1] : T(0);  // unused slots: identity rows
       }
       tile[i * KS + i] = i < k ? T(1) + myeps : T(1);
