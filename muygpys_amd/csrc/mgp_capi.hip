@@ -15,6 +15,7 @@ extern int g_grid_per_cu;
 extern int g_lds_pad;
 extern int g_wave2_enable;
 extern int g_bwd_stage;  // mgp_backward.hip
+extern int g_runtime_pipe;
 
 template <typename T>
 int posterior(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t* ni, int64_t b, int k, const T* tg,
@@ -88,6 +89,7 @@ void mgp_debug_set_grid_per_cu(int n) { mgp::g_grid_per_cu = n; }
 void mgp_debug_set_lds_pad(int n) { mgp::g_lds_pad = n; }
 void mgp_debug_enable_wave2(int on) { mgp::g_wave2_enable = on; }
 void mgp_debug_set_bwd_stage(int n) { mgp::g_bwd_stage = n; }
+void mgp_debug_runtime_pipe(int on) { mgp::g_runtime_pipe = on; }
 
 int mgp_posterior_f32(const float* fq, const float* fn, int d, const int64_t* bi, const int64_t* ni, int64_t b, int k,
                       const float* tg, int R, int nm, double eps, const float* nd, int kid, int mid, const float* ls,

@@ -40,6 +40,9 @@
 // VALU-issue bound, so the code below spends its effort on instruction
 // count: packed f32 math, compile-time shapes for the headline configuration
 // (KFIX/RFIX/DFIX), and a grid sized to exactly the resident capacity.
+#include <cstdio>
+#include <cstdlib>
+
 #include "mgp_wave_common.h"
 
 namespace mgp {
@@ -53,8 +56,9 @@ struct WaveGeom {
   int mask;      // debug: phases to execute (bit0 gather, 1 distances, 2 kernel+exchange, 3 factor)
 };
 
-// KFIX / RFIX / DFIX > 0: nn_count / response_count / feature_count known at compile time
-template <typename T, int NP, int KFIX, int RFIX, int DFIX>
+// KFIX / RFIX / DFIX > 0: nn_count / response_count / feature_count known at compile time.
+// PIPED: software-pipelined direct-to-LDS gather (one feature stage, 16-byte aligned rows).
+template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED>
 __global__ __launch_bounds__(64, (sizeof(T) == 4 ? (NP == 32 ? 3 : 2) : (NP == 32 ? 2 : 2)))
 void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   constexpr int NH = 64 / NP;     // neighbourhoods per wave
@@ -84,7 +88,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   // indices live in the column buffer (only read while the gather is issued, before the
   // factorisation writes there) and the inverse length scales in the tile row of the last slot
   // (a response slot: it has no features, and its distances are never used).
-  constexpr bool PIPE_ = KFIX > 0 && DFIX > 0 && DFIX <= 64;
+  constexpr bool PIPE_ = PIPED;
   T* colbuf = tile + tile_elems;                      // 64 entries
   T* ilbuf = PIPE_ ? tile + (NP - 1) * xs : colbuf + 64;  // dst entries (Anisotropy)
   int64_t* idxbuf = reinterpret_cast<int64_t*>(ilbuf + dst + (dst & 1));  // 64 entries (plain kernels)
@@ -144,32 +148,41 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   // LDS is free (row i of the system sits in registers) -- with direct global->LDS loads, so it
   // costs no registers and its latency hides behind the Cholesky.  One load instruction fills
   // 64 consecutive 16-byte slots of the tile (SPR slots per row, the last one padding).
-  constexpr bool PIPE = KFIX > 0 && DFIX > 0 && DFIX <= 64;
-  constexpr int SPR = DSTFIX / E + 1;                       // 16-byte slots per staged row
-  constexpr int C16V = DFIX / E;                            // ... of which hold data
-  constexpr int NGL = PIPE ? (NH * NP * SPR + 63) / 64 : 1;  // direct-to-LDS loads per task
-  static_assert(!PIPE || (NH * NP * SPR) % 64 == 0, "tile must be a whole number of 1-KiB pieces");
+  constexpr bool PIPE = PIPED;
+  static_assert(!PIPED || DFIX <= 64, "the pipelined gather stages all features at once");
+  const int SPR = xs / E;                                   // 16-byte slots per staged row (NH * NP = 64 rows
+  const int C16V = d / E;                                   //  -> SPR loads per task); C16V of them hold data
+  constexpr int GB = 11;                                    // loads issued per batch (= SPR at d = 40, fp32)
+  const unsigned spr_magic = (1u << 20) / (unsigned)SPR + 1u;  // sigma / SPR for sigma < 64 * 33
   T pre_y = T(0), pre_eps = T(0);
+  int64_t pre_idx = 0;
   auto pipe_issue = [&](int64_t task_n, int64_t idx_n, int lane_) {
     const int h = NH == 1 ? 0 : lane_ / NP;
     const int i = lane_ & (NP - 1);
     // pointer to this slot's feature row; slots without one (idx_n = 0) point at row 0 -- any
     // valid row will do, their tile rows are never used
     rowaddr[lane_] = (i == q ? feat_q : feat_nn) + idx_n * (int64_t)d;
+    pre_idx = idx_n;
     __syncthreads();
     if (g.mask & 1) {
       // 16-byte slot sigma = 64 n + lane of the tile: row = sigma / SPR, column = sigma % SPR
-      // (unsigned 32-bit arithmetic throughout; the padding slot re-reads the last data slot)
-      const T* src[NGL];
+      // (unsigned 32-bit arithmetic throughout; padding slots re-read the last data slot, the
+      // ones inside the padded feature range are zeroed when the tile is consumed)
+      for (int n0 = 0; n0 < SPR; n0 += GB) {
+        const T* src[GB];
 #pragma unroll
-      for (int n = 0; n < NGL; ++n) {
-        const unsigned sigma = 64u * n + (unsigned)lane_;
-        const unsigned row = (sigma * ((1u << 16) / SPR + 1u)) >> 16;
-        const unsigned c = min(sigma - row * SPR, (unsigned)(C16V - 1));
-        src[n] = rowaddr[row] + c * E;
+        for (int u = 0; u < GB; ++u) {
+          if (n0 + u < SPR) {  // uniform; folded for the static shapes
+            const unsigned sigma = 64u * (unsigned)(n0 + u) + (unsigned)lane_;
+            const unsigned row = (sigma * spr_magic) >> 20;
+            const unsigned c = min(sigma - row * (unsigned)SPR, (unsigned)(C16V - 1));
+            src[u] = rowaddr[row] + c * E;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < GB; ++u)
+          if (n0 + u < SPR) glds16(src[u], reinterpret_cast<char*>(tile) + (n0 + u) * 1024);
       }
-#pragma unroll
-      for (int n = 0; n < NGL; ++n) glds16(src[n], reinterpret_cast<char*>(tile) + n * 1024);
     }
     // response and nugget of the slot's row: unconditional single loads (idx_n is 0, a valid
     // row, for slots without one; the values are masked where they are consumed)
@@ -210,6 +223,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     if (PIPE) {
       // the tile of this task was requested during the previous task's factorisation; the
       // barrier at the top of the stage loop below waits for it (vmcnt) before anyone reads it
+      myidx = pre_idx;
       myy0 = i < k ? pre_y : T(0);
       myeps = pre_eps;
     } else {
@@ -232,7 +246,11 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       const int w = min(dst, d - d0);
       const int wp = (w + CH - 1) / CH * CH;
       __syncthreads();
-      if (PIPE || !(g.mask & 1)) {
+      if (PIPE) {
+        // feature columns w .. wp-1 of the staged rows are padding of the 8-wide inner loop: the
+        // direct-to-LDS gather filled them with a repeat of the last data slot
+        if (wp > w) *reinterpret_cast<V*>(Xh + i * xs + w) = V(0);
+      } else if (!(g.mask & 1)) {
       } else if (DFIX > 0 || g.vec_ok) {
         // c16p consecutive lanes walk one row; rpr rows per round; all rounds of a task in flight
         const int c16 = w / E, c16p = wp / E;
@@ -439,6 +457,27 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
           if (yk) yk[nb] = bad ? num<T>::nan() : -sy;
         }
       }
+    } else if constexpr (PIPED) {
+      // The tile (which the exchange matrix aliases) already receives the next task's rows, so
+      // the two entries a lane emits -- column q and the diagonal of its own row -- are picked out
+      // of the registers by a compare-select sweep instead of a round trip through LDS.
+      T aq = T(0), aii = T(0);
+#pragma unroll
+      for (int c = 0; c < NP; ++c) {
+        const T v = A[c / E][c % E];
+        aq = c == q ? v : aq;
+        aii = c == i ? v : aii;
+      }
+      if (live) {
+        if (i == q) {
+          var[nb] = bad ? num<T>::nan() : aq;
+          if (bad && a.info) atomicAdd(a.info, 1);
+        } else if (i > q) {
+          const int r = i - q - 1;
+          mean[nb * R + r] = bad ? num<T>::nan() : -aq;
+          if (yk) yk[nb * R + r] = bad ? num<T>::nan() : -aii;
+        }
+      }
     } else {
       __syncthreads();
 #pragma unroll
@@ -461,8 +500,9 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 int g_phase_mask = 0xF;
 int g_grid_per_cu = 0;  // debug override of resident workgroups per CU
 int g_lds_pad = 0;      // debug: extra dynamic LDS bytes per workgroup
+int g_runtime_pipe = 1; // debug: 0 = register-staged gather for run-time shapes
 
-template <typename T, int NP, int KFIX, int RFIX, int DFIX>
+template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED>
 static int launch_np(const FusedArgs& a, hipStream_t stream) {
   constexpr int NH = 64 / NP;
   constexpr int E = v16<T>::N;
@@ -476,10 +516,11 @@ static int launch_np(const FusedArgs& a, hipStream_t stream) {
   g.xs = g.dst + E;  // dst/E is even -> dst/E + 1 slots: odd
   const uintptr_t align = (uintptr_t)a.feat_q | (uintptr_t)a.feat_nn;
   g.vec_ok = (a.d % E == 0) && (align % 16 == 0);
-  if (DFIX > 0 && !g.vec_ok) return MGP_EUNSUPPORTED;
+  if ((DFIX > 0 || PIPED) && !g.vec_ok) return MGP_EUNSUPPORTED;
+  if (PIPED && a.d > g.dst) return MGP_EUNSUPPORTED;  // more than one feature stage
   g.ntasks = (a.b + NH - 1) / NH;
   const int rowmax = g.xs > KS ? g.xs : KS;
-  constexpr bool PIPE = KFIX > 0 && DFIX > 0 && DFIX <= 64;
+  constexpr bool PIPE = PIPED;
   size_t lds = PIPE ? (size_t)NH * NP * rowmax * sizeof(T) + 64 * sizeof(void*)
                     : ((size_t)NH * NP * rowmax + 64 + g.dst + (g.dst & 1)) * sizeof(T) + 64 * sizeof(int64_t);
   lds = ((lds + 15) & ~(size_t)15) + (size_t)g_lds_pad;
@@ -493,7 +534,7 @@ static int launch_np(const FusedArgs& a, hipStream_t stream) {
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MGP_EHIP;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        &n, reinterpret_cast<const void*>(&fused_wave_kernel<T, NP, KFIX, RFIX, DFIX>), 64, lds);
+        &n, reinterpret_cast<const void*>(&fused_wave_kernel<T, NP, KFIX, RFIX, DFIX, PIPED>), 64, lds);
     if (e != hipSuccess) return -(1000 + (int)e);
     if (n < 1) return MGP_EUNSUPPORTED;
     cached_lds = (int)lds;
@@ -508,7 +549,12 @@ static int launch_np(const FusedArgs& a, hipStream_t stream) {
   int64_t grid = (int64_t)cached_cus * per_cu / 8 * 8;
   if (grid < 8) grid = 8;
   if (grid > g.ntasks) grid = (g.ntasks + 7) / 8 * 8;
-  hipLaunchKernelGGL((fused_wave_kernel<T, NP, KFIX, RFIX, DFIX>), dim3((unsigned)grid), dim3(64), lds, stream, a,
+  static const bool trace = getenv("MGP_TRACE") != nullptr;  // which instantiation served a call
+  if (trace)
+    fprintf(stderr, "mgp: fused_wave_kernel<%s,%d,%d,%d,%d,%s> b=%lld k=%d d=%d R=%d grid=%lld lds=%zu\n",
+            sizeof(T) == 4 ? "float" : "double", NP, KFIX, RFIX, DFIX, PIPED ? "pipe" : "stage", (long long)a.b, a.k,
+            a.d, a.R, (long long)grid, lds);
+  hipLaunchKernelGGL((fused_wave_kernel<T, NP, KFIX, RFIX, DFIX, PIPED>), dim3((unsigned)grid), dim3(64), lds, stream, a,
                      g);
   MGP_HIP_CHECK_LAUNCH();
   return MGP_OK;
@@ -520,15 +566,23 @@ int launch_fused_wave(const FusedArgs& a, hipStream_t stream) {
   if constexpr (sizeof(T) == 4) if (a.k == 30 && a.R == 1 && a.d == 40) {  // BASELINE configs 2/3, all shapes static
     const int rc2 = launch_fused_wave2_f32(a, stream);
     if (rc2 != MGP_EUNSUPPORTED) return rc2;
-    const int rc = launch_np<T, 32, 30, 1, 40>(a, stream);
+    const int rc = launch_np<T, 32, 30, 1, 40, true>(a, stream);
     if (rc != MGP_EUNSUPPORTED) return rc;
   }
   if (a.k == 50 && a.R == 1 && a.d == 8) {  // BASELINE config 4 shape, all shapes static
-    const int rc = launch_np<T, 64, 50, 1, 8>(a, stream);
+    const int rc = launch_np<T, 64, 50, 1, 8, true>(a, stream);
     if (rc != MGP_EUNSUPPORTED) return rc;
   }
-  if (rows <= 32) return launch_np<T, 32, 0, 0, 0>(a, stream);
-  if (rows <= 64) return launch_np<T, 64, 0, 0, 0>(a, stream);
+  // run-time shapes: the pipelined direct-to-LDS gather when the rows allow it (16-byte aligned,
+  // d a multiple of 16 bytes, one feature stage), the register-staged gather otherwise
+  if (rows <= 32) {
+    const int rc = g_runtime_pipe ? launch_np<T, 32, 0, 0, 0, true>(a, stream) : MGP_EUNSUPPORTED;
+    return rc != MGP_EUNSUPPORTED ? rc : launch_np<T, 32, 0, 0, 0, false>(a, stream);
+  }
+  if (rows <= 64) {
+    const int rc = g_runtime_pipe ? launch_np<T, 64, 0, 0, 0, true>(a, stream) : MGP_EUNSUPPORTED;
+    return rc != MGP_EUNSUPPORTED ? rc : launch_np<T, 64, 0, 0, 0, false>(a, stream);
+  }
   return MGP_EUNSUPPORTED;
 }
 

@@ -190,3 +190,58 @@ def test_rhs_columns_kernel_matches_golden(golden, dtype):
     b, k = g["nn_idx"].shape
     sig = yk.double().sum(dim=0).cpu().numpy().reshape(-1) / (b * k)
     assert_close(sig, g["sigma_sq"], rtol, "sigma_sq")
+
+
+PERSISTENT_CASES = [
+    # dtype, kernel, k, d, R, aniso  -- run-time shapes; b is large enough that every workgroup
+    # loops over many tasks (the software-pipelined gather crosses task boundaries)
+    ("float32", "matern15", 29, 40, 1, False),
+    ("float32", "matern25", 20, 36, 1, False),   # d % 8 == 4: zero-filled padding slot
+    ("float32", "rbf", 40, 16, 3, False),        # NP = 64, several responses
+    ("float32", "matern15", 12, 8, 2, True),
+    ("float64", "matern15", 20, 16, 1, False),
+    ("float64", "matern05", 33, 6, 1, True),     # d % 4 == 2 in fp64
+    ("float32", "matern15", 30, 20, 1, False),
+    ("float32", "matern15", 17, 3, 1, False),    # unaligned rows: register-staged gather
+]
+
+
+@pytest.mark.parametrize("case", PERSISTENT_CASES, ids=[f"{c[0]}-{c[1]}-k{c[2]}-d{c[3]}-R{c[4]}-{'aniso' if c[5] else 'iso'}" for c in PERSISTENT_CASES])
+@pytest.mark.parametrize("runtime_pipe", [1, 0])
+def test_persistent_loop_matches_oracle_on_a_sample(case, runtime_pipe):
+    from muygpys_amd import _lib
+    from muygpys_amd.fused import KernelSpec, posterior_mean_var
+
+    dtype, kernel, k, d, R, aniso = case
+    td = getattr(torch, dtype)
+    rng = np.random.default_rng(PERSISTENT_CASES.index(case))
+    N, b = 50_000, 240_000
+    X = rng.normal(size=(N, d))
+    Y = np.sin(X @ rng.normal(size=(d, R)) / np.sqrt(d)) + 0.1 * rng.normal(size=(N, R))
+    bi = rng.integers(0, N, size=b)
+    ni = rng.integers(0, N, size=(b, k))
+    ni = np.where(ni == bi[:, None], (ni + 1) % N, ni)
+    metric = "F2" if kernel == "rbf" else "l2"
+    ls = np.sqrt(d) * rng.uniform(0.8, 1.4, size=d) if aniso else float(np.sqrt(2 * d))
+    if metric == "F2":
+        ls = np.sqrt(ls)
+    spec_o = orc.Spec(kernel, metric, ls, 1e-2)
+    lib = _lib.load()
+    lib.mgp_debug_runtime_pipe(runtime_pipe)
+    try:
+        info = torch.zeros(1, dtype=torch.int32, device="cuda")
+        mean, var, yk = posterior_mean_var(
+            KernelSpec(kernel, metric, ls.tolist() if aniso else ls, 1e-2), to_dev(X, td), to_dev(X, td), to_dev(bi),
+            to_dev(ni), to_dev(Y, td), want_ykinvy=True, info=info,
+        )
+        torch.cuda.synchronize()
+    finally:
+        lib.mgp_debug_runtime_pipe(1)
+    assert int(info.item()) == 0
+    pick = rng.choice(b, size=1500, replace=False)
+    pick[:4] = [0, 1, b - 2, b - 1]
+    m_ref, v_ref = orc.posterior_mean_var(spec_o, X, X, bi[pick], ni[pick], Y)
+    rtol = RTOL[dtype]
+    assert_close(mean.cpu().numpy()[pick], m_ref.reshape(len(pick), R), rtol, "mean")
+    assert_close(var.cpu().numpy()[pick], v_ref, rtol, "var")
+    assert torch.isfinite(mean).all() and torch.isfinite(var).all() and torch.isfinite(yk).all()

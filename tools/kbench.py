@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--grids", default="0")
     ap.add_argument("--ldspad", type=int, default=0)
     ap.add_argument("--wave2", default="0")
+    ap.add_argument("--rtpipe", default="1", help="comma list: 1 = pipelined direct-to-LDS gather for run-time shapes")
     ap.add_argument("--prefer-rhs", type=int, default=0)
     ap.add_argument("--hot-rows", type=int, default=0, help="restrict neighbour rows to the first N (cache-resident gather)")
     args = ap.parse_args()
@@ -54,8 +55,9 @@ def main():
     lib = _lib.load()
     lib.mgp_debug_set_lds_pad(args.ldspad)
     lib.mgp_debug_prefer_rhs(args.prefer_rhs)
-    variants = [(int(m), int(g), int(pc), int(w2)) for g in args.generic.split(",") for m in args.masks.split(",")
-                for pc in args.grids.split(",") for w2 in args.wave2.split(",")]
+    variants = [(int(m), int(g), int(pc), int(w2), int(rp)) for g in args.generic.split(",")
+                for m in args.masks.split(",") for pc in args.grids.split(",") for w2 in args.wave2.split(",")
+                for rp in args.rtpipe.split(",")]
     times = {v: [] for v in variants}
     for r in range(args.rounds + 1):
         for v in variants:
@@ -63,6 +65,7 @@ def main():
             lib.mgp_debug_force_generic(v[1])
             lib.mgp_debug_set_grid_per_cu(v[2])
             lib.mgp_debug_enable_wave2(v[3])
+            lib.mgp_debug_runtime_pipe(v[4])
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             posterior_mean_var(spec, Xd, Xd, bi, ni, yd, out_mean=mean, out_var=var)
@@ -72,7 +75,7 @@ def main():
                 times[v].append(e0.elapsed_time(e1))
     for v in variants:
         t = np.array(times[v])
-        print(f"mask={v[0]:2d} generic={v[1]} grid/cu={v[2]:2d} wave2={v[3]} median {np.median(t):8.3f} ms  min {t.min():8.3f} ms  "
+        print(f"mask={v[0]:2d} generic={v[1]} grid/cu={v[2]:2d} wave2={v[3]} rtpipe={v[4]} median {np.median(t):8.3f} ms  min {t.min():8.3f} ms  "
               f"-> {args.b / np.median(t) / 1e3:8.1f} M nbhd/s")
 
 
