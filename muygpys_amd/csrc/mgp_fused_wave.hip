@@ -372,8 +372,17 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         T kv[NS];
         kernel_dispatch(a.kernel_id, a.metric_id, [&](auto kid, auto mid) {
           constexpr int KID = decltype(kid)::value, MID = decltype(mid)::value;
+          if constexpr (sizeof(T) == 4) {
 #pragma unroll
-          for (int s = 1; s <= NS; ++s) kv[s - 1] = cov_from_sqdist<T>(acc_total(acc[s - 1]), KID, MID, post_scale);
+            for (int s = 0; s < NS; s += 2) {
+              const f2 kk = cov_from_sqdist2(f2{acc_total(acc[s]), acc_total(acc[s + 1])}, KID, MID, post_scale);
+              kv[s] = kk.x;
+              kv[s + 1] = kk.y;
+            }
+          } else {
+#pragma unroll
+            for (int s = 1; s <= NS; ++s) kv[s - 1] = cov_from_sqdist<T>(acc_total(acc[s - 1]), KID, MID, post_scale);
+          }
         });
         const int dump = (NP - 1) * KS + NP;  // columns NP .. KS-1 of a row are padding
 #pragma unroll

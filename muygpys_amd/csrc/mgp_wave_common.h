@@ -94,6 +94,47 @@ __device__ __forceinline__ T cov_from_sqdist(T acc, int kernel_id, int metric_id
   }
 }
 
+// Two covariances at once (fp32): the polynomial / scaling arithmetic runs as packed ops
+// (v_pk_mul_f32 / v_pk_fma_f32), only v_sqrt_f32 and v_exp_f32 stay scalar.  Same formulas and
+// the same two-term log2(e) as the scalar form above.
+__device__ __forceinline__ f2 exp_neg2(f2 t) {
+  const f2 c_hi = {-1.44269502162933349609375f, -1.44269502162933349609375f};
+  const f2 c_lo = {-1.925963033500011e-08f, -1.925963033500011e-08f};
+  const f2 hi = t * c_hi;
+  f2 lo = t * c_hi - hi;  // contracted to v_pk_fma_f32: the rounding error of hi
+  lo = t * c_lo + lo;
+  f2 e;
+  e.x = __builtin_amdgcn_exp2f(hi.x);
+  e.y = __builtin_amdgcn_exp2f(hi.y);
+  const f2 ln2 = {0.693147180559945f, 0.693147180559945f};
+  return (e * lo) * ln2 + e;
+}
+__device__ __forceinline__ f2 cov_from_sqdist2(f2 acc, int kernel_id, int metric_id, float post_scale) {
+  f2 x = acc;
+  if (metric_id == MGP_METRIC_L2) {
+    x.x = sqrt_fast(acc.x);
+    x.y = sqrt_fast(acc.y);
+  }
+  x = x * f2{post_scale, post_scale};
+  switch (kernel_id) {
+    case MGP_KERNEL_RBF:
+      return exp_neg2(x * f2{0.5f, 0.5f});
+    case MGP_KERNEL_MATERN_05:
+      return exp_neg2(x);
+    case MGP_KERNEL_MATERN_15: {
+      const f2 t = x * f2{1.7320508075688772935f, 1.7320508075688772935f};
+      return (f2{1.0f, 1.0f} + t) * exp_neg2(t);
+    }
+    case MGP_KERNEL_MATERN_25: {
+      const f2 t = x * f2{2.2360679774997896964f, 2.2360679774997896964f};
+      const f2 third = {1.0f / 3.0f, 1.0f / 3.0f};
+      return (f2{1.0f, 1.0f} + t + t * t * third) * exp_neg2(t);
+    }
+    default:
+      return exp_neg2(x * x * f2{0.5f, 0.5f});
+  }
+}
+
 // 16 bytes per lane straight from global memory into LDS (no VGPR round trip): the LDS
 // destination is the wave-uniform pointer + lane * 16, the global source is per lane.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
