@@ -99,6 +99,30 @@ int mgp_posterior_f64(const double* feat_q, const double* feat_nn, int d,
                       double* mean, double* var, double* ykinvy, int* info, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * Exact k-nearest-neighbour scan (the step upstream of the hot path).  Replaces
+ * the exact search behind NN_Wrapper (src/MuyGPyS/neighbors.py:106-107 builds a
+ * scikit-learn NearestNeighbors, :129-167 get_nns / :169-211 get_batch_nns query
+ * it; squared-l2 convention :246-250).
+ *
+ *   train (n, d), queries (m, d): fp32, rows 16-byte aligned, d % 4 == 0, d <= 64
+ *   train_sqn (n), query_sqn (m): squared norms of the rows
+ *   self_idx (m) or NULL: training row each query must not return (batch queries
+ *       drop the self match, neighbors.py:207-211)
+ *   best_d / best_i (m, k), k <= 64: IN: an exact k-best list over training rows
+ *       [0, start) (Gram-form squared distances |q|^2+|x|^2-2q.x, any order);
+ *       OUT: the exact k-best over all n rows (unordered; the caller re-measures
+ *       the winners in difference form and sorts them).
+ *   overflow (m), zero-filled by the caller: set to 1 for a query whose candidate
+ *       queue overflowed (adversarial row order); its list is then incomplete
+ *       and the caller recomputes that query on its dense path.
+ *   Returns MGP_EUNSUPPORTED for shapes outside the above (caller falls back).
+ * ------------------------------------------------------------------------- */
+int mgp_knn_scan_f32(const float* train, const float* train_sqn, int64_t n, int d,
+                     const float* queries, const float* query_sqn, const int64_t* self_idx, int64_t m,
+                     int k, int64_t start, float* best_d, int32_t* best_i, int32_t* overflow,
+                     void* stream);
+
+/* ---------------------------------------------------------------------------
  * Backward pass of the fused hot path (vector-Jacobian product).  Replaces what
  * torch autograd derives for the reference's torch backend when a deep-kernel
  * model trains through MuyGPs_layer (torch/muygps_layer.py:129-164,

@@ -50,6 +50,22 @@ struct BackwardArgs {
 template <typename T> int launch_backward(const BackwardArgs&, hipStream_t);
 int max_nn_count_backward(int elem_size);
 
+// Exact k-NN scan on the matrix cores (mgp_knn.hip)
+struct KnnArgs {
+  const float* train;       // (n, d)
+  const float* train_sqn;   // (n)  |x|^2
+  const float* queries;     // (m, d)
+  const float* query_sqn;   // (m)
+  const int64_t* self_idx;  // (m) training row to exclude per query, or nullptr
+  float* best_d;            // (m, k) in/out: current k best (Gram-form squared distances)
+  int* best_i;              // (m, k) in/out
+  int* overflow;            // (m) out: 1 = queue overflowed, recompute this query
+  int64_t n, m;
+  int64_t start;            // first training row to scan (earlier rows are already in the lists)
+  int d, k;
+};
+int launch_knn_scan(const KnnArgs&, hipStream_t);
+
 template <typename T> int launch_fused_generic(const FusedArgs&, hipStream_t);
 template <typename T> int launch_solve_generic(const SolveArgs&, hipStream_t);
 // register-resident wave-per-neighbourhood kernels; MGP_EUNSUPPORTED when the shape is not covered

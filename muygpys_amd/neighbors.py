@@ -4,10 +4,18 @@ The step immediately upstream of the hot path: the reference wraps scikit-learn'
 (or hnswlib) on the CPU (src/MuyGPyS/neighbors.py:32-262).  ``NN_Wrapper`` here keeps that
 interface -- ``get_nns(test)`` / ``get_batch_nns(batch_indices)`` returning ``(indices int64,
 squared-l2 distances)`` with the self-match dropped for batch queries (neighbors.py:207-211,
-246-250) -- and computes it exactly, in row chunks, as a dense ``|q|^2 + |x|^2 - 2 q.x``
-contraction (the one place on the path where a GEMM is the natural shape: rocBLAS/MFMA through
-``torch.matmul``) followed by ``topk``.  Candidate distances are then recomputed in difference
-form for the k winners, so the returned distances carry no cancellation error.
+246-250) -- and computes it exactly.
+
+* fp32, ``d % 4 == 0``, ``d <= 64``, ``k <= 64`` (the shapes of the hot path): the fused MFMA
+  scan ``mgp_knn_scan_f32`` (``csrc/mgp_knn.hip``) -- distances on the matrix cores, one compare
+  per pair against the query's running k-th best, rare survivors merged into per-query k-best
+  lists -- after the lists have been initialised from the first rows of the table on the dense
+  path.  Nothing of size (queries x train) is ever materialised.
+* anything else: the dense path, in row chunks, ``|q|^2 + |x|^2 - 2 q.x`` through
+  ``torch.matmul`` (rocBLAS) followed by ``topk``.
+
+Either way the k winners are then re-measured in difference form and sorted, so the returned
+distances carry no cancellation error and ties resolve by distance then index order of the sort.
 """
 
 from __future__ import annotations
@@ -16,9 +24,14 @@ from typing import Tuple
 
 import torch
 
+from . import _lib
+
+SCAN_INIT_ROWS = 4096  # rows of the table the k-best lists are initialised from (dense path)
+
 
 class NN_Wrapper:
-    def __init__(self, train: torch.Tensor, nn_count: int, nn_method: str = "exact", chunk: int = 4096, **kwargs):
+    def __init__(self, train: torch.Tensor, nn_count: int, nn_method: str = "exact", chunk: int = 4096,
+                 use_scan: bool = True, **kwargs):
         if nn_method.lower() != "exact":
             raise NotImplementedError(f"Nearest Neighbor algorithm {nn_method} is not implemented.")
         if not (isinstance(train, torch.Tensor) and train.is_cuda):
@@ -28,6 +41,7 @@ class NN_Wrapper:
         self.nn_count = int(nn_count)
         self.nn_method = "exact"
         self.chunk = int(chunk)
+        self.use_scan = bool(use_scan)
         self._sq = (self.train.double() ** 2).sum(1).to(self.train.dtype)
 
     def get_nns(self, test: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -43,6 +57,68 @@ class NN_Wrapper:
         return self._get_nns(q, self.nn_count, exclude=batch_indices)
 
     def _get_nns(self, samples, nn_count, exclude=None):
+        out = self._scan_nns(samples, nn_count, exclude)
+        return out if out is not None else self._dense_nns(samples, nn_count, exclude)
+
+    def _scan_supported(self, samples, nn_count) -> bool:
+        d = self.feature_count
+        return (
+            self.use_scan and self.train.dtype == torch.float32 and samples.dtype == torch.float32
+            and d % 4 == 0 and 4 <= d <= 64 and 1 <= nn_count <= 64
+            and self.train_count > 2 * SCAN_INIT_ROWS and self.train_count < 2**31
+        )
+
+    def _scan_nns(self, samples, nn_count, exclude=None):
+        """Fused MFMA scan (see the module docstring); None when the shape is not covered."""
+        if not self._scan_supported(samples, nn_count):
+            return None
+        q = samples.contiguous()
+        m, k = q.shape[0], int(nn_count)
+        if m == 0:
+            return None
+        # exact k-best over the first rows of the table (Gram-form distances, like the scan's)
+        head = self.train[:SCAN_INIT_ROWS]
+        best_d = torch.empty((m, k), device=q.device, dtype=torch.float32)
+        best_i = torch.empty((m, k), device=q.device, dtype=torch.int32)
+        qn = (q * q).sum(1)
+        for s in range(0, m, self.chunk):
+            qq = q[s:s + self.chunk]
+            d2 = self._sq[None, :SCAN_INIT_ROWS] - 2.0 * (qq @ head.T) + qn[s:s + self.chunk, None]
+            if exclude is not None:
+                ex = exclude[s:s + self.chunk]
+                inside = ex < SCAN_INIT_ROWS
+                rows = torch.arange(qq.shape[0], device=q.device)[inside]
+                d2[rows, ex[inside]] = float("inf")
+            bd, bi = d2.topk(k, dim=1, largest=False)
+            best_d[s:s + self.chunk] = bd
+            best_i[s:s + self.chunk] = bi.to(torch.int32)
+        overflow = torch.zeros((m,), device=q.device, dtype=torch.int32)
+        ex64 = None if exclude is None else exclude.to(torch.int64).contiguous()
+        rc = _lib.load().mgp_knn_scan_f32(
+            _lib.ptr(self.train), _lib.ptr(self._sq), self.train_count, self.feature_count,
+            _lib.ptr(q), _lib.ptr(qn), _lib.ptr(ex64), m, k, SCAN_INIT_ROWS,
+            _lib.ptr(best_d), _lib.ptr(best_i), _lib.ptr(overflow), _lib.stream_ptr(),
+        )
+        if rc == -2:  # MGP_EUNSUPPORTED (alignment)
+            return None
+        _lib.check(rc, "mgp_knn_scan_f32")
+        cand = best_i.to(torch.int64)
+        idx = torch.empty((m, k), dtype=torch.int64, device=q.device)
+        dist = torch.empty((m, k), dtype=q.dtype, device=q.device)
+        for s in range(0, m, 65536):
+            c = cand[s:s + 65536]
+            diff = q[s:s + 65536, None, :] - self.train[c]
+            dd = (diff * diff).sum(-1)
+            order = dd.argsort(dim=1, stable=True)
+            idx[s:s + 65536] = c.gather(1, order)
+            dist[s:s + 65536] = dd.gather(1, order)
+        redo = overflow.nonzero().reshape(-1)
+        if redo.numel():  # queues overflowed (adversarial row order): those queries go dense
+            ri, rd = self._dense_nns(q[redo], k, None if exclude is None else exclude[redo])
+            idx[redo], dist[redo] = ri, rd
+        return idx, dist
+
+    def _dense_nns(self, samples, nn_count, exclude=None):
         n = samples.shape[0]
         idx = torch.empty((n, nn_count), dtype=torch.int64, device=samples.device)
         dist = torch.empty((n, nn_count), dtype=samples.dtype, device=samples.device)

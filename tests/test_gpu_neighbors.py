@@ -50,3 +50,44 @@ def test_end_to_end_with_true_neighbours():
     m_ref, v_ref = orc.posterior_mean_var(orc.Spec("matern15", "l2", 5.0, 1e-3), X, X, bi, ni.cpu().numpy(), y)
     assert_close(mean.cpu().numpy(), m_ref, RTOL["float32"], "mean")
     assert_close(var.cpu().numpy(), v_ref, RTOL["float32"], "var")
+
+
+@pytest.mark.parametrize("d,k,n,m", [(40, 30, 30000, 3000), (8, 50, 50000, 2500), (36, 10, 20000, 1000), (64, 64, 12000, 777)])
+def test_mfma_scan_matches_dense_path(d, k, n, m):
+    """The fused MFMA scan (mgp_knn_scan_f32) and the dense matmul+topk path return the same
+    neighbour distances (index sets may differ only where distances tie to fp32 rounding)."""
+    from muygpys_amd.neighbors import NN_Wrapper
+
+    g = torch.Generator().manual_seed(d * 1000 + k)
+    X = torch.randn(n, d, generator=g).cuda()
+    Q = torch.randn(m, d, generator=g).cuda()
+    scan, dense = NN_Wrapper(X, k), NN_Wrapper(X, k, use_scan=False)
+    assert scan._scan_supported(Q, k)
+    for query in ("test", "batch"):
+        if query == "test":
+            (i1, d1), (i2, d2) = scan.get_nns(Q), dense.get_nns(Q)
+        else:
+            bi = torch.randperm(n, generator=g)[:m].cuda()
+            bi[:5] = torch.tensor([0, 1, 4095, 4096, n - 1], device="cuda")  # both sides of the init rows
+            (i1, d1), (i2, d2) = scan.get_batch_nns(bi), dense.get_batch_nns(bi)
+            assert not (i1 == bi[:, None]).any()
+        assert i1.dtype == torch.int64 and i1.shape == (m, k)
+        torch.testing.assert_close(d1, d2, rtol=1e-5, atol=1e-6)
+        assert float((i1 == i2).float().mean()) > 0.999
+        assert bool((d1[:, 1:] >= d1[:, :-1]).all())
+        assert int(i1.min()) >= 0 and int(i1.max()) < n
+        assert all(len(set(row.tolist())) == k for row in i1[:50])
+
+
+def test_mfma_scan_survives_adversarial_row_order():
+    """Rows sorted by distance from the queries, farthest first: every tile beats the running
+    k-th best, queues overflow, and the flagged queries are recomputed on the dense path."""
+    from muygpys_amd.neighbors import NN_Wrapper
+
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn(20000, 8, generator=g)
+    X = X[(X**2).sum(1).argsort(descending=True)].contiguous().cuda()
+    Q = (0.01 * torch.randn(300, 8, generator=g)).cuda()  # near the origin
+    (i1, d1), (i2, d2) = NN_Wrapper(X, 20).get_nns(Q), NN_Wrapper(X, 20, use_scan=False).get_nns(Q)
+    torch.testing.assert_close(d1, d2, rtol=1e-5, atol=1e-6)
+    assert float((i1 == i2).float().mean()) > 0.999
