@@ -105,7 +105,9 @@ int mgp_posterior_f64(const double* feat_q, const double* feat_nn, int d,
  * it; squared-l2 convention :246-250).
  *
  *   train (n, d), queries (m, d): fp32, rows 16-byte aligned, d % 4 == 0, d <= 64
- *   train_sqn (n), query_sqn (m): squared norms of the rows
+ *   train_sqn (n rounded up to a multiple of 64; +inf past n), query_sqn (m):
+ *       squared norms of the rows; train_sqn + start must be 16-byte aligned
+ *       (start % 4 == 0)
  *   self_idx (m) or NULL: training row each query must not return (batch queries
  *       drop the self match, neighbors.py:207-211)
  *   best_d / best_i (m, k), k <= 64: IN: an exact k-best list over training rows

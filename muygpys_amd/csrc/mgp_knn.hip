@@ -7,7 +7,7 @@
 //
 // Work split: a workgroup of four waves owns 128 queries (32 per wave, their feature rows
 // resident in registers as the MFMA A operand) and streams the training table through LDS in
-// tiles of 64 rows.  Per 32x32 block of (query, training point) pairs a wave issues DP/2 MFMAs
+// double-buffered tiles of 64 rows (global_load_lds, the next tile in flight under the MFMAs).  Per 32x32 block of (query, training point) pairs a wave issues DP/2 MFMAs
 // that accumulate  q.x - |x|^2/2  (the accumulator starts at -|x|^2/2 of the lane's column), so a
 // pair is closer than the query's current k-th best distance tau exactly when
 //      acc > (|q|^2 - tau) / 2,
@@ -44,8 +44,8 @@ template <int DP>
 __global__ __launch_bounds__(256) void knn_scan_kernel(KnnArgs a) {
   constexpr int XS = DP + 4;      // LDS row stride: an odd number of 16-byte slots
   constexpr int HD = DP / 2;      // features per lane half
-  __shared__ __attribute__((aligned(16))) float tile[KNN_TN * XS];
-  __shared__ float xn_tile[KNN_TN];
+  __shared__ __attribute__((aligned(16))) float tile[2][KNN_TN * XS + 64];  // + slack of the last partial pass
+  __shared__ __attribute__((aligned(16))) float xn_tile[2][KNN_TN];
   __shared__ float q_d[KNN_QB * KNN_CAP];
   __shared__ int q_i[KNN_QB * KNN_CAP];
   __shared__ int q_cnt[KNN_QB];
@@ -92,30 +92,50 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(KnnArgs a) {
     thr[v] = 0.5f * (qn[v] - tau_s[w * KNN_QW + row]);
   }
 
-  for (int64_t t0 = a.start; t0 < a.n; t0 += KNN_TN) {
-    // ---- stage KNN_TN training rows (zero-filled past n / past d) ---------------------------
-    __syncthreads();
-    for (int s = tid; s < KNN_TN * (DP / 4); s += 256) {
-      const int row = s / (DP / 4), c = (s - row * (DP / 4)) * 4;
-      f4x v = {0.f, 0.f, 0.f, 0.f};
-      if (t0 + row < a.n && c < d) v = *reinterpret_cast<const f4x*>(a.train + (t0 + row) * (int64_t)d + c);
-      *reinterpret_cast<f4x*>(tile + row * XS + c) = v;
+  // Double-buffered staging with direct global->LDS loads: the tile after the current one is in
+  // flight while the MFMAs run, one barrier per tile.  A wave-instruction fills 64 consecutive
+  // 16-byte slots; slot sigma of a tile is row sigma / SPR, column sigma % SPR (the padding column
+  // and the columns past d repeat the row's last data slot -- finite values the zero-padded query
+  // operand cancels).  Rows past n repeat row n-1; their |x|^2 is +inf (host-padded table).
+  constexpr int SPR = XS / 4;
+  constexpr int NPASS = (KNN_TN * SPR + 63) / 64;
+  const int dslots = d / 4;
+  auto issue_tile = [&](int buf, int64_t t0) {
+    for (int p = w; p < NPASS; p += 4) {
+      const int sigma = 64 * p + lane;
+      const int row = min(sigma / SPR, KNN_TN - 1);
+      const int c = min(sigma - row * SPR, dslots - 1);
+      const int64_t grow = min(t0 + row, a.n - 1);
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(a.train + grow * (int64_t)d + c * 4),
+          (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(tile[buf]) + p * 1024), 16, 0, 0);
     }
-    if (tid < KNN_TN) xn_tile[tid] = t0 + tid < a.n ? a.train_sqn[t0 + tid] : __builtin_inff();
-    __syncthreads();
+    if (w == 3 && lane < KNN_TN / 4)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(a.train_sqn + t0 + lane * 4),
+          (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(xn_tile[buf])), 16, 0, 0);
+  };
+  issue_tile(0, a.start);
+  int buf = 0;
+  for (int64_t t0 = a.start; t0 < a.n; t0 += KNN_TN, buf ^= 1) {
+    __builtin_amdgcn_s_waitcnt(0);  // this wave's share of tile `buf` has landed
+    __syncthreads();                // ... everyone's has, and nobody still reads the other buffer
+    if (t0 + KNN_TN < a.n) issue_tile(buf ^ 1, t0 + KNN_TN);
+    const float* tl = tile[buf];
+    const float* xnt = xn_tile[buf];
 
     // ---- two 32 x 32 blocks per wave: MFMA, one compare per pair, rare queue pushes ---------
 #pragma unroll
     for (int ct = 0; ct < KNN_TN / 32; ++ct) {
       const int col = ct * 32 + r32;
-      const float* xrow = tile + col * XS + half * HD;
+      const float* xrow = tl + col * XS + half * HD;
       float bx[HD];
 #pragma unroll
       for (int j = 0; j < HD / 4; ++j) {
         const f4x v = *reinterpret_cast<const f4x*>(xrow + 4 * j);
         bx[4 * j] = v.x, bx[4 * j + 1] = v.y, bx[4 * j + 2] = v.z, bx[4 * j + 3] = v.w;
       }
-      const float xn = xn_tile[col];
+      const float xn = xnt[col];
       const float c0 = -0.5f * xn;
       f16x acc = {c0, c0, c0, c0, c0, c0, c0, c0, c0, c0, c0, c0, c0, c0, c0, c0};
 #pragma unroll
@@ -137,9 +157,8 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(KnnArgs a) {
         }
       }
     }
-    __syncthreads();
 
-    // ---- drain this wave's queues into the k-best lists -------------------------------------
+    // ---- drain this wave's queues into the k-best lists (wave-private state: no barrier) ------
     const int mycnt = lane < KNN_QW ? q_cnt[w * KNN_QW + lane] : 0;
     unsigned long long pending = __ballot(mycnt > 0);
     bool drained = false;
@@ -198,7 +217,8 @@ static int launch_knn_dp(const KnnArgs& a, hipStream_t stream) {
 
 int launch_knn_scan(const KnnArgs& a, hipStream_t stream) {
   if (a.k < 1 || a.k > 64 || a.d < 4 || a.d % 4 != 0 || a.d > 64) return MGP_EUNSUPPORTED;
-  if (((uintptr_t)a.train | (uintptr_t)a.queries) % 16 != 0) return MGP_EUNSUPPORTED;
+  if (((uintptr_t)a.train | (uintptr_t)a.queries | (uintptr_t)(a.train_sqn + a.start)) % 16 != 0)
+    return MGP_EUNSUPPORTED;
   if (a.n >= (int64_t)1 << 31) return MGP_EUNSUPPORTED;  // list indices are 32-bit
   const int dp = (a.d + 7) / 8 * 8;
   switch (dp) {

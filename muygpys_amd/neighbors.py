@@ -43,6 +43,9 @@ class NN_Wrapper:
         self.chunk = int(chunk)
         self.use_scan = bool(use_scan)
         self._sq = (self.train.double() ** 2).sum(1).to(self.train.dtype)
+        # the scan kernel reads |x|^2 in whole 64-row tiles: +inf past the end (never a neighbour)
+        pad = (-self.train_count) % 64
+        self._sq_scan = torch.cat([self._sq, torch.full((pad,), float("inf"), device=self._sq.device, dtype=self._sq.dtype)])
 
     def get_nns(self, test: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """neighbors.py:129-167: nn_count nearest training rows of every test row."""
@@ -95,7 +98,7 @@ class NN_Wrapper:
         overflow = torch.zeros((m,), device=q.device, dtype=torch.int32)
         ex64 = None if exclude is None else exclude.to(torch.int64).contiguous()
         rc = _lib.load().mgp_knn_scan_f32(
-            _lib.ptr(self.train), _lib.ptr(self._sq), self.train_count, self.feature_count,
+            _lib.ptr(self.train), _lib.ptr(self._sq_scan), self.train_count, self.feature_count,
             _lib.ptr(q), _lib.ptr(qn), _lib.ptr(ex64), m, k, SCAN_INIT_ROWS,
             _lib.ptr(best_d), _lib.ptr(best_i), _lib.ptr(overflow), _lib.stream_ptr(),
         )
