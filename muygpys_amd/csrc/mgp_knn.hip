@@ -31,7 +31,7 @@ typedef float f4x __attribute__((ext_vector_type(4)));
 constexpr int KNN_TN = 64;    // training rows per staged tile
 constexpr int KNN_QW = 32;    // queries per wave
 constexpr int KNN_QB = 128;   // queries per workgroup
-constexpr int KNN_CAP = 32;   // queue entries per query
+constexpr int KNN_CAP = 16;   // queue entries per query
 
 template <typename T>
 __device__ __forceinline__ T wave_max(T v) {
