@@ -124,6 +124,19 @@ int mgp_knn_scan_f32(const float* train, const float* train_sqn, int64_t n, int 
                      int k, int64_t start, float* best_d, int32_t* best_i, int32_t* overflow,
                      void* stream);
 
+/* Same search with a split-bf16 pre-filter on the matrix cores (3 bf16 MFMA chains
+ * hi.hi + hi.lo + lo.hi, error < 2^-14 |q||x|, folded into the threshold) and an
+ * exact fp32 difference-form re-measurement of every survivor: exact results,
+ * ~4.4 x fewer matrix-pipe cycles than mgp_knn_scan_f32.
+ *   packed_train (n, 2 KP) / packed_queries (m, 2 KP), KP = 16 ceil(d / 16): per row
+ *       [bf16(x) zero-padded to KP | bf16(x - float(bf16(x))) zero-padded to KP]
+ *   best_d IN/OUT: exact squared distances (difference form); other arguments and
+ *   the overflow contract as for mgp_knn_scan_f32. */
+int mgp_knn_scan_bf16x3(const float* train, const void* packed_train, const float* train_sqn, int64_t n, int d,
+                        const float* queries, const void* packed_queries, const float* query_sqn,
+                        const int64_t* self_idx, int64_t m, int k, int64_t start,
+                        float* best_d, int32_t* best_i, int32_t* overflow, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Backward pass of the fused hot path (vector-Jacobian product).  Replaces what
  * torch autograd derives for the reference's torch backend when a deep-kernel

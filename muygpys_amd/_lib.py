@@ -93,6 +93,8 @@ def load():
     lib.mgp_max_nn_count_backward.restype = _i
     lib.mgp_knn_scan_f32.argtypes = [_p, _p, _l, _i, _p, _p, _p, _l, _i, _l, _p, _p, _p, _p]
     lib.mgp_knn_scan_f32.restype = _i
+    lib.mgp_knn_scan_bf16x3.argtypes = [_p, _p, _p, _l, _i, _p, _p, _p, _p, _l, _i, _l, _p, _p, _p, _p]
+    lib.mgp_knn_scan_bf16x3.restype = _i
     lib.mgp_debug_force_generic.argtypes = [_i]
     lib.mgp_debug_force_generic.restype = None
     lib.mgp_debug_prefer_rhs.argtypes = [_i]

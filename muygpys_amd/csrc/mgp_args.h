@@ -65,6 +65,22 @@ struct KnnArgs {
   int d, k;
 };
 int launch_knn_scan(const KnnArgs&, hipStream_t);
+// split-bf16 pre-filter variant: packed rows [bf16 hi (KP) | bf16 lo (KP)], KP = 16 ceil(d / 16)
+struct KnnPackedArgs {
+  const float* train;           // (n, d) fp32 (exact re-measurement of survivors)
+  const void* packed_train;     // (n, 2 KP) bf16
+  const float* train_sqn;       // (n rounded up to 64, +inf past n)
+  const float* queries;         // (m, d) fp32
+  const void* packed_queries;   // (m, 2 KP) bf16
+  const float* query_sqn;       // (m)
+  const int64_t* self_idx;      // (m) or nullptr
+  float* best_d;                // (m, k) in/out, exact squared distances
+  int* best_i;                  // (m, k) in/out
+  int* overflow;                // (m)
+  int64_t n, m, start;
+  int d, k;
+};
+int launch_knn_scan_packed(const KnnPackedArgs&, hipStream_t);
 
 template <typename T> int launch_fused_generic(const FusedArgs&, hipStream_t);
 template <typename T> int launch_solve_generic(const SolveArgs&, hipStream_t);

@@ -33,6 +33,18 @@ constexpr int KNN_QW = 32;    // queries per wave
 constexpr int KNN_QB = 128;   // queries per workgroup
 constexpr int KNN_CAP = 16;   // queue entries per query
 
+// 16 bytes per lane from global memory straight into LDS at (wave-uniform byte offset) + 16 * lane.
+// Raw instruction on purpose: through the builtin the compiler orders every later LDS write (the
+// candidate queues) behind the transfer with s_waitcnt vmcnt(0), i.e. a full memory latency inside
+// the compare loop for one block in six; the kernels wait for their tiles explicitly instead.
+__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_byte_offset) {
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off"
+               :
+               : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_byte_offset))
+               : "memory");
+}
+__device__ __forceinline__ unsigned lds_offset(const void* p) { return (unsigned)(uintptr_t)p; }
+
 template <typename T>
 __device__ __forceinline__ T wave_max(T v) {
 #pragma unroll
@@ -44,12 +56,16 @@ template <int DP>
 __global__ __launch_bounds__(256) void knn_scan_kernel(KnnArgs a) {
   constexpr int XS = DP + 4;      // LDS row stride: an odd number of 16-byte slots
   constexpr int HD = DP / 2;      // features per lane half
-  __shared__ __attribute__((aligned(16))) float tile[2][KNN_TN * XS + 64];  // + slack of the last partial pass
-  __shared__ __attribute__((aligned(16))) float xn_tile[2][KNN_TN];
-  __shared__ float q_d[KNN_QB * KNN_CAP];
-  __shared__ int q_i[KNN_QB * KNN_CAP];
-  __shared__ int q_cnt[KNN_QB];
-  __shared__ float tau_s[KNN_QB];
+  // dynamic LDS (one extern array, carved by hand: the compiler then does not tie the LDS reads of
+  // the tile being consumed to the direct-to-LDS loads filling the other buffer -- with separate
+  // static arrays it inserts s_waitcnt vmcnt(0) before the first read and the prefetch never overlaps)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tile0 = reinterpret_cast<float*>(smem);                 // [2][KNN_TN * XS]
+  float* xn0 = tile0 + 2 * KNN_TN * XS;                          // [2][KNN_TN]
+  float* q_d = xn0 + 2 * KNN_TN;                                 // [KNN_QB * KNN_CAP]
+  int* q_i = reinterpret_cast<int*>(q_d + KNN_QB * KNN_CAP);     // [KNN_QB * KNN_CAP]
+  int* q_cnt = q_i + KNN_QB * KNN_CAP;                           // [KNN_QB]
+  float* tau_s = reinterpret_cast<float*>(q_cnt + KNN_QB);       // [KNN_QB]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
@@ -106,25 +122,29 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(KnnArgs a) {
       const int row = min(sigma / SPR, KNN_TN - 1);
       const int c = min(sigma - row * SPR, dslots - 1);
       const int64_t grow = min(t0 + row, a.n - 1);
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(a.train + grow * (int64_t)d + c * 4),
-          (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(tile[buf]) + p * 1024), 16, 0, 0);
+      lds_dma16(a.train + grow * (int64_t)d + c * 4, lds_offset(tile0 + buf * KNN_TN * XS) + p * 1024);
     }
-    if (w == 3 && lane < KNN_TN / 4)
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(a.train_sqn + t0 + lane * 4),
-          (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(xn_tile[buf])), 16, 0, 0);
+    if (w == 3 && lane < KNN_TN / 4) lds_dma16(a.train_sqn + t0 + lane * 4, lds_offset(xn0 + buf * KNN_TN));
   };
-  issue_tile(0, a.start);
+  // Every workgroup walks the whole table, but starts at its own tile and wraps around: in lockstep
+  // all workgroups would hammer the same few L2 channels (measured: ~3 us per tile and workgroup,
+  // whatever the arithmetic), staggered they spread over the memory system.
+  const int64_t ntiles = (a.n - a.start + KNN_TN - 1) / KNN_TN;
+  const int64_t tile_off = ((int64_t)blockIdx.x * 7919) % ntiles;
+  auto tile_row = [&](int64_t j) { return a.start + ((j + tile_off) % ntiles) * KNN_TN; };
+  issue_tile(0, tile_row(0));
   int buf = 0;
-  for (int64_t t0 = a.start; t0 < a.n; t0 += KNN_TN, buf ^= 1) {
+  for (int64_t tj = 0; tj < ntiles; ++tj, buf ^= 1) {
+    const int64_t t0 = tile_row(tj);
     __builtin_amdgcn_s_waitcnt(0);  // this wave's share of tile `buf` has landed
     __syncthreads();                // ... everyone's has, and nobody still reads the other buffer
-    if (t0 + KNN_TN < a.n) issue_tile(buf ^ 1, t0 + KNN_TN);
-    const float* tl = tile[buf];
-    const float* xnt = xn_tile[buf];
+    if (tj + 1 < ntiles) issue_tile(buf ^ 1, tile_row(tj + 1));
+    const float* tl = tile0 + buf * KNN_TN * XS;
+    const float* xnt = xn0 + buf * KNN_TN;
 
-    // ---- two 32 x 32 blocks per wave: MFMA, one compare per pair, rare queue pushes ---------
+    // ---- two 32 x 32 blocks per wave: both MFMA chains are issued before the first accumulator is
+    // read, so the compares of block 0 run under the MFMAs of block 1 ----------------------------
+    f16x acc2[KNN_TN / 32];
 #pragma unroll
     for (int ct = 0; ct < KNN_TN / 32; ++ct) {
       const int col = ct * 32 + r32;
@@ -135,11 +155,16 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(KnnArgs a) {
         const f4x v = *reinterpret_cast<const f4x*>(xrow + 4 * j);
         bx[4 * j] = v.x, bx[4 * j + 1] = v.y, bx[4 * j + 2] = v.z, bx[4 * j + 3] = v.w;
       }
-      const float xn = xnt[col];
-      const float c0 = -0.5f * xn;
+      const float c0 = -0.5f * xnt[col];
       f16x acc = {c0, c0, c0, c0, c0, c0, c0, c0, c0, c0, c0, c0, c0, c0, c0, c0};
 #pragma unroll
       for (int t = 0; t < HD; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[t], bx[t], acc, 0, 0, 0);
+      acc2[ct] = acc;
+    }
+#pragma unroll
+    for (int ct = 0; ct < KNN_TN / 32; ++ct) {
+      const int col = ct * 32 + r32;
+      const f16x acc = acc2[ct];
       bool any = false;
 #pragma unroll
       for (int v = 0; v < 16; ++v) any = any || acc[v] > thr[v];
@@ -210,7 +235,8 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(KnnArgs a) {
 template <int DP>
 static int launch_knn_dp(const KnnArgs& a, hipStream_t stream) {
   const int64_t grid = (a.m + KNN_QB - 1) / KNN_QB;
-  hipLaunchKernelGGL(knn_scan_kernel<DP>, dim3((unsigned)grid), dim3(256), 0, stream, a);
+  const size_t lds = (2 * KNN_TN * (DP + 4) + 2 * KNN_TN + 2 * KNN_QB * KNN_CAP + 2 * KNN_QB) * sizeof(float);
+  hipLaunchKernelGGL(knn_scan_kernel<DP>, dim3((unsigned)grid), dim3(256), lds, stream, a);
   MGP_HIP_CHECK_LAUNCH();
   return MGP_OK;
 }
@@ -230,6 +256,258 @@ int launch_knn_scan(const KnnArgs& a, hipStream_t stream) {
     case 48: return launch_knn_dp<48>(a, stream);
     case 56: return launch_knn_dp<56>(a, stream);
     default: return launch_knn_dp<64>(a, stream);
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Split-bf16 pre-filter variant: 4.4 x fewer matrix-pipe cycles and almost no vector work per pair,
+// still exact.
+//
+// Every fp32 feature is split x = hi + lo + r with hi = bf16(x), lo = bf16(x - hi), |r| <= 2^-16 |x|
+// (host side, once per table: rows packed as [hi(KP) | lo(KP)]).  Three bf16 MFMA chains
+// (hi.hi + hi.lo + lo.hi, v_mfma_f32_32x32x16_bf16, 32 cycles each) give q.x with an error below
+// 2^-14 |q| |x| (dropped lo.lo and r terms <= 3.1 * 2^-16 sum|q_i x_i|, fp32 accumulation of
+// <= 240 products, Cauchy-Schwarz).  The whole test  q.x - |x|^2/2 + margin > (|q|^2 - tau)/2  is
+// evaluated BY the MFMAs: the last two of the KP packed slots are not features but
+//      query row:  [ ..., 1, -thr ]      thr = (|q|^2 - tau)/2, nudged down by its own bf16x2 error
+//      table row:  [ ..., c,  1   ]      c = -|x|^2/2 + 2^-14 QMAX |x| (+ its own bf16x2 error)
+// so the accumulator IS  q.x + c - thr  and a pair survives iff it is positive: per 32 x 32 block the
+// vector unit only takes a max over the 16 accumulators of a lane.  When tau of a query tightens,
+// the lane that holds the query's last operand piece rewrites the -thr slot in place.
+// Survivors are re-measured EXACTLY (fp32 difference form, from the fp32 tables) when their queue
+// is drained, so the lists -- and tau -- only ever hold exact distances.
+// A workgroup owns 256 queries (64 per wave, two MFMA row blocks).
+// ------------------------------------------------------------------------------------------------
+
+typedef __bf16 bf8x __attribute__((ext_vector_type(8)));
+typedef unsigned int u4x __attribute__((ext_vector_type(4)));
+
+constexpr int KB_QW = 64;     // queries per wave
+constexpr int KB_QB = 256;    // queries per workgroup
+constexpr int KB_CAP = 16;    // queue entries per query
+
+__device__ __forceinline__ unsigned bf16_rne(float x) {  // bits of bf16(x), round to nearest even
+  const unsigned u = __float_as_uint(x);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+// -thr as (hi, lo) bf16 bits, with thr first lowered by 2^-14 |thr| (covers the split's own error)
+__device__ __forceinline__ void neg_thr_split(float qn, float tau, unsigned& hi, unsigned& lo) {
+  float thr = fminf(0.5f * (qn - tau), 1e38f);  // tau = -inf (rows past the end): nothing ever passes
+  thr -= 6.103515625e-05f * fabsf(thr);
+  const float v = -thr;
+  hi = bf16_rne(v);
+  lo = bf16_rne(v - __uint_as_float(hi << 16));
+}
+
+template <int KP>
+__global__ __launch_bounds__(256) void knn_scan_bf16x3_kernel(KnnPackedArgs a) {
+  constexpr int RB = 4 * KP;            // bytes of a packed row: KP bf16 hi + KP bf16 lo
+  constexpr int SPR = RB / 16 + 1;      // 16-byte slots of a staged row (odd)
+  constexpr int XSB = SPR * 16;         // LDS row stride in bytes
+  constexpr int NQ = KP / 16;           // 16-byte operand pieces per half row = MFMAs per chain
+  constexpr int NPASS = KNN_TN * SPR / 64;
+  static_assert(KNN_TN * SPR % 64 == 0, "tile must be whole wave passes");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // carved by hand, see knn_scan_kernel
+  char* tile0 = smem;                                                     // [2][KNN_TN * XSB]
+  int* q_i = reinterpret_cast<int*>(smem + 2 * KNN_TN * XSB);             // [KB_QB * KB_CAP]
+  int* q_cnt = q_i + KB_QB * KB_CAP;                                      // [KB_QB]
+  float* tau_s = reinterpret_cast<float*>(q_cnt + KB_QB);                 // [KB_QB]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6;
+  const int half = lane >> 5, r32 = lane & 31;
+  const int64_t qbase = (int64_t)blockIdx.x * KB_QB;
+  const int d = a.d, k = a.k;
+
+  if (tid < KB_QB) {
+    const int64_t q = qbase + tid;
+    float t = -__builtin_inff();
+    if (q < a.m) {
+      t = a.best_d[q * k];
+      for (int j = 1; j < k; ++j) t = fmaxf(t, a.best_d[q * k + j]);
+    }
+    tau_s[tid] = t;
+    q_cnt[tid] = 0;
+  }
+  __syncthreads();
+  // A operands: row block rb, lane (r32, half): packed slots [half*KP/2, half*KP/2 + KP/2) of query
+  // qbase + 64 w + 32 rb + r32, hi and lo parts.  The -thr slot (packed slot KP-1) is the upper
+  // half-word of the last dword of the last piece of the half-1 lanes.
+  u4x ahi[2][NQ], alo[2][NQ];
+  float myqn[2];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    const int row = w * KB_QW + rb * 32 + r32;
+    const int64_t q = qbase + row;
+    const char* prow = reinterpret_cast<const char*>(a.packed_queries) + (q < a.m ? q : 0) * (int64_t)RB;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      ahi[rb][j] = *reinterpret_cast<const u4x*>(prow + half * KP + 16 * j);
+      alo[rb][j] = *reinterpret_cast<const u4x*>(prow + 2 * KP + half * KP + 16 * j);
+    }
+    myqn[rb] = q < a.m ? a.query_sqn[q] : 0.f;
+    if (half == 1) {
+      unsigned hi, lo;
+      neg_thr_split(myqn[rb], tau_s[row], hi, lo);
+      ahi[rb][NQ - 1].w = (ahi[rb][NQ - 1].w & 0xFFFFu) | (hi << 16);
+      alo[rb][NQ - 1].w = (alo[rb][NQ - 1].w & 0xFFFFu) | (lo << 16);
+    }
+  }
+
+  auto issue_tile = [&](int buf, int64_t t0) {
+    for (int p = w; p < NPASS; p += 4) {
+      const int sigma = 64 * p + lane;
+      const int row = sigma / SPR;
+      const int c = min(sigma - row * SPR, SPR - 2);
+      const int64_t grow = min(t0 + row, a.n - 1);
+      lds_dma16(reinterpret_cast<const char*>(a.packed_train) + grow * (int64_t)RB + c * 16,
+                lds_offset(tile0 + buf * KNN_TN * XSB) + p * 1024);
+    }
+  };
+  const int64_t ntiles = (a.n - a.start + KNN_TN - 1) / KNN_TN;  // staggered walk, see knn_scan_kernel
+  const int64_t tile_off = ((int64_t)blockIdx.x * 7919) % ntiles;
+  auto tile_row = [&](int64_t j) { return a.start + ((j + tile_off) % ntiles) * KNN_TN; };
+  issue_tile(0, tile_row(0));
+  int buf = 0;
+  for (int64_t tj = 0; tj < ntiles; ++tj, buf ^= 1) {
+    const int64_t t0 = tile_row(tj);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tj + 1 < ntiles) issue_tile(buf ^ 1, tile_row(tj + 1));
+    const char* tl = tile0 + buf * KNN_TN * XSB;
+
+#pragma unroll
+    for (int ct = 0; ct < KNN_TN / 32; ++ct) {
+      const int col = ct * 32 + r32;
+      const char* xrow = tl + col * XSB;
+      u4x bhi[NQ], blo[NQ];
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        bhi[j] = *reinterpret_cast<const u4x*>(xrow + half * KP + 16 * j);
+        blo[j] = *reinterpret_cast<const u4x*>(xrow + 2 * KP + half * KP + 16 * j);
+      }
+      f16x accr[2];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        f16x acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NQ; ++j)
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8x, ahi[rb][j]),
+                                                        __builtin_bit_cast(bf8x, bhi[j]), acc, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j)
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8x, ahi[rb][j]),
+                                                        __builtin_bit_cast(bf8x, blo[j]), acc, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j)
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8x, alo[rb][j]),
+                                                        __builtin_bit_cast(bf8x, bhi[j]), acc, 0, 0, 0);
+        accr[rb] = acc;
+      }
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const f16x acc = accr[rb];
+        float mx = fmaxf(acc[0], acc[1]);
+#pragma unroll
+        for (int v = 2; v < 16; v += 2) mx = fmaxf(mx, fmaxf(acc[v], acc[v + 1]));  // v_max3_f32
+        if (mx > 0.f && t0 + col < a.n) {
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            if (acc[v] > 0.f) {
+              const int qslot = w * KB_QW + rb * 32 + 8 * (v >> 2) + 4 * half + (v & 3);
+              const int pos = atomicAdd(&q_cnt[qslot], 1);
+              if (pos < KB_CAP) q_i[qslot * KB_CAP + pos] = (int)(t0 + col);
+            }
+          }
+        }
+      }
+    }
+
+    // ---- drain: exact re-measurement of the survivors, then the k-best update ------------------
+    const int mycnt = q_cnt[w * KB_QW + lane];
+    unsigned long long pending = __ballot(mycnt > 0);
+    bool drained = false;
+    while (pending) {
+      const int r = __builtin_ctzll(pending);
+      pending &= pending - 1;
+      const int qslot = w * KB_QW + r;
+      const int64_t q = qbase + qslot;
+      int cnt = q_cnt[qslot];
+      if (q >= a.m) continue;
+      if (cnt > KB_CAP) {
+        if (lane == 0) a.overflow[q] = 1;
+        cnt = KB_CAP;
+      }
+      const int self = a.self_idx ? (int)a.self_idx[q] : -1;
+      f4x qv = {0.f, 0.f, 0.f, 0.f};
+      if (4 * lane < d) qv = *reinterpret_cast<const f4x*>(a.queries + q * (int64_t)d + 4 * lane);
+      float bd = lane < k ? a.best_d[q * k + lane] : -__builtin_inff();
+      int bi = lane < k ? a.best_i[q * k + lane] : -1;
+      float tau = wave_max(bd);
+      for (int c = 0; c < cnt; ++c) {
+        const int ci = q_i[qslot * KB_CAP + c];
+        if (ci == self) continue;
+        f4x xv = {0.f, 0.f, 0.f, 0.f};
+        if (4 * lane < d) xv = *reinterpret_cast<const f4x*>(a.train + ci * (int64_t)d + 4 * lane);
+        const f4x df = qv - xv;
+        const float cd = wave_sum(df.x * df.x + df.y * df.y + df.z * df.z + df.w * df.w);
+        if (!(cd < tau)) continue;
+        const unsigned long long at_max = __ballot(bd == tau);
+        if (lane == __builtin_ctzll(at_max)) bd = cd, bi = ci;
+        tau = wave_max(bd);
+      }
+      if (lane < k) {
+        a.best_d[q * k + lane] = bd;
+        a.best_i[q * k + lane] = bi;
+      }
+      if (lane == 0) {
+        tau_s[qslot] = tau;
+        q_cnt[qslot] = 0;
+      }
+      drained = true;
+    }
+    if (__any(drained)) {
+      __builtin_amdgcn_s_waitcnt(0);
+      if (half == 1) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          unsigned hi, lo;
+          neg_thr_split(myqn[rb], tau_s[w * KB_QW + rb * 32 + r32], hi, lo);
+          ahi[rb][NQ - 1].w = (ahi[rb][NQ - 1].w & 0xFFFFu) | (hi << 16);
+          alo[rb][NQ - 1].w = (alo[rb][NQ - 1].w & 0xFFFFu) | (lo << 16);
+        }
+      }
+    }
+  }
+}
+
+template <int KP>
+static int launch_knn_packed_kp(const KnnPackedArgs& a, hipStream_t stream) {
+  const int64_t grid = (a.m + KB_QB - 1) / KB_QB;
+  const size_t lds = 2 * KNN_TN * (4 * KP + 16) + (KB_QB * KB_CAP + 2 * KB_QB) * sizeof(float);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_scan_bf16x3_kernel<KP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return -(1000 + (int)e);
+  }
+  hipLaunchKernelGGL(knn_scan_bf16x3_kernel<KP>, dim3((unsigned)grid), dim3(256), lds, stream, a);
+  MGP_HIP_CHECK_LAUNCH();
+  return MGP_OK;
+}
+
+int launch_knn_scan_packed(const KnnPackedArgs& a, hipStream_t stream) {
+  if (a.k < 1 || a.k > 64 || a.d < 4 || a.d % 4 != 0 || a.d > 64) return MGP_EUNSUPPORTED;
+  const uintptr_t al = (uintptr_t)a.train | (uintptr_t)a.queries | (uintptr_t)a.packed_train |
+                       (uintptr_t)a.packed_queries;
+  if (al % 16 != 0) return MGP_EUNSUPPORTED;
+  if (a.n >= (int64_t)1 << 31) return MGP_EUNSUPPORTED;
+  switch ((a.d + 2 + 15) / 16 * 16) {  // features + the two threshold slots
+    case 16: return launch_knn_packed_kp<16>(a, stream);
+    case 32: return launch_knn_packed_kp<32>(a, stream);
+    case 48: return launch_knn_packed_kp<48>(a, stream);
+    case 64: return launch_knn_packed_kp<64>(a, stream);
+    default: return launch_knn_packed_kp<80>(a, stream);
   }
 }
 

@@ -31,17 +31,26 @@ SCAN_INIT_ROWS = 4096  # rows of the table the k-best lists are initialised from
 
 class NN_Wrapper:
     def __init__(self, train: torch.Tensor, nn_count: int, nn_method: str = "exact", chunk: int = 4096,
-                 use_scan: bool = True, **kwargs):
+                 use_scan: bool = True, scan_kind: str = "bf16x3", **kwargs):
         if nn_method.lower() != "exact":
             raise NotImplementedError(f"Nearest Neighbor algorithm {nn_method} is not implemented.")
         if not (isinstance(train, torch.Tensor) and train.is_cuda):
             raise TypeError("NN_Wrapper takes a torch tensor on the ROCm device")
-        self.train = (train[:, None] if train.ndim == 1 else train).contiguous()
+        # the table is kept centred on its mean (queries are shifted alike): distances are unchanged,
+        # and every Gram-form quantity below (|q|^2 + |x|^2 - 2 q.x, the split-bf16 margin) is computed
+        # at the scale of the data's spread instead of its offset from the origin
+        table = train[:, None] if train.ndim == 1 else train
+        self._mean = table.double().mean(0).to(table.dtype)
+        self.train = (table - self._mean).contiguous()
         self.train_count, self.feature_count = self.train.shape
         self.nn_count = int(nn_count)
         self.nn_method = "exact"
         self.chunk = int(chunk)
         self.use_scan = bool(use_scan)
+        if scan_kind not in ("bf16x3", "f32"):
+            raise ValueError("scan_kind must be 'bf16x3' or 'f32'")
+        self.scan_kind = scan_kind
+        self._packed_train, self._packed_qmax = None, None
         self._sq = (self.train.double() ** 2).sum(1).to(self.train.dtype)
         # the scan kernel reads |x|^2 in whole 64-row tiles: +inf past the end (never a neighbour)
         pad = (-self.train_count) % 64
@@ -57,9 +66,11 @@ class NN_Wrapper:
         reference drops column 0 of a k+1 query and relies on it being the point itself; here the
         self-match is masked explicitly, so duplicate points cannot displace it.)"""
         q = self.train[batch_indices]
-        return self._get_nns(q, self.nn_count, exclude=batch_indices)
+        return self._get_nns(q, self.nn_count, exclude=batch_indices, centred=True)
 
-    def _get_nns(self, samples, nn_count, exclude=None):
+    def _get_nns(self, samples, nn_count, exclude=None, centred=False):
+        if not centred:
+            samples = samples.to(self.train.dtype) - self._mean
         out = self._scan_nns(samples, nn_count, exclude)
         return out if out is not None else self._dense_nns(samples, nn_count, exclude)
 
@@ -70,6 +81,25 @@ class NN_Wrapper:
             and d % 4 == 0 and 4 <= d <= 64 and 1 <= nn_count <= 64
             and self.train_count > 2 * SCAN_INIT_ROWS and self.train_count < 2**31
         )
+
+    @staticmethod
+    def _split_bf16(v: torch.Tensor):
+        hi = v.to(torch.bfloat16)
+        return hi, (v - hi.float()).to(torch.bfloat16)
+
+    @classmethod
+    def _pack_bf16(cls, x: torch.Tensor, slot_a, slot_b) -> torch.Tensor:
+        """Rows [hi(KP) | lo(KP)] of the split x = hi + lo (bf16 each), KP = 16 ceil((d + 2) / 16); the
+        last two slots of each part hold the split of ``slot_a`` / ``slot_b`` (scalars or (n,) tensors):
+        the threshold terms the scan kernel evaluates on the matrix cores (csrc/mgp_knn.hip)."""
+        n, d = x.shape
+        kp = (d + 2 + 15) // 16 * 16
+        packed = torch.zeros((n, 2 * kp), device=x.device, dtype=torch.bfloat16)
+        packed[:, :d], packed[:, kp:kp + d] = cls._split_bf16(x)
+        for pos, val in ((kp - 2, slot_a), (kp - 1, slot_b)):
+            val = torch.as_tensor(val, device=x.device, dtype=torch.float32).expand(n)
+            packed[:, pos], packed[:, kp + pos] = cls._split_bf16(val)
+        return packed
 
     def _scan_nns(self, samples, nn_count, exclude=None):
         """Fused MFMA scan (see the module docstring); None when the shape is not covered."""
@@ -97,11 +127,31 @@ class NN_Wrapper:
             best_i[s:s + self.chunk] = bi.to(torch.int32)
         overflow = torch.zeros((m,), device=q.device, dtype=torch.int32)
         ex64 = None if exclude is None else exclude.to(torch.int64).contiguous()
-        rc = _lib.load().mgp_knn_scan_f32(
-            _lib.ptr(self.train), _lib.ptr(self._sq_scan), self.train_count, self.feature_count,
-            _lib.ptr(q), _lib.ptr(qn), _lib.ptr(ex64), m, k, SCAN_INIT_ROWS,
-            _lib.ptr(best_d), _lib.ptr(best_i), _lib.ptr(overflow), _lib.stream_ptr(),
-        )
+        if self.scan_kind == "bf16x3":
+            # the split-bf16 kernel keeps exact (difference-form) distances in the lists
+            for s in range(0, m, 65536):
+                diff = q[s:s + 65536, None, :] - self.train[best_i[s:s + 65536].to(torch.int64)]
+                best_d[s:s + 65536] = (diff * diff).sum(-1)
+            # table rows carry c = -|x|^2/2 + 2^-14 QMAX |x| (raised by its own split error) and a 1;
+            # query rows a 1 and a slot the kernel fills with -(|q|^2 - tau)/2
+            qmax = float(qn.max().sqrt())
+            if self._packed_train is None or self._packed_qmax != qmax:
+                c = -0.5 * self._sq + (2.0**-14 * qmax) * self._sq.sqrt()
+                c = c + 2.0**-15 * c.abs()
+                self._packed_train = self._pack_bf16(self.train, c, 1.0)
+                self._packed_qmax = qmax
+            packed_q = self._pack_bf16(q, 1.0, 0.0)
+            rc = _lib.load().mgp_knn_scan_bf16x3(
+                _lib.ptr(self.train), _lib.ptr(self._packed_train), _lib.ptr(self._sq_scan), self.train_count,
+                self.feature_count, _lib.ptr(q), _lib.ptr(packed_q), _lib.ptr(qn), _lib.ptr(ex64), m, k,
+                SCAN_INIT_ROWS, _lib.ptr(best_d), _lib.ptr(best_i), _lib.ptr(overflow), _lib.stream_ptr(),
+            )
+        else:
+            rc = _lib.load().mgp_knn_scan_f32(
+                _lib.ptr(self.train), _lib.ptr(self._sq_scan), self.train_count, self.feature_count,
+                _lib.ptr(q), _lib.ptr(qn), _lib.ptr(ex64), m, k, SCAN_INIT_ROWS,
+                _lib.ptr(best_d), _lib.ptr(best_i), _lib.ptr(overflow), _lib.stream_ptr(),
+            )
         if rc == -2:  # MGP_EUNSUPPORTED (alignment)
             return None
         _lib.check(rc, "mgp_knn_scan_f32")

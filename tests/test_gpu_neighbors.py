@@ -52,8 +52,9 @@ def test_end_to_end_with_true_neighbours():
     assert_close(var.cpu().numpy(), v_ref, RTOL["float32"], "var")
 
 
+@pytest.mark.parametrize("scan_kind", ["bf16x3", "f32"])
 @pytest.mark.parametrize("d,k,n,m", [(40, 30, 30000, 3000), (8, 50, 50000, 2500), (36, 10, 20000, 1000), (64, 64, 12000, 777)])
-def test_mfma_scan_matches_dense_path(d, k, n, m):
+def test_mfma_scan_matches_dense_path(d, k, n, m, scan_kind):
     """The fused MFMA scan (mgp_knn_scan_f32) and the dense matmul+topk path return the same
     neighbour distances (index sets may differ only where distances tie to fp32 rounding)."""
     from muygpys_amd.neighbors import NN_Wrapper
@@ -61,7 +62,7 @@ def test_mfma_scan_matches_dense_path(d, k, n, m):
     g = torch.Generator().manual_seed(d * 1000 + k)
     X = torch.randn(n, d, generator=g).cuda()
     Q = torch.randn(m, d, generator=g).cuda()
-    scan, dense = NN_Wrapper(X, k), NN_Wrapper(X, k, use_scan=False)
+    scan, dense = NN_Wrapper(X, k, scan_kind=scan_kind), NN_Wrapper(X, k, use_scan=False)
     assert scan._scan_supported(Q, k)
     for query in ("test", "batch"):
         if query == "test":
@@ -79,7 +80,8 @@ def test_mfma_scan_matches_dense_path(d, k, n, m):
         assert all(len(set(row.tolist())) == k for row in i1[:50])
 
 
-def test_mfma_scan_survives_adversarial_row_order():
+@pytest.mark.parametrize("scan_kind", ["bf16x3", "f32"])
+def test_mfma_scan_survives_adversarial_row_order(scan_kind):
     """Rows sorted by distance from the queries, farthest first: every tile beats the running
     k-th best, queues overflow, and the flagged queries are recomputed on the dense path."""
     from muygpys_amd.neighbors import NN_Wrapper
@@ -88,6 +90,22 @@ def test_mfma_scan_survives_adversarial_row_order():
     X = torch.randn(20000, 8, generator=g)
     X = X[(X**2).sum(1).argsort(descending=True)].contiguous().cuda()
     Q = (0.01 * torch.randn(300, 8, generator=g)).cuda()  # near the origin
-    (i1, d1), (i2, d2) = NN_Wrapper(X, 20).get_nns(Q), NN_Wrapper(X, 20, use_scan=False).get_nns(Q)
+    (i1, d1), (i2, d2) = NN_Wrapper(X, 20, scan_kind=scan_kind).get_nns(Q), NN_Wrapper(X, 20, use_scan=False).get_nns(Q)
     torch.testing.assert_close(d1, d2, rtol=1e-5, atol=1e-6)
+    assert float((i1 == i2).float().mean()) > 0.999
+
+
+def test_split_bf16_scan_is_exact_far_from_the_origin():
+    """The pre-filter's margin scales with |q| |x|: a table far from the origin (offset 50, neighbour
+    distances ~1) lets more near misses through but must not lose a true neighbour.  Reference: fp64
+    brute force (the fp32 Gram form of the dense path itself loses ~5e-3 of absolute accuracy here)."""
+    from muygpys_amd.neighbors import NN_Wrapper
+
+    g = torch.Generator().manual_seed(9)
+    X = (50.0 + torch.randn(30000, 8, generator=g)).cuda()
+    Q = (50.0 + torch.randn(500, 8, generator=g)).cuda()
+    i1, d1 = NN_Wrapper(X, 25, scan_kind="bf16x3").get_nns(Q)
+    ref = torch.cdist(Q.double(), X.double()) ** 2
+    d2, i2 = ref.topk(25, dim=1, largest=False)
+    torch.testing.assert_close(d1.double(), d2, rtol=1e-4, atol=1e-5)
     assert float((i1 == i2).float().mean()) > 0.999

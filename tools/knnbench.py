@@ -21,10 +21,12 @@ def main():
     ap.add_argument("--k", type=int, default=30)
     ap.add_argument("--queries", type=int, default=100_000)
     ap.add_argument("--chunk", type=int, default=4096)
+    ap.add_argument("--scan", default="bf16x3", choices=["bf16x3", "f32", "dense"])
     args = ap.parse_args()
     torch.manual_seed(0)
     X = torch.randn(args.n, args.d, device="cuda")
-    nn = NN_Wrapper(X, args.k, chunk=args.chunk)
+    nn = NN_Wrapper(X, args.k, chunk=args.chunk, use_scan=args.scan != "dense",
+                    scan_kind=args.scan if args.scan != "dense" else "f32")
     bi = torch.arange(args.queries, device="cuda")
     nn.get_batch_nns(bi[:8192])
     torch.cuda.synchronize()
@@ -33,7 +35,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     pairs = args.queries * args.n
-    print(f"kNN {args.queries} queries x {args.n} points, d={args.d}, k={args.k}: {dt * 1e3:.1f} ms "
+    print(f"[{args.scan}] kNN {args.queries} queries x {args.n} points, d={args.d}, k={args.k}: {dt * 1e3:.1f} ms "
           f"-> {args.queries / dt / 1e3:.1f} k queries/s, {pairs / dt / 1e12:.2f} T pair-distances/s, "
           f"{2 * pairs * args.d / dt / 1e12:.1f} TFLOP/s")
 
