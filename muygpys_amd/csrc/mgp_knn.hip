@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(KnnArgs a) {
   auto tile_row = [&](int64_t j) { return a.start + ((j + tile_off) % ntiles) * KNN_TN; };
   issue_tile(0, tile_row(0));
   int buf = 0;
+  int64_t next_drain = 0;
   for (int64_t tj = 0; tj < ntiles; ++tj, buf ^= 1) {
     const int64_t t0 = tile_row(tj);
     __builtin_amdgcn_s_waitcnt(0);  // this wave's share of tile `buf` has landed
@@ -184,6 +185,9 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(KnnArgs a) {
     }
 
     // ---- drain this wave's queues into the k-best lists (wave-private state: no barrier) ------
+    // batched, with an interval that grows with the rows already seen: see knn_scan_bf16x3_kernel
+    if (tj < next_drain && tj + 1 < ntiles) continue;
+    next_drain = tj + (tj < 64 ? 1 : tj < 256 ? 4 : tj < 1024 ? 8 : 16);
     const int mycnt = lane < KNN_QW ? q_cnt[w * KNN_QW + lane] : 0;
     unsigned long long pending = __ballot(mycnt > 0);
     bool drained = false;
@@ -370,12 +374,14 @@ __global__ __launch_bounds__(256) void knn_scan_bf16x3_kernel(KnnPackedArgs a) {
   auto tile_row = [&](int64_t j) { return a.start + ((j + tile_off) % ntiles) * KNN_TN; };
   issue_tile(0, tile_row(0));
   int buf = 0;
+  int64_t next_drain = 0;
   for (int64_t tj = 0; tj < ntiles; ++tj, buf ^= 1) {
     const int64_t t0 = tile_row(tj);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    if (tj + 1 < ntiles) issue_tile(buf ^ 1, tile_row(tj + 1));
+    if (tj + 1 < ntiles && !(a.debug_skip_drain & 4)) issue_tile(buf ^ 1, tile_row(tj + 1));
     const char* tl = tile0 + buf * KNN_TN * XSB;
+    if (a.debug_skip_drain & 2) continue;
 
 #pragma unroll
     for (int ct = 0; ct < KNN_TN / 32; ++ct) {
@@ -425,8 +431,15 @@ __global__ __launch_bounds__(256) void knn_scan_bf16x3_kernel(KnnPackedArgs a) {
     }
 
     // ---- drain: exact re-measurement of the survivors, then the k-best update ------------------
+    // Not after every tile: a drain is a chain of dependent global loads (~2 us), and the four
+    // waves of the workgroup meet at the next tile's barrier, so one wave draining stalls all;
+    // batching makes the waves drain together.  A query collects ~ 64 k / rows_seen candidates per
+    // tile, so the interval grows with the rows already seen (queues hold KB_CAP entries).
+    if (tj < next_drain && tj + 1 < ntiles) continue;
+    next_drain = tj + (tj < 64 ? 1 : tj < 256 ? 4 : tj < 1024 ? 8 : 16);
     const int mycnt = q_cnt[w * KB_QW + lane];
-    unsigned long long pending = __ballot(mycnt > 0);
+    unsigned long long pending = (a.debug_skip_drain & 1) ? 0ull : __ballot(mycnt > 0);
+    if ((a.debug_skip_drain & 1) && mycnt > 0) q_cnt[w * KB_QW + lane] = 0;
     bool drained = false;
     while (pending) {
       const int r = __builtin_ctzll(pending);
@@ -496,7 +509,11 @@ static int launch_knn_packed_kp(const KnnPackedArgs& a, hipStream_t stream) {
   return MGP_OK;
 }
 
-int launch_knn_scan_packed(const KnnPackedArgs& a, hipStream_t stream) {
+int g_knn_skip_drain = 0;  // timing ablation only (results are wrong): never merge the queues
+
+int launch_knn_scan_packed(const KnnPackedArgs& in, hipStream_t stream) {
+  KnnPackedArgs a = in;
+  a.debug_skip_drain = g_knn_skip_drain;
   if (a.k < 1 || a.k > 64 || a.d < 4 || a.d % 4 != 0 || a.d > 64) return MGP_EUNSUPPORTED;
   const uintptr_t al = (uintptr_t)a.train | (uintptr_t)a.queries | (uintptr_t)a.packed_train |
                        (uintptr_t)a.packed_queries;

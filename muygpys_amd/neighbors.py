@@ -31,7 +31,7 @@ SCAN_INIT_ROWS = 4096  # rows of the table the k-best lists are initialised from
 
 class NN_Wrapper:
     def __init__(self, train: torch.Tensor, nn_count: int, nn_method: str = "exact", chunk: int = 4096,
-                 use_scan: bool = True, scan_kind: str = "bf16x3", **kwargs):
+                 use_scan: bool = True, scan_kind: str = "auto", **kwargs):
         if nn_method.lower() != "exact":
             raise NotImplementedError(f"Nearest Neighbor algorithm {nn_method} is not implemented.")
         if not (isinstance(train, torch.Tensor) and train.is_cuda):
@@ -47,9 +47,11 @@ class NN_Wrapper:
         self.nn_method = "exact"
         self.chunk = int(chunk)
         self.use_scan = bool(use_scan)
-        if scan_kind not in ("bf16x3", "f32"):
-            raise ValueError("scan_kind must be 'bf16x3' or 'f32'")
-        self.scan_kind = scan_kind
+        if scan_kind not in ("auto", "bf16x3", "f32"):
+            raise ValueError("scan_kind must be 'auto', 'bf16x3' or 'f32'")
+        # measured (1 M x 1 M, end to end): split-bf16 pre-filter 0.58 s (d = 40) / 0.46 s (d = 8),
+        # plain fp32 scan 0.92 s / 0.44 s
+        self.scan_kind = scan_kind if scan_kind != "auto" else ("bf16x3" if self.feature_count > 16 else "f32")
         self._packed_train, self._packed_qmax = None, None
         self._sq = (self.train.double() ** 2).sum(1).to(self.train.dtype)
         # the scan kernel reads |x|^2 in whole 64-row tiles: +inf past the end (never a neighbour)
