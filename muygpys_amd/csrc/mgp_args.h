@@ -79,7 +79,6 @@ struct KnnPackedArgs {
   int* overflow;                // (m)
   int64_t n, m, start;
   int d, k;
-  int debug_skip_drain;
 };
 int launch_knn_scan_packed(const KnnPackedArgs&, hipStream_t);
 

@@ -16,7 +16,6 @@ extern int g_lds_pad;
 extern int g_wave2_enable;
 extern int g_bwd_stage;  // mgp_backward.hip
 extern int g_runtime_pipe;
-extern int g_knn_skip_drain;
 
 template <typename T>
 int posterior(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t* ni, int64_t b, int k, const T* tg,
@@ -91,7 +90,6 @@ void mgp_debug_set_lds_pad(int n) { mgp::g_lds_pad = n; }
 void mgp_debug_enable_wave2(int on) { mgp::g_wave2_enable = on; }
 void mgp_debug_set_bwd_stage(int n) { mgp::g_bwd_stage = n; }
 void mgp_debug_runtime_pipe(int on) { mgp::g_runtime_pipe = on; }
-void mgp_debug_knn_skip_drain(int on) { mgp::g_knn_skip_drain = on; }
 
 int mgp_posterior_f32(const float* fq, const float* fn, int d, const int64_t* bi, const int64_t* ni, int64_t b, int k,
                       const float* tg, int R, int nm, double eps, const float* nd, int kid, int mid, const float* ls,
@@ -124,7 +122,7 @@ int mgp_knn_scan_bf16x3(const float* train, const void* packed_train, const floa
       !overflow)
     return MGP_EINVAL;
   KnnPackedArgs a{train, packed_train, train_sqn, queries, packed_queries, query_sqn, self_idx, best_d, best_i,
-                  overflow, n, m, start, d, k, 0};
+                  overflow, n, m, start, d, k};
   return launch_knn_scan_packed(a, S_(st));
 }
 

@@ -379,9 +379,8 @@ __global__ __launch_bounds__(256) void knn_scan_bf16x3_kernel(KnnPackedArgs a) {
     const int64_t t0 = tile_row(tj);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    if (tj + 1 < ntiles && !(a.debug_skip_drain & 4)) issue_tile(buf ^ 1, tile_row(tj + 1));
+    if (tj + 1 < ntiles) issue_tile(buf ^ 1, tile_row(tj + 1));
     const char* tl = tile0 + buf * KNN_TN * XSB;
-    if (a.debug_skip_drain & 2) continue;
 
 #pragma unroll
     for (int ct = 0; ct < KNN_TN / 32; ++ct) {
@@ -438,8 +437,7 @@ __global__ __launch_bounds__(256) void knn_scan_bf16x3_kernel(KnnPackedArgs a) {
     if (tj < next_drain && tj + 1 < ntiles) continue;
     next_drain = tj + (tj < 64 ? 1 : tj < 256 ? 4 : tj < 1024 ? 8 : 16);
     const int mycnt = q_cnt[w * KB_QW + lane];
-    unsigned long long pending = (a.debug_skip_drain & 1) ? 0ull : __ballot(mycnt > 0);
-    if ((a.debug_skip_drain & 1) && mycnt > 0) q_cnt[w * KB_QW + lane] = 0;
+    unsigned long long pending = __ballot(mycnt > 0);
     bool drained = false;
     while (pending) {
       const int r = __builtin_ctzll(pending);
@@ -509,11 +507,7 @@ static int launch_knn_packed_kp(const KnnPackedArgs& a, hipStream_t stream) {
   return MGP_OK;
 }
 
-int g_knn_skip_drain = 0;  // timing ablation only (results are wrong): never merge the queues
-
-int launch_knn_scan_packed(const KnnPackedArgs& in, hipStream_t stream) {
-  KnnPackedArgs a = in;
-  a.debug_skip_drain = g_knn_skip_drain;
+int launch_knn_scan_packed(const KnnPackedArgs& a, hipStream_t stream) {
   if (a.k < 1 || a.k > 64 || a.d < 4 || a.d % 4 != 0 || a.d > 64) return MGP_EUNSUPPORTED;
   const uintptr_t al = (uintptr_t)a.train | (uintptr_t)a.queries | (uintptr_t)a.packed_train |
                        (uintptr_t)a.packed_queries;

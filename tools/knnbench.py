@@ -21,12 +21,8 @@ def main():
     ap.add_argument("--k", type=int, default=30)
     ap.add_argument("--queries", type=int, default=100_000)
     ap.add_argument("--chunk", type=int, default=4096)
-    ap.add_argument("--skip-drain", type=int, default=0, help="timing ablation (wrong results): bf16x3 scan without queue merges")
     ap.add_argument("--scan", default="auto", choices=["auto", "bf16x3", "f32", "dense"])
     args = ap.parse_args()
-    from muygpys_amd import _lib
-
-    _lib.load().mgp_debug_knn_skip_drain(args.skip_drain)
     torch.manual_seed(0)
     X = torch.randn(args.n, args.d, device="cuda")
     nn = NN_Wrapper(X, args.k, chunk=args.chunk, use_scan=args.scan != "dense",
