@@ -20,6 +20,8 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          # explicit vector types carry the packed-f32 math; the SLP vectoriser only shuffles registers
          "-fno-slp-vectorize"]
+# the k-NN scans test the MFMA results right away: keep them in VGPRs (no v_accvgpr_read per value)
+PER_FILE_FLAGS = {"mgp_knn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc() -> str:
@@ -54,7 +56,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        cmd = [hipcc, *FLAGS, *os.environ.get("MGP_EXTRA_HIPCC_FLAGS", "").split(), "-c", src, "-o", obj]
+        cmd = [hipcc, *FLAGS, *PER_FILE_FLAGS.get(os.path.basename(src), []),
+               *os.environ.get("MGP_EXTRA_HIPCC_FLAGS", "").split(), "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

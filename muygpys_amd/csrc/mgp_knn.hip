@@ -413,10 +413,12 @@ __global__ __launch_bounds__(256) void knn_scan_bf16x3_kernel(KnnPackedArgs a) {
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
         const f16x acc = accr[rb];
-        float mx = fmaxf(acc[0], acc[1]);
+        // any accumulator positive?  as integers (a positive float is a positive int32): v_max3_i32
+        // without the NaN-quieting canonicalisation fmaxf would put in front of every operand
+        int mx = max(__float_as_int(acc[0]), __float_as_int(acc[1]));
 #pragma unroll
-        for (int v = 2; v < 16; v += 2) mx = fmaxf(mx, fmaxf(acc[v], acc[v + 1]));  // v_max3_f32
-        if (mx > 0.f && t0 + col < a.n) {
+        for (int v = 2; v < 16; v += 2) mx = max(mx, max(__float_as_int(acc[v]), __float_as_int(acc[v + 1])));
+        if (mx > 0 && t0 + col < a.n) {
 #pragma unroll
           for (int v = 0; v < 16; ++v) {
             if (acc[v] > 0.f) {
@@ -436,49 +438,59 @@ __global__ __launch_bounds__(256) void knn_scan_bf16x3_kernel(KnnPackedArgs a) {
     // tile, so the interval grows with the rows already seen (queues hold KB_CAP entries).
     if (tj < next_drain && tj + 1 < ntiles) continue;
     next_drain = tj + (tj < 64 ? 1 : tj < 256 ? 4 : tj < 1024 ? 8 : 16);
-    const int mycnt = q_cnt[w * KB_QW + lane];
-    unsigned long long pending = __ballot(mycnt > 0);
-    bool drained = false;
-    while (pending) {
-      const int r = __builtin_ctzll(pending);
-      pending &= pending - 1;
-      const int qslot = w * KB_QW + r;
-      const int64_t q = qbase + qslot;
-      int cnt = q_cnt[qslot];
-      if (q >= a.m) continue;
+    // Lane-per-query: lane r merges the queue of the wave's query r into that query's k-best list,
+    // so all 64 queries drain at once and a drain costs a few memory latencies however many
+    // queries are pending.  Round e handles every lane's e-th queue entry: exact squared distance
+    // (d/4 independent 16-byte loads from each of the two rows), then one pass over the list that
+    // finds its largest and second largest entry; a closer candidate replaces the largest.
+    const int qslot = w * KB_QW + lane;
+    const int64_t q = qbase + qslot;
+    int cnt = q < a.m ? q_cnt[qslot] : 0;
+    if (__any(cnt > 0)) {
       if (cnt > KB_CAP) {
-        if (lane == 0) a.overflow[q] = 1;
+        a.overflow[q] = 1;
         cnt = KB_CAP;
       }
-      const int self = a.self_idx ? (int)a.self_idx[q] : -1;
-      f4x qv = {0.f, 0.f, 0.f, 0.f};
-      if (4 * lane < d) qv = *reinterpret_cast<const f4x*>(a.queries + q * (int64_t)d + 4 * lane);
-      float bd = lane < k ? a.best_d[q * k + lane] : -__builtin_inff();
-      int bi = lane < k ? a.best_i[q * k + lane] : -1;
-      float tau = wave_max(bd);
-      for (int c = 0; c < cnt; ++c) {
-        const int ci = q_i[qslot * KB_CAP + c];
-        if (ci == self) continue;
-        f4x xv = {0.f, 0.f, 0.f, 0.f};
-        if (4 * lane < d) xv = *reinterpret_cast<const f4x*>(a.train + ci * (int64_t)d + 4 * lane);
-        const f4x df = qv - xv;
-        const float cd = wave_sum(df.x * df.x + df.y * df.y + df.z * df.z + df.w * df.w);
-        if (!(cd < tau)) continue;
-        const unsigned long long at_max = __ballot(bd == tau);
-        if (lane == __builtin_ctzll(at_max)) bd = cd, bi = ci;
-        tau = wave_max(bd);
+      const int self = (cnt > 0 && a.self_idx) ? (int)a.self_idx[q] : -1;
+      const float* qrow = a.queries + (q < a.m ? q : 0) * (int64_t)d;
+      float* ld = a.best_d + (q < a.m ? q : 0) * (int64_t)k;
+      int* li = a.best_i + (q < a.m ? q : 0) * (int64_t)k;
+      float tau = tau_s[qslot];
+      const int rounds = wave_max(cnt);
+      for (int e = 0; e < rounds; ++e) {
+        if (e < cnt) {
+          const int ci = q_i[qslot * KB_CAP + e];
+          if (ci != self) {
+            const float* xrow = a.train + ci * (int64_t)d;
+            float cd = 0.f;
+            for (int c = 0; c < d; c += 4) {
+              const f4x df = *reinterpret_cast<const f4x*>(qrow + c) - *reinterpret_cast<const f4x*>(xrow + c);
+              cd += df.x * df.x + df.y * df.y + df.z * df.z + df.w * df.w;
+            }
+            if (cd < tau) {
+              float m1 = -__builtin_inff(), m2 = -__builtin_inff();
+              int at = 0;
+              for (int j = 0; j < k; ++j) {
+                const float v = ld[j];
+                if (v > m1) {
+                  m2 = m1;
+                  m1 = v;
+                  at = j;
+                } else if (v > m2) {
+                  m2 = v;
+                }
+              }
+              ld[at] = cd;
+              li[at] = ci;
+              tau = fmaxf(m2, cd);
+            }
+          }
+        }
       }
-      if (lane < k) {
-        a.best_d[q * k + lane] = bd;
-        a.best_i[q * k + lane] = bi;
-      }
-      if (lane == 0) {
+      if (cnt > 0) {
         tau_s[qslot] = tau;
         q_cnt[qslot] = 0;
       }
-      drained = true;
-    }
-    if (__any(drained)) {
       __builtin_amdgcn_s_waitcnt(0);
       if (half == 1) {
 #pragma unroll
