@@ -305,7 +305,7 @@ __device__ __forceinline__ void neg_thr_split(float qn, float tau, unsigned& hi,
 }
 
 template <int KP>
-__global__ __launch_bounds__(256) void knn_scan_bf16x3_kernel(KnnPackedArgs a) {
+__global__ __launch_bounds__(256, (KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void knn_scan_bf16x3_kernel(KnnPackedArgs a) {
   constexpr int RB = 4 * KP;            // bytes of a packed row: KP bf16 hi + KP bf16 lo
   constexpr int SPR = RB / 16 + 1;      // 16-byte slots of a staged row (odd)
   constexpr int XSB = SPR * 16;         // LDS row stride in bytes

@@ -49,9 +49,9 @@ class NN_Wrapper:
         self.use_scan = bool(use_scan)
         if scan_kind not in ("auto", "bf16x3", "f32"):
             raise ValueError("scan_kind must be 'auto', 'bf16x3' or 'f32'")
-        # measured (1 M x 1 M, end to end): split-bf16 pre-filter 0.58 s (d = 40) / 0.46 s (d = 8),
-        # plain fp32 scan 0.92 s / 0.44 s
-        self.scan_kind = scan_kind if scan_kind != "auto" else ("bf16x3" if self.feature_count > 16 else "f32")
+        # measured (1 M x 1 M, end to end): split-bf16 pre-filter 0.47 s (d = 40) / 0.36 s (d = 8),
+        # plain fp32 scan 0.90 s / 0.43 s
+        self.scan_kind = "bf16x3" if scan_kind == "auto" else scan_kind
         self._packed_train, self._packed_qmax = None, None
         self._sq = (self.train.double() ** 2).sum(1).to(self.train.dtype)
         # the scan kernel reads |x|^2 in whole 64-row tiles: +inf past the end (never a neighbour)
