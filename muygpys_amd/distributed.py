@@ -168,3 +168,17 @@ def sharded_posterior(spec, test_features, train_features, train_targets, batch_
         dist.all_gather(vars_, var.contiguous(), group=group)
         mean, var = torch.cat(means), torch.cat(vars_)
     return mean, var
+
+
+def sharded_batch_nns(nbrs_lookup, batch_indices: torch.Tensor, group=None, rank: Optional[int] = None,
+                      world_size: Optional[int] = None):
+    """Neighbour search for this rank's block of ``batch_indices`` (reference rule), with the table
+    replicated like every other table of the path: no collective, the ``(rows, nn_count)`` index and
+    distance tensors stay sharded exactly like the posterior outputs they feed.  ``nbrs_lookup`` is
+    a :class:`muygpys_amd.neighbors.NN_Wrapper` built from the (replicated) training features.
+    Returns ``(local_batch_indices, local_nn_indices, local_distances)``."""
+    if rank is None or world_size is None:
+        rank, world_size = _world(group)
+    local = shard_rows(batch_indices, rank, world_size).contiguous()
+    nn_indices, distances = nbrs_lookup.get_batch_nns(local)
+    return local, nn_indices, distances

@@ -43,3 +43,21 @@ def test_partials_and_finish(golden, dtype):
     fin = D.finish_objective(total.tolist(), ni.shape[1])
     assert_close([fin["lool"]], [g["lool"]], rtol, "lool from 3 shards")
     assert_close(torch.cat(means).cpu().numpy(), g["mean"], rtol, "concatenated shard means")
+
+
+def test_sharded_batch_nns_concatenates_to_the_unsharded_search():
+    """Three emulated ranks (reference chunk rule, remainder to the last ranks) each search their
+    block of the batch; concatenated in rank order the result is the single-process search."""
+    from muygpys_amd.distributed import chunk_sizes, sharded_batch_nns
+    from muygpys_amd.neighbors import NN_Wrapper
+
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(20000, 16, generator=g).cuda()
+    nbrs = NN_Wrapper(X, 12)
+    bi = torch.randperm(20000, generator=g)[:1001].cuda()
+    ref_i, ref_d = nbrs.get_batch_nns(bi)
+    parts = [sharded_batch_nns(nbrs, bi, rank=r, world_size=3) for r in range(3)]
+    assert [p[0].shape[0] for p in parts] == chunk_sizes(1001, 3)
+    assert torch.equal(torch.cat([p[0] for p in parts]), bi)
+    assert torch.equal(torch.cat([p[1] for p in parts]), ref_i)
+    torch.testing.assert_close(torch.cat([p[2] for p in parts]), ref_d)
