@@ -98,6 +98,23 @@ int mgp_posterior_f64(const double* feat_q, const double* feat_nn, int d,
                       int kernel_id, int metric_id, const double* length_scale, int ls_count,
                       double* mean, double* var, double* ykinvy, int* info, void* stream);
 
+/* Fused coefficient precompute of the fast posterior mean: coeffs (b, k) = (K_b + eps)^-1 y_b
+ * for the neighbourhoods nn_idx (b, k) of one table (gather -> distances -> kernel -> nugget ->
+ * LDL^T -> back-substitution in one launch).  Replaces _muygps_fast_posterior_mean_precompute
+ * on materialised tensors (_src/gp/muygps/numpy.py:88-95, called from
+ * MuyGPS.fast_coefficients, gp/muygps.py:261-298, in examples/fast_posterior_mean.py:373-386).
+ * One response column (targets (n)); fp32 with k <= 30 runs fused, anything else returns
+ * MGP_EUNSUPPORTED and the caller uses mgp_pairwise_dists / mgp_kernel_apply / mgp_perturb /
+ * mgp_solve (coeffs output). */
+int mgp_fast_coefficients_f32(const float* feat, int d, const int64_t* nn_idx, int64_t b, int k,
+                              const float* targets, int noise_mode, double noise_scalar, const float* noise_dev,
+                              int kernel_id, int metric_id, const float* length_scale, int ls_count,
+                              float* coeffs, int* info, void* stream);
+int mgp_fast_coefficients_f64(const double* feat, int d, const int64_t* nn_idx, int64_t b, int k,
+                              const double* targets, int noise_mode, double noise_scalar, const double* noise_dev,
+                              int kernel_id, int metric_id, const double* length_scale, int ls_count,
+                              double* coeffs, int* info, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Exact k-nearest-neighbour scan (the step upstream of the hot path).  Replaces
  * the exact search behind NN_Wrapper (src/MuyGPyS/neighbors.py:106-107 builds a

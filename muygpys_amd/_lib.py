@@ -64,6 +64,7 @@ _SIGS = {
     "column_sums": [_p, _l, _i, _p, _p],
     "posterior_backward": [_p, _p, _i, _p, _p, _l, _i, _p, _i, _i, _d, _p, _i, _i, _p, _i,
                            _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "fast_coefficients": [_p, _i, _p, _l, _i, _p, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p],
     "fast_posterior_mean": [_p, _p, _i, _p, _p, _l, _i, _p, _p, _i, _i, _i, _p, _i, _p, _p],
 }
 

@@ -20,6 +20,7 @@ struct FusedArgs {
   int64_t b;
   double noise_scalar;
   int d, k, R, noise_mode, kernel_id, metric_id, ls_count, dc;
+  void* coeffs = nullptr;  // (b, k) K^-1 y per neighbourhood (fused fast-mean precompute), or nullptr
 };
 
 struct SolveArgs {

@@ -40,6 +40,25 @@ int posterior(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t*
   return launch_fused_generic<T>(a, s);
 }
 
+// fused fast-mean precompute: coefficients K^-1 y of every neighbourhood (no query involved)
+template <typename T>
+int fast_coefficients(const T* fn, int d, const int64_t* ni, int64_t b, int k, const T* tg, int noise_mode, double eps,
+                      const T* nd, int kernel_id, int metric_id, const T* ls, int ls_count, T* coeffs, int* info,
+                      void* stream) {
+  if (b < 0 || k < 1 || d < 1) return MGP_EINVAL;
+  if (b == 0) return MGP_OK;
+  if (!fn || !ni || !tg || !ls || !coeffs) return MGP_EINVAL;
+  if (!valid_kernel(kernel_id) || !valid_metric(metric_id)) return MGP_EINVAL;
+  if (noise_mode < MGP_NOISE_SCALAR || noise_mode > MGP_NOISE_BATCH) return MGP_EINVAL;
+  if (noise_mode != MGP_NOISE_SCALAR && !nd) return MGP_EINVAL;
+  if (ls_count != 1 && ls_count != d) return MGP_EINVAL;
+  // the query slot is fed the first neighbour of each row: its outputs are not stored
+  FusedArgs a{fn, fn, nullptr, ni, tg, nd, ls, nullptr, nullptr, nullptr, info, b, eps, d, k, 1, noise_mode, kernel_id,
+              metric_id, ls_count, 0};
+  a.coeffs = coeffs;
+  return launch_fused_wave<T>(a, static_cast<hipStream_t>(stream));
+}
+
 template <typename T>
 int posterior_backward(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t* ni, int64_t b, int k,
                        const T* tg, int R, int noise_mode, double eps, const T* nd, int kernel_id, int metric_id,
@@ -125,6 +144,15 @@ int mgp_knn_scan_bf16x3(const float* train, const void* packed_train, const floa
                   overflow, n, m, start, d, k};
   return launch_knn_scan_packed(a, S_(st));
 }
+
+#define MGP_DEFINE_COEF(SUF, T)                                                                                     \
+  int mgp_fast_coefficients_##SUF(const T* fn, int d, const int64_t* ni, int64_t b, int k, const T* tg, int nm,      \
+                                  double eps, const T* nd, int kid, int mid, const T* ls, int lsc, T* coeffs,        \
+                                  int* info, void* st) {                                                             \
+    return fast_coefficients<T>(fn, d, ni, b, k, tg, nm, eps, nd, kid, mid, ls, lsc, coeffs, info, st);              \
+  }
+MGP_DEFINE_COEF(f32, float)
+MGP_DEFINE_COEF(f64, double)
 
 #define MGP_DEFINE_BWD(SUF, T)                                                                                      \
   int mgp_posterior_backward_##SUF(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t* ni, int64_t b, \

@@ -58,7 +58,8 @@ struct WaveGeom {
 
 // KFIX / RFIX / DFIX > 0: nn_count / response_count / feature_count known at compile time.
 // PIPED: software-pipelined direct-to-LDS gather (one feature stage, 16-byte aligned rows).
-template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED>
+// COEFF: also emit K^-1 y (the fast-posterior-mean coefficients): multipliers kept, back-substitution.
+template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF = false>
 __global__ __launch_bounds__(64, (sizeof(T) == 4 ? (NP == 32 ? 3 : 2) : (NP == 32 ? 2 : 2)))
 void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   constexpr int NH = 64 / NP;     // neighbourhoods per wave
@@ -416,8 +417,11 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     // Whole 16-byte groups are updated from the pivot's group on: entries of columns <= j
     // inside that group are dead by then (right-looking: column j is never read again).
     bool bad = false;
+    [[maybe_unused]] T Lm[COEFF ? NP : 1];  // COEFF: multipliers l_ij = a_ij / p_j of this lane's row
+    if constexpr (COEFF) Lm[NP - 2] = Lm[NP - 1] = T(0);
 #pragma unroll
     for (int j = 0; j < NP - 2; ++j) {
+      if constexpr (COEFF) Lm[j] = T(0);
       if (j < k && (g.mask & 8)) {
         const T ajj = A[j / E][j % E];
         colh[i] = ajj;
@@ -442,10 +446,41 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
           const T p = col[j / E][j % E];
           bad = bad || !(p > T(0));
           const V nt = V(-ajj * pivot_rcp(p));
+          if constexpr (COEFF) Lm[j] = -nt[0];
 #pragma unroll
           for (int c4 = j / E; c4 < NP / E; ++c4) A[c4] = col[c4] * nt + A[c4];
         }
       }
+    }
+
+    // ---- phase 4b (COEFF): x = K^-1 y by back-substitution -------------------------------
+    // K = L D L^T with unit lower L; the forward sweep left l_ij (j < i) in Lm of lane i, and the
+    // response row's multipliers are w_j = (D^-1 L^-1 y)_j.  Solve L^T x = w: the multipliers are
+    // transposed through the (now free) tile so that lane j holds column j of L, then for
+    // m = k-1 .. 1 the finished x_m is read from lane m and every lane j < m takes l_mj x_m off.
+    if constexpr (COEFF) {
+      static_assert(!PIPED && NP == 32 && sizeof(T) == 4, "coefficient variant: fp32, 32 slots, staged gather");
+      __syncthreads();
+#pragma unroll
+      for (int c4 = 0; c4 < NP / E; ++c4) {
+        V v;
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = Lm[c4 * E + e];
+        *reinterpret_cast<V*>(Kh + i * KS + c4 * E) = v;
+      }
+      __syncthreads();
+      T x = Kh[(q + 1) * KS + i];  // w_i, from the response row
+#pragma unroll
+      for (int m = NP - 3; m >= 1; --m) {
+        if (m < k) {
+          const T lmj = Kh[m * KS + i];  // l_mi
+          const T xm0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), m));
+          const T xm1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), m + NP));
+          const T xm = h == 0 ? xm0 : xm1;
+          if (i < m) x = fma_t(-lmj, xm, x);
+        }
+      }
+      if (live && i < k) static_cast<T*>(a.coeffs)[(nb0 + h) * (int64_t)k + i] = bad ? num<T>::nan() : x;
     }
 
     // ---- phase 5: Schur block -> outputs ----------------------------------------------
@@ -453,7 +488,9 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     T* var = static_cast<T*>(a.var);
     T* yk = static_cast<T*>(a.ykinvy);
     const int64_t nb = nb0 + h;
-    if (RFIX == 1) {
+    if constexpr (COEFF) {
+      if (live && bad && i == q && a.info) atomicAdd(a.info, 1);  // mean / variance are not emitted
+    } else if (RFIX == 1) {
       // q = NP-2 and the response row NP-1 are compile-time: the Schur block sits in fixed registers
       constexpr int QF = NP - 2, YF = NP - 1;
       const T sq = A[QF / E][QF % E], sy = A[YF / E][YF % E];
@@ -511,7 +548,7 @@ int g_grid_per_cu = 0;  // debug override of resident workgroups per CU
 int g_lds_pad = 0;      // debug: extra dynamic LDS bytes per workgroup
 int g_runtime_pipe = 1; // debug: 0 = register-staged gather for run-time shapes
 
-template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED>
+template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF = false>
 static int launch_np(const FusedArgs& a, hipStream_t stream) {
   constexpr int NH = 64 / NP;
   constexpr int E = v16<T>::N;
@@ -543,7 +580,7 @@ static int launch_np(const FusedArgs& a, hipStream_t stream) {
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MGP_EHIP;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        &n, reinterpret_cast<const void*>(&fused_wave_kernel<T, NP, KFIX, RFIX, DFIX, PIPED>), 64, lds);
+        &n, reinterpret_cast<const void*>(&fused_wave_kernel<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF>), 64, lds);
     if (e != hipSuccess) return -(1000 + (int)e);
     if (n < 1) return MGP_EUNSUPPORTED;
     cached_lds = (int)lds;
@@ -563,7 +600,7 @@ static int launch_np(const FusedArgs& a, hipStream_t stream) {
     fprintf(stderr, "mgp: fused_wave_kernel<%s,%d,%d,%d,%d,%s> b=%lld k=%d d=%d R=%d grid=%lld lds=%zu\n",
             sizeof(T) == 4 ? "float" : "double", NP, KFIX, RFIX, DFIX, PIPED ? "pipe" : "stage", (long long)a.b, a.k,
             a.d, a.R, (long long)grid, lds);
-  hipLaunchKernelGGL((fused_wave_kernel<T, NP, KFIX, RFIX, DFIX, PIPED>), dim3((unsigned)grid), dim3(64), lds, stream, a,
+  hipLaunchKernelGGL((fused_wave_kernel<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF>), dim3((unsigned)grid), dim3(64), lds, stream, a,
                      g);
   MGP_HIP_CHECK_LAUNCH();
   return MGP_OK;
@@ -572,6 +609,12 @@ static int launch_np(const FusedArgs& a, hipStream_t stream) {
 template <typename T>
 int launch_fused_wave(const FusedArgs& a, hipStream_t stream) {
   const int rows = a.k + 1 + a.R;
+  if (a.coeffs != nullptr) {  // fused fast-mean precompute: fp32, one response, 32 slots
+    if constexpr (sizeof(T) == 4) {
+      if (a.R == 1 && rows <= 32) return launch_np<T, 32, 0, 0, 0, false, true>(a, stream);
+    }
+    return MGP_EUNSUPPORTED;
+  }
   if constexpr (sizeof(T) == 4) if (a.k == 30 && a.R == 1 && a.d == 40) {  // BASELINE configs 2/3, all shapes static
     const int rc2 = launch_fused_wave2_f32(a, stream);
     if (rc2 != MGP_EUNSUPPORTED) return rc2;

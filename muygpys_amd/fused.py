@@ -198,6 +198,23 @@ def fast_coefficients(spec: KernelSpec, train_features: torch.Tensor, train_targ
     d = 1 if train_features.ndim == 1 else train_features.shape[1]
     squeeze = train_targets.ndim == 1
     R = 1 if squeeze else train_targets.shape[1]
+    if R == 1:
+        # one launch: mgp_fast_coefficients_* (fused gather .. LDL^T .. back-substitution)
+        fn = (train_features[:, None] if train_features.ndim == 1 else train_features).contiguous()
+        tg = train_targets.reshape(-1).to(fn.dtype).contiguous()
+        ls = _length_scale_tensor(spec.length_scale, d, fn)
+        mode, eps, nz = _noise_args(spec.noise, n, k, fn)
+        out = torch.empty((n, k), device=fn.device, dtype=fn.dtype)
+        info = torch.zeros(1, device=fn.device, dtype=torch.int32)
+        rc = _lib.fn("fast_coefficients", fn.dtype)(
+            _lib.ptr(fn), d, _lib.ptr(nn_fast), n, k, _lib.ptr(tg), mode, eps, _lib.ptr(nz),
+            spec.kernel_id(), spec.metric_id(), _lib.ptr(ls), ls.numel(), _lib.ptr(out), _lib.ptr(info),
+            _lib.stream_ptr(),
+        )
+        if rc != -2:  # anything but MGP_EUNSUPPORTED (shape outside the fused kernel)
+            _lib.check(rc, "mgp_fast_coefficients")
+            _lib.raise_if_not_spd(info, "fast_coefficients")
+            return (out if squeeze else out[:, :, None]), nn_fast
     out = torch.empty((n, k, R), device=train_features.device, dtype=train_features.dtype)
     aniso = not isinstance(spec.length_scale, (int, float)) and len(spec.length_scale) > 1
     for s in range(0, n, chunk):

@@ -58,3 +58,20 @@ def test_fast_workflow(dtype, case):
     mean = fast_posterior_mean(spec, Qd, Xd, None, nn_fast[closest_d], coeffs, closest_d)
     assert mean.shape == mean_ref.shape
     assert_close(mean.cpu().numpy(), mean_ref, rtol, "fast posterior mean")
+
+
+def test_fused_coefficients_match_the_materialising_path_at_scale():
+    """mgp_fast_coefficients_f32 (one launch, every workgroup looping over many tasks) against the
+    per-function path (pairwise distances -> kernel -> nugget -> mgp_solve) in fp64."""
+    from muygpys_amd.fused import KernelSpec, fast_coefficients
+
+    g = torch.Generator().manual_seed(21)
+    n, d, k = 150_000, 40, 30
+    X = torch.randn(n, d, generator=g)
+    y = torch.sin(X @ (torch.randn(d, generator=g) / d**0.5)) + 0.05 * torch.randn(n, generator=g)
+    nn = torch.randint(0, n, (n, k), generator=g)
+    spec = KernelSpec("matern15", "l2", 6.0, 1e-2)
+    c32, nnf = fast_coefficients(spec, X.cuda(), y.cuda(), nn.cuda())
+    c64, nnf64 = fast_coefficients(spec, X.double().cuda(), y.double().cuda(), nn.cuda())
+    assert torch.equal(nnf, nnf64) and c32.dtype == torch.float32 and c32.shape == (n, k)
+    assert_close(c32.cpu().numpy(), c64.cpu().numpy(), 10 * RTOL["float32"], "coefficients")
