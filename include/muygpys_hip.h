@@ -104,8 +104,8 @@ int mgp_posterior_f64(const double* feat_q, const double* feat_nn, int d,
  * on materialised tensors (_src/gp/muygps/numpy.py:88-95, called from
  * MuyGPS.fast_coefficients, gp/muygps.py:261-298, in examples/fast_posterior_mean.py:373-386).
  * One response column (targets (n)); fp32 with k <= 30 runs fused, anything else returns
- * MGP_EUNSUPPORTED and the caller uses mgp_pairwise_dists / mgp_kernel_apply / mgp_perturb /
- * mgp_solve (coeffs output). */
+ * MGP_EUNSUPPORTED and the caller uses the mgp_pairwise_dists_*, mgp_kernel_apply_*, mgp_perturb_*
+ * and mgp_solve_* entry points (the last with its coeffs output). */
 int mgp_fast_coefficients_f32(const float* feat, int d, const int64_t* nn_idx, int64_t b, int k,
                               const float* targets, int noise_mode, double noise_scalar, const float* noise_dev,
                               int kernel_id, int metric_id, const float* length_scale, int ls_count,
