@@ -103,7 +103,7 @@ int mgp_posterior_f64(const double* feat_q, const double* feat_nn, int d,
  * LDL^T -> back-substitution in one launch).  Replaces _muygps_fast_posterior_mean_precompute
  * on materialised tensors (_src/gp/muygps/numpy.py:88-95, called from
  * MuyGPS.fast_coefficients, gp/muygps.py:261-298, in examples/fast_posterior_mean.py:373-386).
- * One response column (targets (n)); fp32 with k <= 30 runs fused, anything else returns
+ * One response column (targets (n)), k <= 62; anything else returns
  * MGP_EUNSUPPORTED and the caller uses the mgp_pairwise_dists_*, mgp_kernel_apply_*, mgp_perturb_*
  * and mgp_solve_* entry points (the last with its coeffs output). */
 int mgp_fast_coefficients_f32(const float* feat, int d, const int64_t* nn_idx, int64_t b, int k,

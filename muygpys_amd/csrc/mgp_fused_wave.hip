@@ -417,11 +417,8 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     // Whole 16-byte groups are updated from the pivot's group on: entries of columns <= j
     // inside that group are dead by then (right-looking: column j is never read again).
     bool bad = false;
-    [[maybe_unused]] T Lm[COEFF ? NP : 1];  // COEFF: multipliers l_ij = a_ij / p_j of this lane's row
-    if constexpr (COEFF) Lm[NP - 2] = Lm[NP - 1] = T(0);
 #pragma unroll
     for (int j = 0; j < NP - 2; ++j) {
-      if constexpr (COEFF) Lm[j] = T(0);
       if (j < k && (g.mask & 8)) {
         const T ajj = A[j / E][j % E];
         colh[i] = ajj;
@@ -433,6 +430,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
           const T p = cp[j % E];
           bad = bad || !(p > T(0));
           const V nt = V(-ajj * pivot_rcp(p));
+          if constexpr (COEFF) Kh[i * KS + j] = -nt[0];
           A[j / E] = cp * nt + A[j / E];
 #pragma unroll
           for (int c4 = j / E + 1; c4 < NP / E; ++c4) {
@@ -446,7 +444,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
           const T p = col[j / E][j % E];
           bad = bad || !(p > T(0));
           const V nt = V(-ajj * pivot_rcp(p));
-          if constexpr (COEFF) Lm[j] = -nt[0];
+          if constexpr (COEFF) Kh[i * KS + j] = -nt[0];  // multiplier l_ij, kept for the back-substitution
 #pragma unroll
           for (int c4 = j / E; c4 < NP / E; ++c4) A[c4] = col[c4] * nt + A[c4];
         }
@@ -454,29 +452,21 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     }
 
     // ---- phase 4b (COEFF): x = K^-1 y by back-substitution -------------------------------
-    // K = L D L^T with unit lower L; the forward sweep left l_ij (j < i) in Lm of lane i, and the
+    // K = L D L^T with unit lower L; the forward sweep formed l_ij (j < i) in lane i, and the
     // response row's multipliers are w_j = (D^-1 L^-1 y)_j.  Solve L^T x = w: the multipliers are
-    // transposed through the (now free) tile so that lane j holds column j of L, then for
-    // m = k-1 .. 1 the finished x_m is read from lane m and every lane j < m takes l_mj x_m off.
+    // written to the (by then free) exchange matrix as they are formed, so lane j can read column j
+    // of L; then for m = k-1 .. 1 the finished x_m is read from lane m (v_readlane) and every lane
+    // j < m takes l_mj x_m off.
     if constexpr (COEFF) {
-      static_assert(!PIPED && NP == 32 && sizeof(T) == 4, "coefficient variant: fp32, 32 slots, staged gather");
-      __syncthreads();
-#pragma unroll
-      for (int c4 = 0; c4 < NP / E; ++c4) {
-        V v;
-#pragma unroll
-        for (int e = 0; e < E; ++e) v[e] = Lm[c4 * E + e];
-        *reinterpret_cast<V*>(Kh + i * KS + c4 * E) = v;
-      }
+      static_assert(!PIPED, "coefficient variant: register-staged gather (the tile must be free)");
       __syncthreads();
       T x = Kh[(q + 1) * KS + i];  // w_i, from the response row
 #pragma unroll
       for (int m = NP - 3; m >= 1; --m) {
         if (m < k) {
           const T lmj = Kh[m * KS + i];  // l_mi
-          const T xm0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), m));
-          const T xm1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), m + NP));
-          const T xm = h == 0 ? xm0 : xm1;
+          T xm = lane_value(x, m);
+          if constexpr (NH == 2) xm = h == 0 ? xm : lane_value(x, m + NP);
           if (i < m) x = fma_t(-lmj, xm, x);
         }
       }
@@ -609,10 +599,9 @@ static int launch_np(const FusedArgs& a, hipStream_t stream) {
 template <typename T>
 int launch_fused_wave(const FusedArgs& a, hipStream_t stream) {
   const int rows = a.k + 1 + a.R;
-  if (a.coeffs != nullptr) {  // fused fast-mean precompute: fp32, one response, 32 slots
-    if constexpr (sizeof(T) == 4) {
-      if (a.R == 1 && rows <= 32) return launch_np<T, 32, 0, 0, 0, false, true>(a, stream);
-    }
+  if (a.coeffs != nullptr) {  // fused fast-mean precompute: one response
+    if (a.R == 1 && rows <= 32) return launch_np<T, 32, 0, 0, 0, false, true>(a, stream);
+    if (a.R == 1 && rows <= 64) return launch_np<T, 64, 0, 0, 0, false, true>(a, stream);
     return MGP_EUNSUPPORTED;
   }
   if constexpr (sizeof(T) == 4) if (a.k == 30 && a.R == 1 && a.d == 40) {  // BASELINE configs 2/3, all shapes static

@@ -135,6 +135,17 @@ __device__ __forceinline__ f2 cov_from_sqdist2(f2 acc, int kernel_id, int metric
   }
 }
 
+// value of x in a given (wave-uniform) lane
+__device__ __forceinline__ float lane_value(float x, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane));
+}
+__device__ __forceinline__ double lane_value(double x, int lane) {
+  const long long b = __double_as_longlong(x);
+  const unsigned lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), lane);
+  const unsigned hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __longlong_as_double(((long long)hi << 32) | lo);
+}
+
 // 16 bytes per lane straight from global memory into LDS (no VGPR round trip): the LDS
 // destination is the wave-uniform pointer + lane * 16, the global source is per lane.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {

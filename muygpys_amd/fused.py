@@ -181,11 +181,12 @@ def fast_posterior_mean(
 
 
 def fast_coefficients(spec: KernelSpec, train_features: torch.Tensor, train_targets: torch.Tensor,
-                      train_nn_indices: torch.Tensor, chunk: int = 262144) -> torch.Tensor:
+                      train_nn_indices: torch.Tensor, chunk: int = 262144, fused: bool = True) -> torch.Tensor:
     """Coefficient table ``C_i = (K_i + eps)^-1 y_i`` over the self-including neighbourhoods
     ``[i, nn[i][:-1]]`` (_fast_nn_update + _muygps_fast_posterior_mean_precompute,
-    _src/gp/tensors/numpy.py:97-108, _src/gp/muygps/numpy.py:88-95), computed once per model in
-    row chunks through the per-function kernels.  Returns ``(n, k)`` or ``(n, k, R)`` together
+    _src/gp/tensors/numpy.py:97-108, _src/gp/muygps/numpy.py:88-95), computed once per model: one
+    fused launch (``mgp_fast_coefficients_*``: one response, k <= 62) or, with ``fused=False`` / for
+    other shapes, row chunks through the per-function kernels.  Returns ``(n, k)`` or ``(n, k, R)`` together
     with the updated index table ``(n, k)``."""
     from muygpys_amd._src.gp.kernels import hip as K
     from muygpys_amd._src.gp.muygps import hip as M
@@ -198,7 +199,7 @@ def fast_coefficients(spec: KernelSpec, train_features: torch.Tensor, train_targ
     d = 1 if train_features.ndim == 1 else train_features.shape[1]
     squeeze = train_targets.ndim == 1
     R = 1 if squeeze else train_targets.shape[1]
-    if R == 1:
+    if R == 1 and fused:
         # one launch: mgp_fast_coefficients_* (fused gather .. LDL^T .. back-substitution)
         fn = (train_features[:, None] if train_features.ndim == 1 else train_features).contiguous()
         tg = train_targets.reshape(-1).to(fn.dtype).contiguous()

@@ -72,6 +72,27 @@ def test_fused_coefficients_match_the_materialising_path_at_scale():
     nn = torch.randint(0, n, (n, k), generator=g)
     spec = KernelSpec("matern15", "l2", 6.0, 1e-2)
     c32, nnf = fast_coefficients(spec, X.cuda(), y.cuda(), nn.cuda())
-    c64, nnf64 = fast_coefficients(spec, X.double().cuda(), y.double().cuda(), nn.cuda())
+    c64, nnf64 = fast_coefficients(spec, X.double().cuda(), y.double().cuda(), nn.cuda(), fused=False)
     assert torch.equal(nnf, nnf64) and c32.dtype == torch.float32 and c32.shape == (n, k)
     assert_close(c32.cpu().numpy(), c64.cpu().numpy(), 10 * RTOL["float32"], "coefficients")
+    f64, _ = fast_coefficients(spec, X.double().cuda(), y.double().cuda(), nn.cuda())
+    assert_close(f64.cpu().numpy(), c64.cpu().numpy(), RTOL["float64"], "fused fp64 coefficients")
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_fused_coefficients_wide_neighbourhoods(dtype):
+    """k = 50 (64-slot kernel, one neighbourhood per wave), anisotropic, heteroscedastic table."""
+    from muygpys_amd.fused import KernelSpec, fast_coefficients
+
+    td = getattr(torch, dtype)
+    g = torch.Generator().manual_seed(8)
+    n, d, k = 30_000, 8, 50
+    X = torch.randn(n, d, generator=g)
+    y = torch.sin(X.sum(1)) + 0.05 * torch.randn(n, generator=g)
+    nn = torch.randint(0, n, (n, k), generator=g)
+    noise = (10.0 ** (-3 + 2 * torch.rand(n, generator=g))).to(td).cuda()
+    spec = KernelSpec("matern25", "l2", [1.5, 2.0, 1.0, 3.0, 2.5, 1.2, 1.8, 2.2], noise)
+    got, _ = fast_coefficients(spec, X.to(td).cuda(), y.to(td).cuda(), nn.cuda())
+    spec64 = KernelSpec("matern25", "l2", [1.5, 2.0, 1.0, 3.0, 2.5, 1.2, 1.8, 2.2], noise.double())
+    ref, _ = fast_coefficients(spec64, X.double().cuda(), y.double().cuda(), nn.cuda(), fused=False)
+    assert_close(got.cpu().numpy(), ref.cpu().numpy(), RTOL[dtype] * (10 if dtype == "float32" else 1), "coefficients")
