@@ -28,18 +28,20 @@ __device__ __forceinline__ void tri_decode(int p, int& row, int& col) {
   col = p - a_ * (a_ - 1) / 2;
 }
 
-// dynamic LDS carve:
-// [idx (k+1) i64][S (k+2)*SP][Q (k+1)*SP][X (k+1)*(dc+1)][il dc][lacc dc][piv k][red 2][flag]
+// dynamic LDS carve (every array 16-byte aligned; dc a multiple of 8):
+// [idx (k+2 & ~1) i64][S (k+2)*SP][Q (k+1)*SP][X (k+1)*XP][il dc][lacc dc][piv k][red 2][flag]
 template <typename T>
 __global__ void backward_kernel(BackwardArgs g, int stage) {
+  using V = typename lds_vec<T>::type;
+  constexpr int E = 16 / (int)sizeof(T);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const FusedArgs& a = g.f;
   const int k = a.k, d = a.d, R = a.R, dc = a.dc;
   const int rows = k + 2;
-  const int SP = lds_row_stride(k);
-  const int XP = dc + 1;
+  const int SP = lds_row_stride<T>(k);
+  const int XP = dc + E;
   int64_t* idx = reinterpret_cast<int64_t*>(smem);
-  T* S = reinterpret_cast<T*>(idx + (k + 1));
+  T* S = reinterpret_cast<T*>(idx + ((k + 2) & ~1));
   T* Q = S + rows * SP;
   T* X = Q + (k + 1) * SP;
   T* il = X + (k + 1) * XP;
@@ -64,6 +66,7 @@ __global__ void backward_kernel(BackwardArgs g, int stage) {
   const bool aniso = a.ls_count > 1;
   const bool l2 = a.metric_id == MGP_METRIC_L2;
   const int npairs = (k + 1) * k / 2;
+  const bool vec_ok = d % E == 0 && dc % E == 0 && ((uintptr_t)feat_q | (uintptr_t)feat_nn) % 16 == 0;
 
   T post_scale = T(1), inv_l = T(1);
   if (!aniso) {
@@ -81,12 +84,10 @@ __global__ void backward_kernel(BackwardArgs g, int stage) {
     // ---- forward recomputation: acc (kept in Q), covariances (S), combined right-hand side ----
     for (int d0 = 0; d0 < d; d0 += dc) {
       const int w = min(dc, d - d0);
-      for (int t = tid; t < (k + 1) * w; t += NT) {
-        const int r = t / w, c = t - r * w;
-        X[r * XP + c] = ((r < k ? feat_nn : feat_q) + idx[r] * (int64_t)d + d0)[c];
-      }
+      const int wp = (w + E - 1) / E * E;  // zero-padded to whole 16-byte pieces
+      gather_tile_lds<T>(X, XP, feat_q, feat_nn, idx, k, d, d0, w, wp, vec_ok, tid, NT);
       if (aniso)
-        for (int c = tid; c < w; c += NT) il[c] = T(1) / ls[d0 + c];
+        for (int c = tid; c < wp; c += NT) il[c] = c < w ? T(1) / ls[d0 + c] : T(0);
       __syncthreads();
       for (int p = tid; p < npairs; p += NT) {
         int a_, c_;
@@ -95,16 +96,17 @@ __global__ void backward_kernel(BackwardArgs g, int stage) {
         const T* xc = X + c_ * XP;
         T acc = T(0);
         if (aniso) {
-#pragma unroll 4
-          for (int j = 0; j < w; ++j) {
-            const T df = (xa[j] - xc[j]) * il[j];
-            acc += df * df;
+#pragma unroll 2
+          for (int j = 0; j < wp; j += E) {
+            const V df = (*reinterpret_cast<const V*>(xa + j) - *reinterpret_cast<const V*>(xc + j)) *
+                         *reinterpret_cast<const V*>(il + j);
+            acc += vec_dot(df, df);
           }
         } else {
-#pragma unroll 4
-          for (int j = 0; j < w; ++j) {
-            const T df = xa[j] - xc[j];
-            acc += df * df;
+#pragma unroll 2
+          for (int j = 0; j < wp; j += E) {
+            const V df = *reinterpret_cast<const V*>(xa + j) - *reinterpret_cast<const V*>(xc + j);
+            acc += vec_dot(df, df);
           }
         }
         T* dst = Q + a_ * SP + c_;
@@ -194,39 +196,43 @@ __global__ void backward_kernel(BackwardArgs g, int stage) {
     if (!gq && !gnn && !(gls && aniso)) continue;
     for (int d0 = 0; d0 < d; d0 += dc) {
       const int w = min(dc, d - d0);
+      const int wp = (w + E - 1) / E * E;
       __syncthreads();
-      for (int t = tid; t < (k + 1) * w; t += NT) {
-        const int r = t / w, c = t - r * w;
-        X[r * XP + c] = ((r < k ? feat_nn : feat_q) + idx[r] * (int64_t)d + d0)[c];
-      }
-      for (int c = tid; c < w; c += NT) {
-        il[c] = aniso ? T(1) / ls[d0 + c] : T(1);
+      gather_tile_lds<T>(X, XP, feat_q, feat_nn, idx, k, d, d0, w, wp, vec_ok, tid, NT);
+      for (int c = tid; c < wp; c += NT) {
+        il[c] = c < w ? (aniso ? T(1) / ls[d0 + c] : T(1)) : T(0);
         lacc[c] = T(0);
       }
       __syncthreads();
-      for (int t = tid; t < (k + 1) * w; t += NT) {
-        const int i = t / w, c = t - i * w;
-        const T xi = X[i * XP + c];
+      // one thread per (point, 16-byte piece of its row): q_ij is read once per four features
+      const int pieces = wp / E;
+      for (int t = tid; t < (k + 1) * pieces; t += NT) {
+        const int i = t / pieces, c0 = (t - i * pieces) * E;
+        const V xi = *reinterpret_cast<const V*>(X + i * XP + c0);
         const T* qi = Q + i * SP;
-        const T* xc = X + c;
-        T s = T(0), s2 = T(0);
-#pragma unroll 4
+        V s = V(0), s2 = V(0);
+#pragma unroll 2
         for (int j = 0; j <= k; ++j) {
-          const T q = qi[j];
-          const T df = xi - xc[j * XP];
-          s += q * df;
-          s2 += q * df * df;
+          const T qv = qi[j];
+          const V df = xi - *reinterpret_cast<const V*>(X + j * XP + c0);
+          s += qv * df;
+          s2 += qv * df * df;
         }
-        s2 *= T(0.5);  // every pair was visited from both ends
-        const T gx = T(2) * s * il[c] * il[c];
-        if (stage == 6) {  // ablation: plain store instead of the atomic
-          if (gnn) gnn[idx[i] * (int64_t)d + d0 + c] = gx;
-        } else if (i < k) {
-          if (gnn) unsafeAtomicAdd(gnn + idx[i] * (int64_t)d + d0 + c, gx);
-        } else if (gq) {
-          unsafeAtomicAdd(gq + idx[k] * (int64_t)d + d0 + c, gx);
+        const V ilv = *reinterpret_cast<const V*>(il + c0);
+        const V gx = T(2) * s * ilv * ilv;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int c = c0 + e;
+          if (c >= w) continue;
+          if (stage == 6) {  // ablation: plain store instead of the atomic
+            if (gnn) gnn[idx[i] * (int64_t)d + d0 + c] = gx[e];
+          } else if (i < k) {
+            if (gnn) unsafeAtomicAdd(gnn + idx[i] * (int64_t)d + d0 + c, gx[e]);
+          } else if (gq) {
+            unsafeAtomicAdd(gq + idx[k] * (int64_t)d + d0 + c, gx[e]);
+          }
+          if (gls && aniso) atomicAdd(&lacc[c], T(0.5) * s2[e]);  // every pair was visited from both ends
         }
-        if (gls && aniso) atomicAdd(&lacc[c], s2);
       }
       __syncthreads();
       if (gls && aniso)
@@ -240,18 +246,18 @@ static const size_t kMaxLdsBwd = 160 * 1024;
 
 template <typename T>
 static size_t backward_lds_bytes(int k, int dc) {
-  const int SP = lds_row_stride(k);
-  size_t n = (size_t)(k + 1) * sizeof(int64_t);
-  n += ((size_t)(k + 2) * SP + (size_t)(k + 1) * SP + (size_t)(k + 1) * (dc + 1) + 2 * (size_t)dc + k + 2) *
-           sizeof(T) + 16;
+  const int SP = lds_row_stride<T>(k);
+  size_t n = (size_t)((k + 2) & ~1) * sizeof(int64_t);
+  n += ((size_t)(k + 2) * SP + (size_t)(k + 1) * SP + (size_t)(k + 1) * (dc + 16 / sizeof(T)) + 2 * (size_t)dc + k +
+        2) * sizeof(T) + 16;
   return (n + 15) & ~(size_t)15;
 }
 
 template <typename T>
 int launch_backward(const BackwardArgs& in, hipStream_t stream) {
   BackwardArgs g = in;
-  int dc = g.f.d < 64 ? g.f.d : 64;
-  while (dc > 4 && backward_lds_bytes<T>(g.f.k, dc) > kMaxLdsBwd) dc /= 2;
+  int dc = g.f.d < 64 ? (g.f.d + 7) / 8 * 8 : 64;  // multiple of 8: whole 16-byte pieces, odd slot count
+  while (dc > 8 && backward_lds_bytes<T>(g.f.k, dc) > kMaxLdsBwd) dc -= 8;
   const size_t lds = backward_lds_bytes<T>(g.f.k, dc);
   if (lds > kMaxLdsBwd) return MGP_EUNSUPPORTED;
   g.f.dc = dc;
@@ -260,7 +266,7 @@ int launch_backward(const BackwardArgs& in, hipStream_t stream) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return -(1000 + (int)e);
   }
-  int per_cu = (int)(kMaxLdsBwd / lds);
+  int per_cu = (int)(kMaxLdsBwd / (((lds + 1279) / 1280) * 1280));  // LDS comes in 1280-byte granules
   per_cu = per_cu < 1 ? 1 : (per_cu > 16 ? 16 : per_cu);
   const int64_t full = 256LL * per_cu;
   const int threads = g.f.k + 2 <= 64 ? 64 : (g.f.k + 2 <= 128 ? 128 : 256);
@@ -274,7 +280,7 @@ template int launch_backward<double>(const BackwardArgs&, hipStream_t);
 
 int max_nn_count_backward(int elem_size) {
   int k = 1;
-  while ((elem_size == 4 ? backward_lds_bytes<float>(k + 1, 4) : backward_lds_bytes<double>(k + 1, 4)) <= kMaxLdsBwd)
+  while ((elem_size == 4 ? backward_lds_bytes<float>(k + 1, 8) : backward_lds_bytes<double>(k + 1, 8)) <= kMaxLdsBwd)
     ++k;
   return k;
 }

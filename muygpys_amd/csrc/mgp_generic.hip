@@ -9,16 +9,24 @@
 
 namespace mgp {
 
-// dynamic LDS carve: [idx: (k+1) int64][S: rows*SP T][X: (k+1)*(dc+1) T][il: dc T][piv: k T][flag]
+// feature-tile row stride for a chunk of dc features (dc a multiple of 2E): 16-byte aligned rows, odd
+// number of 16-byte slots
+template <typename T>
+__host__ __device__ inline int tile_row_stride(int dc) { return dc + 16 / (int)sizeof(T); }
+
+// dynamic LDS carve (every array 16-byte aligned):
+// [idx: (k+2 & ~1) int64][S: rows*SP T][X: (k+1)*XP T][il: dc T][piv: k T][flag]
 template <typename T>
 __global__ void fused_generic_kernel(FusedArgs a) {
+  using V = typename lds_vec<T>::type;
+  constexpr int E = 16 / (int)sizeof(T);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int k = a.k, d = a.d, R = a.R, dc = a.dc;
   const int rows = k + 1 + R;
-  const int SP = lds_row_stride(k);
-  const int XP = dc + 1;
+  const int SP = lds_row_stride<T>(k);
+  const int XP = tile_row_stride<T>(dc);
   int64_t* idx = reinterpret_cast<int64_t*>(smem);
-  T* S = reinterpret_cast<T*>(idx + (k + 1));
+  T* S = reinterpret_cast<T*>(idx + ((k + 2) & ~1));
   T* X = S + rows * SP;
   T* il = X + (k + 1) * XP;
   T* piv = il + dc;
@@ -32,6 +40,7 @@ __global__ void fused_generic_kernel(FusedArgs a) {
   const int tid = threadIdx.x, NT = blockDim.x;
   const bool aniso = a.ls_count > 1;
   const int npairs = (k + 1) * k / 2;
+  const bool vec_ok = d % E == 0 && dc % E == 0 && ((uintptr_t)feat_q | (uintptr_t)feat_nn) % 16 == 0;
 
   T post_scale = T(1);
   if (!aniso) {
@@ -47,14 +56,11 @@ __global__ void fused_generic_kernel(FusedArgs a) {
 
     for (int d0 = 0; d0 < d; d0 += dc) {
       const int w = min(dc, d - d0);
+      const int wp = (w + E - 1) / E * E;  // zero-padded to whole 16-byte pieces
       // coalesced gather of the (k+1) x w feature tile: consecutive lanes walk a row
-      for (int t = tid; t < (k + 1) * w; t += NT) {
-        const int r = t / w, c = t - r * w;
-        const T* src = (r < k ? feat_nn : feat_q) + idx[r] * (int64_t)d + d0 + c;
-        X[r * XP + c] = *src;
-      }
+      gather_tile_lds<T>(X, XP, feat_q, feat_nn, idx, k, d, d0, w, wp, vec_ok, tid, NT);
       if (aniso)
-        for (int c = tid; c < w; c += NT) il[c] = T(1) / ls[d0 + c];
+        for (int c = tid; c < wp; c += NT) il[c] = c < w ? T(1) / ls[d0 + c] : T(0);
       __syncthreads();
       for (int p = tid; p < npairs; p += NT) {
         // p -> (row a_, col c_) of the strict lower triangle of the (k+1)-point set
@@ -66,16 +72,17 @@ __global__ void fused_generic_kernel(FusedArgs a) {
         const T* xc = X + c_ * XP;
         T acc = T(0);
         if (aniso) {
-#pragma unroll 4
-          for (int j = 0; j < w; ++j) {
-            const T df = (xa[j] - xc[j]) * il[j];
-            acc += df * df;
+#pragma unroll 2
+          for (int j = 0; j < wp; j += E) {
+            const V df = (*reinterpret_cast<const V*>(xa + j) - *reinterpret_cast<const V*>(xc + j)) *
+                         *reinterpret_cast<const V*>(il + j);
+            acc += vec_dot(df, df);
           }
         } else {
-#pragma unroll 4
-          for (int j = 0; j < w; ++j) {
-            const T df = xa[j] - xc[j];
-            acc += df * df;
+#pragma unroll 2
+          for (int j = 0; j < wp; j += E) {
+            const V df = *reinterpret_cast<const V*>(xa + j) - *reinterpret_cast<const V*>(xc + j);
+            acc += vec_dot(df, df);
           }
         }
         T* dst = S + a_ * SP + c_;
@@ -120,7 +127,7 @@ __global__ void solve_generic_kernel(SolveArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int k = a.k, R = a.R;
   const int rows = k + 1 + R;
-  const int SP = lds_row_stride(k);
+  const int SP = lds_row_stride<T>(k);
   T* S = reinterpret_cast<T*>(smem);
   T* piv = S + rows * SP;
   int* flag = reinterpret_cast<int*>(piv + k);
@@ -171,21 +178,24 @@ static const size_t kMaxLds = 160 * 1024;
 
 template <typename T>
 static size_t fused_lds_bytes(int k, int R, int dc) {
-  const int rows = k + 1 + R, SP = lds_row_stride(k);
-  size_t n = (size_t)(k + 1) * sizeof(int64_t);
-  n += ((size_t)rows * SP + (size_t)(k + 1) * (dc + 1) + dc + k) * sizeof(T) + 16;
+  const int rows = k + 1 + R, SP = lds_row_stride<T>(k);
+  size_t n = (size_t)((k + 2) & ~1) * sizeof(int64_t);
+  n += ((size_t)rows * SP + (size_t)(k + 1) * tile_row_stride<T>(dc) + dc + k) * sizeof(T) + 16;
   return (n + 15) & ~(size_t)15;
 }
 template <typename T>
 static size_t solve_lds_bytes(int k, int R) {
-  const int rows = k + 1 + R, SP = lds_row_stride(k);
+  const int rows = k + 1 + R, SP = lds_row_stride<T>(k);
   size_t n = ((size_t)rows * SP + k) * sizeof(T) + 16;
   return (n + 15) & ~(size_t)15;
 }
 
 static int grid_for(int64_t b, size_t lds) {
-  // enough resident workgroups to fill 256 CUs; the kernels grid-stride over the rest
-  int per_cu = (int)(kMaxLds / (lds ? lds : 1));
+  // Persistent grid = the resident capacity (the kernels grid-stride over the rest): LDS is handed
+  // out in 1280-byte granules of the CU's 160 KiB (measured, see mgp_fused_wave.hip); one workgroup
+  // more than fits would run as a second, nearly empty round.
+  const size_t granules = (lds + 1279) / 1280;
+  int per_cu = (int)(kMaxLds / ((granules ? granules : 1) * 1280));
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 16) per_cu = 16;
   int64_t g = 256LL * per_cu;
@@ -196,8 +206,9 @@ template <typename T>
 int launch_fused_generic(const FusedArgs& in, hipStream_t stream) {
   FusedArgs a = in;
   // feature chunk: as wide as fits next to the factor (bounded so small problems stay small)
-  int dc = a.d < 64 ? a.d : 64;
-  while (dc > 4 && fused_lds_bytes<T>(a.k, a.R, dc) > kMaxLds) dc /= 2;
+  // feature chunk: a multiple of 8 (whole 16-byte pieces, odd slot count with the pad), as wide as fits
+  int dc = a.d < 64 ? (a.d + 7) / 8 * 8 : 64;
+  while (dc > 8 && fused_lds_bytes<T>(a.k, a.R, dc) > kMaxLds) dc -= 8;
   const size_t lds = fused_lds_bytes<T>(a.k, a.R, dc);
   if (lds > kMaxLds) return MGP_EUNSUPPORTED;
   a.dc = dc;
@@ -235,7 +246,7 @@ template int launch_solve_generic<double>(const SolveArgs&, hipStream_t);
 int max_nn_count(int elem_size, int R) {
   int k = 1;
   while (true) {
-    const size_t lds = elem_size == 4 ? fused_lds_bytes<float>(k + 1, R, 4) : fused_lds_bytes<double>(k + 1, R, 4);
+    const size_t lds = elem_size == 4 ? fused_lds_bytes<float>(k + 1, R, 8) : fused_lds_bytes<double>(k + 1, R, 8);
     if (lds > kMaxLds) break;
     ++k;
   }

@@ -20,33 +20,166 @@
 
 namespace mgp {
 
-// Odd row stride (in elements) -> lane i reading S[i][m] hits distinct banks.
-__host__ __device__ inline int lds_row_stride(int k) { return (k + 1) | 1; }
-
-// S: rows x SP in LDS.  piv: k entries of scratch.  All NT threads of the block call this.
-// Returns (to every thread) whether a non-positive / NaN pivot was met.
+// Row stride (in elements) of the LDS-resident system: rows start on 16-byte boundaries and span an
+// ODD number of 16-byte slots, so that thread i reading 16 bytes of row i at a common column hits
+// distinct banks (the same rule as the feature tiles of the register kernels).
 template <typename T>
-__device__ inline bool factor_augmented_lds(T* S, int SP, int k, int rows, T* piv, int* bad_flag, int tid, int NT) {
-  if (tid == 0) *bad_flag = 0;
-  __syncthreads();
-  for (int j = 0; j < k; ++j) {
-    const T* rowj = S + j * SP;
-    for (int i = j + tid; i < rows; i += NT) {
-      T* rowi = S + i * SP;
-      T s = rowi[j];
-#pragma unroll 4
-      for (int m = 0; m < j; ++m) s -= rowi[m] * rowj[m];
-      if (i == j) {
-        if (!(s > T(0))) *bad_flag = 1;
-        piv[j] = num<T>::rsqrt(s);
-        rowi[j] = num<T>::sqrt(s);
-      } else {
-        rowi[j] = s;
+__host__ __device__ inline int lds_row_stride(int k) {
+  constexpr int E = 16 / (int)sizeof(T);
+  int slots = (k + 1 + E - 1) / E;
+  slots |= 1;
+  return slots * E;
+}
+
+template <typename T> struct lds_vec;
+template <> struct lds_vec<float> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct lds_vec<double> { typedef double type __attribute__((ext_vector_type(2))); };
+template <typename V> __device__ __forceinline__ auto vec_dot(const V& a, const V& b) {
+  auto s = a[0] * b[0];
+#pragma unroll
+  for (int e = 1; e < (int)(sizeof(V) / sizeof(a[0])); ++e) s += a[e] * b[e];
+  return s;
+}
+
+// Gather the (k+1) x w feature tile of one neighbourhood (rows idx[0..k-1] of feat_nn, row idx[k] of
+// feat_q, features d0 .. d0+w-1) into X (row stride XP, 16-byte aligned, zero-padded to wp columns).
+// Every thread first issues up to GU 16-byte loads and only then stores them: the loads of a tile are
+// in flight together instead of one memory latency per element.  vec_ok: rows are 16-byte aligned
+// (d a multiple of the vector width, bases aligned); otherwise the pieces are assembled element-wise.
+template <typename T>
+__device__ inline void gather_tile_lds(T* X, int XP, const T* feat_q, const T* feat_nn, const int64_t* idx, int k,
+                                       int d, int d0, int w, int wp, bool vec_ok, int tid, int NT) {
+  using V = typename lds_vec<T>::type;
+  constexpr int E = 16 / (int)sizeof(T);
+  constexpr int GU = 4;
+  const int pieces = wp / E, total = (k + 1) * pieces;
+  for (int t0 = tid; t0 < total; t0 += NT * GU) {
+    V v[GU];
+#pragma unroll
+    for (int u = 0; u < GU; ++u) {
+      const int t = t0 + u * NT;
+      v[u] = V(0);
+      if (t < total) {
+        const int r = t / pieces, c0 = (t - r * pieces) * E;
+        const T* src = (r < k ? feat_nn : feat_q) + idx[r] * (int64_t)d + d0 + c0;
+        if (vec_ok && c0 + E <= w) {
+          v[u] = *reinterpret_cast<const V*>(src);
+        } else {
+#pragma unroll
+          for (int e = 0; e < E; ++e)
+            if (c0 + e < w) v[u][e] = src[e];
+        }
       }
     }
-    __syncthreads();
-    const T inv = piv[j];
-    for (int i = j + 1 + tid; i < rows; i += NT) S[i * SP + j] *= inv;
+#pragma unroll
+    for (int u = 0; u < GU; ++u) {
+      const int t = t0 + u * NT;
+      if (t < total) {
+        const int r = t / pieces, c0 = (t - r * pieces) * E;
+        *reinterpret_cast<V*>(X + r * XP + c0) = v[u];
+      }
+    }
+  }
+}
+
+// S: rows x SP in LDS (SP = lds_row_stride<T>(k), S 16-byte aligned).  piv: k entries of scratch.
+// All NT threads of the block call this.  Returns (to every thread) whether a non-positive / NaN
+// pivot was met.
+//
+// Left-looking by rows, blocked by JB = 4 columns: the bulk of a column's inner product -- the part
+// over the columns of earlier blocks -- is taken for four columns at once with 16-byte LDS reads
+// (one read of the thread's own row serves four columns; the four pivot rows are broadcasts), i.e.
+// 5 LDS instructions per 16 (fp32) multiply-adds instead of 32; the diagonal block is then
+// factorised redundantly by every thread (see below).
+template <typename T>
+__device__ inline bool factor_augmented_lds(T* S, int SP, int k, int rows, T* piv, int* bad_flag, int tid, int NT) {
+  using V = typename lds_vec<T>::type;
+  constexpr int E = 16 / (int)sizeof(T);
+  constexpr int JB = 4;
+  if (tid == 0) *bad_flag = 0;
+  __syncthreads();
+  for (int j0 = 0; j0 < k; j0 += JB) {
+    const int jb = min(JB, k - j0);
+    if (j0 > 0) {
+      for (int i = j0 + tid; i < rows; i += NT) {
+        T* rowi = S + i * SP;
+        T s0 = T(0), s1 = T(0), s2 = T(0), s3 = T(0);
+        const T* r0 = S + (j0 + 0) * SP;
+        const T* r1 = S + (j0 + (jb > 1 ? 1 : 0)) * SP;
+        const T* r2 = S + (j0 + (jb > 2 ? 2 : 0)) * SP;
+        const T* r3 = S + (j0 + (jb > 3 ? 3 : 0)) * SP;
+        for (int m = 0; m < j0; m += E) {  // j0 is a multiple of JB, hence of E
+          const V li = *reinterpret_cast<const V*>(rowi + m);
+          s0 += vec_dot(li, *reinterpret_cast<const V*>(r0 + m));
+          s1 += vec_dot(li, *reinterpret_cast<const V*>(r1 + m));
+          s2 += vec_dot(li, *reinterpret_cast<const V*>(r2 + m));
+          s3 += vec_dot(li, *reinterpret_cast<const V*>(r3 + m));
+        }
+        rowi[j0] -= s0;
+        if (jb > 1) rowi[j0 + 1] -= s1;
+        if (jb > 2) rowi[j0 + 2] -= s2;
+        if (jb > 3) rowi[j0 + 3] -= s3;
+      }
+      __syncthreads();
+    }
+    // The jb x jb diagonal block (already reduced by the bulk phase) is factorised by EVERY thread,
+    // redundantly, in registers -- 20 flops instead of two barriers per column -- and each thread
+    // then forward-substitutes its own row's jb panel entries: three barriers per block of four
+    // columns instead of eight.
+    T D[JB][JB];
+#pragma unroll
+    for (int r = 0; r < JB; ++r)
+#pragma unroll
+      for (int c = 0; c <= r; ++c) D[r][c] = (r < jb) ? S[(j0 + r) * SP + j0 + c] : (r == c ? T(1) : T(0));
+    bool bad = false;
+    T inv[JB];
+#pragma unroll
+    for (int c = 0; c < JB; ++c) {
+      T p = D[c][c];
+#pragma unroll
+      for (int m = 0; m < c; ++m) p -= D[c][m] * D[c][m];
+      bad = bad || !(p > T(0));
+      inv[c] = num<T>::rsqrt(p);
+      D[c][c] = num<T>::sqrt(p);
+#pragma unroll
+      for (int r = c + 1; r < JB; ++r) {
+        T v = D[r][c];
+#pragma unroll
+        for (int m = 0; m < c; ++m) v -= D[r][m] * D[c][m];
+        D[r][c] = v * inv[c];
+      }
+    }
+    __syncthreads();  // everyone holds the block: its rows may now be overwritten
+    if (tid == 0) {
+      if (bad) *bad_flag = 1;
+      for (int c = 0; c < jb; ++c) piv[j0 + c] = inv[c];
+    }
+    for (int i = j0 + tid; i < rows; i += NT) {
+      T* rowi = S + i * SP;
+      if (i < j0 + jb) {
+        const int r = i - j0;
+#pragma unroll
+        for (int c = 0; c < JB; ++c)
+          if (c <= r) {
+            T v = T(0);
+#pragma unroll
+            for (int rr = 0; rr < JB; ++rr) v = rr == r ? D[rr][c] : v;  // row r of the factor, no dynamic indexing
+            rowi[j0 + c] = v;
+          }
+      } else {
+        T y[JB];
+#pragma unroll
+        for (int c = 0; c < JB; ++c) {
+          T v = c < jb ? rowi[j0 + c] : T(0);
+#pragma unroll
+          for (int m = 0; m < c; ++m) v -= y[m] * D[c][m];
+          y[c] = v * inv[c];
+        }
+#pragma unroll
+        for (int c = 0; c < JB; ++c)
+          if (c < jb) rowi[j0 + c] = y[c];
+      }
+    }
     __syncthreads();
   }
   return *bad_flag != 0;
