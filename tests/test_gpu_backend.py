@@ -152,3 +152,31 @@ def test_backend_rejects_host_arrays():
         T._F2(np.zeros((3, 2)))
     with pytest.raises(TypeError):
         T._F2(torch.zeros((3, 2)))
+
+
+def test_empty_inputs_through_the_new_entry_points():
+    """Empty shards are legal everywhere on the path (a rank can own zero rows): the k-NN search, the
+    differentiable posterior and the fused coefficient precompute return empty results."""
+    from muygpys_amd.autograd import posterior
+    from muygpys_amd.fused import KernelSpec, fast_coefficients
+    from muygpys_amd.neighbors import NN_Wrapper
+
+    X = torch.randn(20000, 8, device="cuda")
+    y = torch.randn(20000, device="cuda")
+    nbrs = NN_Wrapper(X, 10)
+    idx, dist = nbrs.get_nns(X[:0])
+    assert idx.shape == (0, 10) and dist.shape == (0, 10) and idx.dtype == torch.int64
+    idx, dist = nbrs.get_batch_nns(torch.zeros(0, dtype=torch.int64, device="cuda"))
+    assert idx.shape == (0, 10)
+
+    x = X.clone().requires_grad_(True)
+    mean, var = posterior(KernelSpec("matern15", "l2", 2.0, 1e-2), x, x,
+                          torch.zeros(0, dtype=torch.int64, device="cuda"),
+                          torch.zeros((0, 10), dtype=torch.int64, device="cuda"), y)
+    assert mean.shape == (0,) and var.shape == (0,)
+    (mean.sum() + var.sum()).backward()
+    assert x.grad is not None and float(x.grad.abs().sum()) == 0.0
+
+    coeffs, nn_fast = fast_coefficients(KernelSpec("matern15", "l2", 2.0, 1e-2), X[:0], y[:0],
+                                        torch.zeros((0, 10), dtype=torch.int64, device="cuda"))
+    assert coeffs.shape == (0, 10) and nn_fast.shape == (0, 10)
