@@ -31,7 +31,7 @@ SCAN_INIT_ROWS = 4096  # rows of the table the k-best lists are initialised from
 
 class NN_Wrapper:
     def __init__(self, train: torch.Tensor, nn_count: int, nn_method: str = "exact", chunk: int = 4096,
-                 use_scan: bool = True, scan_kind: str = "auto", **kwargs):
+                 use_scan: bool = True, scan_kind: str = "auto", shuffle: bool = True, **kwargs):
         if nn_method.lower() != "exact":
             raise NotImplementedError(f"Nearest Neighbor algorithm {nn_method} is not implemented.")
         if not (isinstance(train, torch.Tensor) and train.is_cuda):
@@ -41,8 +41,22 @@ class NN_Wrapper:
         # at the scale of the data's spread instead of its offset from the origin
         table = train[:, None] if train.ndim == 1 else train
         self._mean = table.double().mean(0).to(table.dtype)
-        self.train = (table - self._mean).contiguous()
-        self.train_count, self.feature_count = self.train.shape
+        self.train_count, self.feature_count = table.shape
+        # Tables the scan kernels serve are also stored in a fixed pseudo-random row order: a table
+        # sorted in space (a grid, a time series) would hand a query all of its neighbours within one or
+        # two consecutive tiles and overflow the kernels' candidate queues; shuffled, candidates arrive
+        # evenly and the first rows are a fair sample for the initial k-best lists.  ``_perm`` maps
+        # stored position -> caller's row, ``_inv`` the other way; both are None for the identity.
+        self._perm = self._inv = None
+        if (shuffle and use_scan and table.dtype == torch.float32 and self.feature_count % 4 == 0 and 4 <= self.feature_count <= 64
+                and self.train_count > 2 * SCAN_INIT_ROWS):
+            gen = torch.Generator(device=table.device).manual_seed(0x5CA9)
+            self._perm = torch.randperm(self.train_count, device=table.device, generator=gen)
+            self._inv = torch.empty_like(self._perm)
+            self._inv[self._perm] = torch.arange(self.train_count, device=table.device)
+            self.train = (table[self._perm] - self._mean).contiguous()
+        else:
+            self.train = (table - self._mean).contiguous()
         self.nn_count = int(nn_count)
         self.nn_method = "exact"
         self.chunk = int(chunk)
@@ -67,14 +81,15 @@ class NN_Wrapper:
         """neighbors.py:169-211: neighbours of training rows, the row itself excluded.  (The
         reference drops column 0 of a k+1 query and relies on it being the point itself; here the
         self-match is masked explicitly, so duplicate points cannot displace it.)"""
-        q = self.train[batch_indices]
-        return self._get_nns(q, self.nn_count, exclude=batch_indices, centred=True)
+        pos = batch_indices if self._inv is None else self._inv[batch_indices]
+        return self._get_nns(self.train[pos], self.nn_count, exclude=pos, centred=True)
 
     def _get_nns(self, samples, nn_count, exclude=None, centred=False):
         if not centred:
             samples = samples.to(self.train.dtype) - self._mean
         out = self._scan_nns(samples, nn_count, exclude)
-        return out if out is not None else self._dense_nns(samples, nn_count, exclude)
+        idx, dist = out if out is not None else self._dense_nns(samples, nn_count, exclude)
+        return (idx if self._perm is None else self._perm[idx]), dist
 
     def _scan_supported(self, samples, nn_count) -> bool:
         d = self.feature_count

@@ -90,7 +90,10 @@ def test_mfma_scan_survives_adversarial_row_order(scan_kind):
     X = torch.randn(20000, 8, generator=g)
     X = X[(X**2).sum(1).argsort(descending=True)].contiguous().cuda()
     Q = (0.01 * torch.randn(300, 8, generator=g)).cuda()  # near the origin
-    (i1, d1), (i2, d2) = NN_Wrapper(X, 20, scan_kind=scan_kind).get_nns(Q), NN_Wrapper(X, 20, use_scan=False).get_nns(Q)
+    # shuffle=False keeps the adversarial order in front of the kernel (the default storage order is
+    # pseudo-random precisely so that this does not happen)
+    (i1, d1), (i2, d2) = (NN_Wrapper(X, 20, scan_kind=scan_kind, shuffle=False).get_nns(Q),
+                          NN_Wrapper(X, 20, use_scan=False).get_nns(Q))
     torch.testing.assert_close(d1, d2, rtol=1e-5, atol=1e-6)
     assert float((i1 == i2).float().mean()) > 0.999
 
@@ -109,3 +112,36 @@ def test_split_bf16_scan_is_exact_far_from_the_origin():
     d2, i2 = ref.topk(25, dim=1, largest=False)
     torch.testing.assert_close(d1.double(), d2, rtol=1e-4, atol=1e-5)
     assert float((i1 == i2).float().mean()) > 0.999
+
+
+def test_spatially_sorted_table_stays_on_the_scan_path():
+    """A table sorted along its first feature puts every query's neighbours in a few consecutive
+    rows; NN_Wrapper stores scan tables in a pseudo-random row order, so the candidate queues do not
+    overflow (no dense-path recomputation) and the result still refers to the caller's rows."""
+    import time
+
+    from muygpys_amd.neighbors import NN_Wrapper
+
+    g = torch.Generator().manual_seed(12)
+    X = torch.rand(200_000, 4, generator=g)
+    X = X[X[:, 0].argsort()].contiguous().cuda()
+    bi = torch.arange(0, 200_000, 7, device="cuda")
+    nbrs = NN_Wrapper(X, 16)
+    nbrs.get_batch_nns(bi[:100])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    idx, dist = nbrs.get_batch_nns(bi)
+    torch.cuda.synchronize()
+    t_scan = time.perf_counter() - t0
+    ref = torch.cdist(X[bi[:500]].double(), X.double()) ** 2
+    ref[torch.arange(500), bi[:500]] = float("inf")
+    rd, ri = ref.topk(16, dim=1, largest=False)
+    torch.testing.assert_close(dist[:500].double(), rd, rtol=1e-4, atol=1e-7)
+    assert float((idx[:500] == ri).float().mean()) > 0.999
+    dense = NN_Wrapper(X, 16, use_scan=False)
+    dense.get_batch_nns(bi[:100])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dense.get_batch_nns(bi)
+    torch.cuda.synchronize()
+    assert t_scan < 0.5 * (time.perf_counter() - t0), "the scan path must not fall back to the dense path"
