@@ -173,7 +173,7 @@ __global__ void solve_generic_kernel(SolveArgs a) {
   }
 }
 
-static int block_threads(int rows) { return rows <= 64 ? 64 : (rows <= 128 ? 128 : 256); }
+static int block_threads(int rows) { return rows <= 64 ? 64 : 256; }
 static const size_t kMaxLds = 160 * 1024;
 
 template <typename T>
