@@ -245,3 +245,46 @@ def test_persistent_loop_matches_oracle_on_a_sample(case, runtime_pipe):
     assert_close(mean.cpu().numpy()[pick], m_ref.reshape(len(pick), R), rtol, "mean")
     assert_close(var.cpu().numpy()[pick], v_ref, rtol, "var")
     assert torch.isfinite(mean).all() and torch.isfinite(var).all() and torch.isfinite(yk).all()
+
+
+WIDE_CASES = [
+    # kernel, k, d, R, aniso  -- more rows than a wave has lanes: the LDS-resident kernel
+    ("matern15", 80, 16, 1, False),
+    ("rbf", 100, 40, 2, False),
+    ("matern25", 126, 8, 1, True),
+    ("matern05", 64, 12, 1, False),   # 66 rows: just past the wave kernels
+    ("matern15", 90, 37, 3, False),   # unaligned rows, several responses
+]
+
+
+@pytest.mark.parametrize("case", WIDE_CASES, ids=[f"{c[0]}-k{c[1]}-d{c[2]}-R{c[3]}-{'aniso' if c[4] else 'iso'}" for c in WIDE_CASES])
+def test_wide_neighbourhoods_match_oracle(case):
+    from muygpys_amd.fused import KernelSpec, posterior_mean_var
+
+    kernel, k, d, R, aniso = case
+    rng = np.random.default_rng(40 + WIDE_CASES.index(case))
+    N, b = 6000, 1200
+    X = rng.normal(size=(N, d))
+    Y = np.sin(X @ rng.normal(size=(d, R)) / np.sqrt(d)) + 0.1 * rng.normal(size=(N, R))
+    bi = rng.integers(0, N, size=b)
+    ni = np.stack([rng.choice(N, size=k, replace=False) for _ in range(b)])
+    metric = "F2" if kernel == "rbf" else "l2"
+    ls = np.sqrt(d) * rng.uniform(0.8, 1.4, size=d) if aniso else float(np.sqrt(2 * d))
+    if metric == "F2":
+        ls = np.sqrt(ls)
+    spec_o = orc.Spec(kernel, metric, ls, 1e-2)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    mean, var, yk = posterior_mean_var(
+        KernelSpec(kernel, metric, ls.tolist() if aniso else ls, 1e-2), to_dev(X, torch.float32),
+        to_dev(X, torch.float32), to_dev(bi), to_dev(ni), to_dev(Y, torch.float32), want_ykinvy=True, info=info,
+    )
+    torch.cuda.synchronize()
+    assert int(info.item()) == 0
+    pick = rng.choice(b, size=150, replace=False)
+    m_ref, v_ref = orc.posterior_mean_var(spec_o, X, X, bi[pick], ni[pick], Y)
+    Kc, Kin = orc.kernel_tensors(spec_o, orc.crosswise_tensor(X, X, bi[pick], ni[pick]), orc.pairwise_tensor(X, ni[pick]))
+    Kin = orc.perturb(spec_o, Kin, ni[pick])
+    yk_ref = np.einsum("bkr,bkr->br", Y[ni[pick]], np.linalg.solve(Kin, Y[ni[pick]]))
+    assert_close(mean.cpu().numpy()[pick].reshape(150, R), m_ref.reshape(150, R), RTOL["float32"], "mean")
+    assert_close(var.cpu().numpy()[pick], v_ref, RTOL["float32"], "var")
+    assert_close(yk.cpu().numpy()[pick].reshape(150, R), yk_ref, RTOL["float32"], "ykinvy")
