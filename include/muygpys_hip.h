@@ -19,6 +19,8 @@
  *   - return value: 0 on success, a negative MGP_E* code on bad arguments, or
  *     -(1000 + hipError_t) when the HIP runtime reports an error.  Nothing throws.
  *   - inputs are never written; outputs never alias inputs.
+ *   - entry points are re-entrant: the library keeps no mutable state besides per-device
+ *     launch geometry computed once under a mutex.
  *   - non-SPD neighbourhoods (non-positive Cholesky pivot; the reference's LU
  *     would raise numpy.linalg.LinAlgError only for an exactly singular matrix)
  *     produce NaN outputs and are counted in `*info` (device int32, may be NULL).
@@ -97,6 +99,79 @@ int mgp_posterior_f64(const double* feat_q, const double* feat_nn, int d,
                       int noise_mode, double noise_scalar, const double* noise_dev,
                       int kernel_id, int metric_id, const double* length_scale, int ls_count,
                       double* mean, double* var, double* ykinvy, int* info, void* stream);
+
+/* The same call served by one named kernel family instead of the dispatcher's choice (parity
+ * tests compare the families with each other; same arguments, same results):
+ *   _generic: one workgroup per neighbourhood, system in LDS (any k up to mgp_max_nn_count)
+ *   _rhs:     one wave per neighbourhood, responses as right-hand-side columns (k <= 64, R <= 16);
+ *             MGP_EUNSUPPORTED outside that. */
+int mgp_posterior_generic_f32(const float* feat_q, const float* feat_nn, int d,
+                              const int64_t* batch_idx, const int64_t* nn_idx, int64_t b, int k,
+                              const float* targets, int R,
+                              int noise_mode, double noise_scalar, const float* noise_dev,
+                              int kernel_id, int metric_id, const float* length_scale, int ls_count,
+                              float* mean, float* var, float* ykinvy, int* info, void* stream);
+int mgp_posterior_generic_f64(const double* feat_q, const double* feat_nn, int d,
+                              const int64_t* batch_idx, const int64_t* nn_idx, int64_t b, int k,
+                              const double* targets, int R,
+                              int noise_mode, double noise_scalar, const double* noise_dev,
+                              int kernel_id, int metric_id, const double* length_scale, int ls_count,
+                              double* mean, double* var, double* ykinvy, int* info, void* stream);
+int mgp_posterior_rhs_f32(const float* feat_q, const float* feat_nn, int d,
+                          const int64_t* batch_idx, const int64_t* nn_idx, int64_t b, int k,
+                          const float* targets, int R,
+                          int noise_mode, double noise_scalar, const float* noise_dev,
+                          int kernel_id, int metric_id, const float* length_scale, int ls_count,
+                          float* mean, float* var, float* ykinvy, int* info, void* stream);
+int mgp_posterior_rhs_f64(const double* feat_q, const double* feat_nn, int d,
+                          const int64_t* batch_idx, const int64_t* nn_idx, int64_t b, int k,
+                          const double* targets, int R,
+                          int noise_mode, double noise_scalar, const double* noise_dev,
+                          int kernel_id, int metric_id, const double* length_scale, int ls_count,
+                          double* mean, double* var, double* ykinvy, int* info, void* stream);
+
+/* Name of the kernel instantiation that serves mgp_posterior_* (path 0), mgp_posterior_generic_*
+ * (path 1) or mgp_posterior_rhs_* (path 2) for a shape, for 16-byte aligned tables; packed != 0:
+ * mgp_posterior_packed_*.  A pure function of its arguments (benchmarks name the kernel whose
+ * duration they report).  Writes a NUL-terminated string into buf. */
+int mgp_posterior_kernel_name(int elem_size, int d, int k, int R, int packed, int path, char* buf, int len);
+
+/* ---------------------------------------------------------------------------
+ * Prepared tables.  The gathers of T1/T2/T4 (_src/gp/tensors/numpy.py:47-69,
+ * gp/muygps.py:474,543,545) read, per neighbour, a feature row and a 4/8-byte
+ * response from two separate arrays; at d = 40 fp32 that is two 128-byte lines
+ * for the row plus one whole line for the response.  A prepared table stores
+ *     row i = [ features (d) | responses (R) | zero pad ]   at stride mgp_packed_row_bytes(d, R, s)
+ * (a multiple of 64 bytes), so row and responses arrive together.  The tables
+ * are constant across all objective evaluations of a hyper-parameter search
+ * (the reference rebuilds its difference tensors never, its kernels every
+ * evaluation: optimize/objective.py:95-103), so the table is packed once.
+ *   mgp_table_pack_*: features (n, d), targets (n, R) or NULL (R = 0 / zeros: a query
+ *       table) -> packed (n * stride bytes).
+ *   mgp_posterior_packed_*: mgp_posterior_* reading two prepared tables (query
+ *       table: rows selected by batch_idx; neighbour table: rows and responses selected
+ *       by nn_idx; the two may be the same table).  Needs d * sizeof(T) % 16 == 0,
+ *       R * sizeof(T) <= 16 and k + 1 + R <= 64; otherwise MGP_EUNSUPPORTED and the caller
+ *       uses mgp_posterior_* on the plain tables.  Results are identical to
+ *       mgp_posterior_* (same kernels, same arithmetic).
+ * ------------------------------------------------------------------------- */
+int64_t mgp_packed_row_bytes(int d, int R, int elem_size);
+int mgp_table_pack_f32(const float* features, const float* targets, int64_t n, int d, int R, void* packed,
+                       int64_t stride_bytes, void* stream);
+int mgp_table_pack_f64(const double* features, const double* targets, int64_t n, int d, int R, void* packed,
+                       int64_t stride_bytes, void* stream);
+int mgp_posterior_packed_f32(const void* packed_q, int64_t q_stride_bytes, const void* packed_nn,
+                             int64_t nn_stride_bytes, int d,
+                             const int64_t* batch_idx, const int64_t* nn_idx, int64_t b, int k, int R,
+                             int noise_mode, double noise_scalar, const float* noise_dev,
+                             int kernel_id, int metric_id, const float* length_scale, int ls_count,
+                             float* mean, float* var, float* ykinvy, int* info, void* stream);
+int mgp_posterior_packed_f64(const void* packed_q, int64_t q_stride_bytes, const void* packed_nn,
+                             int64_t nn_stride_bytes, int d,
+                             const int64_t* batch_idx, const int64_t* nn_idx, int64_t b, int k, int R,
+                             int noise_mode, double noise_scalar, const double* noise_dev,
+                             int kernel_id, int metric_id, const double* length_scale, int ls_count,
+                             double* mean, double* var, double* ykinvy, int* info, void* stream);
 
 /* Fused coefficient precompute of the fast posterior mean: coeffs (b, k) = (K_b + eps)^-1 y_b
  * for the neighbourhoods nn_idx (b, k) of one table (gather -> distances -> kernel -> nugget ->
@@ -275,15 +350,22 @@ int mgp_fast_posterior_mean_f64(const double* feat_q, const double* feat_nn, int
  *   out[2] = sum huber_delta^2 (sqrt(1 + (r/huber_delta)^2) - 1)            (:64-72)
  *   out[3] = sum 2 looph_delta^2 (sqrt(1 + r^2/(looph_delta^2 s v)) - 1) + log(s v)  (:75-117)
  *   out[4] = sum r^2 / v,  out[5] = sum log v   (separable lool pieces for a single allreduce)
- * `out` is a device double[6], overwritten (not accumulated). */
+ * `out` is a device double[6], overwritten (not accumulated).
+ * `scratch`: a device double[mgp_reduce_scratch_doubles()] owned by the call, or NULL.
+ * With scratch the sum is a deterministic two-stage reduction (per-workgroup partials
+ * added in workgroup order: the same inputs always give the same bits); with NULL the
+ * partials meet in fp64 atomics. */
+int mgp_reduce_scratch_doubles(void);
 int mgp_loss_sums_f32(const float* pred, const float* target, const float* var, int64_t n,
-                      const double* scale_dev, double huber_delta, double looph_delta, double* out, void* stream);
+                      const double* scale_dev, double huber_delta, double looph_delta, double* out,
+                      double* scratch, void* stream);
 int mgp_loss_sums_f64(const double* pred, const double* target, const double* var, int64_t n,
-                      const double* scale_dev, double huber_delta, double looph_delta, double* out, void* stream);
+                      const double* scale_dev, double huber_delta, double looph_delta, double* out,
+                      double* scratch, void* stream);
 /* Column sums in fp64: out[r] = sum_i x[i, r]  (x is (n, R)); used for
- * sum_b y^T K^-1 y (scale/numpy.py:9-15).  out is a device double[R]. */
-int mgp_column_sums_f32(const float* x, int64_t n, int R, double* out, void* stream);
-int mgp_column_sums_f64(const double* x, int64_t n, int R, double* out, void* stream);
+ * sum_b y^T K^-1 y (scale/numpy.py:9-15).  out is a device double[R]; scratch as above. */
+int mgp_column_sums_f32(const float* x, int64_t n, int R, double* out, double* scratch, void* stream);
+int mgp_column_sums_f64(const double* x, int64_t n, int R, double* out, double* scratch, void* stream);
 
 #ifdef __cplusplus
 }

@@ -60,8 +60,12 @@ _SIGS = {
     "kernel_apply": [_p, _l, _i, _d, _p, _p],
     "perturb": [_p, _l, _i, _i, _d, _p, _p, _p],
     "solve": [_p, _p, _p, _l, _i, _i, _d, _p, _p, _p, _p, _p, _p],
-    "loss_sums": [_p, _p, _p, _l, _p, _d, _d, _p, _p],
-    "column_sums": [_p, _l, _i, _p, _p],
+    "posterior_generic": [_p, _p, _i, _p, _p, _l, _i, _p, _i, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p],
+    "posterior_rhs": [_p, _p, _i, _p, _p, _l, _i, _p, _i, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p],
+    "posterior_packed": [_p, _l, _p, _l, _i, _p, _p, _l, _i, _i, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p],
+    "table_pack": [_p, _p, _l, _i, _i, _p, _l, _p],
+    "loss_sums": [_p, _p, _p, _l, _p, _d, _d, _p, _p, _p],
+    "column_sums": [_p, _l, _i, _p, _p, _p],
     "posterior_backward": [_p, _p, _i, _p, _p, _l, _i, _p, _i, _i, _d, _p, _i, _i, _p, _i,
                            _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "fast_coefficients": [_p, _i, _p, _l, _i, _p, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p],
@@ -96,14 +100,11 @@ def load():
     lib.mgp_knn_scan_f32.restype = _i
     lib.mgp_knn_scan_bf16x3.argtypes = [_p, _p, _p, _l, _i, _p, _p, _p, _p, _l, _i, _l, _p, _p, _p, _p]
     lib.mgp_knn_scan_bf16x3.restype = _i
-    lib.mgp_debug_force_generic.argtypes = [_i]
-    lib.mgp_debug_force_generic.restype = None
-    lib.mgp_debug_prefer_rhs.argtypes = [_i]
-    lib.mgp_debug_prefer_rhs.restype = None
-    lib.mgp_debug_enable_wave2.argtypes = [_i]
-    lib.mgp_debug_enable_wave2.restype = None
-    lib.mgp_debug_set_phase_mask.argtypes = [_i]
-    lib.mgp_debug_set_phase_mask.restype = None
+    lib.mgp_posterior_kernel_name.argtypes = [_i, _i, _i, _i, _i, _i, C.c_char_p, _i]
+    lib.mgp_posterior_kernel_name.restype = _i
+    lib.mgp_reduce_scratch_doubles.restype = _i
+    lib.mgp_packed_row_bytes.argtypes = [_i, _i, _i]
+    lib.mgp_packed_row_bytes.restype = _l
     for base, sig in _SIGS.items():
         for suf in ("f32", "f64"):
             fn = getattr(lib, f"mgp_{base}_{suf}")
@@ -132,6 +133,50 @@ def ptr(t):
 
 def stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def served_by(d: int, k: int, R: int, dtype, packed: bool = False, path: str = "auto") -> str:
+    """Name of the kernel instantiation the dispatcher picks for a shape (``mgp_posterior_kernel_name``)."""
+    buf = C.create_string_buffer(256)
+    es = 4 if dtype == torch.float32 else 8
+    rc = load().mgp_posterior_kernel_name(es, d, k, R, int(bool(packed)), {"auto": 0, "generic": 1, "rhs": 2}[path], buf, 256)
+    if rc == -2 and packed:
+        return served_by(d, k, R, dtype, False, path)
+    check(rc, "mgp_posterior_kernel_name")
+    return buf.value.decode()
+
+
+def reduce_scratch(device):
+    """Per-call scratch of the deterministic two-stage reductions (mgp_loss_sums_* / mgp_column_sums_*);
+    it comes from torch's stream-aware caching allocator, so concurrent streams never share one."""
+    return torch.empty(load().mgp_reduce_scratch_doubles(), dtype=torch.float64, device=device)
+
+
+def column_sums(x2: "torch.Tensor") -> "torch.Tensor":
+    """Deterministic fp64 column sums of a contiguous (rows, cols) device tensor (``mgp_column_sums_*``)."""
+    rows, cols = x2.shape
+    out = torch.zeros(cols, device=x2.device, dtype=torch.float64)
+    if rows and cols:
+        scratch = reduce_scratch(x2.device)
+        check(
+            fn("column_sums", x2.dtype)(ptr(x2), rows, cols, ptr(out), ptr(scratch), stream_ptr()),
+            "mgp_column_sums",
+        )
+    return out
+
+
+def loss_sums(pred, target, var, scale_dev, huber_delta: float, looph_delta: float) -> "torch.Tensor":
+    """The six fp64 loss sums of ``mgp_loss_sums_*`` (deterministic two-stage reduction)."""
+    out = torch.empty(6, device=pred.device, dtype=torch.float64)
+    scratch = reduce_scratch(pred.device)
+    check(
+        fn("loss_sums", pred.dtype)(
+            ptr(pred), ptr(target), ptr(var), pred.numel(), ptr(scale_dev), float(huber_delta), float(looph_delta),
+            ptr(out), ptr(scratch), stream_ptr(),
+        ),
+        "mgp_loss_sums",
+    )
+    return out
 
 
 def require_cuda(*tensors):

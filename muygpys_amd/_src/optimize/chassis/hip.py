@@ -130,6 +130,11 @@ class _UCBBayesOpt:
 def _bayes_opt_optimize(muygps, obj_fn: Callable, verbose: bool = False, **kwargs):
     """numpy.py:119-149: probe x0 first, then init_points (default 5) + n_iter (default 20)."""
     x0_names, x0, bounds = _get_opt_lists(muygps, verbose=verbose)
+    if kwargs.get("random_state") is None:
+        from muygpys_amd import distributed as _D
+
+        if _D.reductions_active():  # every rank must propose the same points: rank 0's seed
+            kwargs["random_state"] = _D.synchronized_seed(_D._ACTIVE["group"])
     optimizer = _UCBBayesOpt(
         obj_fn, x0_names, bounds, random_state=kwargs.get("random_state"),
         verbose=kwargs.get("verbose", 2 if verbose else 0) if not isinstance(kwargs.get("verbose"), bool) else int(verbose),

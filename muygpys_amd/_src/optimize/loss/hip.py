@@ -12,7 +12,8 @@ import torch
 from muygpys_amd import _lib
 
 
-def _sums(predictions, targets, variances=None, scale=None, huber_delta=1.5, looph_delta=3.0):
+def _sums_and_count(predictions, targets, variances=None, scale=None, huber_delta=1.5, looph_delta=3.0):
+    """(the six fp64 sums, element count): both global when the batch is sharded over ranks."""
     _lib.require_cuda(predictions, targets, variances)
     p = predictions.contiguous()
     t = targets.to(p.dtype).contiguous()
@@ -31,13 +32,20 @@ def _sums(predictions, targets, variances=None, scale=None, huber_delta=1.5, loo
     if scale is not None:
         s = scale.detach() if isinstance(scale, torch.Tensor) else torch.tensor(float(scale), dtype=torch.float64)
         s = s.to(device=p.device, dtype=torch.float64).reshape(-1)[:1].contiguous()
-    out = torch.empty(6, device=p.device, dtype=torch.float64)
-    rc = _lib.fn("loss_sums", p.dtype)(
-        _lib.ptr(p), _lib.ptr(t), _lib.ptr(v), p.numel(), _lib.ptr(s), float(huber_delta), float(looph_delta),
-        _lib.ptr(out), _lib.stream_ptr(),
-    )
-    _lib.check(rc, "mgp_loss_sums")
-    return out
+    out = _lib.loss_sums(p, t, v, s, huber_delta, looph_delta)
+    from muygpys_amd import distributed as _D
+
+    if _D.reductions_active():
+        # sharded batch: the sums (and, for mse, the element count) are global, like the reference's
+        # mpi backend (_src/optimize/loss/mpi.py:20-104)
+        tot = torch.cat([out, torch.tensor([float(p.numel())], device=out.device, dtype=torch.float64)])
+        _D.reduce_if_sharded_(tot)
+        return tot[:6], tot[6]
+    return out, p.numel()
+
+
+def _sums(*args, **kwargs):
+    return _sums_and_count(*args, **kwargs)[0]
 
 
 def _wants_grad(*xs) -> bool:
@@ -69,7 +77,8 @@ class _MseMean(torch.autograd.Function):
     @staticmethod
     def forward(ctx, predictions, targets):
         ctx.save_for_backward(predictions, targets)
-        return (_sums(predictions.detach(), targets)[0] / predictions.numel()).to(predictions.dtype)
+        sums, count = _sums_and_count(predictions.detach(), targets)
+        return (sums[0] / count).to(predictions.dtype)
 
     @staticmethod
     def backward(ctx, g):
@@ -86,7 +95,8 @@ def _mse_fn(predictions, targets, **kwargs):
     """numpy.py:22-31."""
     if _wants_grad(predictions):
         return _MseMean.apply(predictions, targets)
-    return (_sums(predictions, targets)[0] / predictions.numel()).to(predictions.dtype)
+    sums, count = _sums_and_count(predictions, targets)
+    return (sums[0] / count).to(predictions.dtype)
 
 
 def _lool_fn_unscaled(predictions, targets, variances, **kwargs):

@@ -20,14 +20,7 @@ from .fused import KernelSpec, _length_scale_tensor
 
 def _column_sums(x2: torch.Tensor) -> torch.Tensor:
     """fp64 column sums of a (rows, cols) tensor through ``mgp_column_sums_*``."""
-    rows, cols = x2.shape
-    out = torch.zeros(cols, device=x2.device, dtype=torch.float64)
-    if rows:
-        _lib.check(
-            _lib.fn("column_sums", x2.dtype)(_lib.ptr(x2), rows, cols, _lib.ptr(out), _lib.stream_ptr()),
-            "mgp_column_sums",
-        )
-    return out
+    return _lib.column_sums(x2.contiguous())
 
 
 class _FusedPosterior(torch.autograd.Function):

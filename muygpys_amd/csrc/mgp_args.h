@@ -21,7 +21,14 @@ struct FusedArgs {
   double noise_scalar;
   int d, k, R, noise_mode, kernel_id, metric_id, ls_count, dc;
   void* coeffs = nullptr;  // (b, k) K^-1 y per neighbourhood (fused fast-mean precompute), or nullptr
+  // prepared tables (mgp_table_pack_*): rows [features d | responses R | pad], byte strides; when
+  // packed_nn is set feat_q / feat_nn / targets are not read by the pipelined wave kernels
+  const void* packed_q = nullptr;
+  const void* packed_nn = nullptr;
+  int64_t q_stride = 0, nn_stride = 0;
 };
+
+#define MGP_MAX_DEVICES 64
 
 struct SolveArgs {
   const void* Kin;
@@ -89,8 +96,8 @@ template <typename T> int launch_solve_generic(const SolveArgs&, hipStream_t);
 template <typename T> int launch_fused_wave(const FusedArgs&, hipStream_t);
 // k <= 64 with up to 16 responses carried as right-hand-side columns (mgp_fused_rhs.hip)
 template <typename T> int launch_fused_rhs(const FusedArgs&, hipStream_t);
-int launch_fused_wave2_f32(const FusedArgs&, hipStream_t);  // two rows per lane, static headline shape
 int max_nn_count(int elem_size, int R);
+int describe_fused_wave(int elem_size, int d, int k, int R, int packed, char* buf, int len);
 
 template <typename T>
 int launch_crosswise_diffs(const T*, const T*, int, const int64_t*, const int64_t*, int64_t, int, T*, hipStream_t);
@@ -103,8 +110,10 @@ template <typename T> int launch_reduce_diffs(const T*, int64_t, int, const T*, 
 template <typename T> int launch_kernel_apply(const T*, int64_t, int, double, T*, hipStream_t);
 template <typename T> int launch_perturb(const T*, int64_t, int, int, double, const T*, T*, hipStream_t);
 template <typename T>
-int launch_loss_sums(const T*, const T*, const T*, int64_t, const double*, double, double, double*, hipStream_t);
-template <typename T> int launch_column_sums(const T*, int64_t, int, double*, hipStream_t);
+int launch_loss_sums(const T*, const T*, const T*, int64_t, const double*, double, double, double*, double*, hipStream_t);
+template <typename T> int launch_column_sums(const T*, int64_t, int, double*, double*, hipStream_t);
+int reduce_scratch_doubles();
+template <typename T> int launch_table_pack(const T*, const T*, int64_t, int, int, void*, int64_t, hipStream_t);
 template <typename T>
 int launch_fast_mean(const void*, const void*, int, const int64_t*, const int64_t*, int64_t, int, const void*,
                      const int64_t*, int, int, int, const void*, int, void*, hipStream_t);

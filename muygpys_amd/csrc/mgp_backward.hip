@@ -18,7 +18,11 @@
 
 namespace mgp {
 
+#ifdef MGP_DEBUG_HOOKS
 int g_bwd_stage = 0;  // timing ablations only: stop every neighbourhood after stage N (0 = run all)
+#else
+static const int g_bwd_stage = 0;
+#endif
 
 __device__ __forceinline__ void tri_decode(int p, int& row, int& col) {
   int a_ = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);

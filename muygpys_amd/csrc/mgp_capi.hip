@@ -1,5 +1,7 @@
 // extern "C" boundary: argument validation + dispatch to the kernels.  See
 // include/muygpys_hip.h for the contract and the reference functions each entry replaces.
+#include <cstdio>
+
 #include "mgp_args.h"
 
 namespace mgp {
@@ -7,34 +9,49 @@ namespace mgp {
 static bool valid_kernel(int id) { return id >= MGP_KERNEL_RBF && id <= MGP_KERNEL_MATERN_INF; }
 static bool valid_metric(int id) { return id == MGP_METRIC_L2 || id == MGP_METRIC_F2; }
 
-// 0 = let the dispatcher choose; 1 = force the generic LDS kernel (tests / A-B timing)
-static int g_force_generic = 0;
-static int g_prefer_rhs = 0;  // tests: try the rhs-columns kernel before the row form
-extern int g_phase_mask;  // mgp_fused_wave.hip (timing ablations only)
+#ifdef MGP_DEBUG_HOOKS
+extern int g_phase_mask;  // mgp_fused_wave.hip (timing ablations, debug builds only)
 extern int g_grid_per_cu;
 extern int g_lds_pad;
-extern int g_wave2_enable;
 extern int g_bwd_stage;  // mgp_backward.hip
-extern int g_runtime_pipe;
+#endif
+
+// which kernel family serves a fused call: the dispatcher's choice, or one family named by the
+// caller (mgp_posterior_generic_* / mgp_posterior_rhs_*: tests and A/B timing)
+enum { PATH_AUTO = 0, PATH_GENERIC = 1, PATH_RHS = 2 };
 
 template <typename T>
 int posterior(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t* ni, int64_t b, int k, const T* tg,
               int R, int noise_mode, double eps, const T* nd, int kernel_id, int metric_id, const T* ls,
-              int ls_count, T* mean, T* var, T* yk, int* info, void* stream) {
+              int ls_count, T* mean, T* var, T* yk, int* info, void* stream, int path = PATH_AUTO,
+              const void* packed_q = nullptr, int64_t q_stride = 0, const void* packed_nn = nullptr,
+              int64_t nn_stride = 0) {
   if (b < 0 || k < 1 || d < 1 || R < 1) return MGP_EINVAL;
   if (b == 0) return MGP_OK;  // empty shard: nothing to read or write (outputs may be NULL)
-  if (!fq || !fn || !ni || !tg || !ls || !mean || !var) return MGP_EINVAL;
+  const bool packed = packed_nn != nullptr;
+  if (packed) {
+    if (!packed_q || q_stride < (int64_t)(d * sizeof(T)) || nn_stride < (int64_t)((d + R) * sizeof(T))) return MGP_EINVAL;
+  } else if (!fq || !fn || !tg) {
+    return MGP_EINVAL;
+  }
+  if (!ni || !ls || !mean || !var) return MGP_EINVAL;
   if (!valid_kernel(kernel_id) || !valid_metric(metric_id)) return MGP_EINVAL;
   if (noise_mode < MGP_NOISE_SCALAR || noise_mode > MGP_NOISE_BATCH) return MGP_EINVAL;
   if (noise_mode != MGP_NOISE_SCALAR && !nd) return MGP_EINVAL;
   if (ls_count != 1 && ls_count != d) return MGP_EINVAL;
   FusedArgs a{fq, fn, bi, ni, tg, nd, ls, mean, var, yk, info, b, eps, d, k, R, noise_mode, kernel_id, metric_id,
               ls_count, 0};
+  a.packed_q = packed_q;
+  a.packed_nn = packed_nn;
+  a.q_stride = q_stride;
+  a.nn_stride = nn_stride;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (!g_force_generic) {
-    int rc = g_prefer_rhs ? launch_fused_rhs<T>(a, s) : launch_fused_wave<T>(a, s);
+  if (packed) return launch_fused_wave<T>(a, s);  // MGP_EUNSUPPORTED: the caller uses the plain tables
+  if (path == PATH_RHS) return launch_fused_rhs<T>(a, s);
+  if (path == PATH_AUTO) {
+    int rc = launch_fused_wave<T>(a, s);
     if (rc != MGP_EUNSUPPORTED) return rc;
-    rc = g_prefer_rhs ? launch_fused_wave<T>(a, s) : launch_fused_rhs<T>(a, s);
+    rc = launch_fused_rhs<T>(a, s);
     if (rc != MGP_EUNSUPPORTED) return rc;
   }
   return launch_fused_generic<T>(a, s);
@@ -100,15 +117,29 @@ extern "C" {
 
 const char* mgp_version(void) { return "muygpys_amd-hip 0.1 (gfx950)"; }
 int mgp_max_nn_count(int elem_size, int R) { return max_nn_count(elem_size, R); }
-/* test hook, not part of the public header: force the generic LDS kernel */
-void mgp_debug_force_generic(int on) { g_force_generic = on; }
-void mgp_debug_prefer_rhs(int on) { g_prefer_rhs = on; }
+int mgp_reduce_scratch_doubles(void) { return reduce_scratch_doubles(); }
+int mgp_posterior_kernel_name(int elem_size, int d, int k, int R, int packed, int path, char* buf, int len) {
+  if (!buf || len < 1 || (elem_size != 4 && elem_size != 8)) return MGP_EINVAL;
+  if (path == PATH_AUTO && describe_fused_wave(elem_size, d, k, R, packed, buf, len) > 0) return MGP_OK;
+  const char* t = elem_size == 4 ? "float" : "double";
+  if (packed) return snprintf(buf, len, "%s", "") < 0 ? MGP_EINVAL : MGP_EUNSUPPORTED;
+  if (path != PATH_GENERIC && k <= 64 && R <= 16)
+    snprintf(buf, len, "mgp::fused_rhs_kernel<%s,%d>", t, R <= 4 ? 4 : 16);
+  else
+    snprintf(buf, len, "mgp::fused_generic_kernel<%s>", t);
+  return MGP_OK;
+}
+int64_t mgp_packed_row_bytes(int d, int R, int elem_size) {
+  if (d < 1 || R < 0 || (elem_size != 4 && elem_size != 8)) return MGP_EINVAL;
+  return (((int64_t)(d + R) * elem_size) + 63) / 64 * 64;
+}
+#ifdef MGP_DEBUG_HOOKS
+/* timing-ablation hooks of debug builds (tools/kbench.py, tools/bwdbench.py); absent from the shipped library */
 void mgp_debug_set_phase_mask(int mask) { mgp::g_phase_mask = mask; }
 void mgp_debug_set_grid_per_cu(int n) { mgp::g_grid_per_cu = n; }
 void mgp_debug_set_lds_pad(int n) { mgp::g_lds_pad = n; }
-void mgp_debug_enable_wave2(int on) { mgp::g_wave2_enable = on; }
 void mgp_debug_set_bwd_stage(int n) { mgp::g_bwd_stage = n; }
-void mgp_debug_runtime_pipe(int on) { mgp::g_runtime_pipe = on; }
+#endif
 
 int mgp_posterior_f32(const float* fq, const float* fn, int d, const int64_t* bi, const int64_t* ni, int64_t b, int k,
                       const float* tg, int R, int nm, double eps, const float* nd, int kid, int mid, const float* ls,
@@ -120,6 +151,34 @@ int mgp_posterior_f64(const double* fq, const double* fn, int d, const int64_t* 
                       const double* ls, int lsc, double* mean, double* var, double* yk, int* info, void* st) {
   return posterior<double>(fq, fn, d, bi, ni, b, k, tg, R, nm, eps, nd, kid, mid, ls, lsc, mean, var, yk, info, st);
 }
+
+#define MGP_DEFINE_PATHS(SUF, T)                                                                                    \
+  int mgp_posterior_generic_##SUF(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t* ni, int64_t b,  \
+                                  int k, const T* tg, int R, int nm, double eps, const T* nd, int kid, int mid,      \
+                                  const T* ls, int lsc, T* mean, T* var, T* yk, int* info, void* st) {               \
+    return posterior<T>(fq, fn, d, bi, ni, b, k, tg, R, nm, eps, nd, kid, mid, ls, lsc, mean, var, yk, info, st,    \
+                        PATH_GENERIC);                                                                               \
+  }                                                                                                                  \
+  int mgp_posterior_rhs_##SUF(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t* ni, int64_t b,      \
+                              int k, const T* tg, int R, int nm, double eps, const T* nd, int kid, int mid,          \
+                              const T* ls, int lsc, T* mean, T* var, T* yk, int* info, void* st) {                   \
+    return posterior<T>(fq, fn, d, bi, ni, b, k, tg, R, nm, eps, nd, kid, mid, ls, lsc, mean, var, yk, info, st,    \
+                        PATH_RHS);                                                                                   \
+  }                                                                                                                  \
+  int mgp_table_pack_##SUF(const T* feat, const T* targets, int64_t n, int d, int R, void* packed,                   \
+                           int64_t stride_bytes, void* st) {                                                         \
+    if (!feat || !packed || n < 0 || d < 1 || R < 0 || false) return MGP_EINVAL;              \
+    return launch_table_pack<T>(feat, targets, n, d, R, packed, stride_bytes, S_(st));                               \
+  }                                                                                                                  \
+  int mgp_posterior_packed_##SUF(const void* packed_q, int64_t q_stride, const void* packed_nn, int64_t nn_stride,   \
+                                 int d, const int64_t* bi, const int64_t* ni, int64_t b, int k, int R, int nm,       \
+                                 double eps, const T* nd, int kid, int mid, const T* ls, int lsc, T* mean, T* var,   \
+                                 T* yk, int* info, void* st) {                                                       \
+    return posterior<T>(nullptr, nullptr, d, bi, ni, b, k, nullptr, R, nm, eps, nd, kid, mid, ls, lsc, mean, var,   \
+                        yk, info, st, PATH_AUTO, packed_q, q_stride, packed_nn, nn_stride);                          \
+  }
+MGP_DEFINE_PATHS(f32, float)
+MGP_DEFINE_PATHS(f64, double)
 
 int mgp_knn_scan_f32(const float* train, const float* train_sqn, int64_t n, int d, const float* queries,
                      const float* query_sqn, const int64_t* self_idx, int64_t m, int k, int64_t start, float* best_d,
@@ -204,13 +263,13 @@ int mgp_max_nn_count_backward(int elem_size) { return max_nn_count_backward(elem
     return solve<T>(Kin, Kc, Y, b, k, R, kout, mean, var, yk, coeffs, info, st);                                     \
   }                                                                                                                  \
   int mgp_loss_sums_##SUF(const T* pred, const T* target, const T* var, int64_t n, const double* scale_dev,          \
-                          double hd, double ld, double* out, void* st) {                                             \
+                          double hd, double ld, double* out, double* scratch, void* st) {                            \
     if (!pred || !target || !out || n < 0 || !(hd > 0) || !(ld > 0)) return MGP_EINVAL;                              \
-    return launch_loss_sums<T>(pred, target, var, n, scale_dev, hd, ld, out, S_(st));                                \
+    return launch_loss_sums<T>(pred, target, var, n, scale_dev, hd, ld, out, scratch, S_(st));                       \
   }                                                                                                                  \
-  int mgp_column_sums_##SUF(const T* x, int64_t n, int R, double* out, void* st) {                                   \
+  int mgp_column_sums_##SUF(const T* x, int64_t n, int R, double* out, double* scratch, void* st) {                  \
     if (!x || !out || n < 0 || R < 0) return MGP_EINVAL;                                                             \
-    return launch_column_sums<T>(x, n, R, out, S_(st));                                                              \
+    return launch_column_sums<T>(x, n, R, out, scratch, S_(st));                                                     \
   }
 
 #define MGP_DEFINE_FAST(SUF, T)                                                                                     \

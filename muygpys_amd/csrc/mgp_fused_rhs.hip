@@ -284,21 +284,11 @@ static int launch_rhs(const FusedArgs& a, hipStream_t stream) {
   const size_t tile_elems = (size_t)((NP + 1) * g.xs > NP * KS ? (NP + 1) * g.xs : NP * KS);
   size_t lds = (tile_elems + 64 + NRV * E + g.dst + (g.dst & 1)) * sizeof(T) + 66 * sizeof(int64_t);
   lds = (lds + 15) & ~(size_t)15;
-  static int cached_lds = -1, cached_per_cu = 0, cached_cus = 0;
-  if (cached_lds != (int)lds) {
-    int dev = 0, n = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MGP_EHIP;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        &n, reinterpret_cast<const void*>(&fused_rhs_kernel<T, RC>), 64, lds);
-    if (e != hipSuccess) return -(1000 + (int)e);
-    const int by_lds = (int)((160 * 1024) / (((lds + 1279) / 1280) * 1280));
-    cached_per_cu = n < by_lds ? n : by_lds;
-    cached_cus = prop.multiProcessorCount;
-    cached_lds = (int)lds;
-    if (cached_per_cu < 1) return MGP_EUNSUPPORTED;
-  }
-  int64_t grid = (int64_t)cached_cus * cached_per_cu;
+  static Residency res;
+  int per_cu = 0, cus = 0;
+  const int rc = res.lookup(reinterpret_cast<const void*>(&fused_rhs_kernel<T, RC>), 64, lds, &per_cu, &cus);
+  if (rc != MGP_OK) return rc;
+  int64_t grid = (int64_t)cus * per_cu;
   if (grid > g.ntasks) grid = g.ntasks;
   hipLaunchKernelGGL((fused_rhs_kernel<T, RC>), dim3((unsigned)grid), dim3(64), lds, stream, a, g);
   MGP_HIP_CHECK_LAUNCH();
@@ -307,7 +297,7 @@ static int launch_rhs(const FusedArgs& a, hipStream_t stream) {
 
 template <typename T>
 int launch_fused_rhs(const FusedArgs& a, hipStream_t stream) {
-  if (a.k > 64) return MGP_EUNSUPPORTED;
+  if (a.k > 64 || a.packed_nn != nullptr) return MGP_EUNSUPPORTED;
   if (a.R <= 4) return launch_rhs<T, 4>(a, stream);
   if (a.R <= 16) return launch_rhs<T, 16>(a, stream);
   return MGP_EUNSUPPORTED;

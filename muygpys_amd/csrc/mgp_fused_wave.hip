@@ -45,6 +45,13 @@
 
 #include "mgp_wave_common.h"
 
+// Phase tests: WaveGeom::mask is a kernel argument, always 0xF in the shipped library (only builds
+// with -DMGP_DEBUG_HOOKS export a setter, for the timing ablations of tools/kbench.py).  The test
+// stays a run-time one on purpose: with the phases fused into one straight-line region the
+// compiler hoists per-lane addresses of all phases to the top of the task loop and the static
+// shapes spill (168 VGPRs + 164 B scratch instead of 134 and none; 2.78 instead of 2.22 ms).
+#define MGP_PHASE(g, bit) ((g).mask & (bit))
+
 namespace mgp {
 
 struct WaveGeom {
@@ -59,9 +66,13 @@ struct WaveGeom {
 // KFIX / RFIX / DFIX > 0: nn_count / response_count / feature_count known at compile time.
 // PIPED: software-pipelined direct-to-LDS gather (one feature stage, 16-byte aligned rows).
 // COEFF: also emit K^-1 y (the fast-posterior-mean coefficients): multipliers kept, back-substitution.
-template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF = false>
+// PACKED: the tables are prepared tables (mgp_table_pack_*): rows of [features | responses | pad] at a
+//        64-byte multiple stride, so a row and its response arrive with the same two cache lines
+//        and no separate 4-byte response read (a whole line each) is issued.
+template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF = false, bool PACKED = false>
 __global__ __launch_bounds__(64, (sizeof(T) == 4 ? (NP == 32 ? 3 : 2) : (NP == 32 ? 2 : 2)))
 void fused_wave_kernel(FusedArgs a, WaveGeom g) {
+  static_assert(!PACKED || PIPED, "prepared tables are gathered by the direct-to-LDS pipeline");
   constexpr int NH = 64 / NP;     // neighbourhoods per wave
   constexpr int NS = NP / 2;      // pairs per lane
   constexpr int BA = 4;           // own rows per lane        } register blocking of the pair scheme,
@@ -162,10 +173,15 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     const int i = lane_ & (NP - 1);
     // pointer to this slot's feature row; slots without one (idx_n = 0) point at row 0 -- any
     // valid row will do, their tile rows are never used
-    rowaddr[lane_] = (i == q ? feat_q : feat_nn) + idx_n * (int64_t)d;
+    if constexpr (PACKED)
+      rowaddr[lane_] = reinterpret_cast<const T*>(
+          (i == q ? static_cast<const char*>(a.packed_q) + idx_n * a.q_stride
+                  : static_cast<const char*>(a.packed_nn) + idx_n * a.nn_stride));
+    else
+      rowaddr[lane_] = (i == q ? feat_q : feat_nn) + idx_n * (int64_t)d;
     pre_idx = idx_n;
     __syncthreads();
-    if (g.mask & 1) {
+    if (MGP_PHASE(g, 1)) {
       // 16-byte slot sigma = 64 n + lane of the tile: row = sigma / SPR, column = sigma % SPR
       // (unsigned 32-bit arithmetic throughout; padding slots re-read the last data slot, the
       // ones inside the padded feature range are zeroed when the tile is consumed)
@@ -176,7 +192,8 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
           if (n0 + u < SPR) {  // uniform; folded for the static shapes
             const unsigned sigma = 64u * (unsigned)(n0 + u) + (unsigned)lane_;
             const unsigned row = (sigma * spr_magic) >> 20;
-            const unsigned c = min(sigma - row * (unsigned)SPR, (unsigned)(C16V - 1));
+            // prepared tables: the slot after the features holds the responses
+            const unsigned c = min(sigma - row * (unsigned)SPR, (unsigned)(PACKED ? C16V : C16V - 1));
             src[u] = rowaddr[row] + c * E;
           }
         }
@@ -187,7 +204,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     }
     // response and nugget of the slot's row: unconditional single loads (idx_n is 0, a valid
     // row, for slots without one; the values are masked where they are consumed)
-    pre_y = targets[idx_n * (int64_t)R];
+    if constexpr (!PACKED) pre_y = targets[idx_n * (int64_t)R];  // prepared tables: read from the tile
     pre_eps = (T)a.noise_scalar;
     if (a.noise_mode != MGP_NOISE_SCALAR) {
       const int64_t nb0 = task_n * NH;
@@ -221,6 +238,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     // ---- phase 0: indices, responses, nugget -------------------------------------------
     int64_t myidx = 0;
     T myeps = T(0), myy0 = T(0);
+    V myyv = V(0);  // prepared tables: the row's responses, taken from the tile
     if (PIPE) {
       // the tile of this task was requested during the previous task's factorisation; the
       // barrier at the top of the stage loop below waits for it (vmcnt) before anyone reads it
@@ -248,10 +266,15 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       const int wp = (w + CH - 1) / CH * CH;
       __syncthreads();
       if (PIPE) {
+        if constexpr (PACKED) {
+          // the slot behind the features carries the row's responses (before it is zeroed as padding)
+          myyv = *reinterpret_cast<const V*>(Xh + i * xs + d);
+          myy0 = i < k ? myyv[0] : T(0);
+        }
         // feature columns w .. wp-1 of the staged rows are padding of the 8-wide inner loop: the
         // direct-to-LDS gather filled them with a repeat of the last data slot
         if (wp > w) *reinterpret_cast<V*>(Xh + i * xs + w) = V(0);
-      } else if (!(g.mask & 1)) {
+      } else if (!MGP_PHASE(g, 1)) {
       } else if (DFIX > 0 || g.vec_ok) {
         // c16p consecutive lanes walk one row; rpr rows per round; all rounds of a task in flight
         const int c16 = w / E, c16p = wp / E;
@@ -308,7 +331,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) acc[s] = ACC(0);
       }
-      if (g.mask & 2) {
+      if (MGP_PHASE(g, 2)) {
         if (aniso) {
           for (int c0 = 0; c0 < wp; c0 += CH) {
             V own0[BA], own1[BA];
@@ -366,7 +389,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       int i3 = i;
       asm volatile("" : "+v"(i3));
       T* Kh3 = tile + (NH == 1 ? 0 : (lane / NP) * NP * KS);
-      if (g.mask & 4) {
+      if (MGP_PHASE(g, 4)) {
         // All NS covariances first (independent chains the scheduler can interleave), then the
         // stores -- unconditional: an entry whose row is a response slot (hi > q) goes to the
         // unused padding column of the last row instead of being branched around.
@@ -399,7 +422,13 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       }
       Kh3[i3 * KS + i3] = i3 < k ? T(1) + myeps : (i3 <= q ? T(1) : T(0));
       Kh3[(q + 1) * KS + i3] = myy0;
-      for (int r = 1; r < R; ++r) Kh3[(q + 1 + r) * KS + i3] = i3 < k ? targets[myidx * (int64_t)R + r] : T(0);
+      if constexpr (PACKED) {
+#pragma unroll
+        for (int r = 1; r < E; ++r)
+          if (r < R) Kh3[(q + 1 + r) * KS + i3] = i3 < k ? myyv[r] : T(0);
+      } else {
+        for (int r = 1; r < R; ++r) Kh3[(q + 1 + r) * KS + i3] = i3 < k ? targets[myidx * (int64_t)R + r] : T(0);
+      }
     }
     __syncthreads();
     V A[NP / E];
@@ -419,7 +448,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     bool bad = false;
 #pragma unroll
     for (int j = 0; j < NP - 2; ++j) {
-      if (j < k && (g.mask & 8)) {
+      if (j < k && MGP_PHASE(g, 8)) {
         const T ajj = A[j / E][j % E];
         colh[i] = ajj;
         if constexpr (sizeof(T) == 8) {
@@ -533,25 +562,32 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   }
 }
 
+#ifdef MGP_DEBUG_HOOKS
 int g_phase_mask = 0xF;
-int g_grid_per_cu = 0;  // debug override of resident workgroups per CU
-int g_lds_pad = 0;      // debug: extra dynamic LDS bytes per workgroup
-int g_runtime_pipe = 1; // debug: 0 = register-staged gather for run-time shapes
+int g_grid_per_cu = 0;  // override of resident workgroups per CU
+int g_lds_pad = 0;      // extra dynamic LDS bytes per workgroup
+#endif
 
-template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF = false>
+template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF = false, bool PACKED = false>
 static int launch_np(const FusedArgs& a, hipStream_t stream) {
   constexpr int NH = 64 / NP;
   constexpr int E = v16<T>::N;
   constexpr int CH = 2 * E;
   constexpr int KS = NP + E;
   WaveGeom g;
+#ifdef MGP_DEBUG_HOOKS
   g.mask = g_phase_mask;
+#else
+  g.mask = 0xF;
+#endif
   g.q = NP - 1 - a.R;
   const int dpad = (a.d + CH - 1) / CH * CH;
   g.dst = dpad < 64 ? dpad : 64;
   g.xs = g.dst + E;  // dst/E is even -> dst/E + 1 slots: odd
-  const uintptr_t align = (uintptr_t)a.feat_q | (uintptr_t)a.feat_nn;
+  const uintptr_t align = PACKED ? ((uintptr_t)a.packed_q | (uintptr_t)a.packed_nn | (uintptr_t)a.q_stride | (uintptr_t)a.nn_stride)
+                                 : ((uintptr_t)a.feat_q | (uintptr_t)a.feat_nn);
   g.vec_ok = (a.d % E == 0) && (align % 16 == 0);
+  if (PACKED && a.R > E) return MGP_EUNSUPPORTED;  // the responses ride in one 16-byte slot
   if ((DFIX > 0 || PIPED) && !g.vec_ok) return MGP_EUNSUPPORTED;
   if (PIPED && a.d > g.dst) return MGP_EUNSUPPORTED;  // more than one feature stage
   g.ntasks = (a.b + NH - 1) / NH;
@@ -559,39 +595,32 @@ static int launch_np(const FusedArgs& a, hipStream_t stream) {
   constexpr bool PIPE = PIPED;
   size_t lds = PIPE ? (size_t)NH * NP * rowmax * sizeof(T) + 64 * sizeof(void*)
                     : ((size_t)NH * NP * rowmax + 64 + g.dst + (g.dst & 1)) * sizeof(T) + 64 * sizeof(int64_t);
-  lds = ((lds + 15) & ~(size_t)15) + (size_t)g_lds_pad;
+  lds = (lds + 15) & ~(size_t)15;
+#ifdef MGP_DEBUG_HOOKS
+  lds += (size_t)g_lds_pad;
+#endif
   // Persistent grid = exactly the resident capacity: every workgroup owns a fixed share of the
   // tasks, so one workgroup more than fits runs as a second, nearly empty round (measured: 13
   // instead of 12 per CU costs 40 %).  Residency comes from the occupancy query for this kernel
   // at this LDS size; the CU count from the device.
-  static int cached_lds = -1, cached_per_cu = 0, cached_cus = 0;
-  if (cached_lds != (int)lds) {
-    int dev = 0, n = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MGP_EHIP;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        &n, reinterpret_cast<const void*>(&fused_wave_kernel<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF>), 64, lds);
-    if (e != hipSuccess) return -(1000 + (int)e);
-    if (n < 1) return MGP_EUNSUPPORTED;
-    cached_lds = (int)lds;
-    // the occupancy query over-reports for LDS-bound shapes: measured on gfx950, LDS is handed out
-    // in 1280-byte granules of the CU's 160 KiB (13 x 12192 B is refused, 12 x 12704 B fits)
-    const int by_lds = (int)((160 * 1024) / (((lds + 1279) / 1280) * 1280));
-    cached_per_cu = n < by_lds ? n : by_lds;
-    cached_cus = prop.multiProcessorCount;
-  }
-  int per_cu = cached_per_cu;
+  static Residency res;
+  int per_cu = 0, cus = 0;
+  const int rrc = res.lookup(
+      reinterpret_cast<const void*>(&fused_wave_kernel<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF, PACKED>), 64, lds, &per_cu, &cus);
+  if (rrc != MGP_OK) return rrc;
+#ifdef MGP_DEBUG_HOOKS
   if (g_grid_per_cu > 0) per_cu = g_grid_per_cu;
-  int64_t grid = (int64_t)cached_cus * per_cu / 8 * 8;
+#endif
+  int64_t grid = (int64_t)cus * per_cu / 8 * 8;
   if (grid < 8) grid = 8;
   if (grid > g.ntasks) grid = (g.ntasks + 7) / 8 * 8;
   static const bool trace = getenv("MGP_TRACE") != nullptr;  // which instantiation served a call
   if (trace)
-    fprintf(stderr, "mgp: fused_wave_kernel<%s,%d,%d,%d,%d,%s> b=%lld k=%d d=%d R=%d grid=%lld lds=%zu\n",
-            sizeof(T) == 4 ? "float" : "double", NP, KFIX, RFIX, DFIX, PIPED ? "pipe" : "stage", (long long)a.b, a.k,
-            a.d, a.R, (long long)grid, lds);
-  hipLaunchKernelGGL((fused_wave_kernel<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF>), dim3((unsigned)grid), dim3(64), lds, stream, a,
-                     g);
+    fprintf(stderr, "mgp: fused_wave_kernel<%s,%d,%d,%d,%d,%s%s> b=%lld k=%d d=%d R=%d grid=%lld lds=%zu\n",
+            sizeof(T) == 4 ? "float" : "double", NP, KFIX, RFIX, DFIX, PIPED ? "pipe" : "stage", PACKED ? ",packed" : "",
+            (long long)a.b, a.k, a.d, a.R, (long long)grid, lds);
+  hipLaunchKernelGGL((fused_wave_kernel<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF, PACKED>), dim3((unsigned)grid), dim3(64), lds,
+                     stream, a, g);
   MGP_HIP_CHECK_LAUNCH();
   return MGP_OK;
 }
@@ -600,13 +629,20 @@ template <typename T>
 int launch_fused_wave(const FusedArgs& a, hipStream_t stream) {
   const int rows = a.k + 1 + a.R;
   if (a.coeffs != nullptr) {  // fused fast-mean precompute: one response
+    if (a.packed_nn != nullptr) return MGP_EUNSUPPORTED;
     if (a.R == 1 && rows <= 32) return launch_np<T, 32, 0, 0, 0, false, true>(a, stream);
     if (a.R == 1 && rows <= 64) return launch_np<T, 64, 0, 0, 0, false, true>(a, stream);
     return MGP_EUNSUPPORTED;
   }
+  if (a.packed_nn != nullptr) {  // prepared tables: the pipelined kernels only
+    if constexpr (sizeof(T) == 4)
+      if (a.k == 30 && a.R == 1 && a.d == 40) return launch_np<T, 32, 30, 1, 40, true, false, true>(a, stream);
+    if (a.k == 50 && a.R == 1 && a.d == 8) return launch_np<T, 64, 50, 1, 8, true, false, true>(a, stream);
+    if (rows <= 32) return launch_np<T, 32, 0, 0, 0, true, false, true>(a, stream);
+    if (rows <= 64) return launch_np<T, 64, 0, 0, 0, true, false, true>(a, stream);
+    return MGP_EUNSUPPORTED;
+  }
   if constexpr (sizeof(T) == 4) if (a.k == 30 && a.R == 1 && a.d == 40) {  // BASELINE configs 2/3, all shapes static
-    const int rc2 = launch_fused_wave2_f32(a, stream);
-    if (rc2 != MGP_EUNSUPPORTED) return rc2;
     const int rc = launch_np<T, 32, 30, 1, 40, true>(a, stream);
     if (rc != MGP_EUNSUPPORTED) return rc;
   }
@@ -617,14 +653,29 @@ int launch_fused_wave(const FusedArgs& a, hipStream_t stream) {
   // run-time shapes: the pipelined direct-to-LDS gather when the rows allow it (16-byte aligned,
   // d a multiple of 16 bytes, one feature stage), the register-staged gather otherwise
   if (rows <= 32) {
-    const int rc = g_runtime_pipe ? launch_np<T, 32, 0, 0, 0, true>(a, stream) : MGP_EUNSUPPORTED;
+    const int rc = launch_np<T, 32, 0, 0, 0, true>(a, stream);
     return rc != MGP_EUNSUPPORTED ? rc : launch_np<T, 32, 0, 0, 0, false>(a, stream);
   }
   if (rows <= 64) {
-    const int rc = g_runtime_pipe ? launch_np<T, 64, 0, 0, 0, true>(a, stream) : MGP_EUNSUPPORTED;
+    const int rc = launch_np<T, 64, 0, 0, 0, true>(a, stream);
     return rc != MGP_EUNSUPPORTED ? rc : launch_np<T, 64, 0, 0, 0, false>(a, stream);
   }
   return MGP_EUNSUPPORTED;
+}
+
+// The instantiation launch_fused_wave would pick for a shape (pure function of its arguments;
+// mirrors the dispatch above for 16-byte aligned tables).  Empty string: not a wave-kernel shape.
+int describe_fused_wave(int elem_size, int d, int k, int R, int packed, char* buf, int len) {
+  const int rows = k + 1 + R, E = 16 / elem_size;
+  const char* t = elem_size == 4 ? "float" : "double";
+  const bool vec = d % E == 0, one_stage = ((d + 2 * E - 1) / (2 * E)) * (2 * E) <= 64;
+  int np = rows <= 32 ? 32 : (rows <= 64 ? 64 : 0), kf = 0, rf = 0, df = 0;
+  bool piped = vec && one_stage;
+  if (elem_size == 4 && k == 30 && R == 1 && d == 40) kf = 30, rf = 1, df = 40, np = 32, piped = true;
+  else if (k == 50 && R == 1 && d == 8) kf = 50, rf = 1, df = 8, np = 64, piped = true;
+  if (np == 0 || (packed && (!piped || R > E))) return snprintf(buf, len, "%s", "");
+  return snprintf(buf, len, "mgp::fused_wave_kernel<%s,%d,%d,%d,%d,%s,false,%s>", t, np, kf, rf, df,
+                  piped ? "true" : "false", packed ? "true" : "false");
 }
 
 template int launch_fused_wave<float>(const FusedArgs&, hipStream_t);

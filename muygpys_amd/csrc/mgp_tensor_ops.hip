@@ -116,10 +116,16 @@ __global__ void perturb_kernel(const T* Kin, int64_t b, int k, int noise_mode, T
   }
 }
 
-// ---- fp64 reductions (single workgroup finishes; inputs are O(b) scalars) ----------------
+// ---- fp64 reductions --------------------------------------------------------------------
+// Deterministic two-stage form when the caller provides scratch (kReduceBlocks x N doubles): every
+// workgroup stores its partial sums, a second one-workgroup launch adds them in workgroup order,
+// so the result does not depend on arrival order and "sharded == serial" holds bit for bit for
+// equal shard sizes.  Without scratch the partials meet in fp64 atomics (order-dependent rounding).
+
+static const int kReduceBlocks = 1024;
 
 template <int N>
-__device__ inline void block_reduce_store(double (&v)[N], double* out) {
+__device__ inline void block_reduce_store(double (&v)[N], double* out, double* scratch) {
   __shared__ double red[N][kBlock / MGP_WAVE];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
@@ -131,15 +137,33 @@ __device__ inline void block_reduce_store(double (&v)[N], double* out) {
   if (threadIdx.x < N) {
     double s = 0;
     for (int j = 0; j < kBlock / MGP_WAVE; ++j) s += red[threadIdx.x][j];
-    atomicAdd(out + threadIdx.x, s);
+    if (scratch) scratch[(size_t)blockIdx.x * N + threadIdx.x] = s;
+    else atomicAdd(out + threadIdx.x, s);
   }
   __syncthreads();
+}
+
+// out[i] = sum over blocks of scratch[block][i], in block order (one workgroup)
+__global__ void reduce_partials_kernel(const double* scratch, int blocks, int N, double* out) {
+  __shared__ double red[kBlock];
+  for (int i = 0; i < N; ++i) {
+    double s = 0;
+    for (int b = threadIdx.x; b < blocks; b += kBlock) s += scratch[(size_t)b * N + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[i] = red[0];
+    __syncthreads();
+  }
 }
 
 // _src/optimize/loss/numpy.py:22-117 in one pass
 template <typename T>
 __global__ void loss_sums_kernel(const T* pred, const T* target, const T* var, int64_t n, const double* scale_dev,
-                                 double hd, double ld, double* out) {
+                                 double hd, double ld, double* out, double* scratch) {
   const double s = scale_dev ? *scale_dev : 1.0;
   double acc[6] = {0, 0, 0, 0, 0, 0};
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
@@ -156,17 +180,31 @@ __global__ void loss_sums_kernel(const T* pred, const T* target, const T* var, i
       acc[5] += ::log(v);
     }
   }
-  block_reduce_store<6>(acc, out);
+  block_reduce_store<6>(acc, out, scratch);
 }
 
 template <typename T>
-__global__ void column_sums_kernel(const T* x, int64_t n, int R, double* out) {
+__global__ void column_sums_kernel(const T* x, int64_t n, int R, double* out, double* scratch) {
   // one column at a time (R is small); rows strided over the whole grid
   for (int r = 0; r < R; ++r) {
     double acc[1] = {0};
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
       acc[0] += (double)x[t * R + r];
-    block_reduce_store<1>(acc, out + r);
+    block_reduce_store<1>(acc, out + r, scratch ? scratch + (size_t)r * gridDim.x : nullptr);
+  }
+}
+
+// prepared table: out row = [features d | responses R | zero pad] at `stride` bytes
+template <typename T>
+__global__ void table_pack_kernel(const T* feat, const T* targets, int64_t n, int d, int R, T* out, int64_t se) {
+  const int64_t total = n * se;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = t / se;
+    const int c = (int)(t - row * se);
+    T v = T(0);
+    if (c < d) v = feat[row * d + c];
+    else if (c < d + R && targets) v = targets[row * R + (c - d)];
+    out[t] = v;
   }
 }
 
@@ -229,24 +267,51 @@ int launch_perturb(const T* Kin, int64_t b, int k, int mode, double eps, const T
 }
 template <typename T>
 int launch_loss_sums(const T* pred, const T* target, const T* var, int64_t n, const double* scale_dev, double hd,
-                     double ld, double* out, hipStream_t s) {
+                     double ld, double* out, double* scratch, hipStream_t s) {
   hipError_t e = hipMemsetAsync(out, 0, 6 * sizeof(double), s);
   if (e != hipSuccess) return -(1000 + (int)e);
   if (n == 0) return MGP_OK;
   int g = grid_1d(n);
-  if (g > 1024) g = 1024;
-  hipLaunchKernelGGL(loss_sums_kernel<T>, dim3(g), dim3(kBlock), 0, s, pred, target, var, n, scale_dev, hd, ld, out);
+  if (g > kReduceBlocks) g = kReduceBlocks;
+  hipLaunchKernelGGL(loss_sums_kernel<T>, dim3(g), dim3(kBlock), 0, s, pred, target, var, n, scale_dev, hd, ld, out,
+                     scratch);
   MGP_HIP_CHECK_LAUNCH();
+  if (scratch) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kBlock), 0, s, scratch, g, 6, out);
+    MGP_HIP_CHECK_LAUNCH();
+  }
   return MGP_OK;
 }
 template <typename T>
-int launch_column_sums(const T* x, int64_t n, int R, double* out, hipStream_t s) {
+int launch_column_sums(const T* x, int64_t n, int R, double* out, double* scratch, hipStream_t s) {
   hipError_t e = hipMemsetAsync(out, 0, (size_t)R * sizeof(double), s);
   if (e != hipSuccess) return -(1000 + (int)e);
   if (n == 0 || R == 0) return MGP_OK;
   int g = grid_1d(n);
-  if (g > 1024) g = 1024;
-  hipLaunchKernelGGL(column_sums_kernel<T>, dim3(g), dim3(kBlock), 0, s, x, n, R, out);
+  if (g > kReduceBlocks) g = kReduceBlocks;
+  if (scratch && (int64_t)g * R > (int64_t)kReduceBlocks * 6) g = kReduceBlocks * 6 / R;  // scratch capacity
+  if (g < 1) return MGP_EUNSUPPORTED;
+  hipLaunchKernelGGL(column_sums_kernel<T>, dim3(g), dim3(kBlock), 0, s, x, n, R, out, scratch);
+  MGP_HIP_CHECK_LAUNCH();
+  if (scratch) {
+    // scratch holds R runs of g partials: column r at scratch[r * g + block]
+    for (int r = 0; r < R; ++r) {
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kBlock), 0, s, scratch + (size_t)r * g, g, 1, out + r);
+      MGP_HIP_CHECK_LAUNCH();
+    }
+  }
+  return MGP_OK;
+}
+int reduce_scratch_doubles() { return kReduceBlocks * 6; }
+
+template <typename T>
+int launch_table_pack(const T* feat, const T* targets, int64_t n, int d, int R, void* out, int64_t stride,
+                      hipStream_t s) {
+  if (n == 0) return MGP_OK;
+  if (stride % (int64_t)sizeof(T) != 0 || stride < (int64_t)((d + R) * sizeof(T))) return MGP_EINVAL;
+  const int64_t se = stride / (int64_t)sizeof(T);
+  hipLaunchKernelGGL(table_pack_kernel<T>, dim3(grid_1d(n * se)), dim3(kBlock), 0, s, feat, targets, n, d, R,
+                     static_cast<T*>(out), se);
   MGP_HIP_CHECK_LAUNCH();
   return MGP_OK;
 }
@@ -262,8 +327,9 @@ int launch_column_sums(const T* x, int64_t n, int R, double* out, hipStream_t s)
   template int launch_kernel_apply<T>(const T*, int64_t, int, double, T*, hipStream_t);                            \
   template int launch_perturb<T>(const T*, int64_t, int, int, double, const T*, T*, hipStream_t);                  \
   template int launch_loss_sums<T>(const T*, const T*, const T*, int64_t, const double*, double, double, double*,  \
-                                   hipStream_t);                                                                   \
-  template int launch_column_sums<T>(const T*, int64_t, int, double*, hipStream_t);
+                                   double*, hipStream_t);                                                          \
+  template int launch_column_sums<T>(const T*, int64_t, int, double*, double*, hipStream_t);                        \
+  template int launch_table_pack<T>(const T*, const T*, int64_t, int, int, void*, int64_t, hipStream_t);
 MGP_INSTANTIATE(float)
 MGP_INSTANTIATE(double)
 

@@ -3,9 +3,44 @@
 // reciprocal, squared distance -> covariance, direct-to-LDS load, compile-time kernel dispatch.
 #pragma once
 
+#include <mutex>
+
 #include "mgp_args.h"
 
 namespace mgp {
+
+// Resident workgroups per CU of one kernel instantiation at one LDS size, per device.  Queried once
+// per (instantiation, device, LDS size) under a mutex: the entry points stay re-entrant and a
+// second device gets its own CU count.
+struct Residency {
+  std::mutex mu;
+  struct Entry { int lds = -1, per_cu = 0, cus = 0; } dev[MGP_MAX_DEVICES];
+  // -> MGP_OK and (per_cu, cus), or an error status
+  int lookup(const void* kernel, int threads, size_t lds, int* per_cu, int* cus) {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MGP_MAX_DEVICES) return MGP_EHIP;
+    std::lock_guard<std::mutex> lock(mu);
+    Entry& e = dev[d];
+    if (e.lds != (int)lds) {
+      int n = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, d) != hipSuccess) return MGP_EHIP;
+      hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lds);
+      if (err != hipSuccess) return -(1000 + (int)err);
+      if (n < 1) return MGP_EUNSUPPORTED;
+      // the occupancy query over-reports for LDS-bound shapes: measured on gfx950, LDS is handed out
+      // in 1280-byte granules of the CU's 160 KiB (13 x 12192 B is refused, 12 x 12704 B fits)
+      const int by_lds = (int)((160 * 1024) / (((lds + 1279) / 1280) * 1280));
+      e.per_cu = n < by_lds ? n : by_lds;
+      if (e.per_cu < 1) return MGP_EUNSUPPORTED;
+      e.cus = prop.multiProcessorCount;
+      e.lds = (int)lds;
+    }
+    *per_cu = e.per_cu;
+    *cus = e.cus;
+    return MGP_OK;
+  }
+};
 
 template <typename T> struct v16;
 template <> struct v16<float> {

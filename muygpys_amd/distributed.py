@@ -17,7 +17,13 @@ of ``4 + R`` float64 scalars (the reference uses three), because with
     mse            = sum r_i^2 / n
 
 are all functions of the partial sums ``[sum r^2/v, sum log v, sum r^2, n, sum y^T K^-1 y]``.
-``looph`` is not separable in sigma^2 and takes a second pass + all-reduce.
+``looph`` is not separable in sigma^2 and takes a second pass + a one-scalar all-reduce;
+``pseudo_huber`` is one more entry of the same vector.
+
+Two routes reach the optimisers: :func:`spec_objective` (an ``obj_fn`` straight on
+:func:`sharded_loocv`, one all-reduce per evaluation) and :class:`sharded_reductions` /
+:func:`optimize_sharded` (the reference's mpi-backend layout: the functor layer is unchanged and
+the hip loss / scale functions all-reduce their sums, two collectives per evaluation).
 
 ``torch.distributed`` with backend ``nccl`` is RCCL on ROCm; the payload (<= 160 bytes) is
 pure latency over xGMI.  The CPU test-suite drives the same code over ``gloo``.
@@ -67,43 +73,105 @@ def allreduce_sum_(partials: torch.Tensor, group=None) -> torch.Tensor:
     return partials
 
 
+# ---------------------------------------------------------------------------------------------
+# Sharded-reduction mode: the hip backend's loss / scale functions all-reduce their sums, like the
+# reference's mpi backend does inside _mse_fn / _lool_fn / _looph_fn / _pseudo_huber_fn
+# (_src/optimize/loss/mpi.py:20-104) and _analytic_scale_optim (_src/optimize/scale/mpi.py:16-37).
+# With it on, the unchanged functor layer (OptimizeFn, make_loo_crossval_fn, MuyGPS.optimize_scale)
+# evaluates the GLOBAL objective from every rank's shard of the batch, and every rank sees the same
+# scalar -- so deterministic drivers (L-BFGS-B) walk the same trajectory on every rank.
+# ---------------------------------------------------------------------------------------------
+_ACTIVE = {"on": False, "group": None}
+
+
+class sharded_reductions:
+    """Context manager: ``with sharded_reductions(group): L_BFGS_B_optimize(...)``."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def __enter__(self):
+        self._saved = dict(_ACTIVE)
+        _ACTIVE.update(on=True, group=self.group)
+        return self
+
+    def __exit__(self, *exc):
+        _ACTIVE.update(self._saved)
+        return False
+
+
+def reductions_active() -> bool:
+    return bool(_ACTIVE["on"]) and _world(_ACTIVE["group"])[1] > 1
+
+
+def reduce_if_sharded_(sums: torch.Tensor) -> torch.Tensor:
+    """All-reduce a vector of partial sums when the sharded-reduction mode is on (else a no-op)."""
+    if reductions_active():
+        allreduce_sum_(sums, _ACTIVE["group"])
+    return sums
+
+
+def broadcast_scalar(value: float, group=None, root: int = 0) -> float:
+    """Rank ``root``'s value on every rank (reference: comm_world.bcast for sampled hyper-parameters,
+    gp/hyperparameter/scalar.py:145-146)."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return float(value)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.broadcast(t, src=root, group=group)
+    return float(t.item())
+
+
+def synchronized_seed(group=None) -> int:
+    """One random seed for all ranks (drawn on rank 0): the stochastic drivers (Bayes-opt) then
+    propose the same points everywhere."""
+    import numpy as np
+
+    return int(broadcast_scalar(float(np.random.randint(0, 2**31 - 1)), group))
+
+
 # partial-sum vector layout
-P_R2_OVER_V, P_LOG_V, P_R2, P_COUNT, P_YKY0 = 0, 1, 2, 3, 4
+P_R2_OVER_V, P_LOG_V, P_R2, P_COUNT, P_HUBER, P_YKY0 = 0, 1, 2, 3, 4, 5
+LOSSES = ("lool", "mse", "looph", "pseudo_huber")
 
 
-def hip_local_partials(spec, features, targets, batch_indices, nn_indices):
+def hip_local_partials(spec, features, targets, batch_indices, nn_indices, packed="auto", huber_delta: float = 1.5):
     """The local shard's partial sums on the GPU: one fused launch + two fp64 reductions.
 
-    Returns ``(partials float64 [4 + R], mean, var)`` -- all device tensors."""
+    Returns ``(partials float64 [5 + R], mean, var)`` -- all device tensors."""
     from muygpys_amd import _lib
     from muygpys_amd.fused import posterior_mean_var
 
-    mean, var, yk = posterior_mean_var(spec, features, features, batch_indices, nn_indices, targets, want_ykinvy=True)
+    mean, var, yk = posterior_mean_var(spec, features, features, batch_indices, nn_indices, targets, want_ykinvy=True,
+                                       packed=packed)
     b = nn_indices.shape[0]
     R = 1 if targets.ndim == 1 else targets.shape[1]
-    out = torch.zeros(4 + R, device=features.device, dtype=torch.float64)
+    out = torch.zeros(P_YKY0 + R, device=features.device, dtype=torch.float64)
     if b > 0:
         if R != 1:
             raise NotImplementedError("the LOOCV losses are defined for a single response (reference: loss/numpy.py:34-61)")
-        yb = targets[batch_indices]
-        sums = torch.empty(6, device=features.device, dtype=torch.float64)
-        _lib.check(
-            _lib.fn("loss_sums", mean.dtype)(
-                _lib.ptr(mean.contiguous()), _lib.ptr(yb.contiguous()), _lib.ptr(var), b, None, 1.5, 3.0,
-                _lib.ptr(sums), _lib.stream_ptr(),
-            ),
-            "mgp_loss_sums",
-        )
-        yk2 = yk.reshape(b, R).contiguous()
-        _lib.check(
-            _lib.fn("column_sums", yk2.dtype)(_lib.ptr(yk2), b, R, _lib.ptr(out[P_YKY0:]), _lib.stream_ptr()),
-            "mgp_column_sums",
-        )
+        mean_c, yb = mean.contiguous(), targets[batch_indices].contiguous()
+        sums = _lib.loss_sums(mean_c, yb, var, None, huber_delta, 3.0)
+        out[P_YKY0:] = _lib.column_sums(yk.reshape(b, R).contiguous())
         out[P_R2_OVER_V] = sums[4]
         out[P_LOG_V] = sums[5]
         out[P_R2] = sums[0]
         out[P_COUNT] = float(b)
+        out[P_HUBER] = sums[2]
     return out, mean, var
+
+
+def hip_local_looph(mean, targets_b, var, sigma_sq: float, looph_delta: float = 3.0) -> torch.Tensor:
+    """Second pass of ``looph`` (not separable in sigma^2): this shard's
+    sum 2 d^2 (sqrt(1 + r^2 / (d^2 s v)) - 1) + log(s v) as a 1-element float64 device tensor."""
+    from muygpys_amd import _lib
+
+    if mean.numel() == 0:
+        return torch.zeros(1, device=mean.device, dtype=torch.float64)
+    s = torch.tensor([sigma_sq], device=mean.device, dtype=torch.float64)
+    return _lib.loss_sums(mean.contiguous(), targets_b.contiguous(), var, s, 1.5, looph_delta)[3:4].clone()
 
 
 def finish_objective(partials: Sequence[float], nn_count: int, loss: str = "lool") -> Dict[str, float]:
@@ -112,9 +180,10 @@ def finish_objective(partials: Sequence[float], nn_count: int, loss: str = "lool
     n = p[P_COUNT]
     sigma_sq = [yk / (n * nn_count) for yk in p[P_YKY0:]]
     s = sigma_sq[0]
-    out = {"sigma_sq": s, "sigma_sq_all": sigma_sq, "count": n, "mse": p[P_R2] / n}
+    out = {"sigma_sq": s, "sigma_sq_all": sigma_sq, "count": n, "mse": p[P_R2] / n, "pseudo_huber": p[P_HUBER]}
     out["lool"] = p[P_R2_OVER_V] / s + p[P_LOG_V] + n * math.log(s)
-    out["objective"] = -out["lool"] if loss == "lool" else -out["mse"]
+    if loss in out:
+        out["objective"] = -out[loss]
     return out
 
 
@@ -128,24 +197,80 @@ def sharded_loocv(
     group=None,
     presharded: bool = False,
     local_fn: Callable = hip_local_partials,
+    looph_fn: Callable = hip_local_looph,
+    packed="auto",
+    loss_kwargs: Optional[Dict] = None,
 ) -> Dict:
     """One LOOCV objective evaluation over all ranks (objective.py:101-103 semantics: the value
     under ``"objective"`` is MINUS the loss).
 
     ``batch_indices`` / ``nn_indices`` are the global batch unless ``presharded``; each rank
-    evaluates its block and the partial sums meet in one all-reduce.  Returns the global scalars
-    plus this rank's ``mean`` / ``var`` (which stay sharded, like the reference's results)."""
-    if loss not in ("lool", "mse"):
-        raise ValueError(f"sharded_loocv supports 'lool' and 'mse', not {loss!r}")
+    evaluates its block and the partial sums meet in ONE all-reduce (``lool``, ``mse``,
+    ``pseudo_huber``); ``looph`` is not separable in sigma^2 and takes a second, one-scalar
+    all-reduce after sigma^2 is known (reference: three all-reduces, loss/mpi.py:57-104 +
+    scale/mpi.py:35-36).  Returns the global scalars plus this rank's ``mean`` / ``var`` (which stay
+    sharded, like the reference's results)."""
+    if loss not in LOSSES:
+        raise ValueError(f"sharded_loocv supports {LOSSES}, not {loss!r}")
+    loss_kwargs = dict(loss_kwargs or {})
     rank, size = _world(group)
     if not presharded:
         batch_indices = shard_rows(batch_indices, rank, size)
         nn_indices = shard_rows(nn_indices, rank, size)
-    partials, mean, var = local_fn(spec, features, targets, batch_indices, nn_indices)
+    kw = {}
+    if local_fn is hip_local_partials:
+        kw = dict(packed=packed, huber_delta=float(loss_kwargs.get("boundary_scale", 1.5)))
+    partials, mean, var = local_fn(spec, features, targets, batch_indices, nn_indices, **kw)
     allreduce_sum_(partials, group)
     out = finish_objective(partials.tolist(), nn_indices.shape[1], loss)
+    if loss == "looph":
+        part = looph_fn(mean, targets[batch_indices], var, out["sigma_sq"], float(loss_kwargs.get("boundary_scale", 3.0)))
+        allreduce_sum_(part, group)
+        out["looph"] = float(part[0])
+        out["objective"] = -out["looph"]
     out.update(mean=mean, var=var, rank=rank, world_size=size)
     return out
+
+
+def spec_objective(spec_fn: Callable, features, targets, batch_indices, nn_indices, loss: str = "lool", group=None,
+                   presharded: bool = False, **kwargs) -> Callable:
+    """``obj_fn(**hyper)`` for the optimisation drivers, built directly on :func:`sharded_loocv`:
+    ``spec_fn(**hyper)`` returns the :class:`KernelSpec` of a trial point; every rank evaluates its
+    shard, one all-reduce, the same scalar on every rank (reference: _make_mpi_obj_fn,
+    _src/optimize/loss/mpi.py:28-34)."""
+    rank, size = _world(group)
+    if not presharded:
+        batch_indices = shard_rows(batch_indices, rank, size).contiguous()
+        nn_indices = shard_rows(nn_indices, rank, size).contiguous()
+
+    def obj_fn(**hyper):
+        return sharded_loocv(spec_fn(**hyper), features, targets, batch_indices, nn_indices, loss=loss, group=group,
+                             presharded=True, **kwargs)["objective"]
+
+    return obj_fn
+
+
+def optimize_sharded(muygps, features, targets, batch_indices, nn_indices, optimizer: str = "lbfgsb", loss_fn=None,
+                     group=None, loss_kwargs: Optional[Dict] = None, **opt_kwargs):
+    """Hyper-parameter optimisation of a functor-layer model over all ranks: every rank builds the
+    (lazy) training tensors of ITS block of the batch (reference chunk rule), and the unchanged
+    ``L_BFGS_B_optimize`` / ``Bayes_optimize`` run under :class:`sharded_reductions`, so the loss and
+    sigma^2 are global and identical everywhere (reference: the mpi backend's loss / scale functions,
+    optimize/chassis.py:23-195 on scattered tensors).  The Bayes driver's random state is drawn on
+    rank 0.  Returns the optimised model (the same on every rank)."""
+    from muygpys_amd.optimize import Bayes_optimize, L_BFGS_B_optimize
+    from muygpys_amd.optimize.loss import lool_fn
+
+    rank, size = _world(group)
+    bi = shard_rows(batch_indices, rank, size).contiguous()
+    ni = shard_rows(nn_indices, rank, size).contiguous()
+    crosswise, pairwise, batch_targets, batch_nn_targets = muygps.make_train_tensors(bi, ni, features, targets)
+    driver = {"lbfgsb": L_BFGS_B_optimize, "bayes": Bayes_optimize}[optimizer]
+    if optimizer == "bayes" and opt_kwargs.get("random_state") is None:
+        opt_kwargs["random_state"] = synchronized_seed(group)
+    with sharded_reductions(group):
+        return driver(muygps, batch_targets, batch_nn_targets, crosswise, pairwise,
+                      loss_fn=loss_fn or lool_fn, loss_kwargs=dict(loss_kwargs or {}), **opt_kwargs)
 
 
 def sharded_posterior(spec, test_features, train_features, train_targets, batch_indices, nn_indices, group=None,

@@ -9,6 +9,8 @@ and what ``bench.py`` times.
 
 from __future__ import annotations
 
+import os
+from collections import OrderedDict
 from dataclasses import dataclass
 from typing import Optional, Sequence, Union
 
@@ -51,18 +53,98 @@ class KernelSpec:
             raise ValueError(f"unknown metric {self.metric!r}; expected 'l2' or 'F2'")
 
 
+# device-resident length scales of host-valued hyper-parameters, keyed by (values, device, dtype): an
+# optimiser revisits the same KernelSpec values for mean, variance and scale of one evaluation, and
+# a prediction / benchmark loop calls with one spec many times -- no host-to-device copy per call
+_LS_CACHE: "OrderedDict[tuple, torch.Tensor]" = OrderedDict()
+_LS_CACHE_SIZE = 64
+
+
 def _length_scale_tensor(ls, d: int, like: torch.Tensor) -> torch.Tensor:
     if isinstance(ls, torch.Tensor):
-        t = ls.detach().to(device=like.device, dtype=like.dtype).reshape(-1)
-    elif isinstance(ls, (int, float)):
-        t = torch.tensor([float(ls)], device=like.device, dtype=like.dtype)
+        t = ls.detach().to(device=like.device, dtype=like.dtype).reshape(-1).contiguous()
     else:
-        t = torch.tensor([float(v) for v in ls], device=like.device, dtype=like.dtype)
+        vals = (float(ls),) if isinstance(ls, (int, float)) else tuple(float(v) for v in ls)
+        key = (vals, like.device, like.dtype)
+        t = _LS_CACHE.get(key)
+        if t is None:
+            t = torch.tensor(vals, device=like.device, dtype=like.dtype)
+            _LS_CACHE[key] = t
+            if len(_LS_CACHE) > _LS_CACHE_SIZE:
+                _LS_CACHE.popitem(last=False)
+        else:
+            _LS_CACHE.move_to_end(key)
     if t.numel() != 1 and t.numel() != d:
         raise ValueError(
             f"Difference tensor of shape (..., {d}) must have final dimension size of {t.numel()}"
         )
-    return t.contiguous()
+    return t
+
+
+class PackedTable:
+    """A prepared table (``mgp_table_pack_*``): rows ``[features | responses | pad]`` at a 64-byte
+    multiple stride, so that the gather of a neighbour row brings its responses along (two cache
+    lines per neighbour instead of three at d = 40, fp32).  Built once per (features, targets) pair
+    -- the tables do not change across the objective evaluations of a hyper-parameter search."""
+
+    def __init__(self, features: torch.Tensor, targets: Optional[torch.Tensor] = None):
+        _lib.require_cuda(features, targets)
+        f = (features[:, None] if features.ndim == 1 else features).contiguous()
+        t = None
+        if targets is not None:
+            t = (targets[:, None] if targets.ndim == 1 else targets).to(f.dtype).contiguous()
+            if t.shape[0] != f.shape[0]:
+                raise ValueError("features and targets differ in row count")
+        self.n, self.d = f.shape
+        self.R = 0 if t is None else t.shape[1]
+        self.dtype = f.dtype
+        self.stride = int(_lib.load().mgp_packed_row_bytes(self.d, self.R, f.element_size()))
+        self.data = torch.empty(self.n * self.stride, dtype=torch.uint8, device=f.device)
+        _lib.check(
+            _lib.fn("table_pack", f.dtype)(
+                _lib.ptr(f), _lib.ptr(t), self.n, self.d, self.R, _lib.ptr(self.data), self.stride, _lib.stream_ptr()
+            ),
+            "mgp_table_pack",
+        )
+
+    @staticmethod
+    def supported(d: int, R: int, k: int, dtype) -> bool:
+        es = 4 if dtype == torch.float32 else 8
+        return (d * es) % 16 == 0 and R * es <= 16 and k + 1 + R <= 64
+
+
+_PACK_CACHE: "OrderedDict[tuple, PackedTable]" = OrderedDict()
+_PACK_CACHE_SIZE = 4
+
+
+def _tensor_key(t: Optional[torch.Tensor]):
+    return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), t.dtype, t.device)
+
+
+def pack_table(features: torch.Tensor, targets: Optional[torch.Tensor] = None) -> PackedTable:
+    """The prepared table of ``(features, targets)``, cached on the tensors' identity and version
+    (an in-place edit of either tensor invalidates the entry)."""
+    key = (_tensor_key(features), _tensor_key(targets))
+    hit = _PACK_CACHE.get(key)
+    if hit is None:
+        hit = PackedTable(features, targets)
+        _PACK_CACHE[key] = hit
+        if len(_PACK_CACHE) > _PACK_CACHE_SIZE:
+            _PACK_CACHE.popitem(last=False)
+    else:
+        _PACK_CACHE.move_to_end(key)
+    return hit
+
+
+def _check_indices(name: str, idx: Optional[torch.Tensor], n: int) -> None:
+    """Reference behaviour for an index outside the table: IndexError from the fancy index
+    (_src/gp/tensors/numpy.py:47-69).  Costs a device round trip, so only under
+    MUYGPYS_HIP_CHECK_INDICES=1 (debugging a neighbour table built on another data set)."""
+    if idx is None or idx.numel() == 0:
+        return
+    lo, hi = int(idx.amin()), int(idx.amax())
+    if lo < 0 or hi >= n:
+        raise IndexError(f"{name} holds indices in [{lo}, {hi}] but the table has {n} rows")
 
 
 def _noise_args(noise, b: int, k: int, like: torch.Tensor):
@@ -92,6 +174,8 @@ def posterior_mean_var(
     out_mean: Optional[torch.Tensor] = None,
     out_var: Optional[torch.Tensor] = None,
     info: Optional[torch.Tensor] = None,
+    path: str = "auto",
+    packed: Union[str, bool] = "auto",
 ):
     """Posterior mean and *unscaled* variance of every batch element, fused.
 
@@ -100,6 +184,11 @@ def posterior_mean_var(
     _src/gp/muygps/numpy.py:17-41); var ``(b,)`` equals ``1 - Kcross K^-1 Kcross``
     (:44-67 with Kout = 1); ``ykinvy (b, R)`` holds ``y_r^T K^-1 y_r`` per neighbourhood
     (the summand of _analytic_scale_optim_unnormalized, scale/numpy.py:9-15).
+
+    ``path``: "auto" (dispatcher), or one kernel family by name -- "generic" / "rhs" (parity tests).
+    ``packed``: "auto" reads the tables through prepared copies (:class:`PackedTable`, cached per
+    tensor) when the shape allows it and the batch touches the table often enough to pay for the
+    one-time pack; True forces, False disables.
     """
     _lib.require_cuda(test_features, train_features, batch_indices, nn_indices, train_targets)
     dtype = train_features.dtype
@@ -119,20 +208,45 @@ def posterior_mean_var(
     bi = None if batch_indices is None else batch_indices.to(torch.int64).contiguous()
     if bi is not None and bi.shape != (b,):
         raise ValueError("batch_indices must have shape (batch_count,)")
+    if bi is None and fq.shape[0] < b:
+        raise ValueError(f"{b} neighbourhoods but only {fq.shape[0]} query rows (batch_indices is None)")
     squeeze = train_targets.ndim == 1
     tg = (train_targets[:, None] if squeeze else train_targets).contiguous()
+    if tg.shape[0] != fn.shape[0]:
+        raise ValueError("train_features and train_targets differ in row count")
     R = tg.shape[1]
+    if os.environ.get("MUYGPYS_HIP_CHECK_INDICES") == "1":
+        _check_indices("nn_indices", ni, fn.shape[0])
+        _check_indices("batch_indices", bi, fq.shape[0])
     ls = _length_scale_tensor(spec.length_scale, d, fn)
     mode, eps, nz = _noise_args(spec.noise, b, k, fn)
 
     mean = out_mean if out_mean is not None else torch.empty((b, R), device=fn.device, dtype=dtype)
     var = out_var if out_var is not None else torch.empty((b,), device=fn.device, dtype=dtype)
     yk = torch.empty((b, R), device=fn.device, dtype=dtype) if want_ykinvy else None
-    rc = _lib.fn("posterior", dtype)(
-        _lib.ptr(fq), _lib.ptr(fn), d, _lib.ptr(bi), _lib.ptr(ni), b, k, _lib.ptr(tg), R,
-        mode, eps, _lib.ptr(nz), spec.kernel_id(), spec.metric_id(), _lib.ptr(ls), ls.numel(),
-        _lib.ptr(mean), _lib.ptr(var), _lib.ptr(yk), _lib.ptr(info), _lib.stream_ptr(),
-    )
+    if path not in ("auto", "generic", "rhs"):
+        raise ValueError(f"unknown kernel path {path!r}")
+    rc = -2
+    use_packed = path == "auto" and packed is not False and PackedTable.supported(d, R, k, dtype) and b > 0
+    if use_packed and packed == "auto":
+        # a pack is one pass over the table; worth it once the batch gathers a comparable number of rows
+        key = (_tensor_key(train_features), _tensor_key(train_targets))
+        use_packed = key in _PACK_CACHE or b * (k + 1) >= fn.shape[0] // 4
+    if use_packed:
+        pn = pack_table(train_features, train_targets)
+        pq = pn if test_features is train_features else pack_table(test_features, None)
+        rc = _lib.fn("posterior_packed", dtype)(
+            _lib.ptr(pq.data), pq.stride, _lib.ptr(pn.data), pn.stride, d, _lib.ptr(bi), _lib.ptr(ni), b, k, R,
+            mode, eps, _lib.ptr(nz), spec.kernel_id(), spec.metric_id(), _lib.ptr(ls), ls.numel(),
+            _lib.ptr(mean), _lib.ptr(var), _lib.ptr(yk), _lib.ptr(info), _lib.stream_ptr(),
+        )
+    if rc == -2:  # MGP_EUNSUPPORTED on the prepared tables (or not tried): the plain tables
+        base = {"auto": "posterior", "generic": "posterior_generic", "rhs": "posterior_rhs"}[path]
+        rc = _lib.fn(base, dtype)(
+            _lib.ptr(fq), _lib.ptr(fn), d, _lib.ptr(bi), _lib.ptr(ni), b, k, _lib.ptr(tg), R,
+            mode, eps, _lib.ptr(nz), spec.kernel_id(), spec.metric_id(), _lib.ptr(ls), ls.numel(),
+            _lib.ptr(mean), _lib.ptr(var), _lib.ptr(yk), _lib.ptr(info), _lib.stream_ptr(),
+        )
     _lib.check(rc, "mgp_posterior")
     mean_out = mean.reshape(b) if squeeze else mean.reshape(b, R)
     if want_ykinvy:

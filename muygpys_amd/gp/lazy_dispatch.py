@@ -168,12 +168,13 @@ def _scale_from_ykinvy(yk: torch.Tensor, Kin: lazy.LazyCov):
     from muygpys_amd import _lib
 
     b, k = Kin.diffs.nn_indices.shape
-    y2 = yk.reshape(b, -1).contiguous()
-    out = torch.empty((y2.shape[1],), device=yk.device, dtype=torch.float64)
-    _lib.check(
-        _lib.fn("column_sums", y2.dtype)(_lib.ptr(y2), b, y2.shape[1], _lib.ptr(out), _lib.stream_ptr()),
-        "mgp_column_sums",
-    )
+    out = _lib.column_sums(yk.reshape(b, -1).contiguous())
+    from muygpys_amd import distributed as _D
+
+    if _D.reductions_active():  # sharded batch: global sum / global count (scale/mpi.py:16-37)
+        tot = torch.cat([out.sum().reshape(1), torch.tensor([float(b)], device=out.device, dtype=torch.float64)])
+        _D.reduce_if_sharded_(tot)
+        return (tot[0] / (tot[1] * k)).to(yk.dtype)
     return (out.sum() / (b * k)).to(yk.dtype)
 
 

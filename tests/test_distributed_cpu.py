@@ -25,20 +25,29 @@ def _free_port():
 
 
 def oracle_local_partials(spec, features, targets, batch_indices, nn_indices):
+    """CPU stand-in for distributed.hip_local_partials (same partial-sum layout), computed by the oracle."""
+    from muygpys_amd import distributed as D
     from oracle import muygps_oracle as orc
 
     X, y = features.numpy(), targets.numpy()
     bi, ni = batch_indices.numpy(), nn_indices.numpy()
-    out = torch.zeros(5, dtype=torch.float64)
+    out = torch.zeros(D.P_YKY0 + 1, dtype=torch.float64)
     if len(bi) == 0:
         return out, torch.zeros(0, dtype=torch.float64), torch.zeros(0, dtype=torch.float64)
     ospec = orc.Spec(spec.kernel, spec.metric, spec.length_scale, spec.noise)
     mean, var = orc.posterior_mean_var(ospec, X, X, bi, ni, y)
-    r2 = (mean - y[bi]) ** 2
+    r = mean - y[bi]
     b, k = ni.shape
-    out[0], out[1], out[2], out[3] = (r2 / var).sum(), np.log(var).sum(), r2.sum(), b
-    out[4] = orc.sigma_sq(ospec, X, ni, y) * b * k
+    out[D.P_R2_OVER_V], out[D.P_LOG_V], out[D.P_R2], out[D.P_COUNT] = (r**2 / var).sum(), np.log(var).sum(), (r**2).sum(), b
+    out[D.P_HUBER] = (1.5**2 * (np.sqrt(1 + (r / 1.5) ** 2) - 1)).sum()
+    out[D.P_YKY0] = orc.sigma_sq(ospec, X, ni, y) * b * k
     return out, torch.from_numpy(mean), torch.from_numpy(var)
+
+
+def oracle_local_looph(mean, targets_b, var, sigma_sq, delta=3.0):
+    r2 = (mean.numpy() - targets_b.numpy()) ** 2
+    sv = sigma_sq * var.numpy()
+    return torch.tensor([(2 * delta**2 * (np.sqrt(1 + r2 / (delta**2 * sv)) - 1) + np.log(sv)).sum()], dtype=torch.float64)
 
 
 def _worker(rank, world, port, fixture, q):
@@ -55,9 +64,11 @@ def _worker(rank, world, port, fixture, q):
         spec = KernelSpec(meta["kernel"], meta["metric"], meta["length_scale"], meta["noise"])
         X, y = torch.from_numpy(g["features"]), torch.from_numpy(g["targets"])
         bi, ni = torch.from_numpy(g["batch_idx"]), torch.from_numpy(g["nn_idx"])
-        res = D.sharded_loocv(spec, X, y, bi, ni, loss="lool", local_fn=oracle_local_partials)
+        res = D.sharded_loocv(spec, X, y, bi, ni, loss="looph", local_fn=oracle_local_partials,
+                              looph_fn=oracle_local_looph)
         lo, hi = D.shard_bounds(len(bi), rank, world)
-        q.put((rank, res["lool"], res["sigma_sq"], res["mse"], res["count"], lo, hi, res["mean"].numpy()))
+        q.put((rank, res["lool"], res["sigma_sq"], res["mse"], res["count"], lo, hi, res["mean"].numpy(),
+               res["looph"], res["pseudo_huber"], res["objective"]))
     finally:
         dist.destroy_process_group()
 
@@ -79,10 +90,15 @@ def test_two_rank_objective_equals_serial(fixture):
         assert p.exitcode == 0
     b = len(g["batch_idx"])
     means = []
-    for rank, lool, sig, mse, count, lo, hi, mean in got:
+    for rank, lool, sig, mse, count, lo, hi, mean, looph, huber, objective in got:
         np.testing.assert_allclose(lool, g["lool"], rtol=1e-9)
         np.testing.assert_allclose(sig, g["sigma_sq"][0], rtol=1e-9)
         np.testing.assert_allclose(mse, g["mse"], rtol=1e-9)
+        # the non-separable loss (second pass + second all-reduce) and the pseudo-Huber entry,
+        # against the reference-generated values (loss/numpy.py:64-117)
+        np.testing.assert_allclose(looph, g["looph"], rtol=1e-9)
+        np.testing.assert_allclose(huber, g["huber"], rtol=1e-9)
+        assert objective == -looph
         assert count == b
         means.append(mean)
     # shards concatenate in rank order to the serial result; remainder goes to the LAST rank
@@ -102,3 +118,62 @@ def test_chunk_rule_matches_reference_fixture():
         bounds = [D.shard_bounds(n, r, p) for r in range(p)]
         assert bounds[0][0] == 0 and bounds[-1][1] == n
         assert all(bounds[i][1] == bounds[i + 1][0] for i in range(p - 1))
+
+
+def _opt_worker(rank, world, port, q):
+    """L-BFGS-B over a length scale, the objective evaluated shard-wise with one all-reduce."""
+    sys.path.insert(0, ROOT)
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from muygpys_amd import distributed as D
+        from muygpys_amd._src.optimize.chassis.hip import _scipy_optimize
+        from muygpys_amd.fused import KernelSpec
+        from muygpys_amd.gp import MuyGPS
+        from muygpys_amd.gp.deformation import Isotropy, l2
+        from muygpys_amd.gp.hyperparameter import Parameter
+        from muygpys_amd.gp.kernels import Matern
+        from muygpys_amd.gp.noise import HomoscedasticNoise
+        from tests.conftest import load_golden
+
+        g = load_golden("m15_iso_l2_k10_d8")
+        X, y = torch.from_numpy(g["features"]), torch.from_numpy(g["targets"])
+        bi, ni = torch.from_numpy(g["batch_idx"]), torch.from_numpy(g["nn_idx"])
+        # "sample": drawn on rank 0 and broadcast (scalar.py:145-146); ranks seed differently on purpose
+        np.random.seed(100 + rank)
+        ls = Parameter("sample", (0.5, 8.0))
+        model = MuyGPS(Matern(smoothness=Parameter(1.5), deformation=Isotropy(l2, length_scale=ls)),
+                       noise=HomoscedasticNoise(g["meta"]["noise"]))
+        start = model.kernel.deformation.length_scale()
+        model.kernel.deformation.length_scale._set_val(2.0)
+        obj = D.spec_objective(lambda length_scale: KernelSpec("matern15", "l2", length_scale, g["meta"]["noise"]),
+                               X, y, bi, ni, loss="lool", local_fn=oracle_local_partials)
+        opt = _scipy_optimize(model, obj)
+        q.put((rank, float(start), float(opt.kernel.deformation.length_scale()), float(obj(length_scale=3.0))))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def test_two_rank_lbfgsb_equals_serial():
+    """Reference: _make_mpi_obj_fn (loss/mpi.py:28-34) -- every rank runs the same optimiser on the
+    same global objective; the optimum equals the single-process one."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_opt_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    serial = ctx.Process(target=_opt_worker, args=(0, 1, 0, q))
+    serial.start()
+    ref = q.get(timeout=300)
+    serial.join(timeout=60)
+    assert got[0][1] == got[1][1], "the sampled start value must be rank 0's on every rank"
+    assert got[0][2] == got[1][2], "both ranks must walk the same trajectory"
+    np.testing.assert_allclose(got[0][2], ref[2], rtol=1e-6)
+    np.testing.assert_allclose(got[0][3], ref[3], rtol=1e-10)

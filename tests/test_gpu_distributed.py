@@ -31,10 +31,12 @@ def test_partials_and_finish(golden, dtype):
     assert_close([res["sigma_sq"]], g["sigma_sq"], rtol, "sigma_sq")
     assert_close([res["lool"]], [g["lool"]], rtol, "lool")
     assert_close([res["mse"]], [g["mse"]], rtol, "mse")
+    assert_close([res["pseudo_huber"]], [g["huber"]], rtol, "pseudo_huber")
+    assert_close([D.sharded_loocv(spec, X, y, bi, ni, loss="looph")["looph"]], [g["looph"]], rtol, "looph")
     assert res["count"] == len(g["batch_idx"])
     # two manual shards + summed partials == the whole
     P = 3
-    total = torch.zeros(5, device="cuda", dtype=torch.float64)
+    total = torch.zeros(D.P_YKY0 + 1, device="cuda", dtype=torch.float64)
     means = []
     for r in range(P):
         p, mean, _ = D.hip_local_partials(spec, X, y, D.shard_rows(bi, r, P), D.shard_rows(ni, r, P))
@@ -61,3 +63,81 @@ def test_sharded_batch_nns_concatenates_to_the_unsharded_search():
     assert torch.equal(torch.cat([p[0] for p in parts]), bi)
     assert torch.equal(torch.cat([p[1] for p in parts]), ref_i)
     torch.testing.assert_close(torch.cat([p[2] for p in parts]), ref_d)
+
+
+def _gpu_rank(rank, world, port, q):
+    """One of two processes sharing cuda:0 (a 1-GPU box): HIP partial sums + a real collective."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from muygpys_amd import distributed as D
+        from muygpys_amd.fused import KernelSpec
+        from muygpys_amd.gp import MuyGPS
+        from muygpys_amd.gp.deformation import Isotropy, l2
+        from muygpys_amd.gp.hyperparameter import AnalyticScale, Parameter
+        from muygpys_amd.gp.kernels import Matern
+        from muygpys_amd.gp.noise import HomoscedasticNoise
+        from tests.conftest import load_golden
+
+        g = load_golden("m15_iso_knn_k30_d40_c2")
+        td = torch.float64
+        X, y = to_dev(g["features"], td), to_dev(g["targets"], td)
+        bi, ni = to_dev(g["batch_idx"]), to_dev(g["nn_idx"])
+        spec = KernelSpec(g["meta"]["kernel"], g["meta"]["metric"], g["meta"]["length_scale"], g["meta"]["noise"])
+        res = D.sharded_loocv(spec, X, y, bi, ni, loss="looph")
+        model = MuyGPS(Matern(smoothness=Parameter(1.5), deformation=Isotropy(l2, length_scale=Parameter(3.0, (0.5, 20.0)))),
+                       noise=HomoscedasticNoise(g["meta"]["noise"]), scale=AnalyticScale())
+        opt = D.optimize_sharded(model, X, y, bi, ni, optimizer="lbfgsb")
+        q.put((rank, res["lool"], res["sigma_sq"], res["looph"], float(opt.kernel.deformation.length_scale())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_hip_partials_and_collective_match_serial():
+    """HIP partial sums and a real all-reduce together (two ranks on this box's GPU), the functor
+    layer's L-BFGS-B under sharded reductions included: the same numbers as one process."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from muygpys_amd import distributed as D
+    from muygpys_amd.fused import KernelSpec
+    from muygpys_amd.gp import MuyGPS
+    from muygpys_amd.gp.deformation import Isotropy, l2
+    from muygpys_amd.gp.hyperparameter import AnalyticScale, Parameter
+    from muygpys_amd.gp.kernels import Matern
+    from muygpys_amd.gp.noise import HomoscedasticNoise
+    from muygpys_amd.optimize import L_BFGS_B_optimize
+    from tests.conftest import load_golden
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gpu_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    g = load_golden("m15_iso_knn_k30_d40_c2")
+    assert got[0][1:] == got[1][1:], "every rank must hold the same global scalars"
+    np.testing.assert_allclose(got[0][1], g["lool"], rtol=1e-8)
+    np.testing.assert_allclose(got[0][2], g["sigma_sq"][0], rtol=1e-8)
+    np.testing.assert_allclose(got[0][3], g["looph"], rtol=1e-8)
+    td = torch.float64
+    X, y = to_dev(g["features"], td), to_dev(g["targets"], td)
+    bi, ni = to_dev(g["batch_idx"]), to_dev(g["nn_idx"])
+    model = MuyGPS(Matern(smoothness=Parameter(1.5), deformation=Isotropy(l2, length_scale=Parameter(3.0, (0.5, 20.0)))),
+                   noise=HomoscedasticNoise(g["meta"]["noise"]), scale=AnalyticScale())
+    cw, pw, bt, bnt = model.make_train_tensors(bi, ni, X, y)
+    serial = L_BFGS_B_optimize(model, bt, bnt, cw, pw)
+    np.testing.assert_allclose(got[0][4], float(serial.kernel.deformation.length_scale()), rtol=1e-6)

@@ -20,10 +20,11 @@ def _kspec(meta, g, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
-@pytest.mark.parametrize("force_generic", [0, 1])
-def test_fused_matches_golden(golden, dtype, force_generic):
-    from muygpys_amd import _lib
-    from muygpys_amd.fused import posterior_mean_var
+@pytest.mark.parametrize("route", ["auto", "auto-prepared-tables", "generic"])
+def test_fused_matches_golden(golden, dtype, route):
+    """Every fixture through the dispatcher's kernel on the plain tables, through the prepared
+    tables (mgp_table_pack_* + mgp_posterior_packed_*) and through the LDS workgroup kernel."""
+    from muygpys_amd.fused import PackedTable, posterior_mean_var
 
     g, meta = golden, golden["meta"]
     td = getattr(torch, dtype)
@@ -32,13 +33,15 @@ def test_fused_matches_golden(golden, dtype, force_generic):
         pytest.skip("fp32 at tiny nugget / low d is ill-conditioned (reference skips it too)")
     X, y = to_dev(g["features"], td), to_dev(g["targets"], td)
     bi, ni = to_dev(g["batch_idx"]), to_dev(g["nn_idx"])
-    _lib.load().mgp_debug_force_generic(force_generic)
-    try:
-        info = torch.zeros(1, dtype=torch.int32, device="cuda")
-        mean, var, yk = posterior_mean_var(_kspec(meta, g, td), X, X, bi, ni, y, want_ykinvy=True, info=info)
-        torch.cuda.synchronize()
-    finally:
-        _lib.load().mgp_debug_force_generic(0)
+    packed = route == "auto-prepared-tables"
+    if packed and not PackedTable.supported(meta["d"], meta["R"], meta["k"], td):
+        pytest.skip("shape outside the prepared-table kernels (rows not 16-byte multiples / too many responses)")
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    mean, var, yk = posterior_mean_var(
+        _kspec(meta, g, td), X, X, bi, ni, y, want_ykinvy=True, info=info,
+        path="generic" if route == "generic" else "auto", packed=packed,
+    )
+    torch.cuda.synchronize()
     assert int(info.item()) == 0
     rtol = RTOL[dtype]
     assert_close(mean.cpu().numpy(), g["mean"], rtol, "mean")
@@ -46,6 +49,28 @@ def test_fused_matches_golden(golden, dtype, force_generic):
     b, k = g["nn_idx"].shape
     sig = yk.double().sum(dim=0).cpu().numpy().reshape(-1) / (b * k)
     assert_close(sig, g["sigma_sq"], rtol, "sigma_sq")
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_prepared_tables_give_identical_bits(dtype):
+    """The prepared-table route runs the same kernels on the same values: bitwise equal outputs,
+    with a separate (response-free) query table too."""
+    from muygpys_amd.fused import KernelSpec, posterior_mean_var
+
+    td = getattr(torch, dtype)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    N, M, d, k, b = 30000, 5000, 40 if dtype == "float32" else 8, 30, 20001
+    X = torch.randn(N, d, device="cuda", dtype=td, generator=gen)
+    Q = torch.randn(M, d, device="cuda", dtype=td, generator=gen)
+    y = torch.randn(N, device="cuda", dtype=td, generator=gen)
+    bi = torch.randint(0, M, (b,), device="cuda", generator=gen)
+    ni = torch.randint(0, N, (b, k), device="cuda", generator=gen)
+    spec = KernelSpec("matern15", "l2", float(np.sqrt(2 * d)), 1e-3)
+    ref = posterior_mean_var(spec, Q, X, bi, ni, y, want_ykinvy=True, packed=False)
+    got = posterior_mean_var(spec, Q, X, bi, ni, y, want_ykinvy=True, packed=True)
+    torch.cuda.synchronize()
+    for a, c in zip(ref, got):
+        assert torch.equal(a, c)
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
@@ -85,40 +110,6 @@ def test_non_spd_is_flagged():
     assert int(info.item()) == 1
     assert torch.isnan(mean[0]) and torch.isnan(var[0])
     assert torch.isfinite(mean[1]) and torch.isfinite(var[1])
-
-
-@pytest.mark.parametrize("name", ["m15_iso_knn_k30_d40_c2", "m25_iso_l2_k30_d40"])
-def test_two_rows_per_lane_variant_matches_golden(name):
-    """The opt-in two-rows-per-lane kernel (mgp_fused_wave2.hip) on the headline shape."""
-    from muygpys_amd import _lib
-    from muygpys_amd.fused import posterior_mean_var
-    from tests.conftest import load_golden
-
-    g = load_golden(name)
-    meta = g["meta"]
-    td = torch.float32
-    X, y = to_dev(g["features"], td), to_dev(g["targets"], td)
-    bi, ni = to_dev(g["batch_idx"]), to_dev(g["nn_idx"])
-    lib = _lib.load()
-    lib.mgp_debug_enable_wave2(1)
-    try:
-        for kernel in ("matern15", "rbf", "matern05", "matern25", "maternInf"):
-            metric = "F2" if kernel == "rbf" else "l2"
-            from muygpys_amd.fused import KernelSpec
-            from oracle import muygps_oracle as orc
-
-            spec = KernelSpec(kernel, metric, 5.0, 1e-3)
-            mean, var, yk = posterior_mean_var(spec, X, X, bi, ni, y, want_ykinvy=True)
-            torch.cuda.synchronize()
-            m_ref, v_ref = orc.posterior_mean_var(orc.Spec(kernel, metric, 5.0, 1e-3), g["features"], g["features"],
-                                                   g["batch_idx"], g["nn_idx"], g["targets"])
-            assert_close(mean.cpu().numpy(), m_ref, RTOL["float32"], f"mean {kernel}")
-            assert_close(var.cpu().numpy(), v_ref, RTOL["float32"], f"var {kernel}")
-            s_ref = orc.sigma_sq(orc.Spec(kernel, metric, 5.0, 1e-3), g["features"], g["nn_idx"], g["targets"])
-            b, k = g["nn_idx"].shape
-            assert_close([float(yk.double().sum() / (b * k))], [s_ref], RTOL["float32"], f"sigma_sq {kernel}")
-    finally:
-        lib.mgp_debug_enable_wave2(0)
 
 
 @pytest.mark.parametrize("mode", ["aniso", "hetero_table", "hetero_batch", "no_batch_idx", "odd_batch"])
@@ -175,14 +166,9 @@ def test_rhs_columns_kernel_matches_golden(golden, dtype):
     td = getattr(torch, dtype)
     X, y = to_dev(g["features"], td), to_dev(g["targets"], td)
     bi, ni = to_dev(g["batch_idx"]), to_dev(g["nn_idx"])
-    lib = _lib.load()
-    lib.mgp_debug_prefer_rhs(1)
-    try:
-        info = torch.zeros(1, dtype=torch.int32, device="cuda")
-        mean, var, yk = posterior_mean_var(_kspec(meta, g, td), X, X, bi, ni, y, want_ykinvy=True, info=info)
-        torch.cuda.synchronize()
-    finally:
-        lib.mgp_debug_prefer_rhs(0)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    mean, var, yk = posterior_mean_var(_kspec(meta, g, td), X, X, bi, ni, y, want_ykinvy=True, info=info, path="rhs")
+    torch.cuda.synchronize()
     assert int(info.item()) == 0
     rtol = RTOL[dtype]
     assert_close(mean.cpu().numpy(), g["mean"], rtol, "mean")
@@ -207,10 +193,9 @@ PERSISTENT_CASES = [
 
 
 @pytest.mark.parametrize("case", PERSISTENT_CASES, ids=[f"{c[0]}-{c[1]}-k{c[2]}-d{c[3]}-R{c[4]}-{'aniso' if c[5] else 'iso'}" for c in PERSISTENT_CASES])
-@pytest.mark.parametrize("runtime_pipe", [1, 0])
-def test_persistent_loop_matches_oracle_on_a_sample(case, runtime_pipe):
-    from muygpys_amd import _lib
-    from muygpys_amd.fused import KernelSpec, posterior_mean_var
+@pytest.mark.parametrize("packed", [False, True])
+def test_persistent_loop_matches_oracle_on_a_sample(case, packed):
+    from muygpys_amd.fused import KernelSpec, PackedTable, posterior_mean_var
 
     dtype, kernel, k, d, R, aniso = case
     td = getattr(torch, dtype)
@@ -226,17 +211,15 @@ def test_persistent_loop_matches_oracle_on_a_sample(case, runtime_pipe):
     if metric == "F2":
         ls = np.sqrt(ls)
     spec_o = orc.Spec(kernel, metric, ls, 1e-2)
-    lib = _lib.load()
-    lib.mgp_debug_runtime_pipe(runtime_pipe)
-    try:
-        info = torch.zeros(1, dtype=torch.int32, device="cuda")
-        mean, var, yk = posterior_mean_var(
-            KernelSpec(kernel, metric, ls.tolist() if aniso else ls, 1e-2), to_dev(X, td), to_dev(X, td), to_dev(bi),
-            to_dev(ni), to_dev(Y, td), want_ykinvy=True, info=info,
-        )
-        torch.cuda.synchronize()
-    finally:
-        lib.mgp_debug_runtime_pipe(1)
+    if packed and not PackedTable.supported(d, R, k, td):
+        pytest.skip("shape outside the prepared-table kernels")
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    Xd = to_dev(X, td)
+    mean, var, yk = posterior_mean_var(
+        KernelSpec(kernel, metric, ls.tolist() if aniso else ls, 1e-2), Xd, Xd, to_dev(bi),
+        to_dev(ni), to_dev(Y, td), want_ykinvy=True, info=info, packed=packed,
+    )
+    torch.cuda.synchronize()
     assert int(info.item()) == 0
     pick = rng.choice(b, size=1500, replace=False)
     pick[:4] = [0, 1, b - 2, b - 1]

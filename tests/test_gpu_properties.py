@@ -69,16 +69,10 @@ def test_shards_concatenate_exactly(data):
 
 
 def test_wave_and_generic_kernels_agree(data):
-    from muygpys_amd import _lib
-
     sub = slice(0, 200_000)
     bi, ni = data["bi"][sub].contiguous(), data["ni"][sub].contiguous()
     m, v, yk = run(data, data["y1"], bi=bi, ni=ni, want_ykinvy=True)
-    _lib.load().mgp_debug_force_generic(1)
-    try:
-        mg, vg, ykg = run(data, data["y1"], bi=bi, ni=ni, want_ykinvy=True)
-    finally:
-        _lib.load().mgp_debug_force_generic(0)
+    mg, vg, ykg = run(data, data["y1"], bi=bi, ni=ni, want_ykinvy=True, path="generic")
     assert_close(m.cpu().numpy(), mg.cpu().numpy(), 1e-3, "mean")
     assert_close(v.cpu().numpy(), vg.cpu().numpy(), 1e-3, "var")
     assert_close(yk.cpu().numpy(), ykg.cpu().numpy(), 1e-3, "ykinvy")
