@@ -23,7 +23,12 @@ def _npz_names():
 
 def golden_names():
     """Forward-path fixtures (tests/golden/make_golden.py)."""
-    return [n for n in _npz_names() if not n.startswith("grad_")]
+    return [n for n in _npz_names() if not n.startswith(("grad_", "fast_"))]
+
+
+def fast_golden_names():
+    """Fast-posterior-mean fixtures from the reference's own workflow (make_golden_fast.py)."""
+    return [n for n in _npz_names() if n.startswith("fast_")]
 
 
 def grad_golden_names():

@@ -51,13 +51,37 @@ def test_fast_workflow(dtype, case):
     nn_d, _ = nbrs.get_batch_nns(torch.arange(1500, device="cuda"))
     assert np.array_equal(nn_d.cpu().numpy(), nn)
     coeffs, nn_fast = fast_coefficients(spec, Xd, yd, nn_d, chunk=400)
-    rtol = 10 * RTOL[dtype]
+    rtol = 3 * RTOL[dtype]
     assert_close(coeffs.cpu().numpy(), coeffs_ref, rtol, "coefficients")
     closest_d = nbrs.get_nns(Qd)[0][:, 0]
     assert np.array_equal(closest_d.cpu().numpy(), closest)
     mean = fast_posterior_mean(spec, Qd, Xd, None, nn_fast[closest_d], coeffs, closest_d)
     assert mean.shape == mean_ref.shape
     assert_close(mean.cpu().numpy(), mean_ref, rtol, "fast posterior mean")
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("name", __import__("tests.conftest", fromlist=["fast_golden_names"]).fast_golden_names())
+def test_fast_kernels_match_reference_fixture(name, dtype):
+    """The fused coefficient precompute, the materialising precompute and the fused prediction
+    kernel against the reference's own fast-posterior-mean outputs (tests/golden/make_golden_fast.py)."""
+    from muygpys_amd.fused import KernelSpec, fast_coefficients, fast_posterior_mean
+    from tests.conftest import load_golden
+
+    g = load_golden(name)
+    meta = g["meta"]
+    td = getattr(torch, dtype)
+    spec = KernelSpec(meta["kernel"], meta["metric"], meta["length_scale"], meta["noise"])
+    Xd, yd, Qd = to_dev(g["features"], td), to_dev(g["targets"], td), to_dev(g["test_features"], td)
+    nn = to_dev(g["train_nn"])
+    rtol = 3 * RTOL[dtype]
+    for fused in (True, False):
+        coeffs, nn_fast = fast_coefficients(spec, Xd, yd, nn, fused=fused)
+        assert np.array_equal(nn_fast.cpu().numpy(), g["train_nn_fast"])
+        assert_close(coeffs.cpu().numpy(), g["coeffs"], rtol, f"coefficients (fused={fused})")
+    closest = to_dev(g["closest_neighbor"])
+    mean = fast_posterior_mean(spec, Qd, Xd, None, nn_fast[closest], coeffs, closest)
+    assert_close(mean.cpu().numpy(), g["fast_mean"], rtol, "fast posterior mean")
 
 
 def test_fused_coefficients_match_the_materialising_path_at_scale():

@@ -129,3 +129,28 @@ def test_kernels_against_sklearn():
         close(K, Matern(length_scale=ell, nu=nu)(X), rtol=1e-9)
     ells = np.array([0.5, 1.5, 2.5])
     close(orc.matern_15_fn(orc.anisotropy(D, ells, "l2")), Matern(length_scale=ells, nu=1.5)(X), rtol=1e-9)
+
+
+@pytest.mark.parametrize("name", __import__("tests.conftest", fromlist=["fast_golden_names"]).fast_golden_names())
+def test_oracle_fast_posterior_mean_matches_reference(name):
+    """Pins the oracle's fast-mean leg (fast_nn_update, fast_posterior_mean_precompute,
+    fast_posterior_mean) to the reference's own workflow outputs (tests/golden/make_golden_fast.py:
+    gp/tensors.py:52-91, gp/muygps.py:261-341, examples/fast_posterior_mean.py:72-87,374-390)."""
+    from tests.conftest import load_golden, spec_from_meta
+
+    g = load_golden(name)
+    spec = spec_from_meta(g["meta"], g)
+    X, y, Q = g["features"], g["targets"], g["test_features"]
+    nn_fast = orc.fast_nn_update(g["train_nn"])
+    assert np.array_equal(nn_fast, g["train_nn_fast"])
+    pd = orc.pairwise_tensor(X, nn_fast)
+    _, Kin = orc.kernel_tensors(spec, pd[:, 0], pd)
+    coeffs = orc.fast_posterior_mean_precompute(orc.perturb(spec, Kin, nn_fast), y[nn_fast])
+    np.testing.assert_allclose(coeffs, g["coeffs"], rtol=1e-8, atol=1e-10)
+    cset = nn_fast[g["closest_neighbor"]]
+    assert np.array_equal(cset, g["closest_set"])
+    cd = orc.crosswise_tensor(Q, X, np.arange(len(Q)), cset)
+    Kc, _ = orc.kernel_tensors(spec, cd, pd[:1])
+    np.testing.assert_allclose(Kc, g["Kcross"], rtol=1e-10, atol=1e-14)
+    mean = orc.fast_posterior_mean(Kc, coeffs[g["closest_neighbor"]])
+    np.testing.assert_allclose(mean, g["fast_mean"], rtol=1e-8, atol=1e-10)
