@@ -111,7 +111,7 @@ def knn_neighbors(Xd, bi, k: int, chunk: int = 2048):
 def _cpu_worker(args):
     """One host process of the P-process CPU baseline (the reference's `mpirun -n P` layout:
     contiguous row blocks, README.md:99-109)."""
-    k, d, lo, hi, seed, fp32 = args
+    k, d, lo, hi, seed, fp32, chunk = args
     os.environ.setdefault("OMP_NUM_THREADS", "1")
     from oracle import muygps_oracle as orc  # checker/baseline only -- never on the product path
 
@@ -125,7 +125,7 @@ def _cpu_worker(args):
     ni += ni >= bi[:, None]
     spec = orc.Spec("matern15", "l2", 5.0, 1e-3)
     t0 = time.perf_counter()
-    orc.posterior_mean_var_chunked(spec, X, X, bi[lo:hi], ni[lo:hi], y, chunk=1024)
+    orc.posterior_mean_var_chunked(spec, X, X, bi[lo:hi], ni[lo:hi], y, chunk=chunk)
     return time.perf_counter() - t0
 
 
@@ -148,18 +148,19 @@ def cpu_baseline(k: int, d: int, sample: int, seed: int):
         pass
     P = os.cpu_count() or 1
     variants = {}
-    _cpu_worker((k, d, 0, 256, seed, False))  # warm (imports, page-ins)
+    _cpu_worker((k, d, 0, 256, seed, False, 256))  # warm (imports, page-ins)
     for name, fp32, procs in (("fp64_1proc", False, 1), ("fp32_1proc", True, 1), ("fp64_Pproc", False, P),
                               ("fp32_Pproc", True, P)):
-        n_s = sample if procs == 1 else sample * min(procs, 8)
+        n_s = sample if procs == 1 else sample * min(procs, 32)
         if procs == 1:
-            dt = _cpu_worker((k, d, 0, n_s, seed, fp32))
+            dt = _cpu_worker((k, d, 0, n_s, seed, fp32, 1024))
         else:
             # every process computes its block concurrently; the slowest one's compute time counts
             # (process start-up and the synthetic-data set-up are not part of the reference's timing either)
             bounds = np.linspace(0, n_s, procs + 1).astype(int)
             with mp.get_context("spawn").Pool(procs) as pool:
-                dt = max(pool.map(_cpu_worker, [(k, d, int(bounds[i]), int(bounds[i + 1]), seed, fp32)
+                # small chunks: P processes x the (chunk, k, k, d) difference tensor must fit the host
+                dt = max(pool.map(_cpu_worker, [(k, d, int(bounds[i]), int(bounds[i + 1]), seed, fp32, 128)
                                                 for i in range(procs)]))
         variants[name] = {"neighborhoods_per_s": n_s / dt, "processes": procs, "sample": n_s, "seconds": dt}
     v = variants["fp64_1proc"]

@@ -67,6 +67,7 @@ class NN_Wrapper:
         # plain fp32 scan 0.90 s / 0.43 s
         self.scan_kind = "bf16x3" if scan_kind == "auto" else scan_kind
         self._packed_train, self._packed_qmax = None, None
+        self.last_overflow = None  # per-query overflow flags of the most recent scan (device int32)
         self._sq = (self.train.double() ** 2).sum(1).to(self.train.dtype)
         # the scan kernel reads |x|^2 in whole 64-row tiles: +inf past the end (never a neighbour)
         pad = (-self.train_count) % 64
@@ -151,12 +152,15 @@ class NN_Wrapper:
                 best_d[s:s + 65536] = (diff * diff).sum(-1)
             # table rows carry c = -|x|^2/2 + 2^-14 QMAX |x| (raised by its own split error) and a 1;
             # query rows a 1 and a slot the kernel fills with -(|q|^2 - tau)/2
+            # QMAX only has to bound |q| from above (a larger margin lets a few more near misses
+            # through to the exact re-measurement): the packed table is rebuilt only when a batch
+            # exceeds the bound it was packed for, with head-room so that it rarely does
             qmax = float(qn.max().sqrt())
-            if self._packed_train is None or self._packed_qmax != qmax:
-                c = -0.5 * self._sq + (2.0**-14 * qmax) * self._sq.sqrt()
+            if self._packed_train is None or qmax > self._packed_qmax:
+                self._packed_qmax = 1.25 * qmax
+                c = -0.5 * self._sq + (2.0**-14 * self._packed_qmax) * self._sq.sqrt()
                 c = c + 2.0**-15 * c.abs()
                 self._packed_train = self._pack_bf16(self.train, c, 1.0)
-                self._packed_qmax = qmax
             packed_q = self._pack_bf16(q, 1.0, 0.0)
             rc = _lib.load().mgp_knn_scan_bf16x3(
                 _lib.ptr(self.train), _lib.ptr(self._packed_train), _lib.ptr(self._sq_scan), self.train_count,
@@ -182,27 +186,33 @@ class NN_Wrapper:
             order = dd.argsort(dim=1, stable=True)
             idx[s:s + 65536] = c.gather(1, order)
             dist[s:s + 65536] = dd.gather(1, order)
+        self.last_overflow = overflow
         redo = overflow.nonzero().reshape(-1)
         if redo.numel():  # queues overflowed (adversarial row order): those queries go dense
             ri, rd = self._dense_nns(q[redo], k, None if exclude is None else exclude[redo])
             idx[redo], dist[redo] = ri, rd
         return idx, dist
 
+    DENSE_BUDGET_BYTES = 4 << 30  # (chunk x train_count) distance matrix + topk temporaries
+
     def _dense_nns(self, samples, nn_count, exclude=None):
         n = samples.shape[0]
         idx = torch.empty((n, nn_count), dtype=torch.int64, device=samples.device)
         dist = torch.empty((n, nn_count), dtype=samples.dtype, device=samples.device)
-        for s in range(0, n, self.chunk):
-            q = samples[s:s + self.chunk].to(self.train.dtype)
+        # query rows per pass from a memory budget: the distance matrix of a pass is chunk x train_count
+        per_row = 3 * self.train_count * self.train.element_size()
+        chunk = max(1, min(self.chunk, self.DENSE_BUDGET_BYTES // max(per_row, 1)))
+        for s in range(0, n, chunk):
+            q = samples[s:s + chunk].to(self.train.dtype)
             d2 = self._sq[None, :] - 2.0 * (q @ self.train.T) + (q * q).sum(1)[:, None]
             if exclude is not None:
                 rows = torch.arange(q.shape[0], device=q.device)
-                d2[rows, exclude[s:s + self.chunk]] = float("inf")
+                d2[rows, exclude[s:s + chunk]] = float("inf")
             _, cand = d2.topk(nn_count, dim=1, largest=False)
             # exact squared distances of the winners, difference form, then final order
             diff = q[:, None, :] - self.train[cand]
             dd = (diff * diff).sum(-1)
             order = dd.argsort(dim=1, stable=True)
-            idx[s:s + self.chunk] = cand.gather(1, order)
-            dist[s:s + self.chunk] = dd.gather(1, order)
+            idx[s:s + chunk] = cand.gather(1, order)
+            dist[s:s + chunk] = dd.gather(1, order)
         return idx, dist

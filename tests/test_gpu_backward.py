@@ -48,7 +48,7 @@ def test_backward_matches_reference_autograd(grad_golden, dtype):
     shared = not meta["separate_test"]
     out = _run(spec, xq, g["features"], g["batch_indices"], g["nn_indices"], g["targets"], g["grad_mean"],
                g["grad_var"], dtype, shared, meta["hetero"])
-    rtol = RTOL[dtype] * (10 if dtype == "float32" else 1)  # gradients amplify the solve's conditioning
+    rtol = RTOL[dtype] * (3 if dtype == "float32" else 1)  # gradients amplify the solve's conditioning
     assert_close(out["mean"].reshape(g["mean"].shape), g["mean"], RTOL[dtype], "mean")
     assert_close(out["var"], g["var"], RTOL[dtype], "var")
     assert_close(out["x"], g["g_features"], rtol, "g_features")
