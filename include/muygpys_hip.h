@@ -306,6 +306,16 @@ int mgp_reduce_diffs_f64(const double* diffs, int64_t n, int d, const double* le
  * (metric.py:241,264); _src/gp/kernels/numpy.py:12-31. */
 int mgp_kernel_apply_f32(const float* in, int64_t n, int kernel_id, double in_scale, float* out, void* stream);
 int mgp_kernel_apply_f64(const double* in, int64_t n, int kernel_id, double in_scale, double* out, void* stream);
+/* K3 _matern_gen_fn, _src/gp/kernels/numpy.py:34-43 (selected whenever the smoothness is not fixed
+ * at 1/2, 3/2, 5/2 or inf: gp/kernels/matern.py:61-81): out[i] = 2^(1-nu)/Gamma(nu) x^nu K_nu(x),
+ * x = sqrt(2 nu) in[i] in_scale, zeros replaced by eps like the reference.  K_nu is evaluated in
+ * fp64 on the device (Temme's series below x = 2, Steed's continued fraction above, forward
+ * recurrence in the order); the reference calls scipy.special.kv / gamma.  Unlike the reference the
+ * input is not modified.  mgp_matern_gen_constants writes the nu-only host constants
+ * {mu, nl, coef, gam1, gam2, 1/Gamma(1+mu), 1/Gamma(1-mu)} (a CPU-side known-answer check). */
+int mgp_matern_gen_f32(const float* in, int64_t n, double in_scale, double smoothness, float* out, void* stream);
+int mgp_matern_gen_f64(const double* in, int64_t n, double in_scale, double smoothness, double* out, void* stream);
+int mgp_matern_gen_constants(double smoothness, double* out7);
 /* N1/N2 perturb, _src/gp/noise/numpy.py:9-14,56-67: out = Kin + diag(noise). noise_dev
  * is (b,k) when noise_mode == MGP_NOISE_BATCH. */
 int mgp_perturb_f32(const float* Kin, int64_t b, int k, int noise_mode, double noise_scalar,

@@ -59,6 +59,7 @@ _SIGS = {
     "reduce_diffs": [_p, _l, _i, _p, _i, _p, _p],
     "kernel_apply": [_p, _l, _i, _d, _p, _p],
     "perturb": [_p, _l, _i, _i, _d, _p, _p, _p],
+    "matern_gen": [_p, _l, _d, _d, _p, _p],
     "solve": [_p, _p, _p, _l, _i, _i, _d, _p, _p, _p, _p, _p, _p],
     "posterior_generic": [_p, _p, _i, _p, _p, _l, _i, _p, _i, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p],
     "posterior_rhs": [_p, _p, _i, _p, _p, _l, _i, _p, _i, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p],
@@ -103,6 +104,8 @@ def load():
     lib.mgp_posterior_kernel_name.argtypes = [_i, _i, _i, _i, _i, _i, C.c_char_p, _i]
     lib.mgp_posterior_kernel_name.restype = _i
     lib.mgp_reduce_scratch_doubles.restype = _i
+    lib.mgp_matern_gen_constants.argtypes = [_d, C.POINTER(C.c_double)]
+    lib.mgp_matern_gen_constants.restype = _i
     lib.mgp_packed_row_bytes.argtypes = [_i, _i, _i]
     lib.mgp_packed_row_bytes.restype = _l
     for base, sig in _SIGS.items():

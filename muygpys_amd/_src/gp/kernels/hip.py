@@ -44,9 +44,16 @@ def _matern_inf_fn(dists, **kwargs):
 
 
 def _matern_gen_fn(dists, smoothness, **kwargs):
-    """numpy.py:34-43 needs scipy's modified Bessel function kv; like the reference's torch
-    backend (torch.py:26-32) the hip backend does not provide it."""
-    raise NotImplementedError(
-        'The hip backend does not implement the general-smoothness Matern kernel (scipy.special.kv); '
-        "fix smoothness to one of 0.5, 1.5, 2.5, inf."
-    )
+    """numpy.py:34-43: general smoothness, 2^(1-nu)/Gamma(nu) (sqrt(2 nu) r)^nu K_nu(sqrt(2 nu) r)
+    with zeros replaced by eps -- ``mgp_matern_gen_*`` evaluates the modified Bessel function on the
+    device in fp64 (the reference calls scipy.special.kv).  The input is left untouched (the
+    reference overwrites it)."""
+    _lib.require_cuda(dists)
+    nu = float(smoothness.detach().reshape(-1)[0]) if isinstance(smoothness, torch.Tensor) else float(smoothness)
+    if not nu > 0.0:
+        raise ValueError(f"Matern smoothness must be positive, got {nu}")
+    x = dists.contiguous()
+    out = torch.empty_like(x)
+    rc = _lib.fn("matern_gen", x.dtype)(_lib.ptr(x), x.numel(), 1.0, nu, _lib.ptr(out), _lib.stream_ptr())
+    _lib.check(rc, "mgp_matern_gen")
+    return out

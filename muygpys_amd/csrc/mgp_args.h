@@ -113,6 +113,8 @@ template <typename T>
 int launch_loss_sums(const T*, const T*, const T*, int64_t, const double*, double, double, double*, double*, hipStream_t);
 template <typename T> int launch_column_sums(const T*, int64_t, int, double*, double*, hipStream_t);
 int reduce_scratch_doubles();
+template <typename T> int launch_matern_gen(const T*, int64_t, double, double, T*, hipStream_t);
+void matern_gen_constants_host(double nu, double* out7);
 template <typename T> int launch_table_pack(const T*, const T*, int64_t, int, int, void*, int64_t, hipStream_t);
 template <typename T>
 int launch_fast_mean(const void*, const void*, int, const int64_t*, const int64_t*, int64_t, int, const void*,

@@ -118,6 +118,11 @@ extern "C" {
 const char* mgp_version(void) { return "muygpys_amd-hip 0.1 (gfx950)"; }
 int mgp_max_nn_count(int elem_size, int R) { return max_nn_count(elem_size, R); }
 int mgp_reduce_scratch_doubles(void) { return reduce_scratch_doubles(); }
+int mgp_matern_gen_constants(double smoothness, double* out7) {
+  if (!out7 || !(smoothness > 0.0)) return MGP_EINVAL;
+  matern_gen_constants_host(smoothness, out7);
+  return MGP_OK;
+}
 int mgp_posterior_kernel_name(int elem_size, int d, int k, int R, int packed, int path, char* buf, int len) {
   if (!buf || len < 1 || (elem_size != 4 && elem_size != 8)) return MGP_EINVAL;
   if (path == PATH_AUTO && describe_fused_wave(elem_size, d, k, R, packed, buf, len) > 0) return MGP_OK;
@@ -251,6 +256,10 @@ int mgp_max_nn_count_backward(int elem_size) { return max_nn_count_backward(elem
   int mgp_kernel_apply_##SUF(const T* in, int64_t n, int kid, double scale, T* out, void* st) {                      \
     if (!in || !out || n < 0 || !valid_kernel(kid)) return MGP_EINVAL;                                               \
     return launch_kernel_apply<T>(in, n, kid, scale, out, S_(st));                                                   \
+  }                                                                                                                  \
+  int mgp_matern_gen_##SUF(const T* in, int64_t n, double in_scale, double smoothness, T* out, void* st) {           \
+    if (!in || !out || n < 0) return MGP_EINVAL;                                                                     \
+    return launch_matern_gen<T>(in, n, in_scale, smoothness, out, S_(st));                                           \
   }                                                                                                                  \
   int mgp_perturb_##SUF(const T* Kin, int64_t b, int k, int nm, double eps, const T* nd, T* out, void* st) {         \
     if (!Kin || !out || b < 0 || k < 1) return MGP_EINVAL;                                                           \

@@ -2,6 +2,8 @@
 // functions when a caller insists on the intermediate tensors (API parity).  All are
 // HBM-bound elementwise / gather kernels: one output element (or one feature chunk) per
 // lane, consecutive lanes on consecutive addresses.
+#include <cmath>
+
 #include "mgp_device.h"
 
 namespace mgp {
@@ -99,6 +101,136 @@ template <typename T>
 __global__ void kernel_apply_kernel(const T* in, int64_t n, int kernel_id, T in_scale, T* out) {
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
     out[t] = kernel_eval<T>(kernel_id, in[t] * in_scale);
+}
+
+// K3: Matern kernel of general smoothness nu (_src/gp/kernels/numpy.py:34-43):
+//     k(r) = 2^(1-nu) / Gamma(nu) * (sqrt(2 nu) r)^nu * K_nu(sqrt(2 nu) r),   r = 0 -> r = eps
+// The modified Bessel function of the second kind K_nu(x), real nu > 0, in fp64 by the published
+// algorithm of Temme (J. Comput. Phys. 19, 1975) as arranged in Numerical Recipes' bessik: with
+// nu = mu + nl, |mu| <= 1/2, K_mu and K_(mu+1) come from Temme's series (x < 2) or from Steed's
+// evaluation of the second continued fraction (x >= 2), then nl steps of the stable forward
+// recurrence K_(m+1) = (2 m / x) K_m + K_(m-1).  Everything that depends on nu only -- the
+// leading coefficient and the four gamma-function combinations of the series -- is computed once on
+// the host (MaternGenConst).
+struct MaternGenConst {
+  double nu, mu, coef, gam1, gam2, gampl, gammi;
+  int nl;
+};
+
+__device__ inline double bessel_k_scaled_matern(double x, const MaternGenConst c) {
+  const double kEps = 1e-16;
+  const double mu = c.mu, mu2 = mu * mu, xi2 = 2.0 / x;
+  double rkmu, rk1;
+  if (x < 2.0) {
+    const double b = 0.5 * x;
+    double d = -::log(b);
+    double e = mu * d;
+    const double fact2 = ::fabs(e) < kEps ? 1.0 : ::sinh(e) / e;
+    const double pimu = 3.14159265358979323846 * mu;
+    const double fact = ::fabs(pimu) < kEps ? 1.0 : pimu / ::sin(pimu);
+    double ff = fact * (c.gam1 * ::cosh(e) + c.gam2 * fact2 * d);
+    double sum = ff;
+    e = ::exp(e);
+    double p = 0.5 * e / c.gampl;
+    double q = 0.5 / (e * c.gammi);
+    double cc = 1.0;
+    d = b * b;
+    double sum1 = p;
+    for (int i = 1; i <= 500; ++i) {
+      ff = (i * ff + p + q) / (i * (double)i - mu2);
+      cc *= d / i;
+      p /= (i - mu);
+      q /= (i + mu);
+      const double del = cc * ff;
+      sum += del;
+      sum1 += cc * (p - i * ff);
+      if (::fabs(del) < ::fabs(sum) * kEps) break;
+    }
+    rkmu = sum;
+    rk1 = sum1 * xi2;
+  } else {
+    double b = 2.0 * (1.0 + x);
+    double d = 1.0 / b;
+    double h = d, delh = d;
+    double q1 = 0.0, q2 = 1.0;
+    const double a1 = 0.25 - mu2;
+    double q = a1, cc = a1;
+    double a = -a1;
+    double s = 1.0 + q * delh;
+    for (int i = 2; i <= 500; ++i) {
+      a -= 2 * (i - 1);
+      cc = -a * cc / i;
+      const double qnew = (q1 - b * q2) / a;
+      q1 = q2;
+      q2 = qnew;
+      q += cc * qnew;
+      b += 2.0;
+      d = 1.0 / (b + a * d);
+      delh = (b * d - 1.0) * delh;
+      h += delh;
+      const double dels = q * delh;
+      s += dels;
+      if (::fabs(dels / s) < kEps) break;
+    }
+    h = a1 * h;
+    rkmu = ::sqrt(3.14159265358979323846 / (2.0 * x)) * ::exp(-x) / s;
+    rk1 = rkmu * (mu + x + 0.5 - h) / x;
+  }
+  for (int i = 1; i <= c.nl; ++i) {
+    const double rktemp = (mu + i) * xi2 * rk1 + rkmu;
+    rkmu = rk1;
+    rk1 = rktemp;
+  }
+  return rkmu;
+}
+
+template <typename T>
+__global__ void matern_gen_kernel(const T* in, int64_t n, double in_scale, const MaternGenConst c, T* out) {
+  const double s2nu = ::sqrt(2.0 * c.nu);
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+    double r = (double)in[t] * in_scale;
+    if (r == 0.0) r = 2.220446049250313e-16;  // reference: zeros become eps (numpy.py:38)
+    const double x = s2nu * r;
+    double k = 0.0;
+    if (x < 700.0) k = c.coef * ::pow(x, c.nu) * bessel_k_scaled_matern(x, c);
+    out[t] = (T)k;
+  }
+}
+
+// nu-only constants of the general Matern kernel (host).  gam1 = (1/G(1-mu) - 1/G(1+mu)) / (2 mu),
+// gam2 = (1/G(1-mu) + 1/G(1+mu)) / 2; near mu = 0 gam1 comes from the even part of the series
+// 1/Gamma(z) = sum c_k z^k (Abramowitz & Stegun 6.1.34) instead of the cancelling difference.
+static MaternGenConst matern_gen_constants(double nu) {
+  MaternGenConst c;
+  c.nu = nu;
+  c.nl = (int)(nu + 0.5);
+  c.mu = nu - c.nl;
+  c.gampl = 1.0 / std::tgamma(1.0 + c.mu);
+  c.gammi = 1.0 / std::tgamma(1.0 - c.mu);
+  c.gam2 = 0.5 * (c.gammi + c.gampl);
+  const double m2 = c.mu * c.mu;
+  if (std::fabs(c.mu) < 0.05)
+    c.gam1 = -(0.5772156649015329 + m2 * (-0.0420026350340952 + m2 * (-0.0421977345555443 +
+               m2 * (0.0072189432466630 + m2 * -0.0002152416741149))));
+  else
+    c.gam1 = (c.gammi - c.gampl) / (2.0 * c.mu);
+  c.coef = std::exp((1.0 - nu) * 0.6931471805599453 - std::lgamma(nu));
+  return c;
+}
+
+template <typename T>
+int launch_matern_gen(const T* in, int64_t n, double in_scale, double nu, T* out, hipStream_t s) {
+  if (!(nu > 0.0) || !std::isfinite(nu)) return MGP_EINVAL;
+  if (n == 0) return MGP_OK;
+  hipLaunchKernelGGL(matern_gen_kernel<T>, dim3(grid_1d(n)), dim3(kBlock), 0, s, in, n, in_scale,
+                     matern_gen_constants(nu), out);
+  MGP_HIP_CHECK_LAUNCH();
+  return MGP_OK;
+}
+void matern_gen_constants_host(double nu, double* out7) {
+  const MaternGenConst c = matern_gen_constants(nu);
+  out7[0] = c.mu; out7[1] = (double)c.nl; out7[2] = c.coef; out7[3] = c.gam1; out7[4] = c.gam2; out7[5] = c.gampl;
+  out7[6] = c.gammi;
 }
 
 // N1/N2
@@ -329,7 +461,8 @@ int launch_table_pack(const T* feat, const T* targets, int64_t n, int d, int R, 
   template int launch_loss_sums<T>(const T*, const T*, const T*, int64_t, const double*, double, double, double*,  \
                                    double*, hipStream_t);                                                          \
   template int launch_column_sums<T>(const T*, int64_t, int, double*, double*, hipStream_t);                        \
-  template int launch_table_pack<T>(const T*, const T*, int64_t, int, int, void*, int64_t, hipStream_t);
+  template int launch_table_pack<T>(const T*, const T*, int64_t, int, int, void*, int64_t, hipStream_t);          \
+  template int launch_matern_gen<T>(const T*, int64_t, double, double, T*, hipStream_t);
 MGP_INSTANTIATE(float)
 MGP_INSTANTIATE(double)
 

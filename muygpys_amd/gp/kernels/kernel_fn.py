@@ -5,7 +5,8 @@ A kernel functor composes ``kernel_fn(deformation(diffs, **length_scale kwargs),
 and exposes that closure to the optimiser through ``get_opt_fn`` with every non-fixed
 hyper-parameter as a keyword argument.  Matern picks a closed-form backend function only
 when the smoothness is FIXED at 0.5 / 1.5 / 2.5 / inf (matern.py:61-81); anything else is
-the general Bessel form, which the hip backend (like the reference's torch backend) refuses.
+the general Bessel form (``mgp_matern_gen_*``: K_nu evaluated on the device), which runs on
+materialised distances instead of the fused launch.
 """
 
 from __future__ import annotations

@@ -39,8 +39,26 @@ matern_25_fn = _lazy_kernel("matern25", _K._matern_25_fn)
 matern_inf_fn = _lazy_kernel("maternInf", _K._matern_inf_fn)
 
 
+def _scaled_distances(d: lazy.LazyDiffs) -> torch.Tensor:
+    """metric(diffs / length_scale) of a lazy difference handle, materialised (what the deformation
+    functor would have handed to the kernel function: isotropy.py:60-89, anisotropy.py:43-70)."""
+    from muygpys_amd._src.gp.tensors import hip as T
+
+    ls = d.length_scale
+    if d.reduced:
+        scale = 1.0 / float(ls) if d.metric == "l2" else 1.0 / float(ls) ** 2
+        return d.materialize() * scale
+    lsv = torch.as_tensor(ls, device=d.device, dtype=d.dtype).reshape(-1)
+    return T._reduce(d.materialize(), {"l2": 0, "F2": 1}[d.metric], lsv)
+
+
 def matern_gen_fn(dists, smoothness, **kwargs):
-    return _K._matern_gen_fn(lazy.force(dists), smoothness, **kwargs)
+    """General smoothness (a free or non-special nu): not one of the fused kernels' closed forms, so
+    the distances are materialised, the Bessel-function kernel (``mgp_matern_gen_*``) applied, and
+    the posterior goes through ``mgp_solve_*`` on the materialised tensors."""
+    if isinstance(dists, lazy.LazyDiffs):
+        dists = _scaled_distances(dists)
+    return _K._matern_gen_fn(dists, smoothness, **kwargs)
 
 
 def homoscedastic_perturb(Kin, noise_variance):

@@ -140,6 +140,18 @@ def matern_inf_fn(dists):
     return np.exp(-(dists**2) / 2.0)
 
 
+def matern_gen_fn(dists, smoothness):
+    """:34-43 -- general smoothness through the modified Bessel function (scipy.special.kv, the
+    reference's own dependency); zeros become eps.  Returns a new array (the reference overwrites
+    its argument)."""
+    from scipy.special import gamma, kv
+
+    K = np.array(dists, dtype=np.float64, copy=True)
+    K[K == 0.0] += np.finfo(float).eps
+    tmp = np.sqrt(2 * smoothness) * K
+    return (2 ** (1.0 - smoothness)) / gamma(smoothness) * tmp**smoothness * kv(smoothness, tmp)
+
+
 KERNELS = {
     "rbf": rbf_fn,
     "matern05": matern_05_fn,
@@ -153,7 +165,7 @@ def kernel_for_smoothness(nu):
     """gp/kernels/matern.py:61-81 -- special-case selection for fixed nu."""
     table = {0.5: "matern05", 1.5: "matern15", 2.5: "matern25", np.inf: "maternInf"}
     if nu not in table:
-        raise NotImplementedError("general-nu Matern (scipy kv) is outside the HIP path")
+        return lambda dists: matern_gen_fn(dists, nu)
     return table[nu]
 
 
@@ -305,7 +317,8 @@ def chunk_sizes(count, size):
 class Spec:
     """Plain description of a model: kernel, metric, deformation, noise.
 
-    kernel: one of KERNELS; metric: "l2"|"F2"; length_scale: scalar (Isotropy) or
+    kernel: one of KERNELS, or a callable on (scaled) distances such as
+    ``lambda r: matern_gen_fn(r, nu)``; metric: "l2"|"F2"; length_scale: scalar (Isotropy) or
     (d,) array (Anisotropy); noise: scalar (homoscedastic) or (N,) per-training-
     point variances (heteroscedastic, gathered with nn_indices like
     _src/gp/tensors/numpy.py:11-15).
@@ -334,7 +347,7 @@ def kernel_tensors(spec, crosswise_diffs, pairwise_diffs):
     differences (anisotropy.py:73-143).  Both orders are numerically what is done
     here: reduce, then divide (Isotropy) / divide, then reduce (Anisotropy).
     """
-    fn = KERNELS[spec.kernel]
+    fn = spec.kernel if callable(spec.kernel) else KERNELS[spec.kernel]
     if spec.anisotropic:
         Kc = fn(anisotropy(crosswise_diffs, spec.length_scale, spec.metric))
         Kin = fn(anisotropy(pairwise_diffs, spec.length_scale, spec.metric))
@@ -385,7 +398,7 @@ def posterior_mean_var_chunked(spec, test_features, train_features, batch_indice
 def sigma_sq(spec, train_features, nn_indices, train_targets):
     """MuyGPS.optimize_scale, gp/muygps.py:373-403 + scale.py:205-217 (iteration_count 1)."""
     pd = pairwise_tensor(train_features, nn_indices)
-    fn = KERNELS[spec.kernel]
+    fn = spec.kernel if callable(spec.kernel) else KERNELS[spec.kernel]
     if spec.anisotropic:
         Kin = fn(anisotropy(pd, spec.length_scale, spec.metric))
     else:

@@ -70,8 +70,31 @@ def test_kernel_family_against_sklearn(dtype):
     assert_close(K._rbf_fn(F2 / ell**2).cpu().numpy(), RBF(length_scale=ell)(Xn), rtol, "rbf")
     for fn, nu in ((K._matern_05_fn, 0.5), (K._matern_15_fn, 1.5), (K._matern_25_fn, 2.5), (K._matern_inf_fn, np.inf)):
         assert_close(fn(l2 / ell).cpu().numpy(), Matern(length_scale=ell, nu=nu)(Xn), rtol, f"matern {nu}")
-    with pytest.raises(NotImplementedError):
-        K._matern_gen_fn(l2, smoothness=0.42)
+    # general smoothness (K3): the reference pins nu = 0.42 against scikit-learn (tests/kernels.py:429-526)
+    for nu in (0.42, 1.0, 3.7):
+        before = l2.clone()
+        got = K._matern_gen_fn(l2 / ell, smoothness=nu)
+        assert torch.equal(l2, before), "the hip backend does not overwrite its input"
+        assert_close(got.cpu().numpy(), Matern(length_scale=ell, nu=nu)(Xn), rtol, f"matern general {nu}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_general_matern_matches_reference_fixture(dtype):
+    """mgp_matern_gen_* (device Bessel function) against the reference's _matern_gen_fn
+    (scipy.special.kv) on a grid of distances from 0 to 300 (tests/golden/make_golden_gen.py)."""
+    from muygpys_amd._src.gp import kernels as K
+    from tests.conftest import load_golden
+
+    g = load_golden("gen_matern_function")
+    td = getattr(torch, dtype)
+    x = to_dev(g["dists"], td)
+    for nu, want in zip(g["smoothness"], g["values"]):
+        got = K._matern_gen_fn(x, smoothness=float(nu)).cpu().numpy()
+        if dtype == "float64":
+            np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-300)
+        else:  # the fp32 input grid differs from the fp64 one by its own rounding
+            want32 = orc.matern_gen_fn(g["dists"].astype(np.float32).astype(np.float64), float(nu))
+            np.testing.assert_allclose(got, want32, rtol=2e-6, atol=1e-37)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -145,3 +145,42 @@ def test_singular_neighbourhood_raises_linalgerror():
         Kin, Kc = m.kernel(pair), m.kernel(cross)
         with pytest.raises(np.linalg.LinAlgError):
             m.posterior_mean(Kin, Kc, y_nn)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("materialize", [False, True])
+def test_free_smoothness_model_matches_reference(dtype, materialize):
+    """K3 through the functor layer: a Matern whose smoothness is a free hyper-parameter selects the
+    general Bessel form (gp/kernels/matern.py:61-81); kernel tensors, posterior, sigma^2 and LOOCV
+    objective values at smoothness probes against the reference (tests/golden/make_golden_gen.py),
+    from lazy handles and from materialised tensors."""
+    from muygpys_amd.gp import MuyGPS
+    from muygpys_amd.gp.deformation import Isotropy, l2
+    from muygpys_amd.gp.hyperparameter import AnalyticScale, Parameter
+    from muygpys_amd.gp.kernels import Matern
+    from muygpys_amd.gp.noise import HomoscedasticNoise
+    from muygpys_amd.optimize import L_BFGS_B_optimize
+    from muygpys_amd.optimize.loss import lool_fn, mse_fn
+    from tests.conftest import load_golden
+
+    g = load_golden("gen_m042_iso_k10_d6")
+    meta = g["meta"]
+    td = getattr(torch, dtype)
+    rtol = RTOL[dtype]
+    X, y = to_dev(g["features"], td), to_dev(g["targets"], td)
+    bi, ni = to_dev(g["batch_idx"]), to_dev(g["nn_idx"])
+    m = MuyGPS(kernel=Matern(smoothness=Parameter(meta["smoothness"], (0.1, 5.0)),
+                             deformation=Isotropy(l2, length_scale=Parameter(meta["length_scale"]))),
+               noise=HomoscedasticNoise(meta["noise"]), scale=AnalyticScale())
+    cross, pair, y_b, y_nn = m.make_train_tensors(bi, ni, X, y, materialize=materialize)
+    Kin, Kc = m.kernel(pair), m.kernel(cross)
+    assert_close(Kin.cpu().numpy(), g["Kin"], rtol, "Kin")
+    assert_close(Kc.cpu().numpy(), g["Kcross"], rtol, "Kcross")
+    assert_close(m.posterior_mean(Kin, Kc, y_nn).cpu().numpy(), g["mean"], rtol, "mean")
+    assert_close(m.get_opt_var_fn()(Kin, Kc).cpu().numpy(), g["var_unscaled"], rtol, "var")
+    m = m.optimize_scale(pair, y_nn)
+    assert_close(np.asarray(float(m.scale())).reshape(-1), g["sigma_sq"], rtol, "sigma_sq")
+    for loss, want in ((lool_fn, g["probe_lool"]), (mse_fn, g["probe_mse"])):
+        obj = L_BFGS_B_optimize.make_obj_fn(m, y_b, y_nn, cross, pair, loss_fn=loss)
+        got = [float(obj(smoothness=p)) for p in meta["probes"]]
+        assert_close(got, want, rtol, "objective at smoothness probes")

@@ -154,3 +154,26 @@ def test_oracle_fast_posterior_mean_matches_reference(name):
     np.testing.assert_allclose(Kc, g["Kcross"], rtol=1e-10, atol=1e-14)
     mean = orc.fast_posterior_mean(Kc, coeffs[g["closest_neighbor"]])
     np.testing.assert_allclose(mean, g["fast_mean"], rtol=1e-8, atol=1e-10)
+
+
+def test_oracle_general_matern_matches_reference():
+    """K3: the oracle's general-smoothness Matern against the reference's _matern_gen_fn on a grid of
+    distances (zeros included) and inside a model whose smoothness is free (make_golden_gen.py)."""
+    from tests.conftest import load_golden
+
+    g = load_golden("gen_matern_function")
+    for nu, want in zip(g["smoothness"], g["values"]):
+        np.testing.assert_allclose(orc.matern_gen_fn(g["dists"], float(nu)), want, rtol=1e-12, atol=0)
+    g = load_golden("gen_m042_iso_k10_d6")
+    meta = g["meta"]
+    for nu, lool, mse in zip(meta["probes"], g["probe_lool"], g["probe_mse"]):
+        spec = orc.Spec(kernel=(lambda r, nu=nu: orc.matern_gen_fn(r, nu)), metric="l2",
+                        length_scale=meta["length_scale"], noise=meta["noise"])
+        np.testing.assert_allclose(
+            orc.loocv_objective(spec, g["features"], g["batch_idx"], g["nn_idx"], g["targets"], "lool"), lool, rtol=1e-8)
+        np.testing.assert_allclose(
+            orc.loocv_objective(spec, g["features"], g["batch_idx"], g["nn_idx"], g["targets"], "mse"), mse, rtol=1e-8)
+        if nu == meta["smoothness"]:
+            mean, var = orc.posterior_mean_var(spec, g["features"], g["features"], g["batch_idx"], g["nn_idx"], g["targets"])
+            np.testing.assert_allclose(mean, g["mean"], rtol=1e-8, atol=1e-10)
+            np.testing.assert_allclose(var, g["var_unscaled"], rtol=1e-8)
