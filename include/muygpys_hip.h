@@ -130,6 +130,24 @@ int mgp_posterior_rhs_f64(const double* feat_q, const double* feat_nn, int d,
                           int kernel_id, int metric_id, const double* length_scale, int ls_count,
                           double* mean, double* var, double* ykinvy, int* info, void* stream);
 
+/* mgp_posterior_* with the neighbour responses ALREADY GATHERED: nn_targets (b, k, R) =
+ * targets[nn_idx] -- the tensor the reference's MuyGPS.make_predict_tensors / make_train_tensors
+ * return (gp/muygps.py:474,543,545) and pass to _muygps_posterior_mean / _analytic_scale_optim.
+ * Lets the reference's own functor layer, which gathers the responses itself, reach the fused
+ * launch through the lazy family functions.  Everything else as mgp_posterior_*. */
+int mgp_posterior_gathered_f32(const float* feat_q, const float* feat_nn, int d,
+                               const int64_t* batch_idx, const int64_t* nn_idx, int64_t b, int k,
+                               const float* nn_targets, int R,
+                               int noise_mode, double noise_scalar, const float* noise_dev,
+                               int kernel_id, int metric_id, const float* length_scale, int ls_count,
+                               float* mean, float* var, float* ykinvy, int* info, void* stream);
+int mgp_posterior_gathered_f64(const double* feat_q, const double* feat_nn, int d,
+                               const int64_t* batch_idx, const int64_t* nn_idx, int64_t b, int k,
+                               const double* nn_targets, int R,
+                               int noise_mode, double noise_scalar, const double* noise_dev,
+                               int kernel_id, int metric_id, const double* length_scale, int ls_count,
+                               double* mean, double* var, double* ykinvy, int* info, void* stream);
+
 /* Name of the kernel instantiation that serves mgp_posterior_* (path 0), mgp_posterior_generic_*
  * (path 1) or mgp_posterior_rhs_* (path 2) for a shape, for 16-byte aligned tables; packed != 0:
  * mgp_posterior_packed_*.  A pure function of its arguments (benchmarks name the kernel whose

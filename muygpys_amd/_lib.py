@@ -63,6 +63,7 @@ _SIGS = {
     "solve": [_p, _p, _p, _l, _i, _i, _d, _p, _p, _p, _p, _p, _p],
     "posterior_generic": [_p, _p, _i, _p, _p, _l, _i, _p, _i, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p],
     "posterior_rhs": [_p, _p, _i, _p, _p, _l, _i, _p, _i, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p],
+    "posterior_gathered": [_p, _p, _i, _p, _p, _l, _i, _p, _i, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p],
     "posterior_packed": [_p, _l, _p, _l, _i, _p, _p, _l, _i, _i, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p],
     "table_pack": [_p, _p, _l, _i, _i, _p, _l, _p],
     "loss_sums": [_p, _p, _p, _l, _p, _d, _d, _p, _p, _p],

@@ -4,10 +4,14 @@ from __future__ import annotations
 
 import torch
 
-from muygpys_amd import _lib
+from muygpys_amd import _lib, lazy
 
 
 def _apply(dists, kernel: str, in_scale: float = 1.0):
+    if isinstance(dists, lazy.LazyDiffs):
+        if dists.reduced and in_scale == 1.0:
+            return lazy.LazyCov(dists, kernel)  # evaluated by the fused launch (or on demand)
+        dists = dists.materialize()
     _lib.require_cuda(dists)
     x = dists.contiguous()
     out = torch.empty_like(x)
@@ -48,6 +52,10 @@ def _matern_gen_fn(dists, smoothness, **kwargs):
     with zeros replaced by eps -- ``mgp_matern_gen_*`` evaluates the modified Bessel function on the
     device in fp64 (the reference calls scipy.special.kv).  The input is left untouched (the
     reference overwrites it)."""
+    if isinstance(dists, lazy.LazyDiffs):
+        # not one of the fused kernels' closed forms: the distances are materialised here and the
+        # posterior goes through mgp_solve_* on the materialised tensors
+        dists = dists.scaled_distances()
     _lib.require_cuda(dists)
     nu = float(smoothness.detach().reshape(-1)[0]) if isinstance(smoothness, torch.Tensor) else float(smoothness)
     if not nu > 0.0:

@@ -1,14 +1,17 @@
 """hip implementation of the solve family (reference: src/MuyGPyS/_src/gp/muygps/numpy.py).
 
-All of these go through ``mgp_solve_*``: one LDS-resident Cholesky of the (already perturbed)
-``Kin`` per neighbourhood instead of the reference's LU ``linalg.solve``.
+On materialised tensors these go through ``mgp_solve_*``: one LDS-resident Cholesky of the
+(already perturbed) ``Kin`` per neighbourhood instead of the reference's LU ``linalg.solve``.  Given
+the lazy handles of ``muygpys_amd.lazy`` (a complete Kin / Kcross / responses triple) the posterior
+mean and variance come from ONE fused launch (``muygpys_amd.lazy_eval``), shared by the sibling calls
+of one evaluation.
 """
 
 from __future__ import annotations
 
 import torch
 
-from muygpys_amd import _lib
+from muygpys_amd import _lib, lazy, lazy_eval
 
 
 def _solve(Kin, Kcross, Y, kout=1.0, want=("mean",)):
@@ -37,6 +40,9 @@ def _solve(Kin, Kcross, Y, kout=1.0, want=("mean",)):
 
 def _muygps_posterior_mean(Kin, Kcross, nn_targets, **kwargs):
     """numpy.py:17-41: Kcross^T Kin^-1 Y -> (b,) for (b,k) targets, (b,R) for (b,k,R)."""
+    if lazy.fused_triple(Kin, Kcross, nn_targets):
+        return lazy_eval.fused(Kin, Kcross, nn_targets)[0]
+    Kin, Kcross, nn_targets = lazy.force(Kin), lazy.force(Kcross), lazy.force(nn_targets)
     mean, _, _, _ = _solve(Kin, Kcross, nn_targets, want=("mean",))
     b = Kin.shape[0]
     return mean.reshape((b,) + tuple(nn_targets.shape[2:]))
@@ -44,6 +50,11 @@ def _muygps_posterior_mean(Kin, Kcross, nn_targets, **kwargs):
 
 def _muygps_diagonal_variance(Kin, Kcross, Kout, batch_size: int = 1, **kwargs):
     """numpy.py:44-67: Kout - Kcross^T Kin^-1 Kcross -> (b,)."""
+    if isinstance(Kin, lazy.LazyCov) and isinstance(Kcross, lazy.LazyCov):
+        var = lazy_eval.variance(Kin, Kcross)
+        if var is not None:
+            return lazy_eval.rescale_kout(var, Kout)
+    Kin, Kcross = lazy.force(Kin), lazy.force(Kcross)
     kout = float(Kout) if not isinstance(Kout, torch.Tensor) else float(Kout.reshape(-1)[0].item())
     _, var, _, _ = _solve(Kin, Kcross, None, kout=kout, want=("var",))
     return var
@@ -51,6 +62,7 @@ def _muygps_diagonal_variance(Kin, Kcross, Kout, batch_size: int = 1, **kwargs):
 
 def _muygps_fast_posterior_mean_precompute(Kin, train_nn_targets_fast, **kwargs):
     """numpy.py:88-95: coefficients Kin^-1 Y, squeezed."""
+    Kin, train_nn_targets_fast = lazy.force(Kin), lazy.force(train_nn_targets_fast)
     Y = train_nn_targets_fast if train_nn_targets_fast.ndim == 3 else train_nn_targets_fast[:, :, None]
     _, _, _, co = _solve(Kin, None, Y, want=("coeffs",))
     return torch.squeeze(co)
@@ -58,6 +70,7 @@ def _muygps_fast_posterior_mean_precompute(Kin, train_nn_targets_fast, **kwargs)
 
 def _muygps_fast_posterior_mean(Kcross, coeffs_tensor, **kwargs):
     """numpy.py:70-77: einsum('ij,ijk->ik')."""
+    Kcross, coeffs_tensor = lazy.force(Kcross), lazy.force(coeffs_tensor)
     _lib.require_cuda(Kcross, coeffs_tensor)
     C = torch.atleast_3d(coeffs_tensor)  # (k,) -> (1,k,1), (b,k) -> (b,k,1), like np.atleast_3d
     return torch.squeeze(torch.einsum("ij,ijk->ik", Kcross, C))

@@ -4,11 +4,13 @@ from __future__ import annotations
 
 import torch
 
-from muygpys_amd import _lib
+from muygpys_amd import _lib, lazy
 
 
 def _homoscedastic_perturb(Kin, noise_variance):
     """numpy.py:9-27 (3-D case; the 5-D block form belongs to the out-of-scope shear kernel)."""
+    if isinstance(Kin, lazy.LazyCov):
+        return Kin.perturbed(float(noise_variance))  # the nugget is added while the fused kernel assembles K
     _lib.require_cuda(Kin)
     if Kin.ndim != 3:
         raise ValueError(
@@ -26,6 +28,9 @@ def _homoscedastic_perturb(Kin, noise_variance):
 
 def _heteroscedastic_perturb(Kin, noise_variances):
     """numpy.py:56-67: Kin[b,i,i] += eps[b,i]."""
+    noise_variances = lazy.force(noise_variances)
+    if isinstance(Kin, lazy.LazyCov):
+        return Kin.perturbed(noise_variances)
     _lib.require_cuda(Kin, noise_variances)
     x = Kin.contiguous()
     b, k, _ = x.shape

@@ -1,9 +1,10 @@
 """hip implementation of the tensor family (reference: src/MuyGPyS/_src/gp/tensors/numpy.py).
 
-Materialising kernels for API parity: each returns a fresh device tensor like the numpy
-backend does.  The roofline path never calls these (it goes through ``muygpys_amd.fused``
-via the lazy handles of ``muygpys_amd.lazy``); they exist so that a caller that *asks* for
-the intermediate tensors gets them, computed on the GPU.
+Called directly these are materialising kernels for API parity: each returns a fresh device
+tensor like the numpy backend does.  With ``config.state.lazy_tensors`` (what
+``integration.install()`` switches on) ``_pairwise_tensor`` / ``_crosswise_tensor`` return the
+light handles of ``muygpys_amd.lazy`` instead and ``_l2`` / ``_F2`` decorate them, so that the
+functor layer above -- this package's or the reference's own -- ends in one fused launch.
 """
 
 from __future__ import annotations
@@ -12,7 +13,8 @@ from typing import Tuple
 
 import torch
 
-from muygpys_amd import _lib
+from muygpys_amd import _lib, lazy
+from muygpys_amd.config import config as _config
 
 
 def _feat2d(x: torch.Tensor) -> torch.Tensor:
@@ -37,6 +39,13 @@ def _batch_features_tensor(features, batch_indices):
 
 def _crosswise_tensor(data, nn_data, data_indices, nn_indices):
     """numpy.py:47-58: (b, k, d) differences query - neighbour; 1-D data -> (b, k, 1)."""
+    if _config.state.lazy_tensors:
+        _lib.require_cuda(data, nn_data, data_indices, nn_indices)
+        return lazy.LazyDiffs("crosswise", None, False, nn_data, nn_indices, data, data_indices)
+    return _crosswise_tensor_now(data, nn_data, data_indices, nn_indices)
+
+
+def _crosswise_tensor_now(data, nn_data, data_indices, nn_indices):
     _lib.require_cuda(data, nn_data, data_indices, nn_indices)
     fq, fn = _feat2d(data), _feat2d(nn_data)
     bi, ni = _idx(data_indices), _idx(nn_indices)
@@ -52,6 +61,13 @@ def _crosswise_tensor(data, nn_data, data_indices, nn_indices):
 
 def _pairwise_tensor(data, nn_indices):
     """numpy.py:61-69: (b, k, k, d) with [b,i,j,:] = x_i - x_j."""
+    if _config.state.lazy_tensors:
+        _lib.require_cuda(data, nn_indices)
+        return lazy.LazyDiffs("pairwise", None, False, data, nn_indices)
+    return _pairwise_tensor_now(data, nn_indices)
+
+
+def _pairwise_tensor_now(data, nn_indices):
     _lib.require_cuda(data, nn_indices)
     f = _feat2d(data)
     ni = _idx(nn_indices)
@@ -93,14 +109,23 @@ def _reduce(diffs, metric_id, length_scale=None):
     return out
 
 
+def _metric(diffs, name: str):
+    if isinstance(diffs, lazy.LazyDiffs):
+        if not diffs.reduced:
+            return diffs.reduce(name)
+        diffs = diffs.materialize()
+    lsv = None
+    return _reduce(diffs, _lib.METRIC_IDS[name], lsv)
+
+
 def _F2(diffs):
     """numpy.py:89-90."""
-    return _reduce(diffs, _lib.METRIC_IDS["F2"])
+    return _metric(diffs, "F2")
 
 
 def _l2(diffs):
     """numpy.py:93-94."""
-    return _reduce(diffs, _lib.METRIC_IDS["l2"])
+    return _metric(diffs, "l2")
 
 
 def _crosswise_distances(data, nn_data, data_indices, nn_indices, metric: str):

@@ -4,7 +4,7 @@ from __future__ import annotations
 
 import torch
 
-from muygpys_amd import _lib
+from muygpys_amd import _lib, lazy, lazy_eval
 from muygpys_amd._src.gp.muygps.hip import _solve
 
 
@@ -16,6 +16,7 @@ def _ykinvy_sums(Kin, Y):
 
 def _analytic_scale_optim_unnormalized(Kin, nn_targets, **kwargs):
     """numpy.py:9-15: sum over batch AND response columns of y^T Kin^-1 y (0-d tensor)."""
+    Kin, nn_targets = lazy.force(Kin), lazy.force(nn_targets)
     _lib.require_cuda(Kin, nn_targets)
     Y = nn_targets if nn_targets.ndim == 3 else nn_targets[:, :, None]
     from muygpys_amd import distributed as _D
@@ -26,6 +27,11 @@ def _analytic_scale_optim_unnormalized(Kin, nn_targets, **kwargs):
 def _analytic_scale_optim(Kin, nn_targets, batch_dim_count: int = 1, **kwargs):
     """numpy.py:18-34: / (batch_size * nn_count); like the reference, R > 1 is rejected
     (its reshape to (b, k, 1) raises ValueError)."""
+    if isinstance(Kin, lazy.LazyCov):
+        out = lazy_eval.analytic_scale(Kin, nn_targets)
+        if out is not None:
+            return out
+    Kin, nn_targets = lazy.force(Kin), lazy.force(nn_targets)
     _lib.require_cuda(Kin, nn_targets)
     b, k, _ = Kin.shape
     if nn_targets.numel() != b * k:

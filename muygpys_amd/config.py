@@ -26,6 +26,11 @@ class _State:
         # when a neighbourhood is not positive definite; costs one device sync per solve call,
         # MUYGPYS_HIP_CHECK_SPD=0 turns it off (outputs of such neighbourhoods are then NaN)
         self.check_spd = os.environ.get("MUYGPYS_HIP_CHECK_SPD", "1") != "0"
+        # the tensor family returns lazy handles (muygpys_amd.lazy) instead of (b, k, k, d) tensors,
+        # so that a functor layer written against the family functions -- the reference's own, after
+        # integration.install() -- reaches the fused launch; off by default: called directly, the
+        # family functions are the materialising per-function kernels
+        self.lazy_tensors = os.environ.get("MUYGPYS_HIP_LAZY", "0") == "1"
 
     def low_precision(self) -> bool:
         """config.state.low_precision(), config.py:53."""

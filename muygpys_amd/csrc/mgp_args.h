@@ -23,6 +23,9 @@ struct FusedArgs {
   void* coeffs = nullptr;  // (b, k) K^-1 y per neighbourhood (fused fast-mean precompute), or nullptr
   // prepared tables (mgp_table_pack_*): rows [features d | responses R | pad], byte strides; when
   // packed_nn is set feat_q / feat_nn / targets are not read by the pipelined wave kernels
+  // targets_batch != 0: `targets` is the already gathered (b, k, R) tensor (what the reference's
+  // make_*_tensors hand to the solve functions, gp/muygps.py:474,543) instead of the (n, R) table
+  int targets_batch = 0;
   const void* packed_q = nullptr;
   const void* packed_nn = nullptr;
   int64_t q_stride = 0, nn_stride = 0;

@@ -25,7 +25,7 @@ int posterior(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t*
               int R, int noise_mode, double eps, const T* nd, int kernel_id, int metric_id, const T* ls,
               int ls_count, T* mean, T* var, T* yk, int* info, void* stream, int path = PATH_AUTO,
               const void* packed_q = nullptr, int64_t q_stride = 0, const void* packed_nn = nullptr,
-              int64_t nn_stride = 0) {
+              int64_t nn_stride = 0, int targets_batch = 0) {
   if (b < 0 || k < 1 || d < 1 || R < 1) return MGP_EINVAL;
   if (b == 0) return MGP_OK;  // empty shard: nothing to read or write (outputs may be NULL)
   const bool packed = packed_nn != nullptr;
@@ -41,6 +41,7 @@ int posterior(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t*
   if (ls_count != 1 && ls_count != d) return MGP_EINVAL;
   FusedArgs a{fq, fn, bi, ni, tg, nd, ls, mean, var, yk, info, b, eps, d, k, R, noise_mode, kernel_id, metric_id,
               ls_count, 0};
+  a.targets_batch = targets_batch;
   a.packed_q = packed_q;
   a.packed_nn = packed_nn;
   a.q_stride = q_stride;
@@ -169,6 +170,12 @@ int mgp_posterior_f64(const double* fq, const double* fn, int d, const int64_t* 
                               const T* ls, int lsc, T* mean, T* var, T* yk, int* info, void* st) {                   \
     return posterior<T>(fq, fn, d, bi, ni, b, k, tg, R, nm, eps, nd, kid, mid, ls, lsc, mean, var, yk, info, st,    \
                         PATH_RHS);                                                                                   \
+  }                                                                                                                  \
+  int mgp_posterior_gathered_##SUF(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t* ni, int64_t b, \
+                                   int k, const T* nn_tg, int R, int nm, double eps, const T* nd, int kid, int mid,  \
+                                   const T* ls, int lsc, T* mean, T* var, T* yk, int* info, void* st) {              \
+    return posterior<T>(fq, fn, d, bi, ni, b, k, nn_tg, R, nm, eps, nd, kid, mid, ls, lsc, mean, var, yk, info, st, \
+                        PATH_AUTO, nullptr, 0, nullptr, 0, 1);                                                       \
   }                                                                                                                  \
   int mgp_table_pack_##SUF(const T* feat, const T* targets, int64_t n, int d, int R, void* packed,                   \
                            int64_t stride_bytes, void* st) {                                                         \

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
       else myeps = noise_dev[nb * k + i];
 #pragma unroll
       for (int r = 0; r < RC; ++r)
-        if (r < R) rhs[1 + r] = targets[myidx * (int64_t)R + r];
+        if (r < R) rhs[1 + r] = targets[(a.targets_batch ? nb * k + i : myidx) * (int64_t)R + r];
     }
 
     // ---- gather + distances (pairwise: cyclic scheme; crosswise: lane i vs the query) ------

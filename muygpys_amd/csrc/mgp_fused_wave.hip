@@ -167,7 +167,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   constexpr int GB = 11;                                    // loads issued per batch (= SPR at d = 40, fp32)
   const unsigned spr_magic = (1u << 20) / (unsigned)SPR + 1u;  // sigma / SPR for sigma < 64 * 33
   T pre_y = T(0), pre_eps = T(0);
-  int64_t pre_idx = 0;
+  int64_t pre_idx = 0, pre_tg = 0;  // pre_tg: row of the response tensor (table row, or b * k + slot when gathered)
   auto pipe_issue = [&](int64_t task_n, int64_t idx_n, int lane_) {
     const int h = NH == 1 ? 0 : lane_ / NP;
     const int i = lane_ & (NP - 1);
@@ -204,7 +204,12 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     }
     // response and nugget of the slot's row: unconditional single loads (idx_n is 0, a valid
     // row, for slots without one; the values are masked where they are consumed)
-    if constexpr (!PACKED) pre_y = targets[idx_n * (int64_t)R];  // prepared tables: read from the tile
+    {
+      const int64_t nb0 = task_n * NH;
+      const int hh = (NH > 1 && nb0 + h >= a.b) ? 0 : h;
+      pre_tg = a.targets_batch ? (nb0 + hh) * k + (i < k ? i : 0) : idx_n;
+    }
+    if constexpr (!PACKED) pre_y = targets[pre_tg * (int64_t)R];  // prepared tables: read from the tile
     pre_eps = (T)a.noise_scalar;
     if (a.noise_mode != MGP_NOISE_SCALAR) {
       const int64_t nb0 = task_n * NH;
@@ -236,13 +241,14 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     const int hh = live ? h : 0;
 
     // ---- phase 0: indices, responses, nugget -------------------------------------------
-    int64_t myidx = 0;
+    int64_t myidx = 0, mytg = 0;
     T myeps = T(0), myy0 = T(0);
     V myyv = V(0);  // prepared tables: the row's responses, taken from the tile
     if (PIPE) {
       // the tile of this task was requested during the previous task's factorisation; the
       // barrier at the top of the stage loop below waits for it (vmcnt) before anyone reads it
       myidx = pre_idx;
+      mytg = pre_tg;
       myy0 = i < k ? pre_y : T(0);
       myeps = pre_eps;
     } else {
@@ -250,8 +256,9 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       if (task + t_step < t_end) next_idx = load_index(task + t_step, h, i);
       __syncthreads();  // previous task's LDS reads are complete
       idxh[i] = myidx * (int64_t)d;  // element offset of the row
+      mytg = a.targets_batch ? (nb0 + hh) * k + (i < k ? i : 0) : myidx;
       if (i < k) {
-        myy0 = targets[myidx * (int64_t)R];
+        myy0 = targets[mytg * (int64_t)R];
         if (a.noise_mode == MGP_NOISE_SCALAR) myeps = (T)a.noise_scalar;
         else if (a.noise_mode == MGP_NOISE_TABLE) myeps = noise_dev[myidx];
         else myeps = (noise_dev + nb0 * k)[hh * k + i];
@@ -427,7 +434,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         for (int r = 1; r < E; ++r)
           if (r < R) Kh3[(q + 1 + r) * KS + i3] = i3 < k ? myyv[r] : T(0);
       } else {
-        for (int r = 1; r < R; ++r) Kh3[(q + 1 + r) * KS + i3] = i3 < k ? targets[myidx * (int64_t)R + r] : T(0);
+        for (int r = 1; r < R; ++r) Kh3[(q + 1 + r) * KS + i3] = i3 < k ? targets[mytg * (int64_t)R + r] : T(0);
       }
     }
     __syncthreads();

@@ -108,7 +108,7 @@ __global__ void fused_generic_kernel(FusedArgs a) {
     }
     for (int t = tid; t < k * R; t += NT) {
       const int c = t / R, r = t - c * R;
-      S[(k + 1 + r) * SP + c] = targets[idx[c] * (int64_t)R + r];
+      S[(k + 1 + r) * SP + c] = targets[(a.targets_batch ? nb * k + c : idx[c]) * (int64_t)R + r];
     }
     __syncthreads();
     const bool bad = factor_augmented_lds<T>(S, SP, k, rows, piv, flag, tid, NT);

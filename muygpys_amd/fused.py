@@ -176,6 +176,7 @@ def posterior_mean_var(
     info: Optional[torch.Tensor] = None,
     path: str = "auto",
     packed: Union[str, bool] = "auto",
+    gathered: bool = False,
 ):
     """Posterior mean and *unscaled* variance of every batch element, fused.
 
@@ -189,6 +190,8 @@ def posterior_mean_var(
     ``packed``: "auto" reads the tables through prepared copies (:class:`PackedTable`, cached per
     tensor) when the shape allows it and the batch touches the table often enough to pay for the
     one-time pack; True forces, False disables.
+    ``gathered``: ``train_targets`` is the already gathered ``(b, k[, R])`` tensor ``targets[nn_indices]``
+    (what the reference's ``make_*_tensors`` return) instead of the ``(n[, R])`` table.
     """
     _lib.require_cuda(test_features, train_features, batch_indices, nn_indices, train_targets)
     dtype = train_features.dtype
@@ -210,11 +213,19 @@ def posterior_mean_var(
         raise ValueError("batch_indices must have shape (batch_count,)")
     if bi is None and fq.shape[0] < b:
         raise ValueError(f"{b} neighbourhoods but only {fq.shape[0]} query rows (batch_indices is None)")
-    squeeze = train_targets.ndim == 1
-    tg = (train_targets[:, None] if squeeze else train_targets).contiguous()
-    if tg.shape[0] != fn.shape[0]:
-        raise ValueError("train_features and train_targets differ in row count")
-    R = tg.shape[1]
+    if gathered:
+        if tuple(train_targets.shape[:2]) != (b, k):
+            raise ValueError(f"gathered responses must have shape ({b}, {k}[, R]), got {tuple(train_targets.shape)}")
+        squeeze = train_targets.ndim == 2
+        tg = train_targets.reshape(b, k, -1).contiguous()
+        R = tg.shape[2]
+        packed = False
+    else:
+        squeeze = train_targets.ndim == 1
+        tg = (train_targets[:, None] if squeeze else train_targets).contiguous()
+        if tg.shape[0] != fn.shape[0]:
+            raise ValueError("train_features and train_targets differ in row count")
+        R = tg.shape[1]
     if os.environ.get("MUYGPYS_HIP_CHECK_INDICES") == "1":
         _check_indices("nn_indices", ni, fn.shape[0])
         _check_indices("batch_indices", bi, fq.shape[0])
@@ -242,6 +253,10 @@ def posterior_mean_var(
         )
     if rc == -2:  # MGP_EUNSUPPORTED on the prepared tables (or not tried): the plain tables
         base = {"auto": "posterior", "generic": "posterior_generic", "rhs": "posterior_rhs"}[path]
+        if gathered:
+            if path != "auto":
+                raise ValueError("gathered responses go through the dispatcher (path='auto')")
+            base = "posterior_gathered"
         rc = _lib.fn(base, dtype)(
             _lib.ptr(fq), _lib.ptr(fn), d, _lib.ptr(bi), _lib.ptr(ni), b, k, _lib.ptr(tg), R,
             mode, eps, _lib.ptr(nz), spec.kernel_id(), spec.metric_id(), _lib.ptr(ls), ls.numel(),

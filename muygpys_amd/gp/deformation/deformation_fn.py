@@ -86,7 +86,7 @@ class Anisotropy(DeformationFn):
             )
         ls = self.length_scale(**length_scales)
         if isinstance(dists, _lazy.LazyDiffs):
-            return dists.with_length_scale(np.asarray(ls, dtype=np.float64))
+            return dists.with_length_scale(np.asarray(ls, dtype=np.float64)).reduce(self._metric_name())
         import torch
 
         if isinstance(dists, torch.Tensor) and dists.is_cuda and getattr(self.metric, "name", None) in ("l2", "F2"):
@@ -102,11 +102,11 @@ class Anisotropy(DeformationFn):
     def pairwise_tensor(self, data, nn_indices, lazy: bool = False, **kwargs):
         """anisotropy.py:73-100: (b, k, k, d) differences."""
         if lazy:
-            return _lazy.LazyDiffs("pairwise", self._metric_name(), False, data, nn_indices)
+            return _lazy.LazyDiffs("pairwise", None, False, data, nn_indices)
         return self.metric.pairwise_differences(data, nn_indices)
 
     def crosswise_tensor(self, data, nn_data, data_indices, nn_indices, lazy: bool = False, **kwargs):
         """anisotropy.py:103-143: (b, k, d) differences."""
         if lazy:
-            return _lazy.LazyDiffs("crosswise", self._metric_name(), False, nn_data, nn_indices, data, data_indices)
+            return _lazy.LazyDiffs("crosswise", None, False, nn_data, nn_indices, data, data_indices)
         return self.metric.crosswise_differences(data, nn_data, data_indices, nn_indices)

@@ -14,9 +14,13 @@ reference tree:
 What a maintainer would commit instead is shown in INTEGRATION.md: eight three-line
 ``hip.py`` files and one ``elif`` in util.py.
 
-With the reference's own functor layer the per-function (materialising) kernels run; the fused
-single-launch path is reached through this package's functor layer (``muygpys_amd.gp``), which
-hands lazy handles to the same calls.
+With ``lazy=True`` (the default) the tensor family returns the light handles of
+``muygpys_amd.lazy`` instead of (b, k, k, d) difference tensors and the kernel / noise / solve /
+scale families decorate and finally evaluate them, so the reference's OWN functor layer --
+``MuyGPS.make_train_tensors -> kernel -> posterior_mean / posterior_variance / optimize_scale``,
+``make_loo_crossval_fn`` -- ends in one fused launch per evaluation (``mgp_posterior_gathered_*``:
+the reference gathers the neighbour responses itself).  ``lazy=False`` binds the materialising
+per-function kernels.
 """
 
 from __future__ import annotations
@@ -29,7 +33,7 @@ FAMILIES = (
 )
 
 
-def install(package: str = "MuyGPyS", require_device: bool = True) -> None:
+def install(package: str = "MuyGPyS", require_device: bool = True, lazy: bool = True) -> None:
     ref = importlib.import_module(package)
     bound = [m for m in sys.modules if m.startswith(f"{package}._src.") and m.split(".")[-1] in
              ("tensors", "kernels", "muygps", "noise", "loss", "scale", "chassis")]
@@ -41,6 +45,7 @@ def install(package: str = "MuyGPyS", require_device: bool = True) -> None:
 
     if require_device:
         hip_config.require_device()
+    hip_config.state.lazy_tensors = bool(lazy)
     # 1. the family modules MuyGPyS will look for
     for fam in FAMILIES:
         sys.modules[f"{package}._src.{fam}.hip"] = importlib.import_module(f"muygpys_amd._src.{fam}.hip")

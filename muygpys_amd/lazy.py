@@ -25,24 +25,101 @@ from typing import Any, Dict, Optional, Tuple
 import torch
 
 
-@dataclass
-class LazyDiffs:
-    """What ``deformation.pairwise_tensor`` / ``crosswise_tensor`` stand for.
+def _force_tree(x):
+    if isinstance(x, (list, tuple)):
+        return type(x)(_force_tree(v) for v in x)
+    if isinstance(x, dict):
+        return {k: _force_tree(v) for k, v in x.items()}
+    return force(x)
+
+
+class _Lazy:
+    """Anything a handle does not know how to do lazily is done on the materialised tensor: torch
+    functions (``__torch_function__``), tensor methods and attributes, indexing and arithmetic."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        return func(*_force_tree(args), **_force_tree(kwargs or {}))
+
+    def __getattr__(self, name):
+        if name.startswith("__") or name in ("cache",):
+            raise AttributeError(name)
+        return getattr(self.materialize(), name)
+
+    def __getitem__(self, item):
+        return self.materialize()[item]
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __mul__(self, other):
+        return self.materialize() * force(other)
+
+    __rmul__ = __mul__
+
+    def __add__(self, other):
+        return self.materialize() + force(other)
+
+    __radd__ = __add__
+
+    def __sub__(self, other):
+        return self.materialize() - force(other)
+
+    def __rsub__(self, other):
+        return force(other) - self.materialize()
+
+    def __neg__(self):
+        return -self.materialize()
+
+    def __pow__(self, p):
+        return self.materialize() ** p
+
+
+def _is_scalar_like(x) -> bool:
+    if isinstance(x, (int, float)):
+        return True
+    if isinstance(x, torch.Tensor):
+        return x.numel() == 1
+    try:
+        import numpy as np
+
+        return np.ndim(x) == 0 or np.size(x) == 1
+    except Exception:
+        return False
+
+
+def _as_float(x) -> float:
+    if isinstance(x, torch.Tensor):
+        return float(x.detach().reshape(-1)[0])
+    import numpy as np
+
+    return float(np.asarray(x).reshape(-1)[0])
+
+
+@dataclass(eq=False)
+class LazyDiffs(_Lazy):
+    """What the tensor family's ``_pairwise_tensor`` / ``_crosswise_tensor`` (and the deformation
+    functors' ``pairwise_tensor`` / ``crosswise_tensor``) stand for.
 
     kind "pairwise": data (n, d) + nn_indices (b, k)  ->  (b, k, k[, d])
     kind "crosswise": data (n_q, d), data_indices (b,), nn_data, nn_indices -> (b, k[, d])
-    reduced: the metric has been applied (Isotropy hands distances to the kernel,
-    isotropy.py:92-161); False = raw differences (Anisotropy, anisotropy.py:73-143).
+
+    The handle follows the reference's order of operations without computing anything:
+      raw differences         (metric None,  reduced False)   _src/gp/tensors/numpy.py:47-69
+      / per-feature scales    (length_scale vector)           Anisotropy.__call__, anisotropy.py:70
+      metric: _l2 / _F2       (metric set,   reduced True)    numpy.py:89-94
+      / l  or  / l^2          (length_scale scalar)           Isotropy.__call__, metric.py:241,264
+    ``reduced``: the handle stands for DISTANCES (b, k[, k]); otherwise for differences (..., d).
     """
 
     kind: str
-    metric: str
+    metric: Optional[str]
     reduced: bool
     nn_data: torch.Tensor
     nn_indices: torch.Tensor
     data: Optional[torch.Tensor] = None
     data_indices: Optional[torch.Tensor] = None
-    length_scale: Any = None  # set by the deformation functor: float or (d,) sequence
+    length_scale: Any = None  # float, or (d,) sequence / tensor
 
     @property
     def shape(self) -> Tuple[int, ...]:
@@ -68,20 +145,72 @@ class LazyDiffs:
     def with_length_scale(self, length_scale) -> "LazyDiffs":
         return replace(self, length_scale=length_scale)
 
-    def materialize(self) -> torch.Tensor:
+    def reduce(self, metric: str) -> "LazyDiffs":
+        """``_l2`` / ``_F2`` of a difference handle."""
+        if self.reduced:
+            raise ValueError("the metric has already been applied to this tensor")
+        return replace(self, metric=metric, reduced=True)
+
+    def __truediv__(self, other):
+        other = force(other)
+        if not self.reduced and self.length_scale is None:
+            # differences / per-feature length scales (Anisotropy) or / one length scale
+            d = self.shape[-1]
+            n = 1 if _is_scalar_like(other) else (other.numel() if isinstance(other, torch.Tensor) else len(other))
+            if n == 1:
+                return self.with_length_scale(_as_float(other))
+            if n == d and (not isinstance(other, torch.Tensor) or other.ndim == 1):
+                return self.with_length_scale(other)
+        elif self.reduced and self.length_scale is None and _is_scalar_like(other):
+            # distances / l (l2) or / l^2 (F2): metric.py:241,264
+            v = _as_float(other)
+            return self.with_length_scale(v if self.metric == "l2" else v**0.5)
+        return self.materialize() / other
+
+    def _raw(self) -> torch.Tensor:
         from muygpys_amd._src.gp.tensors import hip as T
 
         if self.kind == "pairwise":
-            if self.reduced:
-                return T._pairwise_distances(self.nn_data, self.nn_indices, self.metric)
-            return T._pairwise_tensor(self.nn_data, self.nn_indices)
-        if self.reduced:
-            return T._crosswise_distances(self.data, self.nn_data, self.data_indices, self.nn_indices, self.metric)
-        return T._crosswise_tensor(self.data, self.nn_data, self.data_indices, self.nn_indices)
+            return T._pairwise_tensor_now(self.nn_data, self.nn_indices)
+        return T._crosswise_tensor_now(self.data, self.nn_data, self.data_indices, self.nn_indices)
+
+    def _ls_vector(self):
+        ls = self.length_scale
+        if ls is None or _is_scalar_like(ls):
+            return None
+        return torch.as_tensor(ls, device=self.device, dtype=self.dtype).reshape(-1)
+
+    def materialize(self) -> torch.Tensor:
+        """The tensor the handle stands for (differences, or -- once the metric is applied --
+        distances with whatever length scale has been attached)."""
+        from muygpys_amd._src.gp.tensors import hip as T
+
+        lsv = self._ls_vector()
+        if not self.reduced:
+            raw = self._raw()
+            if self.length_scale is None:
+                return raw
+            return raw / (lsv if lsv is not None else _as_float(self.length_scale))
+        if lsv is not None:  # per-feature scales act before the metric
+            return T._reduce(self._raw(), {"l2": 0, "F2": 1}[self.metric], lsv)
+        if self.kind == "pairwise":
+            out = T._pairwise_distances(self.nn_data, self.nn_indices, self.metric)
+        else:
+            out = T._crosswise_distances(self.data, self.nn_data, self.data_indices, self.nn_indices, self.metric)
+        if self.length_scale is not None:
+            ell = _as_float(self.length_scale)
+            out = out * (1.0 / ell if self.metric == "l2" else 1.0 / ell**2)
+        return out
+
+    def scaled_distances(self) -> torch.Tensor:
+        """metric(differences / length_scale): what the deformation hands to the kernel function."""
+        if not self.reduced:
+            raise ValueError("no metric has been applied to this difference tensor")
+        return self.materialize()
 
 
-@dataclass
-class LazyCov:
+@dataclass(eq=False)
+class LazyCov(_Lazy):
     """What ``kernel(LazyDiffs)`` stands for: Kin (pairwise) or Kcross (crosswise)."""
 
     diffs: LazyDiffs
@@ -115,17 +244,9 @@ class LazyCov:
         """kernel(metric(diffs / length_scale)) [+ nugget] through the per-function kernels."""
         from muygpys_amd._src.gp.kernels import hip as K
         from muygpys_amd._src.gp.noise import hip as N
-        from muygpys_amd._src.gp.tensors import hip as T
 
         d = self.diffs
-        ls = d.length_scale
-        if d.reduced:
-            scale = 1.0 / float(ls) if d.metric == "l2" else 1.0 / float(ls) ** 2
-            out = K._apply(d.materialize(), self.kernel, scale)
-        else:
-            lsv = torch.as_tensor(ls, device=d.device, dtype=d.dtype).reshape(-1)
-            dist = T._reduce(d.materialize(), {"l2": 0, "F2": 1}[d.metric], lsv)
-            out = K._apply(dist, self.kernel, 1.0)
+        out = K._apply(d.scaled_distances(), self.kernel, 1.0)
         if self.noise is not None and d.kind == "pairwise":
             if isinstance(self.noise, torch.Tensor) and self.noise.ndim >= 1:
                 out = N._heteroscedastic_perturb(out, self.noise)
@@ -134,8 +255,8 @@ class LazyCov:
         return out
 
 
-@dataclass
-class LazyTargets:
+@dataclass(eq=False)
+class LazyTargets(_Lazy):
     """What ``train_targets[batch_nn_indices]`` stands for."""
 
     targets: torch.Tensor
@@ -162,21 +283,41 @@ def force(x):
     return x.materialize() if is_lazy(x) else x
 
 
+def _same_tensor(x, y) -> bool:
+    return x is y or (
+        isinstance(x, torch.Tensor) and isinstance(y, torch.Tensor) and x.data_ptr() == y.data_ptr()
+        and x.shape == y.shape and x.stride() == y.stride() and x.dtype == y.dtype
+    )
+
+
 def fused_triple(Kin, Kcross, nn_targets) -> bool:
     """True when (Kin, Kcross, targets) describe one fused launch: same neighbour table and
-    index tensor, same kernel and deformation."""
-    if not (isinstance(Kin, LazyCov) and isinstance(Kcross, LazyCov) and isinstance(nn_targets, LazyTargets)):
+    index tensor, same kernel and deformation.  ``nn_targets`` is a :class:`LazyTargets` handle or
+    the already gathered (b, k[, R]) tensor (the reference's functor layer gathers it itself)."""
+    if not (isinstance(Kin, LazyCov) and isinstance(Kcross, LazyCov)):
         return False
     a, c = Kin.diffs, Kcross.diffs
+    b, k = a.nn_indices.shape
+    if isinstance(nn_targets, LazyTargets):
+        if not _same_tensor(a.nn_indices, nn_targets.nn_indices):
+            return False
+    elif not (isinstance(nn_targets, torch.Tensor) and tuple(nn_targets.shape[:2]) == (b, k)):
+        return False
     return (
-        a.kind == "pairwise" and c.kind == "crosswise" and Kin.kernel == Kcross.kernel
-        and a.nn_indices is c.nn_indices and a.nn_indices is nn_targets.nn_indices
-        and a.nn_data is c.nn_data and a.metric == c.metric and a.reduced == c.reduced
-        and _same_ls(a.length_scale, c.length_scale)
+        a.kind == "pairwise" and c.kind == "crosswise" and a.reduced and c.reduced and Kin.kernel == Kcross.kernel
+        and _same_tensor(a.nn_indices, c.nn_indices) and _same_tensor(a.nn_data, c.nn_data)
+        and a.metric == c.metric and a.metric in ("l2", "F2") and _same_ls(a.length_scale, c.length_scale)
     )
 
 
 def _same_ls(x, y) -> bool:
     import numpy as np
 
-    return np.array_equal(np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64))
+    def host(v):
+        if v is None:
+            return np.asarray(1.0)
+        if isinstance(v, torch.Tensor):
+            return v.detach().double().cpu().numpy()
+        return np.asarray(v, dtype=np.float64)
+
+    return x is y or np.array_equal(host(x), host(y))

@@ -203,3 +203,62 @@ def test_empty_inputs_through_the_new_entry_points():
     coeffs, nn_fast = fast_coefficients(KernelSpec("matern15", "l2", 2.0, 1e-2), X[:0], y[:0],
                                         torch.zeros((0, 10), dtype=torch.int64, device="cuda"))
     assert coeffs.shape == (0, 10) and nn_fast.shape == (0, 10)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_family_level_lazy_route_matches_golden(golden, dtype):
+    """The call sequence of the reference's functor layer written against the family functions
+    (what integration.install() binds): with config.state.lazy_tensors the tensor family returns
+    handles, the metric / deformation / kernel / noise steps decorate them, and posterior mean,
+    variance and sigma^2 come out of ONE fused launch on gathered responses
+    (mgp_posterior_gathered_*) -- same numbers as the fixtures."""
+    from muygpys_amd import lazy
+    from muygpys_amd._src.gp import kernels as K
+    from muygpys_amd._src.gp import muygps as M
+    from muygpys_amd._src.gp import noise as N
+    from muygpys_amd._src.gp import tensors as T
+    from muygpys_amd._src.optimize import scale as S
+    from muygpys_amd.config import config
+
+    g, meta = golden, golden["meta"]
+    if dtype == "float32" and meta["d"] < 10 and meta["noise"] < 1e-4 and not meta.get("hetero"):
+        pytest.skip("fp32 at tiny nugget / low d is ill-conditioned (reference skips it too)")
+    td = getattr(torch, dtype)
+    rtol = RTOL[dtype]
+    X, y = to_dev(g["features"], td), to_dev(g["targets"], td)
+    bi, ni = to_dev(g["batch_idx"]), to_dev(g["nn_idx"])
+    metric = T._l2 if meta["metric"] == "l2" else T._F2
+    kfn = {"rbf": K._rbf_fn, "matern05": K._matern_05_fn, "matern15": K._matern_15_fn, "matern25": K._matern_25_fn,
+           "maternInf": K._matern_inf_fn}[meta["kernel"]]
+    ls = meta["length_scale"]
+    config.state.lazy_tensors = True
+    try:
+        pair, cross = T._pairwise_tensor(X, ni), T._crosswise_tensor(X, X, bi, ni)
+        assert isinstance(pair, lazy.LazyDiffs) and tuple(pair.shape) == tuple(ni.shape) + (ni.shape[1], meta["d"])
+        if isinstance(ls, list):  # Anisotropy.__call__: metric(diffs / l_vec), anisotropy.py:70
+            lsv = to_dev(np.asarray(ls), td)
+            dp, dc = metric(pair / lsv), metric(cross / lsv)
+        else:                     # Isotropy: metric at construction, then x / l or x / l^2, metric.py:241,264
+            div = ls if meta["metric"] == "l2" else ls**2
+            dp, dc = metric(pair) / div, metric(cross) / div
+        Kin, Kc = kfn(dp), kfn(dc)
+        assert isinstance(Kin, lazy.LazyCov) and tuple(Kin.shape) == tuple(ni.shape) + (ni.shape[1],)
+        ynn = y[ni]
+        if meta.get("hetero"):
+            Kp = N._heteroscedastic_perturb(Kin, T._make_heteroscedastic_tensor(to_dev(g["noise_table"], td), ni))
+        else:
+            Kp = N._homoscedastic_perturb(Kin, meta["noise"])
+        mean = M._muygps_posterior_mean(Kp, Kc, ynn)
+        var = M._muygps_diagonal_variance(Kp, Kc, 1.0)
+        assert len(Kin.cache["entries"]) == 1, "mean and variance share one launch"
+        assert_close(mean.cpu().numpy().reshape(g["mean"].shape), g["mean"], rtol, "mean")
+        assert_close(var.cpu().numpy(), g["var_unscaled"], rtol, "var")
+        if meta["R"] == 1:
+            sig = S._analytic_scale_optim(Kp, ynn)
+            assert len(Kin.cache["entries"]) == 1, "sigma^2 comes from the same launch"
+            assert_close(sig.cpu().numpy().reshape(-1), g["sigma_sq"], rtol, "sigma_sq")
+        # a handle is still a tensor on demand
+        if "Kin" in g:
+            assert_close(torch.as_tensor(Kin.materialize()).cpu().numpy(), g["Kin"], rtol, "Kin materialised")
+    finally:
+        config.state.lazy_tensors = False

@@ -39,3 +39,81 @@ def test_install_into_reference_package():
     env = dict(os.environ, PYTHONPATH=REF + os.pathsep + ROOT, PYTHONDONTWRITEBYTECODE="1", MUYGPYS_BACKEND="numpy")
     r = subprocess.run([sys.executable, "-c", SCRIPT], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "installed" in r.stdout, r.stderr[-2000:]
+
+
+LAZY_SCRIPT = r"""
+import collections, importlib.metadata as md, sys, types
+_v = md.version; md.version = lambda n: "0.9.0" if n == "MuyGPyS" else _v(n)
+bo = types.ModuleType("bayes_opt"); bo.BayesianOptimization = object; sys.modules["bayes_opt"] = bo
+import numpy as np, torch
+import MuyGPyS
+import muygpys_amd.integration as hip_backend
+hip_backend.install(require_device=False)            # lazy handles at the family level
+# no GPU in the build container: record the C-ABI calls instead of making them
+from muygpys_amd import _lib
+import muygpys_amd._src.math.hip as mmh
+calls = collections.Counter()
+def fake_fn(base, dtype):
+    def call(*args):
+        calls[base] += 1
+        return 0
+    return call
+_lib.fn = fake_fn
+def fake_column_sums(x2):
+    calls["column_sums"] += 1
+    return torch.ones(x2.shape[1], dtype=torch.float64)
+def fake_loss_sums(*a):
+    calls["loss_sums"] += 1
+    return torch.ones(6, dtype=torch.float64)
+_lib.column_sums, _lib.loss_sums = fake_column_sums, fake_loss_sums
+_lib.require_cuda = lambda *a: None
+_lib.stream_ptr = lambda: None
+mmh._device = lambda: torch.device("cpu")
+from MuyGPyS.gp import MuyGPS
+from MuyGPyS.gp.deformation import Anisotropy, Isotropy, l2
+from MuyGPyS.gp.hyperparameter import AnalyticScale, Parameter, VectorParameter
+from MuyGPyS.gp.kernels import Matern
+from MuyGPyS.gp.noise import HomoscedasticNoise
+from MuyGPyS.optimize import L_BFGS_B_optimize
+from MuyGPyS.optimize.loss import lool_fn
+rng = np.random.default_rng(0)
+X = torch.from_numpy(rng.normal(size=(200, 6))); y = torch.from_numpy(rng.normal(size=200))
+bi = torch.arange(0, 40); ni = torch.from_numpy(rng.integers(40, 200, size=(40, 8)))
+for deformation, probe in (
+    (Isotropy(l2, length_scale=Parameter(2.0, (0.1, 10.0))), {"length_scale": 1.5}),
+    (Anisotropy(l2, length_scale=VectorParameter(*[Parameter(1.0 + 0.1 * i, (0.1, 10.0)) for i in range(6)])),
+     {f"length_scale{i}": 2.0 for i in range(6)}),
+):
+    calls.clear()
+    m = MuyGPS(kernel=Matern(smoothness=Parameter(1.5), deformation=deformation),
+               noise=HomoscedasticNoise(1e-3), scale=AnalyticScale())
+    cross, pair, y_b, y_nn = m.make_train_tensors(bi, ni, X, y)
+    assert type(pair).__name__ == "LazyDiffs" and type(cross).__name__ == "LazyDiffs", (type(pair), type(cross))
+    assert tuple(pair.shape)[:3] == (40, 8, 8)
+    assert not calls, calls                             # building the tensors launches nothing
+    obj = L_BFGS_B_optimize.make_obj_fn(m, y_b, y_nn, cross, pair, loss_fn=lool_fn)
+    for rep in range(2):
+        calls.clear()
+        obj(**probe)
+        assert calls["posterior_gathered"] == 1, dict(calls)   # ONE fused launch per objective evaluation
+        assert set(calls) <= {"posterior_gathered", "loss_sums", "column_sums"}, dict(calls)
+    # prediction-style calls share one launch too
+    calls.clear()
+    Kin, Kc = m.kernel(pair), m.kernel(cross)
+    m.posterior_mean(Kin, Kc, y_nn); m.posterior_variance(Kin, Kc)
+    assert calls["posterior_gathered"] == 1 and "solve" not in calls and "pairwise_diffs" not in calls, dict(calls)
+    calls.clear()
+    m.optimize_scale(pair, y_nn)
+    assert calls["posterior_gathered"] == 1 and "solve" not in calls, dict(calls)
+print("lazy-ok")
+"""
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree exists only in the build container")
+def test_reference_functor_layer_reaches_the_fused_launch():
+    """integration.install() + the reference's OWN MuyGPS / Matern / Isotropy / Anisotropy /
+    make_loo_crossval_fn: the tensor family hands out lazy handles and every objective evaluation is
+    exactly one mgp_posterior_gathered_* call (recorded; the build container has no GPU)."""
+    env = dict(os.environ, PYTHONPATH=REF + os.pathsep + ROOT, PYTHONDONTWRITEBYTECODE="1", MUYGPYS_BACKEND="numpy")
+    r = subprocess.run([sys.executable, "-c", LAZY_SCRIPT], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "lazy-ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
