@@ -1,0 +1,332 @@
+// Register-resident fused kernel for wide neighbourhoods: 64 < k + 1 + R <= 128 (fp32).
+//
+// Same algebra and slot layout as mgp_fused_wave.hip -- slots 0..k-1 neighbour rows, padding,
+// slot q = 127 - R the query, slots q+1..127 the R response rows; k steps of a row-per-lane
+// right-looking Cholesky on the lower triangle of the augmented system leave
+//     var = S[q][q],  mean_r = -S[q+1+r][q],  y_r^T K^-1 y_r = -S[q+1+r][q+1+r]
+// -- but one neighbourhood is 128 slots, i.e. TWO wavefronts (one workgroup of 128 threads), and a
+// lane's row is 128 registers.  What that changes:
+//
+//   * distances: the cyclic pair scheme with NP = 128: 64 pairs per lane, register blocked
+//     4 own rows x 16 partner rows (pair {i+p, i+o_j}, o = 0, 33, 49, 65: cyclic distances
+//     1..64, each once, 64 twice);
+//   * exchange into row-per-lane registers through a PACKED lower-triangular matrix (34 KB; the
+//     square would be 68 KB per workgroup), one pass;
+//   * Cholesky: blocked by four columns -- two workgroup barriers per block instead of one per
+//     column (the barrier + LDS round trip per step is what two waves per SIMD cannot hide); the row
+//     is updated by streaming the eliminated block columns (load 16 B, two packed FMAs), so no copy
+//     of a column is held next to the 128 row registers.
+//
+// 2 waves per SIMD (<= 256 VGPRs), 4 workgroups per CU (38 KB of LDS each).  The LDS workgroup kernel
+// (mgp_generic.hip) remains the path for fp64 and for more than 128 slots.
+#include "mgp_wave_common.h"
+
+#include <utility>
+
+namespace mgp {
+
+// f(ic<0>{}), f(ic<1>{}), ... f(ic<N-1>{}): a loop whose index is a compile-time constant in every
+// iteration (a `#pragma unroll` the compiler declines leaves the 128-register row indexed at run
+// time, i.e. in scratch memory)
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(ic<I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+struct WideGeom {
+  int q, dst, xs, vec_ok;
+};
+
+__global__ __launch_bounds__(128, 2) void fused_wide_kernel(FusedArgs a, WideGeom g) {
+  using T = float;
+  constexpr int NP = 128;
+  constexpr int NS = NP / 2;  // pairs per lane
+  constexpr int BA = 4, BP = NS / BA;
+  auto own_offset = [](int j) { return j == 0 ? 0 : (j + 1) * BP + 1; };
+  constexpr int E = 4, CH = 8;
+  constexpr int TRI = 8 * 32 * 33 + 2 * NP + 2 * E;  // packed lower-triangular exchange matrix (+ over-read pad)
+  using V = v16<T>::type;
+  using ACC = v16<T>::acc;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int k = a.k, R = a.R, d = a.d, q = g.q, dst = g.dst, xs = g.xs;
+  const int tile_elems = NP * xs > TRI ? NP * xs : TRI;
+  T* tile = reinterpret_cast<T*>(smem);   // feature tile, later the exchange matrix
+  T* colbuf = tile + tile_elems;          // 2 x 512: raw / eliminated block entries of a Cholesky block
+  T* ilbuf = colbuf + 2 * NP * E;         // dst inverse length scales (Anisotropy)
+  T* outbuf = ilbuf + dst;                // (R + 1) x 2: Schur-block entries on their way out
+  int64_t* idxbuf = reinterpret_cast<int64_t*>(outbuf + 2 * 17 + ((dst + 2 * 17) & 1));  // 128 row offsets
+
+  const T* feat_q = static_cast<const T*>(a.feat_q);
+  const T* feat_nn = static_cast<const T*>(a.feat_nn);
+  const T* targets = static_cast<const T*>(a.targets);
+  const T* noise_dev = static_cast<const T*>(a.noise_dev);
+  const T* ls = static_cast<const T*>(a.length_scale);
+  const bool aniso = a.ls_count > 1;
+  T post_scale = T(1);
+  if (!aniso) {
+    const T l = ls[0];
+    post_scale = a.metric_id == MGP_METRIC_L2 ? T(1) / l : T(1) / (l * l);
+  }
+
+  for (int64_t nb = blockIdx.x; nb < a.b; nb += gridDim.x) {
+    int i = threadIdx.x;
+    asm volatile("" : "+v"(i));  // keep per-lane addresses of the unrolled phases out of LICM
+    // ---- phase 0: indices, nugget ------------------------------------------------------------
+    int64_t myidx = 0;
+    T myeps = T(0);
+    if (i < k) {
+      myidx = a.nn_idx[nb * k + i];
+      if (a.noise_mode == MGP_NOISE_SCALAR) myeps = (T)a.noise_scalar;
+      else if (a.noise_mode == MGP_NOISE_TABLE) myeps = noise_dev[myidx];
+      else myeps = noise_dev[nb * k + i];
+    } else if (i == q) {
+      myidx = a.batch_idx ? a.batch_idx[nb] : nb;
+    }
+    const int64_t mytg = a.targets_batch ? nb * k + (i < k ? i : 0) : myidx;
+    __syncthreads();  // the previous neighbourhood's LDS reads are complete
+    idxbuf[i] = myidx * (int64_t)d;
+
+    // ---- phase 1: stage the features (one stage: d <= 64) -----------------------------------------
+    const int w = d, wp = (d + CH - 1) / CH * CH;
+    __syncthreads();
+    if (g.vec_ok) {
+      // consecutive lanes walk a row in 16-byte pieces; slots without features are zero rows
+      const int c16 = w / E, c16p = wp / E;
+      for (int t = i; t < NP * c16p; t += NP) {
+        const int row = t / c16p, c = t - row * c16p;
+        V v = V(0);
+        if (c < c16 && (row < k || row == q))
+          v = *reinterpret_cast<const V*>((row < k ? feat_nn : feat_q) + idxbuf[row] + c * E);
+        *reinterpret_cast<V*>(tile + row * xs + c * E) = v;
+      }
+    } else {
+      for (int t = i; t < NP * wp; t += NP) {
+        const int row = t / wp, c = t - row * wp;
+        T v = T(0);
+        if (c < w && (row < k || row == q)) v = ((row < k ? feat_nn : feat_q) + idxbuf[row])[c];
+        tile[row * xs + c] = v;
+      }
+    }
+    if (aniso)
+      for (int c = i; c < wp; c += NP) ilbuf[c] = c < w ? T(1) / ls[c] : T(0);
+    __syncthreads();
+
+    // ---- phase 2: squared distances, then covariances; two halves of the own rows so that the
+    //      64 packed accumulators of a lane never coexist (register budget: 256 with the 128-entry row)
+    T kv[NS];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      constexpr int HB = BA / 2;
+      ACC acc[HB * BP];
+#pragma unroll
+      for (int s = 0; s < HB * BP; ++s) acc[s] = ACC(0);
+      for (int c0 = 0; c0 < wp; c0 += CH) {
+        V own0[HB], own1[HB];
+#pragma unroll
+        for (int j = 0; j < HB; ++j) {
+          const T* xj = tile + ((i + own_offset(half * HB + j)) & (NP - 1)) * xs + c0;
+          own0[j] = *reinterpret_cast<const V*>(xj);
+          own1[j] = *reinterpret_cast<const V*>(xj + E);
+        }
+        V il0 = V(1), il1 = V(1);
+        if (aniso) {
+          il0 = *reinterpret_cast<const V*>(ilbuf + c0);
+          il1 = *reinterpret_cast<const V*>(ilbuf + c0 + E);
+        }
+#pragma unroll
+        for (int s = 1; s <= BP; ++s) {
+          const T* xo = tile + ((i + s) & (NP - 1)) * xs + c0;
+          const V o0 = *reinterpret_cast<const V*>(xo);
+          const V o1 = *reinterpret_cast<const V*>(xo + E);
+#pragma unroll
+          for (int j = 0; j < HB; ++j) {
+            if (aniso) {
+              accum(acc[j * BP + s - 1], vsub(own0[j], o0) * il0);
+              accum(acc[j * BP + s - 1], vsub(own1[j], o1) * il1);
+            } else {
+              accum(acc[j * BP + s - 1], vsub(own0[j], o0));
+              accum(acc[j * BP + s - 1], vsub(own1[j], o1));
+            }
+          }
+        }
+      }
+      kernel_dispatch(a.kernel_id, a.metric_id, [&](auto kid, auto mid) {
+        constexpr int KID = decltype(kid)::value, MID = decltype(mid)::value;
+#pragma unroll
+        for (int s = 0; s < HB * BP; s += 2) {
+          const f2 kk = cov_from_sqdist2(f2{acc_total(acc[s]), acc_total(acc[s + 1])}, KID, MID, post_scale);
+          kv[half * HB * BP + s] = kk.x;
+          kv[half * HB * BP + s + 1] = kk.y;
+        }
+      });
+    }
+
+    // ---- phase 3: covariances -> packed lower-triangular exchange matrix -> row per lane ------------
+    // Row r of the exchange matrix holds its r + 1 lower-triangle entries and starts at
+    // tri(r) = 8 a (a + 1) + 4 (r & 3) (a + 1), a = r >> 2 (every row padded to whole 16-byte groups):
+    // 34 KB for 128 rows instead of 68 KB for the square, written in ONE pass.  A lane then reads 32
+    // groups from the start of its row: what lies beyond column i belongs to later rows (upper-triangle
+    // garbage the elimination never uses).
+    const T mydiag = i < k ? T(1) + myeps : (i <= q ? T(1) : T(0));
+    auto tri = [](int r) { const int a = r >> 2; return (a + 1) * (8 * a + 4 * (r & 3)); };
+    V A[NP / E];
+    __syncthreads();  // every lane is done reading the feature tile (the exchange matrix aliases it)
+    {
+      int i3 = i;
+      asm volatile("" : "+v"(i3));
+      const int dump = tri(NP - 1) + NP + E;  // behind the last row
+#pragma unroll
+      for (int s = 1; s <= NS; ++s) {
+        const int r1 = (i3 + own_offset((s - 1) / BP)) & (NP - 1);
+        const int c = (i3 + (s - 1) % BP + 1) & (NP - 1);
+        const int hi = max(r1, c), lo = min(r1, c);
+        const T v = (lo < k && (hi < k || hi == q)) ? kv[s - 1] : T(0);
+        tile[hi <= q ? tri(hi) + lo : dump] = v;
+      }
+      const int myrow = tri(i3);
+      tile[myrow + i3] = mydiag;
+      for (int r = 0; r < R; ++r)
+        if (i3 <= q + 1 + r) tile[tri(q + 1 + r) + i3] = i3 < k ? targets[mytg * (int64_t)R + r] : T(0);
+      __syncthreads();
+#pragma unroll
+      for (int c4 = 0; c4 < NP / E; ++c4) A[c4] = *reinterpret_cast<const V*>(tile + myrow + c4 * E);
+    }
+
+    // ---- phase 4: blocked Cholesky, row per lane, FOUR columns per exchange ------------------------
+    // A step-by-step elimination costs a workgroup barrier and an LDS round trip per column, and with
+    // two waves per SIMD that latency is what the kernel waits on.  A block of four columns J0..J0+3
+    // (one 16-byte register group) takes two barriers instead:
+    //   1. every lane posts its raw block entries a_i[0..3]; all read the four rows of the diagonal
+    //      block and factor it redundantly (pivots p_m, and u_m'(J0+m) for m' < m), then eliminate
+    //      the block inside their own row:  u_m(i) = a_i[m] - sum_{m'<m} u_m'(i) u_m'(J0+m) / p_m';
+    //   2. every lane posts u_0..3(i) (transposed: ubuf[m][i]); the trailing groups take
+    //      A[i][c] -= sum_m (u_m(i) / p_m) u_m(c), four independent packed-FMA streams per group.
+    // Same arithmetic as the column-at-a-time form (the sum over m is applied in the same order).
+    // Fully unrolled (compile-time block index: no register-group switches, the loads of a block issue
+    // together).
+    bool bad = false;
+    T* rawbuf = colbuf;            // 128 x 4 raw block entries (row-major: lane i at rawbuf + 4 i)
+    T* ubuf = colbuf + NP * E;     // 4 x 128 eliminated entries, transposed: ubuf[m * 128 + i]
+    static_for<NP / E>([&](auto jbc) {
+      constexpr int jb = decltype(jbc)::value;
+      constexpr int J0 = jb * E;
+      if (J0 < k) {  // uniform
+        V pg = A[jb];
+        const int mlim = min(E, k - J0);  // columns of this block that are eliminated (the last block may be short)
+        *reinterpret_cast<V*>(rawbuf + i * E) = pg;
+        __syncthreads();
+        // diagonal block rows J0 .. J0+3 (raw), factored redundantly by every lane
+        V dr[E];
+#pragma unroll
+        for (int r = 0; r < E; ++r) dr[r] = *reinterpret_cast<const V*>(rawbuf + (J0 + r) * E);
+        T rp[E];
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+          // dr[r][m] for r >= m now holds u_m(J0 + r)
+          const T pm = dr[m][m];
+          const bool on = m < mlim;
+          bad = bad || (on && !(pm > T(0)));
+          rp[m] = on ? pivot_rcp(pm) : T(0);
+#pragma unroll
+          for (int r = m + 1; r < E; ++r) {
+            const T t = dr[r][m] * rp[m];
+#pragma unroll
+            for (int c = m + 1; c <= r; ++c) dr[r][c] = fma_t(-t, dr[c][m], dr[r][c]);
+          }
+        }
+        // own row: u_m(i) and the multipliers nt_m(i) = -u_m(i) / p_m
+        T nt[E];
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+          nt[m] = -pg[m] * rp[m];
+#pragma unroll
+          for (int c = m + 1; c < E; ++c) pg[c] = fma_t(nt[m], dr[c][m], pg[c]);
+        }
+#pragma unroll
+        for (int m = 0; m < E; ++m) ubuf[m * NP + i] = pg[m];
+        __syncthreads();
+        // trailing groups, the block's own included (it stays current: the outputs read the last
+        // groups).  Groups that hold padding columns only are updated too: a uniform test around them
+        // splits the block's loads into separately scheduled pieces and costs more than it saves
+        // (measured: k = 100 20.0 -> 22.1 ms per 200 k neighbourhoods).
+#pragma unroll
+        for (int c4 = jb; c4 < NP / E; ++c4) {
+#pragma unroll
+          for (int m = 0; m < E; ++m) {
+            const V cv = *reinterpret_cast<const V*>(ubuf + m * NP + c4 * E);
+            A[c4] = cv * V(nt[m]) + A[c4];
+          }
+        }
+      }
+    });
+
+    // ---- phase 5: Schur block -> outputs --------------------------------------------------------
+    // lane q holds S[q][q]; lane q+1+r holds S[q+1+r][q] and S[q+1+r][q+1+r]: picked out of the
+    // registers by a compare-select sweep over the last 32 columns (q >= 111 as R <= 16)
+    T aq = T(0), aii = T(0);
+#pragma unroll
+    for (int c = NP - 32; c < NP; ++c) {
+      const T v = A[c / E][c % E];
+      aq = c == q ? v : aq;
+      aii = c == i ? v : aii;
+    }
+    T* mean = static_cast<T*>(a.mean);
+    T* var = static_cast<T*>(a.var);
+    T* yk = static_cast<T*>(a.ykinvy);
+    if (i == q) {
+      var[nb] = bad ? num<T>::nan() : aq;
+      if (bad && a.info) atomicAdd(a.info, 1);
+    } else if (i > q) {
+      const int r = i - q - 1;
+      mean[nb * R + r] = bad ? num<T>::nan() : -aq;
+      if (yk) yk[nb * R + r] = bad ? num<T>::nan() : -aii;
+    }
+  }
+}
+
+template <typename T>
+int launch_fused_wide(const FusedArgs& a, hipStream_t stream) {
+  if constexpr (sizeof(T) != 4) {
+    return MGP_EUNSUPPORTED;  // a row of 128 doubles does not fit the register file
+  } else {
+    constexpr int NP = 128, E = 4, CH = 8, TRI = 8 * 32 * 33 + 2 * NP + 2 * E;
+    const int rows = a.k + 1 + a.R;
+    // below ~76 rows the LDS workgroup kernel is faster (the 128-slot kernel pays for all 128 slots:
+    // k = 70: 11.4 vs 14.1 M neighbourhoods/s; k = 80: 10.9 vs 9.4; k = 100: 10.0 vs 4.7; k = 126: 9.4 vs 1.7)
+    if (rows < 76 || rows > NP || a.R > 16 || a.d > 64 || a.packed_nn != nullptr || a.coeffs != nullptr)
+      return MGP_EUNSUPPORTED;  // more slots / responses / feature stages: the LDS workgroup kernel
+    WideGeom g;
+    g.q = NP - 1 - a.R;
+    const int dpad = (a.d + CH - 1) / CH * CH;
+    g.dst = dpad < 64 ? dpad : 64;
+    g.xs = g.dst + E;
+    const uintptr_t align = (uintptr_t)a.feat_q | (uintptr_t)a.feat_nn;
+    g.vec_ok = (a.d % E == 0) && (align % 16 == 0);
+    const size_t tile_elems = (size_t)NP * g.xs > TRI ? (size_t)NP * g.xs : TRI;
+    size_t lds = (tile_elems + 2 * NP * E + g.dst + 2 * 17 + ((g.dst + 2 * 17) & 1)) * sizeof(float) + NP * sizeof(int64_t);
+    lds = (lds + 15) & ~(size_t)15;
+    static Residency res;
+    int per_cu = 0, cus = 0;
+    const int rc = res.lookup(reinterpret_cast<const void*>(&fused_wide_kernel), NP, lds, &per_cu, &cus);
+    if (rc != MGP_OK) return rc;
+    int64_t grid = (int64_t)cus * per_cu;
+    if (grid > a.b) grid = a.b;
+    static const bool trace = getenv("MGP_TRACE") != nullptr;
+    if (trace)
+      fprintf(stderr, "mgp: fused_wide_kernel b=%lld k=%d d=%d R=%d grid=%lld lds=%zu per_cu=%d\n", (long long)a.b, a.k, a.d,
+              a.R, (long long)grid, lds, per_cu);
+    hipLaunchKernelGGL(fused_wide_kernel, dim3((unsigned)grid), dim3(NP), lds, stream, a, g);
+    MGP_HIP_CHECK_LAUNCH();
+    return MGP_OK;
+  }
+}
+
+template int launch_fused_wide<float>(const FusedArgs&, hipStream_t);
+template int launch_fused_wide<double>(const FusedArgs&, hipStream_t);
+
+}  // namespace mgp

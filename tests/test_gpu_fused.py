@@ -237,7 +237,8 @@ WIDE_CASES = [
     ("matern15", 80, 16, 1, False),
     ("rbf", 100, 40, 2, False),
     ("matern25", 126, 8, 1, True),
-    ("matern05", 64, 12, 1, False),   # 66 rows: just past the wave kernels
+    ("matern05", 64, 12, 1, False),   # 66 rows: just past the wave kernels (LDS workgroup kernel)
+    ("matern15", 75, 24, 1, False),   # 77 rows: the first shape of the 128-slot kernel
     ("matern15", 90, 37, 3, False),   # unaligned rows, several responses
 ]
 

@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
-"""Interleaved in-process A/B timing of the fused kernel variants (GPU box only).
+"""Interleaved in-process A/B timing of the fused kernel families (GPU box only).
 
-    python tools/kbench.py [--b 1000000] [--rounds 5] masks=15,1,3,7 generic=0,1
+    python tools/kbench.py --k 100 --d 40 --paths auto,generic [--b 200000] [--rounds 5]
+
+``--paths``: auto (dispatcher), generic (LDS workgroup kernel), rhs (responses as columns);
+``--packed``: 0/1 prepared tables (auto path only).  The phase-mask / grid ablations of round 1 need a
+debug build of the library (MGP_EXTRA_HIPCC_FLAGS=-DMGP_DEBUG_HOOKS) and ``--masks``.
 """
 import argparse
 import os
@@ -11,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 
-from bench import random_neighbors, synth
+from bench import algorithmic_flops, random_neighbors, synth
 from muygpys_amd import _lib
 from muygpys_amd.fused import KernelSpec, posterior_mean_var
 
@@ -22,27 +26,21 @@ def main():
     ap.add_argument("--b", type=int, default=1_000_000)
     ap.add_argument("--k", type=int, default=30)
     ap.add_argument("--d", type=int, default=40)
+    ap.add_argument("--R", type=int, default=1)
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--rounds", type=int, default=5)
-    ap.add_argument("--masks", default="15")
-    ap.add_argument("--generic", default="0")
+    ap.add_argument("--paths", default="auto")
+    ap.add_argument("--packed", default="1")
     ap.add_argument("--aniso", type=int, default=0)
-    ap.add_argument("--R", type=int, default=1)
     ap.add_argument("--kernel", default="matern15")
     ap.add_argument("--metric", default="l2")
-    ap.add_argument("--grids", default="0")
-    ap.add_argument("--ldspad", type=int, default=0)
-    ap.add_argument("--wave2", default="0")
-    ap.add_argument("--rtpipe", default="1", help="comma list: 1 = pipelined direct-to-LDS gather for run-time shapes")
-    ap.add_argument("--prefer-rhs", type=int, default=0)
+    ap.add_argument("--masks", default="", help="debug builds only: comma list of phase masks")
     ap.add_argument("--hot-rows", type=int, default=0, help="restrict neighbour rows to the first N (cache-resident gather)")
     args = ap.parse_args()
     dev = torch.device("cuda")
     td = torch.float32 if args.dtype == "f32" else torch.float64
-    X, y = synth(args.n, args.d, 20241008)
+    X, y = synth(args.n, args.d, 20241008, args.R)
     Xd, yd = torch.from_numpy(X).to(dev, td), torch.from_numpy(y).to(dev, td)
-    if args.R > 1:
-        yd = yd[:, None].repeat(1, args.R).contiguous() * torch.linspace(0.5, 1.5, args.R, device=dev, dtype=td)
     bi, ni = random_neighbors(args.n, args.b, args.k, 1)
     bi, ni = torch.from_numpy(bi).to(dev), torch.from_numpy(ni).to(dev)
     if args.hot_rows:
@@ -53,30 +51,29 @@ def main():
     mean = torch.empty((args.b, args.R), device=dev, dtype=td)
     var = torch.empty((args.b,), device=dev, dtype=td)
     lib = _lib.load()
-    lib.mgp_debug_set_lds_pad(args.ldspad)
-    lib.mgp_debug_prefer_rhs(args.prefer_rhs)
-    variants = [(int(m), int(g), int(pc), int(w2), int(rp)) for g in args.generic.split(",")
-                for m in args.masks.split(",") for pc in args.grids.split(",") for w2 in args.wave2.split(",")
-                for rp in args.rtpipe.split(",")]
+    masks = [int(m) for m in args.masks.split(",")] if args.masks else [None]
+    if args.masks and not hasattr(lib, "mgp_debug_set_phase_mask"):
+        raise SystemExit("--masks needs a library built with -DMGP_DEBUG_HOOKS")
+    variants = [(p, int(pk), m) for p in args.paths.split(",") for pk in (args.packed.split(",") if p == "auto" else ["0"])
+                for m in masks]
     times = {v: [] for v in variants}
     for r in range(args.rounds + 1):
         for v in variants:
-            lib.mgp_debug_set_phase_mask(v[0])
-            lib.mgp_debug_force_generic(v[1])
-            lib.mgp_debug_set_grid_per_cu(v[2])
-            lib.mgp_debug_enable_wave2(v[3])
-            lib.mgp_debug_runtime_pipe(v[4])
+            if v[2] is not None:
+                lib.mgp_debug_set_phase_mask(v[2])
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            posterior_mean_var(spec, Xd, Xd, bi, ni, yd, out_mean=mean, out_var=var)
+            posterior_mean_var(spec, Xd, Xd, bi, ni, yd, out_mean=mean, out_var=var, path=v[0], packed=bool(v[1]))
             e1.record()
             torch.cuda.synchronize()
             if r > 0:
                 times[v].append(e0.elapsed_time(e1))
+    flops = algorithmic_flops(args.k, args.d, args.R)
     for v in variants:
         t = np.array(times[v])
-        print(f"mask={v[0]:2d} generic={v[1]} grid/cu={v[2]:2d} wave2={v[3]} rtpipe={v[4]} median {np.median(t):8.3f} ms  min {t.min():8.3f} ms  "
-              f"-> {args.b / np.median(t) / 1e3:8.1f} M nbhd/s")
+        name = _lib.served_by(args.d, args.k, args.R, td, bool(v[1]), v[0])
+        print(f"path={v[0]:8s} packed={v[1]} mask={v[2]} median {np.median(t):9.3f} ms  min {t.min():9.3f} ms -> "
+              f"{args.b / np.median(t) / 1e3:8.1f} M nbhd/s  {flops * args.b / np.median(t) / 1e9:7.2f} TFLOP/s  [{name}]")
 
 
 if __name__ == "__main__":
