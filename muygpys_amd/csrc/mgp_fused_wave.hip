@@ -80,7 +80,22 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   auto own_offset = [](int j) { return j == 0 ? 0 : (j + 1) * BP + 1; };
   constexpr int E = v16<T>::N;    // elements per 16 bytes
   constexpr int CH = 2 * E;       // feature chunk per inner iteration (two 16-B reads per row)
-  constexpr int KS = NP + E;      // row stride of the exchange matrix: NP/E + 1 (odd) 16-B slots
+  constexpr int KS = NP + E;      // row stride of the (square) exchange matrix: NP/E + 1 (odd) 16-B slots
+  // 64-slot neighbourhoods keep the exchange matrix PACKED lower-triangular: row r holds its r + 1
+  // entries, padded to whole 16-byte groups, at rowoff(r) = E (a + 1) (E a / 2 + r % E), a = r / E --
+  // 17 KB instead of 34 KB in fp64, so LDS no longer holds these shapes at one wave per SIMD.  A lane
+  // reads NP entries from the start of its row; what lies beyond its diagonal belongs to later rows
+  // (upper-triangle garbage the elimination never uses).
+  constexpr bool TRI = NP == 64 && !COEFF;
+  auto rowoff = [](int r) {
+    if constexpr (TRI) {
+      const int a = r / E;
+      return E * (a + 1) * (E * a / 2 + r % E);
+    } else {
+      return r * KS;
+    }
+  };
+  constexpr int KMAT = TRI ? E * (NP / E + 1) * (E * (NP / E) / 2) + NP + E : NP * KS;  // elements per matrix
   constexpr int DPADFIX = (DFIX + CH - 1) / CH * CH;
   constexpr int DSTFIX = DFIX > 0 ? (DPADFIX < 64 ? DPADFIX : 64) : CH;
   using V = typename v16<T>::type;
@@ -93,7 +108,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   const int q = RFIX > 0 ? NP - 1 - RFIX : g.q;
   const int dst = DFIX > 0 ? DSTFIX : g.dst;
   const int xs = DFIX > 0 ? DSTFIX + E : g.xs;
-  const int tile_elems = NH * NP * (xs > KS ? xs : KS);
+  const int tile_elems = NH * (NP * xs > KMAT ? NP * xs : KMAT);
   T* tile = reinterpret_cast<T*>(smem);               // feature tile, later the exchange matrix
   // Plain kernels: [tile][colbuf 64][ilbuf dst][idxbuf 64 x int64].  Pipelined kernels keep LDS
   // at tile + 256 bytes (9 allocation granules of 1280 B -> 14 workgroups per CU): the 32-bit row
@@ -233,7 +248,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     const int h = NH == 1 ? 0 : lane / NP;
     const int i = lane & (NP - 1);
     T* Xh = tile + h * NP * xs;
-    T* Kh = tile + h * NP * KS;
+    T* Kh = tile + h * KMAT;
     T* colh = colbuf + h * NP;
     int64_t* idxh = idxbuf + h * NP;
     const int64_t nb0 = task * NH;
@@ -395,7 +410,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       // are computed now and not kept alive (or spilled) across the distance loop
       int i3 = i;
       asm volatile("" : "+v"(i3));
-      T* Kh3 = tile + (NH == 1 ? 0 : (lane / NP) * NP * KS);
+      T* Kh3 = tile + (NH == 1 ? 0 : (lane / NP) * KMAT);
       if (MGP_PHASE(g, 4)) {
         // All NS covariances first (independent chains the scheduler can interleave), then the
         // stores -- unconditional: an entry whose row is a response slot (hi > q) goes to the
@@ -415,7 +430,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
             for (int s = 1; s <= NS; ++s) kv[s - 1] = cov_from_sqdist<T>(acc_total(acc[s - 1]), KID, MID, post_scale);
           }
         });
-        const int dump = (NP - 1) * KS + NP;  // columns NP .. KS-1 of a row are padding
+        const int dump = TRI ? KMAT - E : (NP - 1) * KS + NP;  // padding behind the last row / columns NP .. KS-1
 #pragma unroll
         for (int s = 1; s <= NS; ++s) {
           // pair j * BP + p - 1: (own row j, partner p)
@@ -424,23 +439,25 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
           const int hi = max(r1, c), lo = min(r1, c);
           T v = kv[s - 1];
           if (!nopad) v = (lo < k && (hi < k || hi == q)) ? v : T(0);
-          Kh3[hi <= q ? hi * KS + lo : dump] = v;
+          Kh3[hi <= q ? rowoff(hi) + lo : dump] = v;
         }
       }
-      Kh3[i3 * KS + i3] = i3 < k ? T(1) + myeps : (i3 <= q ? T(1) : T(0));
-      Kh3[(q + 1) * KS + i3] = myy0;
+      Kh3[rowoff(i3) + i3] = i3 < k ? T(1) + myeps : (i3 <= q ? T(1) : T(0));
+      // response rows: lower-triangle columns only (a packed row ends at its diagonal)
+      if (!TRI || i3 <= q + 1) Kh3[rowoff(q + 1) + i3] = myy0;
       if constexpr (PACKED) {
 #pragma unroll
         for (int r = 1; r < E; ++r)
-          if (r < R) Kh3[(q + 1 + r) * KS + i3] = i3 < k ? myyv[r] : T(0);
+          if (r < R && (!TRI || i3 <= q + 1 + r)) Kh3[rowoff(q + 1 + r) + i3] = i3 < k ? myyv[r] : T(0);
       } else {
-        for (int r = 1; r < R; ++r) Kh3[(q + 1 + r) * KS + i3] = i3 < k ? targets[mytg * (int64_t)R + r] : T(0);
+        for (int r = 1; r < R; ++r)
+          if (!TRI || i3 <= q + 1 + r) Kh3[rowoff(q + 1 + r) + i3] = i3 < k ? targets[mytg * (int64_t)R + r] : T(0);
       }
     }
     __syncthreads();
     V A[NP / E];
 #pragma unroll
-    for (int c4 = 0; c4 < NP / E; ++c4) A[c4] = *reinterpret_cast<const V*>(Kh + i * KS + c4 * E);
+    for (int c4 = 0; c4 < NP / E; ++c4) A[c4] = *reinterpret_cast<const V*>(Kh + rowoff(i) + c4 * E);
 
     // the next task's rows are requested now: their latency hides behind the factorisation, and
     // the registers they land in are not live during the (register-hungry) distance phase
@@ -529,8 +546,9 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
           if (yk) yk[nb] = bad ? num<T>::nan() : -sy;
         }
       }
-    } else if constexpr (PIPED) {
-      // The tile (which the exchange matrix aliases) already receives the next task's rows, so
+    } else if constexpr (PIPED || TRI) {
+      // The tile (which the exchange matrix aliases) already receives the next task's rows (and a
+      // packed exchange matrix has no room for whole rows), so
       // the two entries a lane emits -- column q and the diagonal of its own row -- are picked out
       // of the registers by a compare-select sweep instead of a round trip through LDS.
       T aq = T(0), aii = T(0);
@@ -581,6 +599,8 @@ static int launch_np(const FusedArgs& a, hipStream_t stream) {
   constexpr int E = v16<T>::N;
   constexpr int CH = 2 * E;
   constexpr int KS = NP + E;
+  constexpr bool TRI = NP == 64 && !COEFF;
+  constexpr int KMAT = TRI ? E * (NP / E + 1) * (E * (NP / E) / 2) + NP + E : NP * KS;
   WaveGeom g;
 #ifdef MGP_DEBUG_HOOKS
   g.mask = g_phase_mask;
@@ -598,10 +618,10 @@ static int launch_np(const FusedArgs& a, hipStream_t stream) {
   if ((DFIX > 0 || PIPED) && !g.vec_ok) return MGP_EUNSUPPORTED;
   if (PIPED && a.d > g.dst) return MGP_EUNSUPPORTED;  // more than one feature stage
   g.ntasks = (a.b + NH - 1) / NH;
-  const int rowmax = g.xs > KS ? g.xs : KS;
+  const size_t tile_elems = (size_t)NH * ((size_t)NP * g.xs > (size_t)KMAT ? (size_t)NP * g.xs : (size_t)KMAT);
   constexpr bool PIPE = PIPED;
-  size_t lds = PIPE ? (size_t)NH * NP * rowmax * sizeof(T) + 64 * sizeof(void*)
-                    : ((size_t)NH * NP * rowmax + 64 + g.dst + (g.dst & 1)) * sizeof(T) + 64 * sizeof(int64_t);
+  size_t lds = PIPE ? tile_elems * sizeof(T) + 64 * sizeof(void*)
+                    : (tile_elems + 64 + g.dst + (g.dst & 1)) * sizeof(T) + 64 * sizeof(int64_t);
   lds = (lds + 15) & ~(size_t)15;
 #ifdef MGP_DEBUG_HOOKS
   lds += (size_t)g_lds_pad;
