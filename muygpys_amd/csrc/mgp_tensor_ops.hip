@@ -44,25 +44,39 @@ __global__ void pairwise_diffs_kernel(const T* f, int d, const int64_t* nidx, in
   }
 }
 
-// T1+T3: out[b,j] = metric(q - x_j)
+// Sum over a group of 8 consecutive lanes (a row is walked by 8 lanes, 16 bytes each per step, so the
+// rows of a wave are read as contiguous 128-byte pieces).
+template <typename T>
+__device__ __forceinline__ T group8_sum(T v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  return v;
+}
+
+// T1+T3: out[b,j] = metric(q - x_j): 8 lanes per output
 template <typename T>
 __global__ void crosswise_dists_kernel(const T* fq, const T* fn, int d, const int64_t* bidx, const int64_t* nidx,
                                        int64_t b, int k, int metric_id, T* out) {
   const int64_t n = b * k;
-  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+  const int sub = threadIdx.x & 7;
+  const int64_t rows_per_pass = (int64_t)gridDim.x * blockDim.x / 8;
+  // the 8 lanes of a group share t: a group is wholly inside or outside the loop (shuffles stay in-group)
+  for (int64_t t = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / 8; t < n; t += rows_per_pass) {
     const int64_t bi = t / k;
     const T* q = fq + (bidx ? bidx[bi] : bi) * d;
     const T* x = fn + nidx[t] * d;
     T acc = T(0);
-    for (int c = 0; c < d; ++c) {
+    for (int c = sub; c < d; c += 8) {
       const T df = q[c] - x[c];
       acc += df * df;
     }
-    out[t] = metric_id == MGP_METRIC_L2 ? num<T>::sqrt(acc) : acc;
+    acc = group8_sum(acc);
+    if (sub == 0) out[t] = metric_id == MGP_METRIC_L2 ? num<T>::sqrt(acc) : acc;
   }
 }
 
-// T2+T3: out[b,i,j] = metric(x_i - x_j)
+// T2+T3: out[b,i,j] = metric(x_i - x_j).  Fallback form, one thread per output (any k, d).
 template <typename T>
 __global__ void pairwise_dists_kernel(const T* f, int d, const int64_t* nidx, int64_t b, int k, int metric_id,
                                       T* out) {
@@ -82,17 +96,53 @@ __global__ void pairwise_dists_kernel(const T* f, int d, const int64_t* nidx, in
   }
 }
 
-// T3 (+D2): out[n] = metric(diffs[n,:] / ls[:])
+// T2+T3, tiled: one wave per neighbourhood; its k rows are gathered once into LDS (consecutive lanes
+// walk a row) and every output reads both of its rows from there -- the one-thread-per-output form
+// above fetches 2 k d elements per neighbourhood ROW from the table (k-fold redundant).  Row stride
+// d | 1 elements: lanes of consecutive j read consecutive rows, an odd stride keeps them on distinct banks.
+template <typename T>
+__global__ void pairwise_dists_tile_kernel(const T* f, int d, const int64_t* nidx, int64_t b, int k, int metric_id,
+                                           T* out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_pd[];
+  T* X = reinterpret_cast<T*>(smem_pd);
+  const int xs = d | 1;
+  const int lane = threadIdx.x;
+  for (int64_t nb = blockIdx.x; nb < b; nb += gridDim.x) {
+    __syncthreads();
+    for (int t = lane; t < k * d; t += 64) {
+      const int row = t / d, c = t - row * d;
+      X[row * xs + c] = f[nidx[nb * k + row] * d + c];
+    }
+    __syncthreads();
+    T* o = out + nb * (int64_t)k * k;
+    for (int t = lane; t < k * k; t += 64) {
+      const int i = t / k, j = t - i * k;
+      const T* xi = X + i * xs;
+      const T* xj = X + j * xs;
+      T acc = T(0);
+      for (int c = 0; c < d; ++c) {
+        const T df = xi[c] - xj[c];
+        acc += df * df;
+      }
+      o[t] = metric_id == MGP_METRIC_L2 ? num<T>::sqrt(acc) : acc;
+    }
+  }
+}
+
+// T3 (+D2): out[n] = metric(diffs[n,:] / ls[:]): 8 lanes per row
 template <typename T>
 __global__ void reduce_diffs_kernel(const T* diffs, int64_t n, int d, const T* ls, int metric_id, T* out) {
-  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+  const int sub = threadIdx.x & 7;
+  const int64_t rows_per_pass = (int64_t)gridDim.x * blockDim.x / 8;
+  for (int64_t t = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / 8; t < n; t += rows_per_pass) {
     const T* x = diffs + t * d;
     T acc = T(0);
-    for (int c = 0; c < d; ++c) {
+    for (int c = sub; c < d; c += 8) {
       const T df = ls ? x[c] / ls[c] : x[c];
       acc += df * df;
     }
-    out[t] = metric_id == MGP_METRIC_L2 ? num<T>::sqrt(acc) : acc;
+    acc = group8_sum(acc);
+    if (sub == 0) out[t] = metric_id == MGP_METRIC_L2 ? num<T>::sqrt(acc) : acc;
   }
 }
 
@@ -361,7 +411,7 @@ template <typename T>
 int launch_crosswise_dists(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t* ni, int64_t b, int k,
                            int metric, T* out, hipStream_t s) {
   if (b * k == 0) return MGP_OK;
-  hipLaunchKernelGGL(crosswise_dists_kernel<T>, dim3(grid_1d(b * k)), dim3(kBlock), 0, s, fq, fn, d, bi, ni, b, k,
+  hipLaunchKernelGGL(crosswise_dists_kernel<T>, dim3(grid_1d(b * k * 8)), dim3(kBlock), 0, s, fq, fn, d, bi, ni, b, k,
                      metric, out);
   MGP_HIP_CHECK_LAUNCH();
   return MGP_OK;
@@ -370,6 +420,15 @@ template <typename T>
 int launch_pairwise_dists(const T* f, int d, const int64_t* ni, int64_t b, int k, int metric, T* out,
                           hipStream_t s) {
   if (b * k == 0) return MGP_OK;
+  const size_t lds = (size_t)k * (d | 1) * sizeof(T);
+  if (lds <= 40 * 1024) {  // the neighbourhood's rows fit LDS: gather them once
+    const int64_t cap = 256LL * (lds ? (int64_t)((160 * 1024) / (((lds + 1279) / 1280) * 1280)) : 32);
+    int64_t g = cap < 256LL * 32 ? cap : 256LL * 32;
+    if (g > b) g = b;
+    hipLaunchKernelGGL(pairwise_dists_tile_kernel<T>, dim3((unsigned)g), dim3(64), lds, s, f, d, ni, b, k, metric, out);
+    MGP_HIP_CHECK_LAUNCH();
+    return MGP_OK;
+  }
   hipLaunchKernelGGL(pairwise_dists_kernel<T>, dim3(grid_1d(b * k * k)), dim3(kBlock), 0, s, f, d, ni, b, k, metric,
                      out);
   MGP_HIP_CHECK_LAUNCH();
@@ -378,7 +437,7 @@ int launch_pairwise_dists(const T* f, int d, const int64_t* ni, int64_t b, int k
 template <typename T>
 int launch_reduce_diffs(const T* diffs, int64_t n, int d, const T* ls, int metric, T* out, hipStream_t s) {
   if (n == 0) return MGP_OK;
-  hipLaunchKernelGGL(reduce_diffs_kernel<T>, dim3(grid_1d(n)), dim3(kBlock), 0, s, diffs, n, d, ls, metric, out);
+  hipLaunchKernelGGL(reduce_diffs_kernel<T>, dim3(grid_1d(n * 8)), dim3(kBlock), 0, s, diffs, n, d, ls, metric, out);
   MGP_HIP_CHECK_LAUNCH();
   return MGP_OK;
 }
