@@ -151,13 +151,16 @@ def cpu_baseline(k: int, d: int, sample: int, seed: int):
     _cpu_worker((k, d, 0, 256, seed, False, 256))  # warm (imports, page-ins)
     for name, fp32, procs in (("fp64_1proc", False, 1), ("fp32_1proc", True, 1), ("fp64_Pproc", False, P),
                               ("fp32_Pproc", True, P)):
-        n_s = sample if procs == 1 else sample * min(procs, 32)
+        n_s = sample if procs == 1 else sample * min(procs, 16)
         if procs == 1:
             dt = _cpu_worker((k, d, 0, n_s, seed, fp32, 1024))
         else:
             # every process computes its block concurrently; the slowest one's compute time counts
             # (process start-up and the synthetic-data set-up are not part of the reference's timing either)
             bounds = np.linspace(0, n_s, procs + 1).astype(int)
+            # one BLAS / OpenMP thread per worker process (set before the children import numpy)
+            for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+                os.environ[var] = "1"
             with mp.get_context("spawn").Pool(procs) as pool:
                 # small chunks: P processes x the (chunk, k, k, d) difference tensor must fit the host
                 dt = max(pool.map(_cpu_worker, [(k, d, int(bounds[i]), int(bounds[i + 1]), seed, fp32, 128)

@@ -232,12 +232,17 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
           const V cv = *reinterpret_cast<const V*>(colbuf + c4 * E);
           A[c4] = cv * nt + A[c4];
         }
+        // right-hand sides in whole 16-byte groups: packed FMAs (the tail of the last group is unused)
 #pragma unroll
         for (int r4 = 0; r4 < NRV; ++r4) {
           const V rv = *reinterpret_cast<const V*>(rhsbuf + r4 * E);
+          V mine;
+#pragma unroll
+          for (int e = 0; e < E; ++e) mine[e] = r4 * E + e < NR ? rhs[r4 * E + e] : T(0);
+          mine = rv * nt + mine;
 #pragma unroll
           for (int e = 0; e < E; ++e)
-            if (r4 * E + e < NR) rhs[r4 * E + e] = fma_t(-t, rv[e], rhs[r4 * E + e]);
+            if (r4 * E + e < NR) rhs[r4 * E + e] = mine[e];
         }
       }
     }

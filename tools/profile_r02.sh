@@ -19,3 +19,5 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_grbm -- python3 be
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 find $O -name "*.csv" -size +3000k -delete
 ls -la $O $O/*/* | head -80
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_wide -- python3 tools/kbench.py --k 100 --d 40 --b 200000 --paths auto,generic --rounds 3 > $O/stats_wide.log 2> $O/stats_wide.err
+find $O -name "*kernel_trace.csv" -size +2000k -delete
