@@ -95,6 +95,9 @@ class PackedTable:
             t = (targets[:, None] if targets.ndim == 1 else targets).to(f.dtype).contiguous()
             if t.shape[0] != f.shape[0]:
                 raise ValueError("features and targets differ in row count")
+        # the source tensors stay referenced for as long as this table lives: the cache below is keyed on
+        # their addresses, which must not be handed to another tensor meanwhile
+        self._sources = (features, targets)
         self.n, self.d = f.shape
         self.R = 0 if t is None else t.shape[1]
         self.dtype = f.dtype
@@ -134,6 +137,13 @@ def pack_table(features: torch.Tensor, targets: Optional[torch.Tensor] = None) -
     else:
         _PACK_CACHE.move_to_end(key)
     return hit
+
+
+def clear_caches() -> None:
+    """Drop the cached prepared tables (and with them the references to their source tensors) and the
+    cached device-resident length scales."""
+    _PACK_CACHE.clear()
+    _LS_CACHE.clear()
 
 
 def _check_indices(name: str, idx: Optional[torch.Tensor], n: int) -> None:
