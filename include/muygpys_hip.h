@@ -191,6 +191,47 @@ int mgp_posterior_packed_f64(const void* packed_q, int64_t q_stride_bytes, const
                              int kernel_id, int metric_id, const double* length_scale, int ls_count,
                              double* mean, double* var, double* ykinvy, int* info, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * One LOOCV objective evaluation of a shard in one call: mgp_posterior_* with
+ * the training table on both sides (gp/muygps.py:406-551 under
+ * optimize/objective.py:95-103), followed -- on the same stream, without the
+ * host touching mean / var -- by the fp64 partial sums the losses and the
+ * analytic scale are made of (optimize/loss.py:159-168, _src/optimize/loss/
+ * numpy.py:22-61, _src/optimize/scale/numpy.py:11-18):
+ *     partials[6] = { sum r^2/v, sum log v, sum r^2, b, sum pseudo-Huber(r; huber_delta),
+ *                     sum y^T K^-1 y },   r = mean - y[batch row]
+ * from which sigma^2 = partials[5] / (b k) and lool = partials[0] / sigma^2 +
+ * partials[1] + b log sigma^2 (mse = partials[2] / b) follow on the host -- and,
+ * sharded, after ONE all-reduce of the six numbers (_src/optimize/loss/mpi.py:
+ * 57-70, scale/mpi.py:35-36).  One response (the losses' domain).  mean / var /
+ * ykinvy (b each) are written as by mgp_posterior_*; scratch =
+ * mgp_reduce_scratch_doubles() doubles; the reduction is a fixed-order two-stage
+ * one (bit-reproducible).  mgp_loocv_packed_* reads one prepared table
+ * (MGP_EUNSUPPORTED where mgp_posterior_packed_* is).
+ * ------------------------------------------------------------------------- */
+int mgp_loocv_f32(const float* features, int d, const int64_t* batch_idx, const int64_t* nn_idx, int64_t b, int k,
+                  const float* targets, int noise_mode, double noise_scalar, const float* noise_dev,
+                  int kernel_id, int metric_id, const float* length_scale, int ls_count,
+                  float* mean, float* var, float* ykinvy, int* info,
+                  double huber_delta, double* partials, double* scratch, void* stream);
+int mgp_loocv_f64(const double* features, int d, const int64_t* batch_idx, const int64_t* nn_idx, int64_t b, int k,
+                  const double* targets, int noise_mode, double noise_scalar, const double* noise_dev,
+                  int kernel_id, int metric_id, const double* length_scale, int ls_count,
+                  double* mean, double* var, double* ykinvy, int* info,
+                  double huber_delta, double* partials, double* scratch, void* stream);
+int mgp_loocv_packed_f32(const void* packed, int64_t stride_bytes, int d, const int64_t* batch_idx,
+                         const int64_t* nn_idx, int64_t b, int k,
+                         int noise_mode, double noise_scalar, const float* noise_dev,
+                         int kernel_id, int metric_id, const float* length_scale, int ls_count,
+                         float* mean, float* var, float* ykinvy, int* info,
+                         double huber_delta, double* partials, double* scratch, void* stream);
+int mgp_loocv_packed_f64(const void* packed, int64_t stride_bytes, int d, const int64_t* batch_idx,
+                         const int64_t* nn_idx, int64_t b, int k,
+                         int noise_mode, double noise_scalar, const double* noise_dev,
+                         int kernel_id, int metric_id, const double* length_scale, int ls_count,
+                         double* mean, double* var, double* ykinvy, int* info,
+                         double huber_delta, double* partials, double* scratch, void* stream);
+
 /* Fused coefficient precompute of the fast posterior mean: coeffs (b, k) = (K_b + eps)^-1 y_b
  * for the neighbourhoods nn_idx (b, k) of one table (gather -> distances -> kernel -> nugget ->
  * LDL^T -> back-substitution in one launch).  Replaces _muygps_fast_posterior_mean_precompute

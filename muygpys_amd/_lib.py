@@ -66,6 +66,8 @@ _SIGS = {
     "posterior_gathered": [_p, _p, _i, _p, _p, _l, _i, _p, _i, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p],
     "posterior_packed": [_p, _l, _p, _l, _i, _p, _p, _l, _i, _i, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p],
     "table_pack": [_p, _p, _l, _i, _i, _p, _l, _p],
+    "loocv": [_p, _i, _p, _p, _l, _i, _p, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p, _p, _d, _p, _p, _p],
+    "loocv_packed": [_p, _l, _i, _p, _p, _l, _i, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p, _p, _d, _p, _p, _p],
     "loss_sums": [_p, _p, _p, _l, _p, _d, _d, _p, _p, _p],
     "column_sums": [_p, _l, _i, _p, _p, _p],
     "posterior_backward": [_p, _p, _i, _p, _p, _l, _i, _p, _i, _i, _d, _p, _i, _i, _p, _i,

@@ -117,6 +117,9 @@ template <typename T> int launch_perturb(const T*, int64_t, int, int, double, co
 template <typename T>
 int launch_loss_sums(const T*, const T*, const T*, int64_t, const double*, double, double, double*, double*, hipStream_t);
 template <typename T> int launch_column_sums(const T*, int64_t, int, double*, double*, hipStream_t);
+template <typename T>
+int launch_loocv_partials(const T*, const T*, const T*, const void*, int64_t, const int64_t*, int64_t, double, double*,
+                          double*, hipStream_t);
 int reduce_scratch_doubles();
 template <typename T> int launch_matern_gen(const T*, int64_t, double, double, T*, hipStream_t);
 void matern_gen_constants_host(double nu, double* out7);

@@ -183,7 +183,7 @@ int mgp_posterior_f64(const double* fq, const double* fn, int d, const int64_t* 
   }                                                                                                                  \
   int mgp_table_pack_##SUF(const T* feat, const T* targets, int64_t n, int d, int R, void* packed,                   \
                            int64_t stride_bytes, void* st) {                                                         \
-    if (!feat || !packed || n < 0 || d < 1 || R < 0 || false) return MGP_EINVAL;              \
+    if (!feat || !packed || n < 0 || d < 1 || R < 0) return MGP_EINVAL;                                              \
     return launch_table_pack<T>(feat, targets, n, d, R, packed, stride_bytes, S_(st));                               \
   }                                                                                                                  \
   int mgp_posterior_packed_##SUF(const void* packed_q, int64_t q_stride, const void* packed_nn, int64_t nn_stride,   \
@@ -192,6 +192,27 @@ int mgp_posterior_f64(const double* fq, const double* fn, int d, const int64_t* 
                                  T* yk, int* info, void* st) {                                                       \
     return posterior<T>(nullptr, nullptr, d, bi, ni, b, k, nullptr, R, nm, eps, nd, kid, mid, ls, lsc, mean, var,   \
                         yk, info, st, PATH_AUTO, packed_q, q_stride, packed_nn, nn_stride);                          \
+  }                                                                                                                  \
+  int mgp_loocv_##SUF(const T* feat, int d, const int64_t* bi, const int64_t* ni, int64_t b, int k, const T* tg,     \
+                      int nm, double eps, const T* nd, int kid, int mid, const T* ls, int lsc, T* mean, T* var,      \
+                      T* yk, int* info, double huber_delta, double* partials, double* scratch, void* st) {           \
+    if ((b > 0 && (!mean || !var || !yk)) || !partials || !scratch || !(huber_delta > 0)) return MGP_EINVAL;         \
+    const int rc = posterior<T>(feat, feat, d, bi, ni, b, k, tg, 1, nm, eps, nd, kid, mid, ls, lsc, mean, var, yk,  \
+                                info, st);                                                                           \
+    if (rc != MGP_OK) return rc;                                                                                     \
+    return launch_loocv_partials<T>(mean, var, yk, tg, (int64_t)sizeof(T), bi, b, huber_delta, partials, scratch,    \
+                                    S_(st));                                                                         \
+  }                                                                                                                  \
+  int mgp_loocv_packed_##SUF(const void* packed, int64_t stride, int d, const int64_t* bi, const int64_t* ni,        \
+                             int64_t b, int k, int nm, double eps, const T* nd, int kid, int mid, const T* ls,       \
+                             int lsc, T* mean, T* var, T* yk, int* info, double huber_delta, double* partials,       \
+                             double* scratch, void* st) {                                                            \
+    if ((b > 0 && (!mean || !var || !yk)) || !partials || !scratch || !(huber_delta > 0)) return MGP_EINVAL;         \
+    const int rc = posterior<T>(nullptr, nullptr, d, bi, ni, b, k, nullptr, 1, nm, eps, nd, kid, mid, ls, lsc, mean, \
+                                var, yk, info, st, PATH_AUTO, packed, stride, packed, stride);                       \
+    if (rc != MGP_OK) return rc;                                                                                     \
+    return launch_loocv_partials<T>(mean, var, yk, static_cast<const char*>(packed) + (size_t)d * sizeof(T), stride, \
+                                    bi, b, huber_delta, partials, scratch, S_(st));                                  \
   }
 MGP_DEFINE_PATHS(f32, float)
 MGP_DEFINE_PATHS(f64, double)

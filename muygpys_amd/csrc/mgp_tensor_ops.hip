@@ -365,6 +365,29 @@ __global__ void loss_sums_kernel(const T* pred, const T* target, const T* var, i
   block_reduce_store<6>(acc, out, scratch);
 }
 
+// LOOCV partial sums of one shard (optimize/loss.py:159-168 with scale/numpy.py:11-18 folded in):
+// [sum r^2/v, sum log v, sum r^2, n, sum pseudo-Huber(r), sum y^T K^-1 y], r = mean - y(batch row).
+// The batch row's response is read where the fused launch read it: resp + row * stride (bytes) --
+// the response tensor (stride = sizeof T) or a prepared table (stride = row bytes, resp offset d).
+template <typename T>
+__global__ void loocv_partials_kernel(const T* mean, const T* var, const T* yk, const char* resp, int64_t stride,
+                                      const int64_t* batch_idx, int64_t n, double hd, double* scratch) {
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = batch_idx ? batch_idx[t] : t;
+    const double y = (double)*reinterpret_cast<const T*>(resp + row * stride);
+    const double r = (double)mean[t] - y, v = (double)var[t];
+    const double r2 = r * r;
+    acc[0] += r2 / v;
+    acc[1] += ::log(v);
+    acc[2] += r2;
+    acc[3] += 1.0;
+    acc[4] += hd * hd * (::sqrt(1.0 + (r / hd) * (r / hd)) - 1.0);
+    acc[5] += (double)yk[t];
+  }
+  block_reduce_store<6>(acc, nullptr, scratch);
+}
+
 template <typename T>
 __global__ void column_sums_kernel(const T* x, int64_t n, int R, double* out, double* scratch) {
   // one column at a time (R is small); rows strided over the whole grid
@@ -493,6 +516,23 @@ int launch_column_sums(const T* x, int64_t n, int R, double* out, double* scratc
   }
   return MGP_OK;
 }
+template <typename T>
+int launch_loocv_partials(const T* mean, const T* var, const T* yk, const void* resp, int64_t stride,
+                          const int64_t* batch_idx, int64_t n, double hd, double* out, double* scratch, hipStream_t s) {
+  if (!scratch || !out) return MGP_EINVAL;
+  if (n == 0) {
+    hipError_t e = hipMemsetAsync(out, 0, 6 * sizeof(double), s);
+    return e == hipSuccess ? MGP_OK : -(1000 + (int)e);
+  }
+  int g = grid_1d(n);
+  if (g > kReduceBlocks) g = kReduceBlocks;
+  hipLaunchKernelGGL(loocv_partials_kernel<T>, dim3(g), dim3(kBlock), 0, s, mean, var, yk,
+                     static_cast<const char*>(resp), stride, batch_idx, n, hd, scratch);
+  MGP_HIP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kBlock), 0, s, scratch, g, 6, out);
+  MGP_HIP_CHECK_LAUNCH();
+  return MGP_OK;
+}
 int reduce_scratch_doubles() { return kReduceBlocks * 6; }
 
 template <typename T>
@@ -520,6 +560,8 @@ int launch_table_pack(const T* feat, const T* targets, int64_t n, int d, int R, 
   template int launch_loss_sums<T>(const T*, const T*, const T*, int64_t, const double*, double, double, double*,  \
                                    double*, hipStream_t);                                                          \
   template int launch_column_sums<T>(const T*, int64_t, int, double*, double*, hipStream_t);                        \
+  template int launch_loocv_partials<T>(const T*, const T*, const T*, const void*, int64_t, const int64_t*, int64_t, \
+                                        double, double*, double*, hipStream_t);                                     \
   template int launch_table_pack<T>(const T*, const T*, int64_t, int, int, void*, int64_t, hipStream_t);          \
   template int launch_matern_gen<T>(const T*, int64_t, double, double, T*, hipStream_t);
 MGP_INSTANTIATE(float)

@@ -138,29 +138,13 @@ LOSSES = ("lool", "mse", "looph", "pseudo_huber")
 
 
 def hip_local_partials(spec, features, targets, batch_indices, nn_indices, packed="auto", huber_delta: float = 1.5):
-    """The local shard's partial sums on the GPU: one fused launch + two fp64 reductions.
+    """The local shard's partial sums on the GPU: ONE library call (``mgp_loocv_*``: the fused launch
+    and a fixed-order fp64 reduction on the same stream; nothing returns to the host in between).
 
-    Returns ``(partials float64 [5 + R], mean, var)`` -- all device tensors."""
-    from muygpys_amd import _lib
-    from muygpys_amd.fused import posterior_mean_var
+    Returns ``(partials float64 [6], mean, var)`` -- all device tensors."""
+    from muygpys_amd.fused import loocv_partials
 
-    mean, var, yk = posterior_mean_var(spec, features, features, batch_indices, nn_indices, targets, want_ykinvy=True,
-                                       packed=packed)
-    b = nn_indices.shape[0]
-    R = 1 if targets.ndim == 1 else targets.shape[1]
-    out = torch.zeros(P_YKY0 + R, device=features.device, dtype=torch.float64)
-    if b > 0:
-        if R != 1:
-            raise NotImplementedError("the LOOCV losses are defined for a single response (reference: loss/numpy.py:34-61)")
-        mean_c, yb = mean.contiguous(), targets[batch_indices].contiguous()
-        sums = _lib.loss_sums(mean_c, yb, var, None, huber_delta, 3.0)
-        out[P_YKY0:] = _lib.column_sums(yk.reshape(b, R).contiguous())
-        out[P_R2_OVER_V] = sums[4]
-        out[P_LOG_V] = sums[5]
-        out[P_R2] = sums[0]
-        out[P_COUNT] = float(b)
-        out[P_HUBER] = sums[2]
-    return out, mean, var
+    return loocv_partials(spec, features, targets, batch_indices, nn_indices, huber_delta=huber_delta, packed=packed)
 
 
 def hip_local_looph(mean, targets_b, var, sigma_sq: float, looph_delta: float = 3.0) -> torch.Tensor:

@@ -279,6 +279,65 @@ def posterior_mean_var(
     return mean_out, var
 
 
+def loocv_partials(
+    spec: KernelSpec,
+    train_features: torch.Tensor,
+    train_targets: torch.Tensor,
+    batch_indices: torch.Tensor,
+    nn_indices: torch.Tensor,
+    huber_delta: float = 1.5,
+    packed: Union[str, bool] = "auto",
+    info: Optional[torch.Tensor] = None,
+):
+    """One shard's LOOCV evaluation in one library call (``mgp_loocv_*``): the fused launch over
+    the training table on both sides, then the six fp64 partial sums
+    ``[sum r^2/v, sum log v, sum r^2, b, sum pseudo-Huber, sum y^T K^-1 y]`` the losses
+    (_src/optimize/loss/numpy.py:22-61) and the analytic scale (scale/numpy.py:11-18) are built
+    from -- no host work between the two.  Returns ``(partials float64 (6,), mean (b,), var (b,))``,
+    all on the device.  One response."""
+    _lib.require_cuda(train_features, train_targets, batch_indices, nn_indices)
+    dtype = train_features.dtype
+    if train_targets.dtype != dtype:
+        raise TypeError("features and targets must share one float dtype")
+    fn = (train_features[:, None] if train_features.ndim == 1 else train_features).contiguous()
+    tg = train_targets.reshape(train_targets.shape[0], -1).contiguous()
+    if tg.shape[1] != 1:
+        raise NotImplementedError("the LOOCV losses are defined for a single response (reference: loss/numpy.py:34-61)")
+    if tg.shape[0] != fn.shape[0]:
+        raise ValueError("train_features and train_targets differ in row count")
+    d = fn.shape[1]
+    ni = nn_indices.to(torch.int64).contiguous()
+    b, k = ni.shape
+    bi = batch_indices.to(torch.int64).contiguous()
+    if bi.shape != (b,):
+        raise ValueError("batch_indices must have shape (batch_count,)")
+    if os.environ.get("MUYGPYS_HIP_CHECK_INDICES") == "1":
+        _check_indices("nn_indices", ni, fn.shape[0])
+        _check_indices("batch_indices", bi, fn.shape[0])
+    ls = _length_scale_tensor(spec.length_scale, d, fn)
+    mode, eps, nz = _noise_args(spec.noise, b, k, fn)
+    mean = torch.empty((b,), device=fn.device, dtype=dtype)
+    var = torch.empty((b,), device=fn.device, dtype=dtype)
+    yk = torch.empty((b,), device=fn.device, dtype=dtype)
+    partials = torch.empty(6, device=fn.device, dtype=torch.float64)
+    scratch = _lib.reduce_scratch(fn.device)
+    tail = (mode, eps, _lib.ptr(nz), spec.kernel_id(), spec.metric_id(), _lib.ptr(ls), ls.numel(), _lib.ptr(mean),
+            _lib.ptr(var), _lib.ptr(yk), _lib.ptr(info), float(huber_delta), _lib.ptr(partials), _lib.ptr(scratch),
+            _lib.stream_ptr())
+    rc = -2
+    use_packed = packed is not False and PackedTable.supported(d, 1, k, dtype) and b > 0
+    if use_packed and packed == "auto":
+        key = (_tensor_key(train_features), _tensor_key(train_targets))
+        use_packed = key in _PACK_CACHE or b * (k + 1) >= fn.shape[0] // 4
+    if use_packed:
+        pn = pack_table(train_features, train_targets)
+        rc = _lib.fn("loocv_packed", dtype)(_lib.ptr(pn.data), pn.stride, d, _lib.ptr(bi), _lib.ptr(ni), b, k, *tail)
+    if rc == -2:
+        rc = _lib.fn("loocv", dtype)(_lib.ptr(fn), d, _lib.ptr(bi), _lib.ptr(ni), b, k, _lib.ptr(tg), *tail)
+    _lib.check(rc, "mgp_loocv")
+    return partials, mean, var
+
+
 def fast_posterior_mean(
     spec: KernelSpec,
     test_features: torch.Tensor,

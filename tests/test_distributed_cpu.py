@@ -177,3 +177,51 @@ def test_two_rank_lbfgsb_equals_serial():
     assert got[0][2] == got[1][2], "both ranks must walk the same trajectory"
     np.testing.assert_allclose(got[0][2], ref[2], rtol=1e-6)
     np.testing.assert_allclose(got[0][3], ref[3], rtol=1e-10)
+
+
+def _bayes_worker(rank, world, port, q):
+    """The Bayes driver under sharded reductions: no random_state given, ranks seeded differently."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from muygpys_amd import distributed as D
+        from muygpys_amd._src.optimize.chassis.hip import _bayes_opt_optimize
+        from muygpys_amd.fused import KernelSpec
+        from muygpys_amd.gp import MuyGPS
+        from muygpys_amd.gp.deformation import Isotropy, l2
+        from muygpys_amd.gp.hyperparameter import Parameter
+        from muygpys_amd.gp.kernels import Matern
+        from muygpys_amd.gp.noise import HomoscedasticNoise
+        from tests.conftest import load_golden
+
+        g = load_golden("m15_iso_l2_k10_d8")
+        X, y = torch.from_numpy(g["features"]), torch.from_numpy(g["targets"])
+        bi, ni = torch.from_numpy(g["batch_idx"]), torch.from_numpy(g["nn_idx"])
+        np.random.seed(7 + 13 * rank)  # the drivers' own seeds would differ
+        model = MuyGPS(Matern(smoothness=Parameter(1.5), deformation=Isotropy(l2, length_scale=Parameter(2.0, (0.5, 8.0)))),
+                       noise=HomoscedasticNoise(g["meta"]["noise"]))
+        obj = D.spec_objective(lambda length_scale: KernelSpec("matern15", "l2", length_scale, g["meta"]["noise"]),
+                               X, y, bi, ni, loss="lool", local_fn=oracle_local_partials)
+        with D.sharded_reductions():
+            opt = _bayes_opt_optimize(model, obj, init_points=3, n_iter=4)
+        q.put((rank, float(opt.kernel.deformation.length_scale())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_bayes_driver_proposes_the_same_points():
+    """Config-4 style loop: the GP-UCB driver's random state is rank 0's when the reductions are
+    sharded, so both ranks evaluate the same trial points and return the same model."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bayes_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][1] == got[1][1]
+    assert 0.5 <= got[0][1] <= 8.0

@@ -47,6 +47,40 @@ def test_partials_and_finish(golden, dtype):
     assert_close(torch.cat(means).cpu().numpy(), g["mean"], rtol, "concatenated shard means")
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("packed", [False, True])
+def test_loocv_call_equals_the_three_call_composition(dtype, packed):
+    """``mgp_loocv_*`` (one call) against ``mgp_posterior_*`` + ``mgp_loss_sums_*`` + ``mgp_column_sums_*``:
+    the same kernels and the same fixed-order reductions, so the six sums agree to the last bit."""
+    from muygpys_amd import _lib
+    from muygpys_amd.fused import KernelSpec, loocv_partials, posterior_mean_var
+
+    td = getattr(torch, dtype)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    n, d, k, b = 30000, 40, 30, 20011
+    X = torch.randn((n, d), device="cuda", dtype=td, generator=g)
+    y = torch.sin(X[:, 0]) + 0.1 * torch.randn((n,), device="cuda", dtype=td, generator=g)
+    bi = torch.randperm(n, device="cuda", generator=g)[:b]
+    ni = torch.randint(0, n - 1, (b, k), device="cuda", generator=g)
+    ni = ni + (ni >= bi[:, None])
+    spec = KernelSpec("matern15", "l2", 5.0, 1e-3)
+    p, mean, var = loocv_partials(spec, X, y, bi, ni, huber_delta=1.5, packed=packed)
+    m2, v2, yk2 = posterior_mean_var(spec, X, X, bi, ni, y, want_ykinvy=True, packed=packed)
+    assert torch.equal(mean, m2) and torch.equal(var, v2)
+    sums = _lib.loss_sums(m2.contiguous(), y[bi].contiguous(), v2, None, 1.5, 3.0)
+    yks = _lib.column_sums(yk2.reshape(b, 1).contiguous())
+    expect = torch.stack([sums[4], sums[5], sums[0], torch.tensor(float(b), device="cuda", dtype=torch.float64),
+                          sums[2], yks[0]])
+    assert torch.equal(p, expect), (p.tolist(), expect.tolist())
+    # and against plain fp64 torch arithmetic on the same outputs
+    r = m2.double() - y[bi].double()
+    ref = torch.stack([(r * r / v2.double()).sum(), v2.double().log().sum(), (r * r).sum()])
+    torch.testing.assert_close(p[:3], ref, rtol=1e-12, atol=0)
+    # an empty shard contributes zeros
+    p0, m0, _ = loocv_partials(spec, X, y, bi[:0], ni[:0], packed=packed)
+    assert m0.shape == (0,) and torch.equal(p0, torch.zeros(6, device="cuda", dtype=torch.float64))
+
+
 def test_sharded_batch_nns_concatenates_to_the_unsharded_search():
     """Three emulated ranks (reference chunk rule, remainder to the last ranks) each search their
     block of the batch; concatenated in rank order the result is the single-process search."""
