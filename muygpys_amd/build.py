@@ -21,7 +21,12 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-
          # explicit vector types carry the packed-f32 math; the SLP vectoriser only shuffles registers
          "-fno-slp-vectorize"]
 # the k-NN scans test the MFMA results right away: keep them in VGPRs (no v_accvgpr_read per value)
-PER_FILE_FLAGS = {"mgp_knn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+PER_FILE_FLAGS = {
+    "mgp_knn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+    # the 64-step elimination must unroll completely (the fp64 / 16-response body exceeds the default
+    # pragma-unroll budget, and a rolled loop indexes the 128-register row at run time = in scratch)
+    "mgp_fused_rhs.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
+}
 
 
 def _hipcc() -> str:

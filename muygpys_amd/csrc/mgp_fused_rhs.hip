@@ -77,16 +77,10 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
     idxbuf[i] = myidx * (int64_t)d;
     if (i == 0) idxbuf[NP] = qidx * (int64_t)d;
     T myeps = T(0);
-    T rhs[NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) rhs[r] = T(0);
     if (i < k) {
       if (a.noise_mode == MGP_NOISE_SCALAR) myeps = (T)a.noise_scalar;
       else if (a.noise_mode == MGP_NOISE_TABLE) myeps = noise_dev[myidx];
       else myeps = noise_dev[nb * k + i];
-#pragma unroll
-      for (int r = 0; r < RC; ++r)
-        if (r < R) rhs[1 + r] = targets[(a.targets_batch ? nb * k + i : myidx) * (int64_t)R + r];
     }
 
     // ---- gather + distances (pairwise: cyclic scheme; crosswise: lane i vs the query) ------
@@ -155,31 +149,44 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
         if (aniso) {
           accum(accq, vsub(own0[0], q0) * il0);
           accum(accq, vsub(own1[0], q1) * il1);
-#pragma unroll
-          for (int s = 1; s <= BP; ++s) {
+          // compile-time pair indices (an unroll the compiler declines would put acc[] in scratch)
+          static_for<BP>([&](auto sc) {
+            constexpr int s = decltype(sc)::value + 1;
             const T* xo = tile + ((i + s) & (NP - 1)) * xs + c0;
             const V o0 = *reinterpret_cast<const V*>(xo), o1 = *reinterpret_cast<const V*>(xo + E);
-#pragma unroll
-            for (int j = 0; j < BA; ++j) {
+            static_for<BA>([&](auto jc) {
+              constexpr int j = decltype(jc)::value;
               accum(acc[j * BP + s - 1], vsub(own0[j], o0) * il0);
               accum(acc[j * BP + s - 1], vsub(own1[j], o1) * il1);
-            }
-          }
+            });
+          });
         } else {
           accum(accq, vsub(own0[0], q0));
           accum(accq, vsub(own1[0], q1));
-#pragma unroll
-          for (int s = 1; s <= BP; ++s) {
+          static_for<BP>([&](auto sc) {
+            constexpr int s = decltype(sc)::value + 1;
             const T* xo = tile + ((i + s) & (NP - 1)) * xs + c0;
             const V o0 = *reinterpret_cast<const V*>(xo), o1 = *reinterpret_cast<const V*>(xo + E);
-#pragma unroll
-            for (int j = 0; j < BA; ++j) {
+            static_for<BA>([&](auto jc) {
+              constexpr int j = decltype(jc)::value;
               accum(acc[j * BP + s - 1], vsub(own0[j], o0));
               accum(acc[j * BP + s - 1], vsub(own1[j], o1));
-            }
-          }
+            });
+          });
         }
       }
+    }
+
+    // ---- responses of the lane's row: requested only now (1 + R registers the distance phase has
+    // no room for); the loads fly while the covariances are evaluated and exchanged -----------------
+    T rhs[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) rhs[r] = T(0);
+    if (i < k) {
+      const T* ty = targets + (a.targets_batch ? nb * k + i : myidx) * (int64_t)R;
+#pragma unroll
+      for (int r = 0; r < RC; ++r)
+        if (r < R) rhs[1 + r] = ty[r];
     }
 
     // ---- covariances -> exchange matrix -> row per lane; cross-covariance stays in the lane ----
@@ -189,17 +196,19 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
       T kq = T(0);
       kernel_dispatch(a.kernel_id, a.metric_id, [&](auto kid, auto mid) {
         constexpr int KID = decltype(kid)::value, MID = decltype(mid)::value;
-#pragma unroll
-        for (int s = 1; s <= NS; ++s) kv[s - 1] = cov_from_sqdist<T>(acc_total(acc[s - 1]), KID, MID, post_scale);
+        static_for<NS>([&](auto sc) {
+          constexpr int s = decltype(sc)::value;
+          kv[s] = cov_from_sqdist<T>(acc_total(acc[s]), KID, MID, post_scale);
+        });
         kq = cov_from_sqdist<T>(acc_total(accq), KID, MID, post_scale);
       });
-#pragma unroll
-      for (int s = 1; s <= NS; ++s) {
+      static_for<NS>([&](auto sc) {
+        constexpr int s = decltype(sc)::value + 1;
         const int r1 = (i + own_offset((s - 1) / BP)) & (NP - 1);  // pair j * BP + p - 1: (own row j, partner p)
         const int c = (i + (s - 1) % BP + 1) & (NP - 1);
         const int hi = max(r1, c), lo = min(r1, c);
         tile[hi * KS + lo] = hi < k ? kv[s - 1] : T(0);  // unused slots: identity rows
-      }
+      });
       tile[i * KS + i] = i < k ? T(1) + myeps : T(1);
       rhs[0] = i < k ? kq : T(0);
     }
@@ -209,43 +218,66 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
     for (int c4 = 0; c4 < NP / E; ++c4) A[c4] = *reinterpret_cast<const V*>(tile + i * KS + c4 * E);
 
     // ---- elimination with rhs columns ----------------------------------------------------------
+    // Per step: every lane posts its column-j entry (one ds_write_b32), all trailing 16-byte groups of
+    // the column are requested at once (the reads stay in flight together: serialised read -> wait ->
+    // FMA pairs cost an LDS round trip per group), and lane j's 1 + R right-hand sides are broadcast
+    // through SGPRs (v_readlane, j is a compile-time lane) instead of a second LDS round trip.
+    V rv[NRV];
+#pragma unroll
+    for (int r4 = 0; r4 < NRV; ++r4)
+#pragma unroll
+      for (int e = 0; e < E; ++e) rv[r4][e] = r4 * E + e < NR ? rhs[r4 * E + e] : T(0);
     bool bad = false;
     T mypiv = T(1);
+    // unused slots (k .. 63) are identity rows: eliminating them changes nothing, so the k test is
+    // made once per JB steps (a branch per step costs a register shuffle at every merge point)
+    constexpr int JB = 8;
 #pragma unroll
-    for (int j = 0; j < NP; ++j) {
-      if (j < k) {
+    for (int jb = 0; jb < NP; jb += JB) {
+      if (jb < k)
+#pragma unroll
+      for (int j = jb; j < jb + JB; ++j) {
         const T ajj = A[j / E][j % E];
         colbuf[i] = ajj;
-        if (i == j) {
+        V bj[NRV];
 #pragma unroll
-          for (int r = 0; r < NR; ++r) rhsbuf[r] = rhs[r];
-        }
-        const V cp = *reinterpret_cast<const V*>(colbuf + (j / E) * E);
-        const T p = cp[j % E];
-        bad = bad || !(p > T(0));
-        if (i == j) mypiv = p;
-        const T t = i > j ? ajj * pivot_rcp(p) : T(0);  // rows <= j are finished: leave them alone
-        const V nt = V(-t);
-        A[j / E] = cp * nt + A[j / E];
+        for (int r4 = 0; r4 < NRV; ++r4)
 #pragma unroll
-        for (int c4 = j / E + 1; c4 < NP / E; ++c4) {
-          const V cv = *reinterpret_cast<const V*>(colbuf + c4 * E);
-          A[c4] = cv * nt + A[c4];
-        }
-        // right-hand sides in whole 16-byte groups: packed FMAs (the tail of the last group is unused)
+          for (int e = 0; e < E; ++e) bj[r4][e] = r4 * E + e < NR ? lane_value(rv[r4][e], j) : T(0);
+        if constexpr (sizeof(T) == 4) {
+          V col[NP / E];
 #pragma unroll
-        for (int r4 = 0; r4 < NRV; ++r4) {
-          const V rv = *reinterpret_cast<const V*>(rhsbuf + r4 * E);
-          V mine;
+          for (int c4 = j / E; c4 < NP / E; ++c4) col[c4] = *reinterpret_cast<const V*>(colbuf + c4 * E);
+          const T p = col[j / E][j % E];
+          bad = bad || !(p > T(0));
+          if (i == j) mypiv = p;
+          const T t = i > j ? ajj * pivot_rcp(p) : T(0);  // rows <= j are finished: leave them alone
+          const V nt = V(-t);
 #pragma unroll
-          for (int e = 0; e < E; ++e) mine[e] = r4 * E + e < NR ? rhs[r4 * E + e] : T(0);
-          mine = rv * nt + mine;
+          for (int c4 = j / E; c4 < NP / E; ++c4) A[c4] = col[c4] * nt + A[c4];
 #pragma unroll
-          for (int e = 0; e < E; ++e)
-            if (r4 * E + e < NR) rhs[r4 * E + e] = mine[e];
+          for (int r4 = 0; r4 < NRV; ++r4) rv[r4] = bj[r4] * nt + rv[r4];
+        } else {
+          // fp64: a full copy of the column would not fit beside the 128-register row; streamed
+          const V cp = *reinterpret_cast<const V*>(colbuf + (j / E) * E);
+          const T p = cp[j % E];
+          bad = bad || !(p > T(0));
+          if (i == j) mypiv = p;
+          const T t = i > j ? ajj * pivot_rcp(p) : T(0);
+          const V nt = V(-t);
+          A[j / E] = cp * nt + A[j / E];
+#pragma unroll
+          for (int c4 = j / E + 1; c4 < NP / E; ++c4) {
+            const V cv = *reinterpret_cast<const V*>(colbuf + c4 * E);
+            A[c4] = cv * nt + A[c4];
+          }
+#pragma unroll
+          for (int r4 = 0; r4 < NRV; ++r4) rv[r4] = bj[r4] * nt + rv[r4];
         }
       }
     }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) rhs[r] = rv[r / E][r % E];
 
     // ---- outputs: cross-lane sums over the k rows ---------------------------------------------
     const T inv_d = i < k ? pivot_rcp(mypiv) : T(0);

@@ -25,18 +25,6 @@
 
 namespace mgp {
 
-// f(ic<0>{}), f(ic<1>{}), ... f(ic<N-1>{}): a loop whose index is a compile-time constant in every
-// iteration (a `#pragma unroll` the compiler declines leaves the 128-register row indexed at run
-// time, i.e. in scratch memory)
-template <typename F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-  (f(ic<I>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
 struct WideGeom {
   int q, dst, xs, vec_ok;
 };
@@ -243,12 +231,14 @@ __global__ __launch_bounds__(128, 2) void fused_wide_kernel(FusedArgs a, WideGeo
         T nt[E];
 #pragma unroll
         for (int m = 0; m < E; ++m) {
-          nt[m] = -pg[m] * rp[m];
+          // a select, not a product with rp = 0: columns behind the last eliminated one hold, in the rows
+          // above them, whatever the packed matrix had beyond the row's diagonal (possibly NaN)
+          nt[m] = m < mlim ? -pg[m] * rp[m] : T(0);
 #pragma unroll
           for (int c = m + 1; c < E; ++c) pg[c] = fma_t(nt[m], dr[c][m], pg[c]);
         }
 #pragma unroll
-        for (int m = 0; m < E; ++m) ubuf[m * NP + i] = pg[m];
+        for (int m = 0; m < E; ++m) ubuf[m * NP + i] = m < mlim ? pg[m] : T(0);  // 0 x 0, never 0 x garbage
         __syncthreads();
         // trailing groups, the block's own included (it stays current: the outputs read the last
         // groups).  Groups that hold padding columns only are updated too: a uniform test around them

@@ -4,6 +4,7 @@
 #pragma once
 
 #include <mutex>
+#include <utility>
 
 #include "mgp_args.h"
 
@@ -217,6 +218,18 @@ template <typename F>
 __device__ __forceinline__ void kernel_dispatch(int kernel_id, int metric_id, F&& f) {
   if (metric_id == MGP_METRIC_L2) kernel_dispatch_m<MGP_METRIC_L2>(kernel_id, f);
   else kernel_dispatch_m<MGP_METRIC_F2>(kernel_id, f);
+}
+
+// f(ic<0>{}), f(ic<1>{}), ... f(ic<N-1>{}): a loop whose index is a compile-time constant in every
+// iteration (a `#pragma unroll` the compiler declines leaves the 128-register row indexed at run
+// time, i.e. in scratch memory)
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(ic<I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
 }  // namespace mgp

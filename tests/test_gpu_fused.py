@@ -274,3 +274,43 @@ def test_wide_neighbourhoods_match_oracle(case):
     assert_close(mean.cpu().numpy()[pick].reshape(150, R), m_ref.reshape(150, R), RTOL["float32"], "mean")
     assert_close(var.cpu().numpy()[pick], v_ref, RTOL["float32"], "var")
     assert_close(yk.cpu().numpy()[pick].reshape(150, R), yk_ref, RTOL["float32"], "ykinvy")
+
+
+STALE_LDS_CASES = [
+    # k, R, dtype -- the 128-slot kernel (partial / full last block), the packed 64-slot exchange matrix,
+    # the square exchange matrices of the 32-slot and the rhs-column kernels
+    (126, 1, "float32"), (125, 1, "float32"), (122, 3, "float32"), (99, 2, "float32"),
+    (50, 1, "float32"), (50, 1, "float64"), (61, 1, "float32"), (30, 1, "float32"), (29, 2, "float64"),
+    (64, 16, "float32"), (63, 4, "float64"),
+]
+
+
+@pytest.mark.parametrize("k,R,dtype", STALE_LDS_CASES)
+def test_register_kernels_ignore_stale_lds(k, R, dtype):
+    """The exchange matrices of the register kernels have slots nobody writes (row padding, the upper
+    triangle a lane over-reads, the pad behind the last row); they hold whatever an earlier launch left in
+    LDS.  A launch on NaN features (d = 64: its feature tile covers the exchange region) poisons them; the
+    results of the next launch must not change.  (The 128-slot kernel used to multiply such a slot by 0 in
+    a partial last block -- k not a multiple of 4 -- and returned NaN variances, depending on what ran before.)"""
+    from muygpys_amd.fused import KernelSpec, posterior_mean_var
+
+    td = getattr(torch, dtype)
+    rng = np.random.default_rng(k * 7 + R)
+    N, b, d = 8000, 4096, 8
+    X = torch.from_numpy(rng.normal(size=(N, d))).to("cuda", td)
+    Y = torch.from_numpy(rng.normal(size=(N, R))).to("cuda", td)
+    bi = torch.from_numpy(rng.integers(0, N, size=b)).cuda()
+    ni = torch.from_numpy(np.stack([rng.choice(N, size=k, replace=False) for _ in range(b)])).cuda()
+    spec = KernelSpec("matern25", "l2", 3.0, 1e-2)
+    poison = torch.full((N, 64), float("nan"), device="cuda", dtype=td)
+    ref = None
+    for attempt in range(3):
+        posterior_mean_var(spec, poison, poison, bi, ni, Y, packed=False)  # NaN rows through every resident workgroup's LDS
+        info = torch.zeros(1, dtype=torch.int32, device="cuda")
+        mean, var = posterior_mean_var(spec, X, X, bi, ni, Y, info=info, packed=False)
+        torch.cuda.synchronize()
+        assert int(info.item()) == 0
+        assert bool(torch.isfinite(mean).all()) and bool(torch.isfinite(var).all()), f"NaN leaked (attempt {attempt})"
+        if ref is None:
+            ref = (mean.clone(), var.clone())
+        assert torch.equal(mean, ref[0]) and torch.equal(var, ref[1])
