@@ -240,6 +240,27 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       next_idx = load_index(task0 + t_step, NH == 1 ? 0 : (int)threadIdx.x / NP, threadIdx.x & (NP - 1));
   }
 
+  // Exchange-matrix slot of each of the lane's NS pairs (phase 3) and which of them are real
+  // (both rows neighbours, or neighbour x query): functions of the lane only, so computed once per
+  // kernel instead of once per task (8 integer instructions per pair: 9 % of the headline kernel's
+  // VALU work).  NS registers: the 32-slot kernels and the static shapes have them to spare.
+  constexpr bool XPRE = (NP == 32 || KFIX > 0) && !COEFF;
+  int xoff[XPRE ? NS : 1];
+  unsigned xkeep = 0;
+  if constexpr (XPRE) {
+    const int i0 = threadIdx.x & (NP - 1);
+    const int hbase = (NH == 1 ? 0 : (int)threadIdx.x / NP) * KMAT;
+    const int dump0 = TRI ? KMAT - E : (NP - 1) * KS + NP;
+#pragma unroll
+    for (int s = 1; s <= NS; ++s) {
+      const int r1 = (i0 + own_offset((s - 1) / BP)) & (NP - 1);
+      const int c = (i0 + (s - 1) % BP + 1) & (NP - 1);
+      const int hi = max(r1, c), lo = min(r1, c);
+      xoff[s - 1] = hbase + (hi <= q ? rowoff(hi) + lo : dump0);
+      if (lo < k && (hi < k || hi == q)) xkeep |= 1u << (s - 1);
+    }
+  }
+
   for (int64_t task = task0; task < t_end; task += t_step) {
     // The lane id is made opaque per task: otherwise LICM hoists every per-lane address, mask
     // and index of the unrolled phases out of this loop and the kernel runs out of registers.
@@ -434,12 +455,17 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 #pragma unroll
         for (int s = 1; s <= NS; ++s) {
           // pair j * BP + p - 1: (own row j, partner p)
-          const int r1 = (i3 + own_offset((s - 1) / BP)) & (NP - 1);
-          const int c = (i3 + (s - 1) % BP + 1) & (NP - 1);
-          const int hi = max(r1, c), lo = min(r1, c);
           T v = kv[s - 1];
-          if (!nopad) v = (lo < k && (hi < k || hi == q)) ? v : T(0);
-          Kh3[hi <= q ? rowoff(hi) + lo : dump] = v;
+          if constexpr (XPRE) {
+            if (!nopad) v = (xkeep >> (s - 1)) & 1u ? v : T(0);
+            tile[xoff[s - 1]] = v;
+          } else {
+            const int r1 = (i3 + own_offset((s - 1) / BP)) & (NP - 1);
+            const int c = (i3 + (s - 1) % BP + 1) & (NP - 1);
+            const int hi = max(r1, c), lo = min(r1, c);
+            if (!nopad) v = (lo < k && (hi < k || hi == q)) ? v : T(0);
+            Kh3[hi <= q ? rowoff(hi) + lo : dump] = v;
+          }
         }
       }
       Kh3[rowoff(i3) + i3] = i3 < k ? T(1) + myeps : (i3 <= q ? T(1) : T(0));
