@@ -86,6 +86,24 @@ __device__ __forceinline__ T wave_sum(T v) {
   return v;
 }
 
+// Sum over the 64 lanes, valid in LANE 63 only, on the VALU's data-parallel-primitive path (no LDS
+// crossbar round trips like __shfl_xor = ds_bpermute): neighbours, pairs of neighbours, then the four
+// quads of a 16-lane row by rotation, then the row totals handed down rows 0 -> 1, 2 -> 3 and 1 -> 2, 3.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_term(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+  v += dpp_term<0xb1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v += dpp_term<0x4e, 0xf>(v);   // quad_perm [2,3,0,1]
+  v += dpp_term<0x124, 0xf>(v);  // row_ror:4
+  v += dpp_term<0x128, 0xf>(v);  // row_ror:8   -> every lane of a row holds the row's total
+  v += dpp_term<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_term<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+__device__ __forceinline__ double wave_sum_lane63(double v) { return wave_sum(v); }
+
 __host__ __device__ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 }  // namespace mgp

@@ -196,10 +196,19 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
       T kq = T(0);
       kernel_dispatch(a.kernel_id, a.metric_id, [&](auto kid, auto mid) {
         constexpr int KID = decltype(kid)::value, MID = decltype(mid)::value;
-        static_for<NS>([&](auto sc) {
-          constexpr int s = decltype(sc)::value;
-          kv[s] = cov_from_sqdist<T>(acc_total(acc[s]), KID, MID, post_scale);
-        });
+        if constexpr (sizeof(T) == 4) {
+          static_for<NS / 2>([&](auto sc) {  // two covariances per packed instruction
+            constexpr int s = 2 * decltype(sc)::value;
+            const f2 kk = cov_from_sqdist2(f2{acc_total(acc[s]), acc_total(acc[s + 1])}, KID, MID, post_scale);
+            kv[s] = kk.x;
+            kv[s + 1] = kk.y;
+          });
+        } else {
+          static_for<NS>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            kv[s] = cov_from_sqdist<T>(acc_total(acc[s]), KID, MID, post_scale);
+          });
+        }
         kq = cov_from_sqdist<T>(acc_total(accq), KID, MID, post_scale);
       });
       static_for<NS>([&](auto sc) {
@@ -285,19 +294,20 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
     T* mean = static_cast<T*>(a.mean);
     T* var = static_cast<T*>(a.var);
     T* yk = static_cast<T*>(a.ykinvy);
-    const T sv = wave_sum(u * u * inv_d);
-    if (i == 0) {
+    // 1 + 2 R cross-lane sums, each landing in lane 63
+    const T sv = wave_sum_lane63(u * u * inv_d);
+    if (i == NP - 1) {
       var[nb] = bad ? num<T>::nan() : T(1) - sv;
       if (bad && a.info) atomicAdd(a.info, 1);
     }
 #pragma unroll
     for (int r = 0; r < RC; ++r) {
       if (r < R) {
-        const T sm = wave_sum(u * rhs[1 + r] * inv_d);
-        if (i == 0) mean[nb * R + r] = bad ? num<T>::nan() : sm;
+        const T sm = wave_sum_lane63(u * rhs[1 + r] * inv_d);
+        if (i == NP - 1) mean[nb * R + r] = bad ? num<T>::nan() : sm;
         if (yk) {
-          const T sy = wave_sum(rhs[1 + r] * rhs[1 + r] * inv_d);
-          if (i == 0) yk[nb * R + r] = bad ? num<T>::nan() : sy;
+          const T sy = wave_sum_lane63(rhs[1 + r] * rhs[1 + r] * inv_d);
+          if (i == NP - 1) yk[nb * R + r] = bad ? num<T>::nan() : sy;
         }
       }
     }

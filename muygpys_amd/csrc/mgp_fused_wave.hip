@@ -261,6 +261,18 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     }
   }
 
+  // feature-tile rows of the lane's own and partner rows (phase 2), static shapes: lane-only as well
+  constexpr bool DPRE = XPRE && DFIX > 0 && NP == 32;  // (the 64-slot static kernels have no registers left for it)
+  int down[DPRE ? BA : 1], dpar[DPRE ? BP : 1];
+  if constexpr (DPRE) {
+    const int i0 = threadIdx.x & (NP - 1);
+    const int hb = (NH == 1 ? 0 : (int)threadIdx.x / NP) * NP * xs;
+#pragma unroll
+    for (int j = 0; j < BA; ++j) down[j] = hb + ((i0 + own_offset(j)) & (NP - 1)) * xs;
+#pragma unroll
+    for (int s2 = 1; s2 <= BP; ++s2) dpar[s2 - 1] = hb + ((i0 + s2) & (NP - 1)) * xs;
+  }
+
   for (int64_t task = task0; task < t_end; task += t_step) {
     // The lane id is made opaque per task: otherwise LICM hoists every per-lane address, mask
     // and index of the unrolled phases out of this loop and the kernel runs out of registers.
@@ -404,13 +416,13 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
             V own0[BA], own1[BA];
 #pragma unroll
             for (int j = 0; j < BA; ++j) {
-              const T* xj = Xh + ((i + own_offset(j)) & (NP - 1)) * xs + c0;
+              const T* xj = DPRE ? tile + down[DPRE ? j : 0] + c0 : Xh + ((i + own_offset(j)) & (NP - 1)) * xs + c0;
               own0[j] = *reinterpret_cast<const V*>(xj);
               own1[j] = *reinterpret_cast<const V*>(xj + E);
             }
 #pragma unroll
             for (int s = 1; s <= BP; ++s) {
-              const T* xo = Xh + ((i + s) & (NP - 1)) * xs + c0;
+              const T* xo = DPRE ? tile + dpar[DPRE ? s - 1 : 0] + c0 : Xh + ((i + s) & (NP - 1)) * xs + c0;
               const V o0 = *reinterpret_cast<const V*>(xo);
               const V o1 = *reinterpret_cast<const V*>(xo + E);
 #pragma unroll
