@@ -241,13 +241,21 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
     // unused slots (k .. 63) are identity rows: eliminating them changes nothing, so the k test is
     // made once per JB steps (a branch per step costs a register shuffle at every merge point)
     constexpr int JB = 8;
+    // fp32: LOOK-AHEAD -- step j first finishes the one register group that holds column j + 1, posts
+    // that column and requests the 16 bytes with its pivot, and only then updates the rest of the row:
+    // the LDS round trip in front of the next step's reciprocal runs under the packed FMAs of this one.
+    // (Requesting the whole next column that early would need a second 64-register copy: spills.)
+    V piv = V(0);
+    if constexpr (sizeof(T) == 4) {
+      colbuf[i] = A[0][0];
+      piv = *reinterpret_cast<const V*>(colbuf);
+    }
 #pragma unroll
     for (int jb = 0; jb < NP; jb += JB) {
       if (jb < k)
 #pragma unroll
       for (int j = jb; j < jb + JB; ++j) {
         const T ajj = A[j / E][j % E];
-        colbuf[i] = ajj;
         V bj[NRV];
 #pragma unroll
         for (int r4 = 0; r4 < NRV; ++r4)
@@ -255,19 +263,29 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
           for (int e = 0; e < E; ++e) bj[r4][e] = r4 * E + e < NR ? lane_value(rv[r4][e], j) : T(0);
         if constexpr (sizeof(T) == 4) {
           V col[NP / E];
+          col[j / E] = piv;
 #pragma unroll
-          for (int c4 = j / E; c4 < NP / E; ++c4) col[c4] = *reinterpret_cast<const V*>(colbuf + c4 * E);
-          const T p = col[j / E][j % E];
+          for (int c4 = j / E + 1; c4 < NP / E; ++c4) col[c4] = *reinterpret_cast<const V*>(colbuf + c4 * E);
+          const T p = piv[j % E];
           bad = bad || !(p > T(0));
           if (i == j) mypiv = p;
           const T t = i > j ? ajj * pivot_rcp(p) : T(0);  // rows <= j are finished: leave them alone
           const V nt = V(-t);
+          constexpr int JN = NP - 1;
+          const int g1 = (j < JN ? j + 1 : j) / E;  // group of the next column (compile-time after unrolling)
+          A[g1] = col[g1] * nt + A[g1];
+          if (j < JN) {
+            colbuf[i] = A[g1][(j + 1) % E];
+            piv = *reinterpret_cast<const V*>(colbuf + g1 * E);
+          }
 #pragma unroll
-          for (int c4 = j / E; c4 < NP / E; ++c4) A[c4] = col[c4] * nt + A[c4];
+          for (int c4 = j / E; c4 < NP / E; ++c4)
+            if (c4 != g1) A[c4] = col[c4] * nt + A[c4];
 #pragma unroll
           for (int r4 = 0; r4 < NRV; ++r4) rv[r4] = bj[r4] * nt + rv[r4];
         } else {
           // fp64: a full copy of the column would not fit beside the 128-register row; streamed
+          colbuf[i] = ajj;
           const V cp = *reinterpret_cast<const V*>(colbuf + (j / E) * E);
           const T p = cp[j % E];
           bad = bad || !(p > T(0));
