@@ -23,6 +23,10 @@
 
 #include <utility>
 
+#ifndef MGP_WIDE_GC
+#define MGP_WIDE_GC 2
+#endif
+
 namespace mgp {
 
 struct WideGeom {
@@ -113,36 +117,50 @@ __global__ __launch_bounds__(128, 2) void fused_wide_kernel(FusedArgs a, WideGeo
       ACC acc[HB * BP];
 #pragma unroll
       for (int s = 0; s < HB * BP; ++s) acc[s] = ACC(0);
-      for (int c0 = 0; c0 < wp; c0 += CH) {
-        V own0[HB], own1[HB];
-#pragma unroll
-        for (int j = 0; j < HB; ++j) {
-          const T* xj = tile + ((i + own_offset(half * HB + j)) & (NP - 1)) * xs + c0;
-          own0[j] = *reinterpret_cast<const V*>(xj);
-          own1[j] = *reinterpret_cast<const V*>(xj + E);
-        }
-        V il0 = V(1), il1 = V(1);
-        if (aniso) {
-          il0 = *reinterpret_cast<const V*>(ilbuf + c0);
-          il1 = *reinterpret_cast<const V*>(ilbuf + c0 + E);
-        }
-#pragma unroll
-        for (int s = 1; s <= BP; ++s) {
-          const T* xo = tile + ((i + s) & (NP - 1)) * xs + c0;
-          const V o0 = *reinterpret_cast<const V*>(xo);
-          const V o1 = *reinterpret_cast<const V*>(xo + E);
+      // one instance per deformation (the Anisotropy test inside the pair loop is a branch per
+      // accumulate); partner rows are requested PB at a time, then consumed
+      auto chunks = [&](auto anis) {
+        constexpr bool ANISO = decltype(anis)::value != 0;
+        constexpr int PB = 4;
+        for (int c0 = 0; c0 < wp; c0 += CH) {
+          V own0[HB], own1[HB];
 #pragma unroll
           for (int j = 0; j < HB; ++j) {
-            if (aniso) {
-              accum(acc[j * BP + s - 1], vsub(own0[j], o0) * il0);
-              accum(acc[j * BP + s - 1], vsub(own1[j], o1) * il1);
-            } else {
-              accum(acc[j * BP + s - 1], vsub(own0[j], o0));
-              accum(acc[j * BP + s - 1], vsub(own1[j], o1));
+            const T* xj = tile + ((i + own_offset(half * HB + j)) & (NP - 1)) * xs + c0;
+            own0[j] = *reinterpret_cast<const V*>(xj);
+            own1[j] = *reinterpret_cast<const V*>(xj + E);
+          }
+          V il0 = V(1), il1 = V(1);
+          if constexpr (ANISO) {
+            il0 = *reinterpret_cast<const V*>(ilbuf + c0);
+            il1 = *reinterpret_cast<const V*>(ilbuf + c0 + E);
+          }
+#pragma unroll
+          for (int s0 = 1; s0 <= BP; s0 += PB) {
+            V o0[PB], o1[PB];
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+              const T* xo = tile + ((i + s0 + u) & (NP - 1)) * xs + c0;
+              o0[u] = *reinterpret_cast<const V*>(xo);
+              o1[u] = *reinterpret_cast<const V*>(xo + E);
             }
+#pragma unroll
+            for (int u = 0; u < PB; ++u)
+#pragma unroll
+              for (int j = 0; j < HB; ++j) {
+                if constexpr (ANISO) {
+                  accum(acc[j * BP + s0 + u - 1], vsub(own0[j], o0[u]) * il0);
+                  accum(acc[j * BP + s0 + u - 1], vsub(own1[j], o1[u]) * il1);
+                } else {
+                  accum(acc[j * BP + s0 + u - 1], vsub(own0[j], o0[u]));
+                  accum(acc[j * BP + s0 + u - 1], vsub(own1[j], o1[u]));
+                }
+              }
           }
         }
-      }
+      };
+      if (aniso) chunks(ic<1>{});
+      else chunks(ic<0>{});
       kernel_dispatch(a.kernel_id, a.metric_id, [&](auto kid, auto mid) {
         constexpr int KID = decltype(kid)::value, MID = decltype(mid)::value;
 #pragma unroll
@@ -244,13 +262,22 @@ __global__ __launch_bounds__(128, 2) void fused_wide_kernel(FusedArgs a, WideGeo
         // groups).  Groups that hold padding columns only are updated too: a uniform test around them
         // splits the block's loads into separately scheduled pieces and costs more than it saves
         // (measured: k = 100 20.0 -> 22.1 ms per 200 k neighbourhoods).
+        // GC groups at a time: their 4 GC loads are issued together, then the 8 GC packed FMAs (a load
+        // followed at once by its two FMAs pays a full LDS round trip per 16 bytes)
+        constexpr int GC = MGP_WIDE_GC;
 #pragma unroll
-        for (int c4 = jb; c4 < NP / E; ++c4) {
+        for (int c0 = jb; c0 < NP / E; c0 += GC) {
+          V cv[GC][E];
 #pragma unroll
-          for (int m = 0; m < E; ++m) {
-            const V cv = *reinterpret_cast<const V*>(ubuf + m * NP + c4 * E);
-            A[c4] = cv * V(nt[m]) + A[c4];
-          }
+          for (int g2 = 0; g2 < GC; ++g2)
+#pragma unroll
+            for (int m = 0; m < E; ++m)
+              if (c0 + g2 < NP / E) cv[g2][m] = *reinterpret_cast<const V*>(ubuf + m * NP + (c0 + g2) * E);
+#pragma unroll
+          for (int g2 = 0; g2 < GC; ++g2)
+#pragma unroll
+            for (int m = 0; m < E; ++m)
+              if (c0 + g2 < NP / E) A[c0 + g2] = cv[g2][m] * V(nt[m]) + A[c0 + g2];
         }
       }
     });
