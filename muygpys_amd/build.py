@@ -26,6 +26,7 @@ PER_FILE_FLAGS = {
     # the 64-step elimination must unroll completely (the fp64 / 16-response body exceeds the default
     # pragma-unroll budget, and a rolled loop indexes the 128-register row at run time = in scratch)
     "mgp_fused_rhs.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
+    "mgp_fused_wave.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
 }
 
 

@@ -52,6 +52,10 @@
 // shapes spill (168 VGPRs + 164 B scratch instead of 134 and none; 2.78 instead of 2.22 ms).
 #define MGP_PHASE(g, bit) ((g).mask & (bit))
 
+#ifndef MGP_F64_GC
+#define MGP_F64_GC 6
+#endif
+
 namespace mgp {
 
 struct WaveGeom {
@@ -523,10 +527,18 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
           const V nt = V(-ajj * pivot_rcp(p));
           if constexpr (COEFF) Kh[i * KS + j] = -nt[0];
           A[j / E] = cp * nt + A[j / E];
+          // trailing groups GC at a time: the GC loads are in flight together, then the 2 GC FMAs (a
+          // single wave needs ~8 outstanding 16-byte reads to cover the LDS latency with FMAs)
+          constexpr int GC = MGP_F64_GC;
 #pragma unroll
-          for (int c4 = j / E + 1; c4 < NP / E; ++c4) {
-            const V cv = *reinterpret_cast<const V*>(colh + c4 * E);
-            A[c4] = cv * nt + A[c4];
+          for (int c0 = j / E + 1; c0 < NP / E; c0 += GC) {
+            V cv[GC];
+#pragma unroll
+            for (int u = 0; u < GC; ++u)
+              if (c0 + u < NP / E) cv[u] = *reinterpret_cast<const V*>(colh + (c0 + u) * E);
+#pragma unroll
+            for (int u = 0; u < GC; ++u)
+              if (c0 + u < NP / E) A[c0 + u] = cv[u] * nt + A[c0 + u];
           }
         } else {
           V col[NP / E];
