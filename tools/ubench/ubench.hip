@@ -664,6 +664,28 @@ __global__ __launch_bounds__(64) void gather_kernel(const char* table, int strid
   out[blockIdx.x * 64 + lane] = ysum + reinterpret_cast<float*>(smem)[lane];
 }
 
+// Column-major variant: lane = row, load n takes 16-byte column n of all 64 rows (no row / column
+// arithmetic, no pointer table in LDS; every lane of a load touches a different cache line).
+template <int SPR>
+__global__ __launch_bounds__(64) void gather_colmajor_kernel(const char* table, int stride, const float* targets,
+                                                             const int64_t* idx, int64_t ntasks, float* out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x;
+  int64_t task = blockIdx.x;
+  int64_t nidx = task < ntasks ? idx[task * 64 + lane] : 0;
+  for (; task < ntasks; task += gridDim.x) {
+    const char* row = table + nidx * stride;
+    if (task + gridDim.x < ntasks) nidx = idx[(task + gridDim.x) * 64 + lane];
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < SPR; ++n) glds16(row + n * 16, smem + n * 1024);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SPR + 1));
+  }
+  asm volatile("s_waitcnt vmcnt(0)");
+  __syncthreads();
+  out[blockIdx.x * 64 + lane] = reinterpret_cast<float*>(smem)[lane];
+}
+
 template <int SPR, int DSLOTS, bool SEP>
 static void run_gather(const char* name, int stride, int64_t nrows, int64_t ntasks, int per_cu, const int64_t* didx) {
   char* table;
@@ -683,7 +705,10 @@ static void run_gather(const char* name, int stride, int64_t nrows, int64_t ntas
   const int reps = 5;
   for (int r = 0; r <= reps; ++r) {
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL((gather_kernel<SPR, DSLOTS, SEP>), dim3(grid), dim3(64), lds, 0, table, stride, targets, didx, ntasks, out);
+    if (DSLOTS == 0)
+      hipLaunchKernelGGL((gather_colmajor_kernel<SPR>), dim3(grid), dim3(64), lds, 0, table, stride, targets, didx, ntasks, out);
+    else
+      hipLaunchKernelGGL((gather_kernel<SPR, (DSLOTS > 0 ? DSLOTS : 1), SEP>), dim3(grid), dim3(64), lds, 0, table, stride, targets, didx, ntasks, out);
     CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
     float ms;
@@ -830,6 +855,7 @@ int main(int argc, char** argv) {
         run_gather<11, 11, false>("packed192", 192, nrows, ntasks, per_cu, didx);
         run_gather<11, 11, false>("packed256", 256, nrows, ntasks, per_cu, didx);
         run_gather<12, 12, false>("packed192x12", 192, nrows, ntasks, per_cu, didx);
+        run_gather<11, 0, false>("packed192-colmajor", 192, nrows, ntasks, per_cu, didx);
       }
       CK(hipFree(didx));
     }
