@@ -52,6 +52,9 @@
 // shapes spill (168 VGPRs + 164 B scratch instead of 134 and none; 2.78 instead of 2.22 ms).
 #define MGP_PHASE(g, bit) ((g).mask & (bit))
 
+#ifndef MGP_LOOKAHEAD
+#define MGP_LOOKAHEAD 1
+#endif
 #ifndef MGP_F64_GC
 #define MGP_F64_GC 6
 #endif
@@ -512,11 +515,22 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     // Whole 16-byte groups are updated from the pivot's group on: entries of columns <= j
     // inside that group are dead by then (right-looking: column j is never read again).
     bool bad = false;
+    // fp32: LOOK-AHEAD.  Step j first finishes the register group that holds column j + 1, posts that
+    // column and requests the 16 bytes with its pivot; the rest of the row is updated while that LDS round
+    // trip is under way, so the reciprocal of the next step does not wait for it.
+    constexpr bool LOOK = sizeof(T) == 4 && KFIX > 0 && MGP_LOOKAHEAD;  // (the run-time shapes gain nothing measurable and one of them spills)
+    V piv = V(0);
+    if constexpr (LOOK) {
+      if (MGP_PHASE(g, 8)) {
+        colh[i] = A[0][0];
+        piv = *reinterpret_cast<const V*>(colh);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NP - 2; ++j) {
       if (j < k && MGP_PHASE(g, 8)) {
         const T ajj = A[j / E][j % E];
-        colh[i] = ajj;
+        if constexpr (!LOOK) colh[i] = ajj;
         if constexpr (sizeof(T) == 8) {
           // fp64: the pivot first (one group), then the trailing groups streamed: load, FMA,
           // next -- no full copy of the column is held, which keeps the 128-register rows of
@@ -540,6 +554,25 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
             for (int u = 0; u < GC; ++u)
               if (c0 + u < NP / E) A[c0 + u] = cv[u] * nt + A[c0 + u];
           }
+        } else if constexpr (LOOK) {
+          V col[NP / E];
+          col[j / E] = piv;
+#pragma unroll
+          for (int c4 = j / E + 1; c4 < NP / E; ++c4) col[c4] = *reinterpret_cast<const V*>(colh + c4 * E);
+          const T p = piv[j % E];
+          bad = bad || !(p > T(0));
+          const V nt = V(-ajj * pivot_rcp(p));
+          if constexpr (COEFF) Kh[i * KS + j] = -nt[0];  // multiplier l_ij, kept for the back-substitution
+          constexpr int JL = NP - 3;                       // last step of the loop
+          const int g1 = (j < JL ? j + 1 : j) / E;         // compile-time after unrolling
+          A[g1] = col[g1] * nt + A[g1];
+          if (j < JL && j + 1 < k) {
+            colh[i] = A[g1][(j + 1) % E];
+            piv = *reinterpret_cast<const V*>(colh + g1 * E);
+          }
+#pragma unroll
+          for (int c4 = j / E; c4 < NP / E; ++c4)
+            if (c4 != g1) A[c4] = col[c4] * nt + A[c4];
         } else {
           V col[NP / E];
 #pragma unroll
