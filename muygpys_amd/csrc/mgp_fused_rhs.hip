@@ -20,6 +20,10 @@
 // crosswise distance per lane; covariances exchanged through LDS into row-per-lane registers).
 #include "mgp_wave_common.h"
 
+#ifndef MGP_RHS_PRIO
+#define MGP_RHS_PRIO 2
+#endif
+
 namespace mgp {
 
 struct RhsGeom {
@@ -190,6 +194,11 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
     }
 
     // ---- covariances -> exchange matrix -> row per lane; cross-covariance stays in the lane ----
+    // from here to the end of the elimination the wave runs chains of short dependent steps: it goes
+    // before the other wave's distance phase (long independent streams) at the issue arbiter
+#if MGP_RHS_PRIO
+    __builtin_amdgcn_s_setprio(MGP_RHS_PRIO);
+#endif
     __syncthreads();
     {
       T kv[NS];
@@ -306,6 +315,9 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
 #pragma unroll
     for (int r = 0; r < NR; ++r) rhs[r] = rv[r / E][r % E];
 
+#if MGP_RHS_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     // ---- outputs: cross-lane sums over the k rows ---------------------------------------------
     const T inv_d = i < k ? pivot_rcp(mypiv) : T(0);
     const T u = rhs[0];

@@ -52,6 +52,15 @@
 // shapes spill (168 VGPRs + 164 B scratch instead of 134 and none; 2.78 instead of 2.22 ms).
 #define MGP_PHASE(g, bit) ((g).mask & (bit))
 
+#ifndef MGP_PRIO_LATE_DROP
+#define MGP_PRIO_LATE_DROP 0
+#endif
+#ifndef MGP_XCHG_PRIO
+#define MGP_XCHG_PRIO 1
+#endif
+#ifndef MGP_CHOL_PRIO
+#define MGP_CHOL_PRIO 2
+#endif
 #ifndef MGP_LOOKAHEAD
 #define MGP_LOOKAHEAD 1
 #endif
@@ -321,6 +330,9 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     }
 
     ACC acc[NS];
+#if MGP_CHOL_PRIO && MGP_PRIO_LATE_DROP
+    __builtin_amdgcn_s_setprio(0);  // the distance phase: long independent streams, lowest priority
+#endif
 
     // ---- phases 1+2: stage features, accumulate squared distances ---------------------
     for (int d0 = 0; d0 < d; d0 += dst) {
@@ -444,6 +456,9 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     }
 
     // ---- phase 3: covariances, nugget, responses -> exchange matrix -> row per lane ----
+#if MGP_XCHG_PRIO
+    __builtin_amdgcn_s_setprio(MGP_XCHG_PRIO);
+#endif
     __syncthreads();  // every lane is done reading the feature tile (Kh aliases it)
     {
       // re-materialise the slot index here so that the per-offset masks/addresses of this phase
@@ -515,6 +530,11 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     // Whole 16-byte groups are updated from the pivot's group on: entries of columns <= j
     // inside that group are dead by then (right-looking: column j is never read again).
     bool bad = false;
+#if MGP_CHOL_PRIO
+    // the elimination is a chain of short dependent steps: let its instructions go first, the other
+    // waves' distance phases (long independent streams) fill the gaps
+    __builtin_amdgcn_s_setprio(MGP_CHOL_PRIO);
+#endif
     // fp32: LOOK-AHEAD.  Step j first finishes the register group that holds column j + 1, posts that
     // column and requests the 16 bytes with its pivot; the rest of the row is updated while that LDS round
     // trip is under way, so the reciprocal of the next step does not wait for it.
@@ -587,6 +607,9 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       }
     }
 
+#if MGP_CHOL_PRIO && !MGP_PRIO_LATE_DROP
+    __builtin_amdgcn_s_setprio(0);
+#endif
     // ---- phase 4b (COEFF): x = K^-1 y by back-substitution -------------------------------
     // K = L D L^T with unit lower L; the forward sweep formed l_ij (j < i) in lane i, and the
     // response row's multipliers are w_j = (D^-1 L^-1 y)_j.  Solve L^T x = w: the multipliers are

@@ -23,6 +23,9 @@
 
 #include <utility>
 
+#ifndef MGP_WIDE_PRIO
+#define MGP_WIDE_PRIO 2
+#endif
 #ifndef MGP_WIDE_GC
 #define MGP_WIDE_GC 2
 #endif
@@ -178,6 +181,9 @@ __global__ __launch_bounds__(128, 2) void fused_wide_kernel(FusedArgs a, WideGeo
     // 34 KB for 128 rows instead of 68 KB for the square, written in ONE pass.  A lane then reads 32
     // groups from the start of its row: what lies beyond column i belongs to later rows (upper-triangle
     // garbage the elimination never uses).
+#if MGP_WIDE_PRIO
+    __builtin_amdgcn_s_setprio(MGP_WIDE_PRIO);  // exchange + elimination before other workgroups' distance phases
+#endif
     const T mydiag = i < k ? T(1) + myeps : (i <= q ? T(1) : T(0));
     auto tri = [](int r) { const int a = r >> 2; return (a + 1) * (8 * a + 4 * (r & 3)); };
     V A[NP / E];
@@ -282,6 +288,9 @@ __global__ __launch_bounds__(128, 2) void fused_wide_kernel(FusedArgs a, WideGeo
       }
     });
 
+#if MGP_WIDE_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     // ---- phase 5: Schur block -> outputs --------------------------------------------------------
     // lane q holds S[q][q]; lane q+1+r holds S[q+1+r][q] and S[q+1+r][q+1+r]: picked out of the
     // registers by a compare-select sweep over the last 32 columns (q >= 111 as R <= 16)
