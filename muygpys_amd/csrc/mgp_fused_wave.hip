@@ -52,6 +52,9 @@
 // shapes spill (168 VGPRs + 164 B scratch instead of 134 and none; 2.78 instead of 2.22 ms).
 #define MGP_PHASE(g, bit) ((g).mask & (bit))
 
+#ifndef MGP_W4
+#define MGP_W4 0
+#endif
 #ifndef MGP_PRIO_LATE_DROP
 #define MGP_PRIO_LATE_DROP 0
 #endif
@@ -86,7 +89,7 @@ struct WaveGeom {
 //        64-byte multiple stride, so a row and its response arrive with the same two cache lines
 //        and no separate 4-byte response read (a whole line each) is issued.
 template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF = false, bool PACKED = false>
-__global__ __launch_bounds__(64, (sizeof(T) == 4 ? (NP == 32 ? 3 : 2) : (NP == 32 ? 2 : 2)))
+__global__ __launch_bounds__(64, (sizeof(T) == 4 ? (NP == 32 ? (KFIX == 30 && MGP_W4 ? 4 : 3) : 2) : (NP == 32 ? 2 : 2)))
 void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   static_assert(!PACKED || PIPED, "prepared tables are gathered by the direct-to-LDS pipeline");
   constexpr int NH = 64 / NP;     // neighbourhoods per wave

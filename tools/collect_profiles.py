@@ -131,8 +131,10 @@ def main():
            "* VALU issue model (tools/ubench, profiles/r02_ubench.jsonl): ~990 packed ops x 4.4 cycles + 64 transcendental x 8.2 + the "
            f"remaining plain ops x 2.3 = ~{990 * 4.4 + 64 * 8.2 + (t['SQ_INSTS_VALU'] - 1054) * 2.3:.0f} SIMD cycles per task of "
            f"{simd_cycles_per_task:.0f}: the VALU is ~{100 * (990 * 4.4 + 64 * 8.2 + (t['SQ_INSTS_VALU'] - 1054) * 2.3) / simd_cycles_per_task:.0f} % "
-           "occupied, the LDS ~half, the HBM side ~55 % (1.11 ms gather floor of the prepared tables); the three overlap only across "
-           "the 3 waves of a SIMD.", ""]
+           f"occupied, the LDS ~{100 * t['SQ_LDS_IDX_ACTIVE'] / (simd_cycles_per_task / 4):.0f} %, the HBM side "
+           f"~{100 * 1.11 / (clk_cycles / 2.03e6):.0f} % (1.11 ms gather floor of the prepared tables); the three overlap only across "
+           "the 3 waves of a SIMD -- since the exchange and elimination phases issue at a higher priority than the distance phase "
+           "(s_setprio), better than round-robin arbitration let them (the same stream took 8 500 cycles per task before).", ""]
     with open(os.path.join(OUT, "r02_wave_pmc_sq.md"), "w") as f:
         f.write("\n".join(md) + "\n")
     print("headline: traffic/algorithmic = %.3f, VALU %.0f, LDS %.0f, SALU %.0f per task" % (
