@@ -133,7 +133,7 @@ int mgp_posterior_kernel_name(int elem_size, int d, int k, int R, int packed, in
   if (packed) return snprintf(buf, len, "%s", "") < 0 ? MGP_EINVAL : MGP_EUNSUPPORTED;
   if (path != PATH_GENERIC && k <= 64 && R <= 16)
     snprintf(buf, len, "mgp::fused_rhs_kernel<%s,%d>", t, R <= 4 ? 4 : 16);
-  else if (path == PATH_AUTO && elem_size == 4 && k + 1 + R >= 76 && k + 1 + R <= 128 && R <= 16 && d <= 64)
+  else if (path == PATH_AUTO && elem_size == 4 && k + 1 + R >= 65 && k + 1 + R <= 128 && R <= 16 && d <= 64)
     snprintf(buf, len, "mgp::fused_wide_kernel");
   else
     snprintf(buf, len, "mgp::fused_generic_kernel<%s>", t);

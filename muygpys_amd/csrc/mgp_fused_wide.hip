@@ -23,6 +23,9 @@
 
 #include <utility>
 
+#ifndef MGP_WIDE_MIN_ROWS
+#define MGP_WIDE_MIN_ROWS 65
+#endif
 #ifndef MGP_WIDE_PRIO
 #define MGP_WIDE_PRIO 2
 #endif
@@ -322,9 +325,10 @@ int launch_fused_wide(const FusedArgs& a, hipStream_t stream) {
   } else {
     constexpr int NP = 128, E = 4, CH = 8, TRI = 8 * 32 * 33 + 2 * NP + 2 * E;
     const int rows = a.k + 1 + a.R;
-    // below ~76 rows the LDS workgroup kernel is faster (the 128-slot kernel pays for all 128 slots:
-    // k = 70: 11.4 vs 14.1 M neighbourhoods/s; k = 80: 10.9 vs 9.4; k = 100: 10.0 vs 4.7; k = 126: 9.4 vs 1.7)
-    if (rows < 76 || rows > NP || a.R > 16 || a.d > 64 || a.packed_nn != nullptr || a.coeffs != nullptr)
+    // every shape past the 64 slots of a wave that the rhs-column kernel (k <= 64) did not take: faster
+    // than the LDS workgroup kernel from the first row on (k = 68: 19.8 vs 15.1, k = 75: 18.8 vs 13.0,
+    // k = 100: 17.6 vs 4.7, k = 126: 15.6 vs 1.7 M neighbourhoods/s) although it pays for all 128 slots
+    if (rows < MGP_WIDE_MIN_ROWS || rows > NP || a.R > 16 || a.d > 64 || a.packed_nn != nullptr || a.coeffs != nullptr)
       return MGP_EUNSUPPORTED;  // more slots / responses / feature stages: the LDS workgroup kernel
     WideGeom g;
     g.q = NP - 1 - a.R;

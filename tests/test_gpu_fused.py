@@ -233,12 +233,13 @@ def test_persistent_loop_matches_oracle_on_a_sample(case, packed):
 
 
 WIDE_CASES = [
-    # kernel, k, d, R, aniso  -- more rows than a wave has lanes: the LDS-resident kernel
+    # kernel, k, d, R, aniso  -- more rows than a wave has lanes
     ("matern15", 80, 16, 1, False),
     ("rbf", 100, 40, 2, False),
     ("matern25", 126, 8, 1, True),
-    ("matern05", 64, 12, 1, False),   # 66 rows: just past the wave kernels (LDS workgroup kernel)
-    ("matern15", 75, 24, 1, False),   # 77 rows: the first shape of the 128-slot kernel
+    ("matern05", 64, 12, 1, False),   # 66 rows, k = 64: the rhs-column kernel
+    ("matern15", 65, 12, 1, False),   # 67 rows, k > 64: the first shape of the 128-slot kernel
+    ("matern15", 75, 24, 1, False),
     ("matern15", 90, 37, 3, False),   # unaligned rows, several responses
 ]
 
