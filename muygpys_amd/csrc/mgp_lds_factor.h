@@ -103,17 +103,44 @@ __device__ inline bool factor_augmented_lds(T* S, int SP, int k, int rows, T* pi
     if (j0 > 0) {
       for (int i = j0 + tid; i < rows; i += NT) {
         T* rowi = S + i * SP;
-        T s0 = T(0), s1 = T(0), s2 = T(0), s3 = T(0);
         const T* r0 = S + (j0 + 0) * SP;
         const T* r1 = S + (j0 + (jb > 1 ? 1 : 0)) * SP;
         const T* r2 = S + (j0 + (jb > 2 ? 2 : 0)) * SP;
         const T* r3 = S + (j0 + (jb > 3 ? 3 : 0)) * SP;
-        for (int m = 0; m < j0; m += E) {  // j0 is a multiple of JB, hence of E
+        // vector accumulators (packed FMAs, one horizontal sum at the end) and two 16-byte steps per
+        // iteration with all ten reads issued before the first FMA: the one-step scalar form waited a
+        // full LDS round trip for 20 plain VALU instructions
+        V a0 = V(0), a1 = V(0), a2 = V(0), a3 = V(0);
+        int m = 0;
+        for (; m + 2 * E <= j0; m += 2 * E) {  // j0 is a multiple of JB, hence of E
+          const V li = *reinterpret_cast<const V*>(rowi + m), lj = *reinterpret_cast<const V*>(rowi + m + E);
+          const V p0 = *reinterpret_cast<const V*>(r0 + m), q0 = *reinterpret_cast<const V*>(r0 + m + E);
+          const V p1 = *reinterpret_cast<const V*>(r1 + m), q1 = *reinterpret_cast<const V*>(r1 + m + E);
+          const V p2 = *reinterpret_cast<const V*>(r2 + m), q2 = *reinterpret_cast<const V*>(r2 + m + E);
+          const V p3 = *reinterpret_cast<const V*>(r3 + m), q3 = *reinterpret_cast<const V*>(r3 + m + E);
+          a0 = li * p0 + a0;
+          a1 = li * p1 + a1;
+          a2 = li * p2 + a2;
+          a3 = li * p3 + a3;
+          a0 = lj * q0 + a0;
+          a1 = lj * q1 + a1;
+          a2 = lj * q2 + a2;
+          a3 = lj * q3 + a3;
+        }
+        if (m < j0) {
           const V li = *reinterpret_cast<const V*>(rowi + m);
-          s0 += vec_dot(li, *reinterpret_cast<const V*>(r0 + m));
-          s1 += vec_dot(li, *reinterpret_cast<const V*>(r1 + m));
-          s2 += vec_dot(li, *reinterpret_cast<const V*>(r2 + m));
-          s3 += vec_dot(li, *reinterpret_cast<const V*>(r3 + m));
+          a0 = li * *reinterpret_cast<const V*>(r0 + m) + a0;
+          a1 = li * *reinterpret_cast<const V*>(r1 + m) + a1;
+          a2 = li * *reinterpret_cast<const V*>(r2 + m) + a2;
+          a3 = li * *reinterpret_cast<const V*>(r3 + m) + a3;
+        }
+        T s0 = a0[0], s1 = a1[0], s2 = a2[0], s3 = a3[0];
+#pragma unroll
+        for (int e = 1; e < E; ++e) {
+          s0 += a0[e];
+          s1 += a1[e];
+          s2 += a2[e];
+          s3 += a3[e];
         }
         rowi[j0] -= s0;
         if (jb > 1) rowi[j0 + 1] -= s1;
@@ -185,32 +212,32 @@ __device__ inline bool factor_augmented_lds(T* S, int SP, int k, int rows, T* pi
   return *bad_flag != 0;
 }
 
-// mean (R), var, ykinvy (R) from the factored S; one output per thread, strided.
+// mean (R), var, ykinvy (R) from the factored S: 1 + 2 R inner products of length k, each taken by
+// the whole first wave (lanes stride over the k entries, one cross-lane sum) -- one thread per output
+// walked its k entries alone, a serial chain of k LDS round trips at the end of every neighbourhood.
 template <typename T>
 __device__ inline void emit_outputs_lds(const T* S, int SP, int k, int R, T kout, bool bad, bool has_cross,
                                         T* mean, T* var, T* ykinvy, int tid, int NT) {
+  if (tid >= MGP_WAVE) return;
   const T* z = S + k * SP;
-  for (int o = tid; o < 1 + 2 * R; o += NT) {
+  for (int o = 0; o < 1 + 2 * R; ++o) {
+    const T* x = z;
+    const T* y = z;
+    T* dst = nullptr;
     if (o == 0) {
-      if (var != nullptr && has_cross) {
-        T s = T(0);
-        for (int m = 0; m < k; ++m) s += z[m] * z[m];
-        *var = bad ? num<T>::nan() : kout - s;
-      }
+      if (var != nullptr && has_cross) dst = var;
     } else if (o <= R) {
-      if (mean != nullptr && has_cross) {
-        const T* zy = S + (k + o) * SP;
-        T s = T(0);
-        for (int m = 0; m < k; ++m) s += z[m] * zy[m];
-        mean[o - 1] = bad ? num<T>::nan() : s;
-      }
-    } else if (ykinvy != nullptr) {
-      const int r = o - R - 1;
-      const T* zy = S + (k + 1 + r) * SP;
-      T s = T(0);
-      for (int m = 0; m < k; ++m) s += zy[m] * zy[m];
-      ykinvy[r] = bad ? num<T>::nan() : s;
+      y = S + (k + o) * SP;
+      if (mean != nullptr && has_cross) dst = mean + (o - 1);
+    } else {
+      x = y = S + (k + 1 + (o - R - 1)) * SP;
+      if (ykinvy != nullptr) dst = ykinvy + (o - R - 1);
     }
+    if (dst == nullptr) continue;  // uniform
+    T s = T(0);
+    for (int m = tid; m < k; m += MGP_WAVE) s += x[m] * y[m];
+    s = wave_sum(s);
+    if (tid == 0) *dst = bad ? num<T>::nan() : (o == 0 ? kout - s : s);
   }
 }
 
