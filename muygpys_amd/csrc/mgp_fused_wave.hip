@@ -52,6 +52,12 @@
 // shapes spill (168 VGPRs + 164 B scratch instead of 134 and none; 2.78 instead of 2.22 ms).
 #define MGP_PHASE(g, bit) ((g).mask & (bit))
 
+#ifndef MGP_DIST_PRIO
+#define MGP_DIST_PRIO 1
+#endif
+#ifndef MGP_PRIO_EARLY_RAISE
+#define MGP_PRIO_EARLY_RAISE 0
+#endif
 #ifndef MGP_W4
 #define MGP_W4 0
 #endif
@@ -59,7 +65,7 @@
 #define MGP_PRIO_LATE_DROP 0
 #endif
 #ifndef MGP_XCHG_PRIO
-#define MGP_XCHG_PRIO 1
+#define MGP_XCHG_PRIO 0
 #endif
 #ifndef MGP_CHOL_PRIO
 #define MGP_CHOL_PRIO 2
@@ -336,6 +342,9 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 #if MGP_CHOL_PRIO && MGP_PRIO_LATE_DROP
     __builtin_amdgcn_s_setprio(0);  // the distance phase: long independent streams, lowest priority
 #endif
+#if MGP_DIST_PRIO
+    __builtin_amdgcn_s_setprio(MGP_DIST_PRIO);
+#endif
 
     // ---- phases 1+2: stage features, accumulate squared distances ---------------------
     for (int d0 = 0; d0 < d; d0 += dst) {
@@ -459,7 +468,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     }
 
     // ---- phase 3: covariances, nugget, responses -> exchange matrix -> row per lane ----
-#if MGP_XCHG_PRIO
+#if MGP_XCHG_PRIO || MGP_DIST_PRIO
     __builtin_amdgcn_s_setprio(MGP_XCHG_PRIO);
 #endif
     __syncthreads();  // every lane is done reading the feature tile (Kh aliases it)
@@ -518,6 +527,9 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       }
     }
     __syncthreads();
+#if MGP_CHOL_PRIO && MGP_PRIO_EARLY_RAISE
+    __builtin_amdgcn_s_setprio(MGP_CHOL_PRIO);  // row read-back and the next task's gather already at elimination priority
+#endif
     V A[NP / E];
 #pragma unroll
     for (int c4 = 0; c4 < NP / E; ++c4) A[c4] = *reinterpret_cast<const V*>(Kh + rowoff(i) + c4 * E);

@@ -29,6 +29,12 @@
 #ifndef MGP_WIDE_PRIO
 #define MGP_WIDE_PRIO 2
 #endif
+#ifndef MGP_WIDE_DIST_PRIO
+#define MGP_WIDE_DIST_PRIO 1
+#endif
+#ifndef MGP_WIDE_XCHG_PRIO
+#define MGP_WIDE_XCHG_PRIO 0
+#endif
 #ifndef MGP_WIDE_GC
 #define MGP_WIDE_GC 2
 #endif
@@ -114,6 +120,9 @@ __global__ __launch_bounds__(128, 2) void fused_wide_kernel(FusedArgs a, WideGeo
       for (int c = i; c < wp; c += NP) ilbuf[c] = c < w ? T(1) / ls[c] : T(0);
     __syncthreads();
 
+#if MGP_WIDE_PRIO
+    __builtin_amdgcn_s_setprio(MGP_WIDE_DIST_PRIO);
+#endif
     // ---- phase 2: squared distances, then covariances; two halves of the own rows so that the
     //      64 packed accumulators of a lane never coexist (register budget: 256 with the 128-entry row)
     T kv[NS];
@@ -185,7 +194,7 @@ __global__ __launch_bounds__(128, 2) void fused_wide_kernel(FusedArgs a, WideGeo
     // groups from the start of its row: what lies beyond column i belongs to later rows (upper-triangle
     // garbage the elimination never uses).
 #if MGP_WIDE_PRIO
-    __builtin_amdgcn_s_setprio(MGP_WIDE_PRIO);  // exchange + elimination before other workgroups' distance phases
+    __builtin_amdgcn_s_setprio(MGP_WIDE_XCHG_PRIO);
 #endif
     const T mydiag = i < k ? T(1) + myeps : (i <= q ? T(1) : T(0));
     auto tri = [](int r) { const int a = r >> 2; return (a + 1) * (8 * a + 4 * (r & 3)); };
@@ -212,6 +221,9 @@ __global__ __launch_bounds__(128, 2) void fused_wide_kernel(FusedArgs a, WideGeo
       for (int c4 = 0; c4 < NP / E; ++c4) A[c4] = *reinterpret_cast<const V*>(tile + myrow + c4 * E);
     }
 
+#if MGP_WIDE_PRIO
+    __builtin_amdgcn_s_setprio(MGP_WIDE_PRIO);  // elimination > distances > covariances / exchange
+#endif
     // ---- phase 4: blocked Cholesky, row per lane, FOUR columns per exchange ------------------------
     // A step-by-step elimination costs a workgroup barrier and an LDS round trip per column, and with
     // two waves per SIMD that latency is what the kernel waits on.  A block of four columns J0..J0+3
