@@ -783,14 +783,13 @@ int launch_fused_wave(const FusedArgs& a, hipStream_t stream) {
     return MGP_EUNSUPPORTED;
   }
   if (a.packed_nn != nullptr) {  // prepared tables: the pipelined kernels only
-    if constexpr (sizeof(T) == 4)
-      if (a.k == 30 && a.R == 1 && a.d == 40) return launch_np<T, 32, 30, 1, 40, true, false, true>(a, stream);
+    if (a.k == 30 && a.R == 1 && a.d == 40) return launch_np<T, 32, 30, 1, 40, true, false, true>(a, stream);
     if (a.k == 50 && a.R == 1 && a.d == 8) return launch_np<T, 64, 50, 1, 8, true, false, true>(a, stream);
     if (rows <= 32) return launch_np<T, 32, 0, 0, 0, true, false, true>(a, stream);
     if (rows <= 64) return launch_np<T, 64, 0, 0, 0, true, false, true>(a, stream);
     return MGP_EUNSUPPORTED;
   }
-  if constexpr (sizeof(T) == 4) if (a.k == 30 && a.R == 1 && a.d == 40) {  // BASELINE configs 2/3, all shapes static
+  if (a.k == 30 && a.R == 1 && a.d == 40) {  // BASELINE configs 2/3 (and their fp64 form), all shapes static
     const int rc = launch_np<T, 32, 30, 1, 40, true>(a, stream);
     if (rc != MGP_EUNSUPPORTED) return rc;
   }
@@ -819,7 +818,7 @@ int describe_fused_wave(int elem_size, int d, int k, int R, int packed, char* bu
   const bool vec = d % E == 0, one_stage = ((d + 2 * E - 1) / (2 * E)) * (2 * E) <= 64;
   int np = rows <= 32 ? 32 : (rows <= 64 ? 64 : 0), kf = 0, rf = 0, df = 0;
   bool piped = vec && one_stage;
-  if (elem_size == 4 && k == 30 && R == 1 && d == 40) kf = 30, rf = 1, df = 40, np = 32, piped = true;
+  if (k == 30 && R == 1 && d == 40) kf = 30, rf = 1, df = 40, np = 32, piped = true;
   else if (k == 50 && R == 1 && d == 8) kf = 50, rf = 1, df = 8, np = 64, piped = true;
   if (np == 0 || (packed && (!piped || R > E))) return snprintf(buf, len, "%s", "");
   return snprintf(buf, len, "mgp::fused_wave_kernel<%s,%d,%d,%d,%d,%s,false,%s>", t, np, kf, rf, df,

@@ -12,7 +12,10 @@ bi, ni = random_neighbors(n, b, k, 1)
 bi, ni = torch.from_numpy(bi).cuda(), torch.from_numpy(ni).cuda()
 spec = KernelSpec("matern15", "l2", 5.0, 1e-3)
 mean = torch.empty((b, 1), device="cuda"); var = torch.empty((b,), device="cuda")
-for per_cu in (12, 11, 10, 9, 8, 6, 12):
+import os
+TD = torch.float64 if os.environ.get("OCC_F64") else torch.float32
+Xd, yd = Xd.to(TD), yd.to(TD); mean = mean.to(TD); var = var.to(TD)
+for per_cu in [int(v) for v in os.environ.get("OCC_LIST", "12,11,10,9,8,6,12").split(",")]:
     lib.mgp_debug_set_grid_per_cu(per_cu)
     ts = []
     for r in range(8):
