@@ -101,6 +101,7 @@ template <typename T> int launch_fused_wave(const FusedArgs&, hipStream_t);
 template <typename T> int launch_fused_rhs(const FusedArgs&, hipStream_t);
 // 64 < k + 1 + R <= 128, fp32: two waves per neighbourhood, rows in registers (mgp_fused_wide.hip)
 template <typename T> int launch_fused_wide(const FusedArgs&, hipStream_t);
+int launch_fused_wide64(const FusedArgs&, hipStream_t);  // fp64, two lanes per row
 int max_nn_count(int elem_size, int R);
 int describe_fused_wave(int elem_size, int d, int k, int R, int packed, char* buf, int len);
 

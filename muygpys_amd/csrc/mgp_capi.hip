@@ -56,6 +56,10 @@ int posterior(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t*
     if (rc != MGP_EUNSUPPORTED) return rc;
     rc = launch_fused_wide<T>(a, s);
     if (rc != MGP_EUNSUPPORTED) return rc;
+    if constexpr (sizeof(T) == 8) {
+      rc = launch_fused_wide64(a, s);
+      if (rc != MGP_EUNSUPPORTED) return rc;
+    }
   }
   return launch_fused_generic<T>(a, s);
 }
@@ -133,8 +137,8 @@ int mgp_posterior_kernel_name(int elem_size, int d, int k, int R, int packed, in
   if (packed) return snprintf(buf, len, "%s", "") < 0 ? MGP_EINVAL : MGP_EUNSUPPORTED;
   if (path != PATH_GENERIC && k <= 64 && R <= 16)
     snprintf(buf, len, "mgp::fused_rhs_kernel<%s,%d>", t, R <= 4 ? 4 : 16);
-  else if (path == PATH_AUTO && elem_size == 4 && k + 1 + R >= 65 && k + 1 + R <= 128 && R <= 16 && d <= 64)
-    snprintf(buf, len, "mgp::fused_wide_kernel");
+  else if (path == PATH_AUTO && k + 1 + R >= 65 && k + 1 + R <= 128 && R <= 16 && d <= 64)
+    snprintf(buf, len, elem_size == 4 ? "mgp::fused_wide_kernel" : "mgp::fused_wide64_kernel");
   else
     snprintf(buf, len, "mgp::fused_generic_kernel<%s>", t);
   return MGP_OK;

@@ -244,9 +244,14 @@ WIDE_CASES = [
 ]
 
 
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
 @pytest.mark.parametrize("case", WIDE_CASES, ids=[f"{c[0]}-k{c[1]}-d{c[2]}-R{c[3]}-{'aniso' if c[4] else 'iso'}" for c in WIDE_CASES])
-def test_wide_neighbourhoods_match_oracle(case):
+def test_wide_neighbourhoods_match_oracle(case, dtype):
+    """More than 64 slots: the rhs-column kernel (k <= 64), the 128-slot kernels (fp32: one lane per
+    row; fp64: two lanes per row), against the oracle."""
     from muygpys_amd.fused import KernelSpec, posterior_mean_var
+
+    td = getattr(torch, dtype)
 
     kernel, k, d, R, aniso = case
     rng = np.random.default_rng(40 + WIDE_CASES.index(case))
@@ -262,8 +267,8 @@ def test_wide_neighbourhoods_match_oracle(case):
     spec_o = orc.Spec(kernel, metric, ls, 1e-2)
     info = torch.zeros(1, dtype=torch.int32, device="cuda")
     mean, var, yk = posterior_mean_var(
-        KernelSpec(kernel, metric, ls.tolist() if aniso else ls, 1e-2), to_dev(X, torch.float32),
-        to_dev(X, torch.float32), to_dev(bi), to_dev(ni), to_dev(Y, torch.float32), want_ykinvy=True, info=info,
+        KernelSpec(kernel, metric, ls.tolist() if aniso else ls, 1e-2), to_dev(X, td),
+        to_dev(X, td), to_dev(bi), to_dev(ni), to_dev(Y, td), want_ykinvy=True, info=info,
     )
     torch.cuda.synchronize()
     assert int(info.item()) == 0
@@ -272,9 +277,9 @@ def test_wide_neighbourhoods_match_oracle(case):
     Kc, Kin = orc.kernel_tensors(spec_o, orc.crosswise_tensor(X, X, bi[pick], ni[pick]), orc.pairwise_tensor(X, ni[pick]))
     Kin = orc.perturb(spec_o, Kin, ni[pick])
     yk_ref = np.einsum("bkr,bkr->br", Y[ni[pick]], np.linalg.solve(Kin, Y[ni[pick]]))
-    assert_close(mean.cpu().numpy()[pick].reshape(150, R), m_ref.reshape(150, R), RTOL["float32"], "mean")
-    assert_close(var.cpu().numpy()[pick], v_ref, RTOL["float32"], "var")
-    assert_close(yk.cpu().numpy()[pick].reshape(150, R), yk_ref, RTOL["float32"], "ykinvy")
+    assert_close(mean.cpu().numpy()[pick].reshape(150, R), m_ref.reshape(150, R), RTOL[dtype], "mean")
+    assert_close(var.cpu().numpy()[pick], v_ref, RTOL[dtype], "var")
+    assert_close(yk.cpu().numpy()[pick].reshape(150, R), yk_ref, RTOL[dtype], "ykinvy")
 
 
 STALE_LDS_CASES = [
@@ -283,6 +288,7 @@ STALE_LDS_CASES = [
     (126, 1, "float32"), (125, 1, "float32"), (122, 3, "float32"), (99, 2, "float32"),
     (50, 1, "float32"), (50, 1, "float64"), (61, 1, "float32"), (30, 1, "float32"), (29, 2, "float64"),
     (64, 16, "float32"), (63, 4, "float64"),
+    (126, 1, "float64"), (125, 1, "float64"), (99, 2, "float64"), (65, 1, "float64"),   # two lanes per row
 ]
 
 
