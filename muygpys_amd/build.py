@@ -27,6 +27,7 @@ PER_FILE_FLAGS = {
     # pragma-unroll budget, and a rolled loop indexes the 128-register row at run time = in scratch)
     "mgp_fused_rhs.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
     "mgp_fused_wave.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
+    "mgp_solve_wave.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
 }
 
 

@@ -95,6 +95,7 @@ int launch_knn_scan_packed(const KnnPackedArgs&, hipStream_t);
 
 template <typename T> int launch_fused_generic(const FusedArgs&, hipStream_t);
 template <typename T> int launch_solve_generic(const SolveArgs&, hipStream_t);
+template <typename T> int launch_solve_wave(const SolveArgs&, hipStream_t);  // k + 1 + R <= 64, no coefficients
 // register-resident wave-per-neighbourhood kernels; MGP_EUNSUPPORTED when the shape is not covered
 template <typename T> int launch_fused_wave(const FusedArgs&, hipStream_t);
 // k <= 64 with up to 16 responses carried as right-hand-side columns (mgp_fused_rhs.hip)

@@ -113,6 +113,8 @@ int solve(const T* Kin, const T* Kc, const T* Y, int64_t b, int k, int R, double
   if ((mean || yk || coeffs) && R == 0) return MGP_EINVAL;
   if (b == 0) return MGP_OK;
   SolveArgs a{Kin, Kc, Y, mean, var, yk, coeffs, info, b, kout, k, R};
+  const int rc = launch_solve_wave<T>(a, static_cast<hipStream_t>(stream));
+  if (rc != MGP_EUNSUPPORTED) return rc;
   return launch_solve_generic<T>(a, static_cast<hipStream_t>(stream));
 }
 }  // namespace mgp

@@ -62,6 +62,13 @@ def main():
     rows.append(("mgp_matern_gen (nu = 0.42, fp64 Bessel K)", timed(lambda: K._matern_gen_fn(dist * 0.2, 0.42)), 2 * dist.numel() * s))
     Kin = K._apply(dist, "matern15", 0.2)
     rows.append(("mgp_perturb", timed(lambda: N._homoscedastic_perturb(Kin, 1e-3)), 2 * Kin.numel() * s))
+    from muygpys_amd._src.gp.muygps import hip as M
+    Kp = N._homoscedastic_perturb(Kin, 1e-3)
+    Kc = K._apply(T._crosswise_distances(X, X, bi, ni, "l2"), "matern15", 0.2)
+    ynn = y[ni]
+    rows.append(("mgp_solve (posterior mean on materialised Kin)", timed(lambda: M._muygps_posterior_mean(Kp, Kc, ynn)),
+                 b * (k * k + 2 * k + 1) * s))
+    rows.append(("mgp_solve (diagonal variance)", timed(lambda: M._muygps_diagonal_variance(Kp, Kc, 1.0)), b * (k * k + k + 1) * s))
     v = torch.rand(n, device="cuda") + 0.1
     rows.append(("mgp_loss_sums (deterministic)", timed(lambda: _lib.loss_sums(y, y * 0.9, v, None, 1.5, 3.0)), 3 * n * s))
     y2 = torch.randn(n, 4, device="cuda", generator=g)
