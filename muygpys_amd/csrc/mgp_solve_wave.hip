@@ -22,7 +22,7 @@ namespace mgp {
 
 template <typename T, int NP>
 __global__ __launch_bounds__(64, (sizeof(T) == 4 ? (NP == 32 ? 4 : 2) : 2)) void solve_wave_kernel(SolveArgs a, int q,
-                                                                                                  int vec_ok) {
+                                                                                                  int vec) {
   constexpr int NH = 64 / NP;
   constexpr int E = v16<T>::N;
   using V = typename v16<T>::type;
@@ -33,26 +33,32 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? (NP == 32 ? 4 : 2) : 2)) void
   const T* Y = static_cast<const T*>(a.Y);
   const int64_t ntasks = (a.b + NH - 1) / NH;
 
-  for (int64_t task = blockIdx.x; task < ntasks; task += gridDim.x) {
-    int lane = threadIdx.x;
-    asm volatile("" : "+v"(lane));
+  // The lane's row of one task (rows of the next task are requested before the elimination of the
+  // current one starts: their latency hides behind it).  vec: 2 = 16-byte loads (k s % 16 == 0),
+  // 1 = 8-byte loads (k s % 8 == 0), 0 = element loads; Kcross / Y rows are strided: element loads.
+  typedef T V8 __attribute__((ext_vector_type(8 / sizeof(T) > 1 ? 8 / sizeof(T) : 1)));
+  auto load_row = [&](int64_t task, auto& A) {
+    const int lane = threadIdx.x;
     const int h = NH == 1 ? 0 : lane / NP;
     const int i = lane & (NP - 1);
-    T* colh = colbuf + h * NP;
     const int64_t nb = task * NH + h;
-    const bool live = nb < a.b;
-    const int64_t nbb = live ? nb : task * NH;  // odd tail: replay the first neighbourhood
-
-    // ---- the lane's row -----------------------------------------------------------------------
-    V A[NP / E];
+    const int64_t nbb = nb < a.b ? nb : task * NH;  // odd tail: replay the first neighbourhood
 #pragma unroll
     for (int c4 = 0; c4 < NP / E; ++c4) A[c4] = V(0);
     if (i < k) {
       const T* src = Kin + (nbb * k + i) * (int64_t)k;
-      if (vec_ok) {
+      if (vec == 2) {
 #pragma unroll
         for (int c4 = 0; c4 < NP / E; ++c4)
           if (c4 * E < k) A[c4] = *reinterpret_cast<const V*>(src + c4 * E);  // k % E == 0: whole groups
+      } else if (sizeof(T) == 4 && vec == 1) {
+#pragma unroll
+        for (int c2 = 0; c2 < NP / 2; ++c2)
+          if (c2 * 2 < k) {  // k even: whole pairs
+            const V8 p = *reinterpret_cast<const V8*>(src + c2 * 2);
+            A[(c2 * 2) / E][(c2 * 2) % E] = p[0];
+            A[(c2 * 2 + 1) / E][(c2 * 2 + 1) % E] = p[sizeof(T) == 4 ? 1 : 0];
+          }
       } else {
 #pragma unroll
         for (int c4 = 0; c4 < NP / E; ++c4)
@@ -76,6 +82,29 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? (NP == 32 ? 4 : 2) : 2)) void
 #pragma unroll
         for (int e = 0; e < E; ++e)
           if (c4 * E + e < k) A[c4][e] = src[(c4 * E + e) * (int64_t)R];
+    }
+  };
+
+  constexpr bool PREFETCH = !(sizeof(T) == 8 && NP == 64);  // a second 128-register row does not fit
+  V Anext[PREFETCH ? NP / E : 1];
+  if constexpr (PREFETCH)
+    if ((int64_t)blockIdx.x < ntasks) load_row(blockIdx.x, Anext);
+  for (int64_t task = blockIdx.x; task < ntasks; task += gridDim.x) {
+    int lane = threadIdx.x;
+    asm volatile("" : "+v"(lane));
+    const int h = NH == 1 ? 0 : lane / NP;
+    const int i = lane & (NP - 1);
+    T* colh = colbuf + h * NP;
+    const int64_t nb = task * NH + h;
+    const bool live = nb < a.b;
+
+    V A[NP / E];
+    if constexpr (PREFETCH) {
+#pragma unroll
+      for (int c4 = 0; c4 < NP / E; ++c4) A[c4] = Anext[c4];
+      if (task + gridDim.x < ntasks) load_row(task + gridDim.x, Anext);
+    } else {
+      load_row(task, A);
     }
     // diagonal of the padding rows and of the query row (compare-select: no dynamic register index)
     {
@@ -156,7 +185,9 @@ static int launch_solve_np(const SolveArgs& a, hipStream_t stream) {
   constexpr int NH = 64 / NP;
   constexpr int E = v16<T>::N;
   const int q = NP - 1 - (a.R > 0 ? a.R : 1);  // no responses (variance only): one empty response slot
-  const int vec_ok = (a.k % E == 0) && (reinterpret_cast<uintptr_t>(a.Kin) % 16 == 0);
+  const size_t row_bytes = (size_t)a.k * sizeof(T);
+  const uintptr_t base = reinterpret_cast<uintptr_t>(a.Kin);
+  const int vec_ok = (row_bytes % 16 == 0 && base % 16 == 0) ? 2 : ((row_bytes % 8 == 0 && base % 8 == 0) ? 1 : 0);
   static Residency res;
   int per_cu = 0, cus = 0;
   const int rc = res.lookup(reinterpret_cast<const void*>(&solve_wave_kernel<T, NP>), 64, 0, &per_cu, &cus);
