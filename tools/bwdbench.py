@@ -60,9 +60,11 @@ def main():
     lib = _lib.load()
 
     def staged(o, st):
-        lib.mgp_debug_set_bwd_stage(st)
+        if st or hasattr(lib, "mgp_debug_set_bwd_stage"):
+            lib.mgp_debug_set_bwd_stage(st)  # stages need a build with -DMGP_DEBUG_HOOKS
         bwd(o)
-        lib.mgp_debug_set_bwd_stage(0)
+        if hasattr(lib, "mgp_debug_set_bwd_stage"):
+            lib.mgp_debug_set_bwd_stage(0)
 
     variants = [("forward", fwd)] + [
         (f"backward[{o}] stage={st}", (lambda o=o, st=st: staged(o, st)))
