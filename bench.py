@@ -40,6 +40,7 @@ HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 T
 FP32_VECTOR_TFLOPS = 157.3  # same guide: peak FP32 (vector)
 FP64_VECTOR_TFLOPS = 78.6   # half the fp32 vector rate (v_fma_f64 at the v_pk_fma_f32 issue cost, tools/ubench)
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_wave_pmc_traffic.json")
+TRAFFIC45_JSON = os.path.join(ROOT, "profiles", "r02_c45_pmc_traffic.json")
 
 # BASELINE.json configs: shape, model and what one step does
 CONFIGS = {
@@ -63,6 +64,13 @@ def measured_traffic(b: int, k: int, d: int, dtype: str):
     collected separately, gfx950 correction applied; see profiles/).  The counters were taken on
     the headline shape; scaled by neighbourhood count, else null."""
     if not (k == 30 and d == 40 and dtype == "f32" and os.path.exists(TRAFFIC_JSON)):
+        # configs 4 / 5: their own PMC passes (profiles/r02_c45_pmc_traffic.json)
+        if os.path.exists(TRAFFIC45_JSON):
+            with open(TRAFFIC45_JSON) as f:
+                t = json.load(f)["configs"]
+            for c, shape in (("4", (50, 8, "f64")), ("5", (64, 40, "f32"))):
+                if shape == (k, d, dtype) and c in t:
+                    return t[c]["hbm_bytes_per_launch_corrected"] / t[c]["neighbourhoods_per_launch"] * b
         return None
     with open(TRAFFIC_JSON) as f:
         t = json.load(f)

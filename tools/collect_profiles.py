@@ -86,6 +86,27 @@ def main():
         json.dump(traffic, f, indent=1)
         f.write("\n")
 
+    # HBM-side traffic of the config-4 / config-5 kernels (same correction)
+    other = {}
+    for c, kern in ((4, "fused_wave_kernel<double, 64, 50, 1, 8"), (5, "fused_rhs_kernel<float, 16>")):
+        if not os.path.isdir(os.path.join(RAW45, f"fetch_c{c}")):
+            continue
+        f_, inf = counters(os.path.join(RAW45, f"fetch_c{c}"), kern)
+        w_, _ = counters(os.path.join(RAW45, f"write_c{c}"), kern)
+        bj = last_json_line(os.path.join(RAW45, f"fetch_c{c}.json"))
+        hb = per_dispatch(f_, "FETCH_SIZE") * 1024 * 2 + per_dispatch(w_, "WRITE_SIZE") * 1024
+        algc = bj["roofline"]["algorithmic_bytes_per_launch"]
+        other[str(c)] = {"kernel": inf["kernel"], "neighbourhoods_per_launch": bj["config"]["batch_per_gpu"],
+                         "FETCH_SIZE_KiB": per_dispatch(f_, "FETCH_SIZE"), "WRITE_SIZE_KiB": per_dispatch(w_, "WRITE_SIZE"),
+                         "hbm_bytes_per_launch_corrected": hb, "algorithmic_bytes_per_launch": algc,
+                         "traffic_over_algorithmic": hb / algc}
+    if other:
+        with open(os.path.join(OUT, "r02_c45_pmc_traffic.json"), "w") as f:
+            json.dump({"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --cpu-sample 0 "
+                                  "--config N --steps 3 --warmup 1 (tools/profile_r02_c45.sh); gfx950 FETCH_SIZE x 2 correction",
+                       "configs": other}, f, indent=1)
+            f.write("\n")
+
     # SQ counters: headline kernel (per two-neighbourhood task), config 4 / 5 kernels (per neighbourhood)
     def sq_table(dirs, kernel, units, unit_name):
         rows, info = {}, {}

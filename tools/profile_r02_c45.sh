@@ -7,6 +7,10 @@ for c in ${CONFIGS:-5 4}; do
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAVES --output-format csv -d $O/sq1_c$c -- python3 bench.py --cpu-sample 0 --config $c --steps 3 --warmup 1 > $O/sq1_c$c.json 2> $O/sq1_c$c.err
   rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM SQ_LDS_ADDR_CONFLICT --output-format csv -d $O/sq2_c$c -- python3 bench.py --cpu-sample 0 --config $c --steps 3 --warmup 1 > $O/sq2_c$c.json 2> $O/sq2_c$c.err
 done
+for c in ${CONFIGS:-5 4}; do
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_c$c -- python3 bench.py --cpu-sample 0 --config $c --steps 3 --warmup 1 > $O/fetch_c$c.json 2> $O/fetch_c$c.err
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_c$c -- python3 bench.py --cpu-sample 0 --config $c --steps 3 --warmup 1 > $O/write_c$c.json 2> $O/write_c$c.err
+done
 python3 - <<'PY'
 import csv, glob, collections
 for c in (5, 4, 2):
