@@ -52,6 +52,9 @@
 // shapes spill (168 VGPRs + 164 B scratch instead of 134 and none; 2.78 instead of 2.22 ms).
 #define MGP_PHASE(g, bit) ((g).mask & (bit))
 
+#ifndef MGP_F64_SAME_PRIO
+#define MGP_F64_SAME_PRIO 0
+#endif
 #ifndef MGP_DIST_PRIO
 #define MGP_DIST_PRIO 1
 #endif
@@ -343,7 +346,9 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     __builtin_amdgcn_s_setprio(0);  // the distance phase: long independent streams, lowest priority
 #endif
 #if MGP_DIST_PRIO
-    __builtin_amdgcn_s_setprio(MGP_DIST_PRIO);
+    // fp32: elimination (2) > distances (1) > covariances / exchange (0); fp64 (software exp in the
+    // covariances, few distance instructions at small d): elimination (2) > exchange (1) > distances (0)
+    __builtin_amdgcn_s_setprio(sizeof(T) == 4 || MGP_F64_SAME_PRIO ? MGP_DIST_PRIO : MGP_XCHG_PRIO);
 #endif
 
     // ---- phases 1+2: stage features, accumulate squared distances ---------------------
@@ -469,7 +474,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 
     // ---- phase 3: covariances, nugget, responses -> exchange matrix -> row per lane ----
 #if MGP_XCHG_PRIO || MGP_DIST_PRIO
-    __builtin_amdgcn_s_setprio(MGP_XCHG_PRIO);
+    __builtin_amdgcn_s_setprio(sizeof(T) == 4 || MGP_F64_SAME_PRIO ? MGP_XCHG_PRIO : MGP_DIST_PRIO);
 #endif
     __syncthreads();  // every lane is done reading the feature tile (Kh aliases it)
     {
