@@ -162,6 +162,90 @@ __global__ void pairwise_dists_tile_kernel(const T* f, int d, const int64_t* nid
   }
 }
 
+template <int V> struct icn { static constexpr int value = V; };
+
+// Register form of the same (k <= 64, d <= 64): one wave owns 64 / NP neighbourhoods, lane i keeps row i
+// of its neighbourhood in registers (DG 16-byte groups, zero padded) and walks the rows j of the LDS tile
+// as uniform 16-byte broadcasts; entry (j, i) is stored -- the matrix is symmetric -- so that the lanes of
+// a wave write consecutive addresses.  k d / 4 broadcast reads per neighbourhood instead of 2 k^2 d / 64
+// scalar ones per lane.
+template <typename T, int NP, int DG>
+__global__ __launch_bounds__(64) void pairwise_dists_wave_kernel(const T* f, int d, const int64_t* nidx, int64_t b, int k,
+                                                                 int metric_id, T* out, int vec_ok) {
+  constexpr int NH = 64 / NP;
+  constexpr int E = 16 / (int)sizeof(T);
+  using V = T __attribute__((ext_vector_type(E)));
+  constexpr int XS = DG * E + E;  // odd number of 16-byte slots per row
+  extern __shared__ __attribute__((aligned(16))) char smem_pw[];
+  T* X = reinterpret_cast<T*>(smem_pw);
+  __shared__ int64_t idxs[64];
+  const int lane = threadIdx.x;
+  const int h = NH == 1 ? 0 : lane / NP, i = lane & (NP - 1);
+  const int64_t ntasks = (b + NH - 1) / NH;
+  for (int64_t task = blockIdx.x; task < ntasks; task += gridDim.x) {
+    __syncthreads();
+    // gather: row offsets first (one per lane), then the lanes of the wave walk the 64 rows in 16-byte
+    // pieces with all DG loads of a lane in flight before the first LDS store
+    const int dv = (d + E - 1) / E;
+    {
+      const int64_t nbh = task * NH + h;
+      idxs[lane] = (i < k && nbh < b) ? nidx[nbh * k + i] * (int64_t)d : (int64_t)-1;
+    }
+    __syncthreads();
+    {
+      V v[DG];
+#pragma unroll
+      for (int u = 0; u < DG; ++u) {
+        const int t = lane + 64 * u;
+        const int row = t / DG, c = t - row * DG;
+        const int64_t off = idxs[row];
+        v[u] = V(0);
+        if (off >= 0 && c < dv) {
+          const T* src = f + off + c * E;
+          if (vec_ok) {
+            v[u] = *reinterpret_cast<const V*>(src);
+          } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+              if (c * E + e < d) v[u][e] = src[e];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < DG; ++u) {
+        const int t = lane + 64 * u;
+        const int row = t / DG, c = t - row * DG;
+        *reinterpret_cast<V*>(X + row * XS + c * E) = v[u];
+      }
+    }
+    __syncthreads();
+    V own[DG];
+#pragma unroll
+    for (int c = 0; c < DG; ++c) own[c] = *reinterpret_cast<const V*>(X + (h * NP + i) * XS + c * E);
+    const int64_t nb = task * NH + h;
+    T* o = out + nb * (int64_t)k * k;
+#pragma unroll 4
+    for (int j = 0; j < k; ++j) {
+      const T* xj = X + (h * NP + j) * XS;
+      V a0 = V(0), a1 = V(0);
+#pragma unroll
+      for (int c = 0; c < DG; c += 2) {
+        const V d0 = own[c] - *reinterpret_cast<const V*>(xj + c * E);
+        a0 = d0 * d0 + a0;
+        if (c + 1 < DG) {
+          const V d1 = own[c + 1] - *reinterpret_cast<const V*>(xj + (c + 1) * E);
+          a1 = d1 * d1 + a1;
+        }
+      }
+      const V a = a0 + a1;
+      T acc = a[0];
+#pragma unroll
+      for (int e = 1; e < E; ++e) acc += a[e];
+      if (i < k && nb < b) o[j * (int64_t)k + i] = metric_id == MGP_METRIC_L2 ? num<T>::sqrt(acc) : acc;
+    }
+  }
+}
+
 // T3 (+D2): out[n] = metric(diffs[n,:] / ls[:]): 8 lanes per row
 template <typename T>
 __global__ void reduce_diffs_kernel(const T* diffs, int64_t n, int d, const T* ls, int metric_id, T* out) {
@@ -490,6 +574,36 @@ template <typename T>
 int launch_pairwise_dists(const T* f, int d, const int64_t* ni, int64_t b, int k, int metric, T* out,
                           hipStream_t s) {
   if (b * k == 0) return MGP_OK;
+  if (k <= 64 && d <= 64) {
+    constexpr int E = 16 / (int)sizeof(T);
+    const int vec_ok = (d % E == 0) && (reinterpret_cast<uintptr_t>(f) % 16 == 0);
+    const int dg = (d + E - 1) / E;  // 16-byte groups per row
+    auto go = [&](auto npc, auto dgc) {
+      constexpr int NP = decltype(npc)::value, DG = decltype(dgc)::value;
+      const size_t lds = (size_t)64 * (DG * E + E) * sizeof(T);
+      const int64_t ntasks = (b + 64 / NP - 1) / (64 / NP);
+      int64_t g = 256LL * (int64_t)((160 * 1024) / (((lds + 1279) / 1280) * 1280));
+      if (g > 256LL * 16) g = 256LL * 16;
+      if (g > ntasks) g = ntasks;
+      hipLaunchKernelGGL((pairwise_dists_wave_kernel<T, NP, DG>), dim3((unsigned)g), dim3(64), lds, s, f, d, ni, b, k, metric,
+                         out, vec_ok);
+    };
+    constexpr int G16 = 16 / E * 1;  // groups per 16 features: 4 (fp32) / 8 (fp64)
+    const int steps = (dg + G16 - 1) / G16;  // 1 .. 4 blocks of 16 features
+    if (k <= 32) {
+      if (steps == 1) go(icn<32>{}, icn<G16>{});
+      else if (steps == 2) go(icn<32>{}, icn<2 * G16>{});
+      else if (steps == 3) go(icn<32>{}, icn<3 * G16>{});
+      else go(icn<32>{}, icn<4 * G16>{});
+    } else {
+      if (steps == 1) go(icn<64>{}, icn<G16>{});
+      else if (steps == 2) go(icn<64>{}, icn<2 * G16>{});
+      else if (steps == 3) go(icn<64>{}, icn<3 * G16>{});
+      else go(icn<64>{}, icn<4 * G16>{});
+    }
+    MGP_HIP_CHECK_LAUNCH();
+    return MGP_OK;
+  }
   const size_t lds = (size_t)k * (d | 1) * sizeof(T);
   if (lds <= 40 * 1024) {  // the neighbourhood's rows fit LDS: gather them once
     const int64_t cap = 256LL * (lds ? (int64_t)((160 * 1024) / (((lds + 1279) / 1280) * 1280)) : 32);
