@@ -102,3 +102,43 @@ def test_query_inside_its_own_neighbourhood_interpolates(data):
     assert bool((v > -1e-5).all()) and bool((v <= eps + 1e-5).all())
     resid = (m - data["y1"][bi]).abs()
     assert float(resid.max()) < 0.05, "the mean must (nearly) interpolate the observed response"
+
+
+def test_materialised_route_agrees_with_the_fused_launch(data):
+    """The per-function route (mgp_pairwise_dists -> mgp_kernel_apply -> mgp_perturb -> mgp_solve on
+    materialised tensors, the register-resident solve kernel) and the fused launch compute the same
+    posterior on a 100 k-neighbourhood slice of the full-size problem."""
+    from muygpys_amd._src.gp.kernels import hip as KF
+    from muygpys_amd._src.gp.muygps import hip as MF
+    from muygpys_amd._src.gp.noise import hip as NF
+    from muygpys_amd._src.gp.tensors import hip as TF
+
+    nb = 100_000
+    bi, ni = data["bi"][:nb], data["ni"][:nb]
+    m, v = run(data, data["y1"], bi=bi, ni=ni)
+    Kin = NF._homoscedastic_perturb(KF._apply(TF._pairwise_distances(data["X"], ni, "l2"), "matern15", 1.0 / 5.0), 1e-3)
+    Kc = KF._apply(TF._crosswise_distances(data["X"], data["X"], bi, ni, "l2"), "matern15", 1.0 / 5.0)
+    m2 = MF._muygps_posterior_mean(Kin, Kc, data["y1"][ni])
+    v2 = MF._muygps_diagonal_variance(Kin, Kc, 1.0)
+    assert_close(m2.cpu().numpy(), m.cpu().numpy(), 1e-3, "mean, materialised vs fused")
+    assert_close(v2.cpu().numpy(), v.cpu().numpy(), 1e-3, "var, materialised vs fused")
+
+
+def test_loocv_partials_of_shards_sum_to_the_whole(data):
+    """mgp_loocv_*: the six fp64 partial sums of four shards (reference chunk rule) add up to those of the
+    whole batch (to fp64 rounding of a different summation order), at full size."""
+    from muygpys_amd import distributed as D_
+    from muygpys_amd.fused import loocv_partials
+
+    whole, mean, var = loocv_partials(data["spec"], data["X"], data["y1"], data["bi"], data["ni"])
+    total = torch.zeros(6, device="cuda", dtype=torch.float64)
+    means = []
+    for r in range(4):
+        p, mr, _ = loocv_partials(data["spec"], data["X"], data["y1"], D_.shard_rows(data["bi"], r, 4), D_.shard_rows(data["ni"], r, 4))
+        total += p
+        means.append(mr)
+    assert torch.equal(torch.cat(means), mean), "shard outputs concatenate exactly"
+    torch.testing.assert_close(total, whole, rtol=1e-11, atol=0)
+    assert float(whole[3]) == float(B)
+    fin = D_.finish_objective(whole.tolist(), K)
+    assert 0 < fin["sigma_sq"] < 10 and np.isfinite(fin["lool"])
