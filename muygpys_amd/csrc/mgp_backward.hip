@@ -32,10 +32,79 @@ __device__ __forceinline__ void tri_decode(int p, int& row, int& col) {
   col = p - a_ * (a_ - 1) / 2;
 }
 
-// dynamic LDS carve (every array 16-byte aligned; dc a multiple of 8):
-// [idx (k+2 & ~1) i64][S (k+2)*SP][Q (k+1)*SP][X (k+1)*XP][il dc][lacc dc][piv k][red 2][flag]
+// Single-wave form of "factor, then solve for two right-hand sides" (k + 2 <= 64 rows, 64 threads): the
+// row-per-lane register elimination of mgp_fused_wave.hip (column broadcast through a 64-entry LDS
+// buffer) on the system assembled in S, multipliers kept in S's lower triangle, then the
+// back-substitution L^T [a w] = D^-1 L^-1 [c yt] with the finished component handed down by v_readlane.
+// Leaves a = K^-1 c in row k and w = K^-1 yt in row k+1 of S, like the LDS path.  Returns "bad pivot".
 template <typename T>
-__global__ void backward_kernel(BackwardArgs g, int stage) {
+__device__ inline bool wave_factor_solve2(T* S, int SP, int k, T* colb, int lane) {
+  constexpr int NP = 64;
+  constexpr int E = 16 / (int)sizeof(T);
+  using V = typename lds_vec<T>::type;
+  const int rows = k + 2;
+  V A[NP / E];
+#pragma unroll
+  for (int c4 = 0; c4 < NP / E; ++c4) A[c4] = V(0);
+  if (lane < rows) {
+    const T* src = S + lane * SP;
+#pragma unroll
+    for (int c4 = 0; c4 < NP / E; ++c4)
+      if (c4 * E < k) A[c4] = *reinterpret_cast<const V*>(src + c4 * E);  // rows are 16-byte aligned, SP >= k + 1
+  }
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < NP - 2; ++j) {
+    if (j < k) {
+      const T ajj = A[j / E][j % E];
+      __syncthreads();
+      colb[lane] = ajj;
+      __syncthreads();
+      const V cp = *reinterpret_cast<const V*>(colb + (j / E) * E);
+      const T p = cp[j % E];
+      bad = bad || !(p > T(0));
+      const T t = lane > j && lane < rows ? ajj / p : T(0);
+      if (lane > j && lane < rows) S[lane * SP + j] = t;  // multiplier l_ij (rows k, k+1: D^-1 L^-1 of the rhs)
+      const V nt = V(-t);
+      A[j / E] = cp * nt + A[j / E];
+      constexpr int GC = sizeof(T) == 4 ? 8 : 4;
+#pragma unroll
+      for (int c0 = j / E + 1; c0 < NP / E; c0 += GC) {
+        V cv[GC];
+#pragma unroll
+        for (int u = 0; u < GC; ++u)
+          if (c0 + u < NP / E) cv[u] = *reinterpret_cast<const V*>(colb + (c0 + u) * E);
+#pragma unroll
+        for (int u = 0; u < GC; ++u)
+          if (c0 + u < NP / E) A[c0 + u] = cv[u] * nt + A[c0 + u];
+      }
+    }
+  }
+  __syncthreads();
+  // back-substitution, both vectors at once: lane j < k holds x_a(j), x_w(j)
+  T xa = lane < k ? S[k * SP + lane] : T(0);
+  T xw = lane < k ? S[(k + 1) * SP + lane] : T(0);
+  for (int m = k - 1; m >= 1; --m) {
+    const T am = __shfl(xa, m, 64), wm = __shfl(xw, m, 64);
+    if (lane < m) {
+      const T l = S[m * SP + lane];
+      xa -= l * am;
+      xw -= l * wm;
+    }
+  }
+  __syncthreads();
+  if (lane < k) {
+    S[k * SP + lane] = xa;
+    S[(k + 1) * SP + lane] = xw;
+  }
+  __syncthreads();
+  return bad;
+}
+
+// dynamic LDS carve (every array 16-byte aligned; dc a multiple of 8):
+// [idx (k+2 & ~1) i64][S (k+2)*SP][Q (k+1)*SP][X (k+1)*XP][il dc][lacc dc][colb 64][piv k][red 2][flag]
+template <typename T>
+__global__ __launch_bounds__(256) void backward_kernel(BackwardArgs g, int stage) {
   using V = typename lds_vec<T>::type;
   constexpr int E = 16 / (int)sizeof(T);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -50,7 +119,8 @@ __global__ void backward_kernel(BackwardArgs g, int stage) {
   T* X = Q + (k + 1) * SP;
   T* il = X + (k + 1) * XP;
   T* lacc = il + dc;
-  T* piv = lacc + dc;
+  T* colb = lacc + dc;  // 64-entry column broadcast buffer of the single-wave factorisation
+  T* piv = colb + 64;
   T* red = piv + k;
   int* flag = reinterpret_cast<int*>(red + 2);
 
@@ -136,26 +206,34 @@ __global__ void backward_kernel(BackwardArgs g, int stage) {
     }
     __syncthreads();
     if (stage == 1) continue;
-    const bool bad = factor_augmented_lds<T>(S, SP, k, rows, piv, flag, tid, NT);
+    const bool wave_path = NT == 64 && rows <= 64;  // uniform
+    bool bad;
+    if (wave_path) {
+      bad = wave_factor_solve2<T>(S, SP, k, colb, tid);
+    } else {
+      bad = factor_augmented_lds<T>(S, SP, k, rows, piv, flag, tid, NT);
+    }
     if (stage == 2) continue;
     if (bad) {
       if (tid == 0 && a.info) atomicAdd(a.info, 1);
       continue;  // cotangents of a non-SPD neighbourhood are left untouched
     }
-    // ---- back-substitution L^T [a w] = [z zy], both vectors at once, column oriented ----
     T* av = S + k * SP;
     T* wv = S + (k + 1) * SP;
-    for (int j = k - 1; j >= 0; --j) {
-      if (tid < 2) S[(k + tid) * SP + j] *= piv[j];
-      __syncthreads();
-      const T aj = av[j], wj = wv[j];
-      const T* Lj = S + j * SP;
-      for (int m = tid; m < j; m += NT) {
-        const T l = Lj[m];
-        av[m] -= l * aj;
-        wv[m] -= l * wj;
+    if (!wave_path) {
+      // ---- back-substitution L^T [a w] = [z zy], both vectors at once, column oriented ----
+      for (int j = k - 1; j >= 0; --j) {
+        if (tid < 2) S[(k + tid) * SP + j] *= piv[j];
+        __syncthreads();
+        const T aj = av[j], wj = wv[j];
+        const T* Lj = S + j * SP;
+        for (int m = tid; m < j; m += NT) {
+          const T l = Lj[m];
+          av[m] -= l * aj;
+          wv[m] -= l * wj;
+        }
+        __syncthreads();
       }
-      __syncthreads();
     }
     if (stage == 3) continue;
     const T gv = gvar ? gvar[nb] : T(0);
@@ -252,7 +330,7 @@ template <typename T>
 static size_t backward_lds_bytes(int k, int dc) {
   const int SP = lds_row_stride<T>(k);
   size_t n = (size_t)((k + 2) & ~1) * sizeof(int64_t);
-  n += ((size_t)(k + 2) * SP + (size_t)(k + 1) * SP + (size_t)(k + 1) * (dc + 16 / sizeof(T)) + 2 * (size_t)dc + k +
+  n += ((size_t)(k + 2) * SP + (size_t)(k + 1) * SP + (size_t)(k + 1) * (dc + 16 / sizeof(T)) + 2 * (size_t)dc + 64 + k +
         2) * sizeof(T) + 16;
   return (n + 15) & ~(size_t)15;
 }
