@@ -29,6 +29,7 @@ PER_FILE_FLAGS = {
     "mgp_fused_wave.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
     "mgp_solve_wave.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
     "mgp_backward.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
+    "mgp_backward_wave.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
 }
 
 

@@ -59,6 +59,7 @@ struct BackwardArgs {
   void* grad_noise;        // (b, k) per-neighbourhood diagonal cotangent
 };
 template <typename T> int launch_backward(const BackwardArgs&, hipStream_t);
+template <typename T> int launch_backward_wave(const BackwardArgs&, hipStream_t);  // Isotropy, k + 2 <= 64: on the wave kernel's phases
 int max_nn_count_backward(int elem_size);
 
 // Exact k-NN scan on the matrix cores (mgp_knn.hip)

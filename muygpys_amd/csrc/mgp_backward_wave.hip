@@ -1,0 +1,363 @@
+// Backward pass (vector-Jacobian product) on the phases of the wave kernel: k + 2 <= 64 slots,
+// Isotropy, d <= 64.  mgp_backward.hip states the maths (and remains the path for everything else):
+//
+//   a = K^-1 c,  w = K^-1 (Y gm),   gK_ij = 2 gv a_i a_j - (a_i w_j + a_j w_i),  gc_j = w_j - 2 gv a_j
+//   q_ij = gK_ij dkappa/dacc_ij ;  gx_i = 2 / l^2 sum_j q_ij (x_i - x_j)        (reference: torch autograd
+//   over torch/muygps_layer.py:129-164, examples/muygps_torch.py:425-437)
+//
+// One wavefront owns 64 / NP neighbourhoods; slot i < k a neighbour row, slot k the query, slot k + 1
+// the combined right-hand side Y gm.  Phases: gather (LDS tile, kept for the last phase) -> cyclic
+// register-blocked pair distances (kept in registers: the derivative needs them) -> covariances ->
+// exchange -> row-per-lane elimination with the multipliers kept in LDS -> back-substitution for the
+// two vectors (finished components handed down by v_readlane) -> pair cotangents q (each pair once,
+// written symmetrically to LDS) -> per-row feature sweep (row i in registers, rows j as uniform LDS
+// broadcasts) -> one atomic add per (point, feature).
+#include "mgp_wave_common.h"
+
+namespace mgp {
+
+// DG: 16-byte groups of a (zero-padded) feature row: the tile rows hold DG groups + one pad slot, so the
+// loops over features are compile-time and read zeros past d
+template <typename T, int NP, int DG>
+__global__ __launch_bounds__(64, 2) void backward_wave_kernel(BackwardArgs g, int vec_ok) {
+  constexpr int NH = 64 / NP;
+  constexpr int NS = NP / 2, BA = 4, BP = NS / BA;
+  auto own_offset = [](int j) { return j == 0 ? 0 : (j + 1) * BP + 1; };
+  constexpr int E = v16<T>::N, CH = 2 * E, KS = NP + E;
+  constexpr int xs = DG * E + E;  // odd number of 16-byte slots per tile row
+  using V = typename v16<T>::type;
+  using ACC = typename v16<T>::acc;
+  const FusedArgs& a = g.f;
+  const int k = a.k, d = a.d, R = a.R;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* X = reinterpret_cast<T*>(smem);             // NH * NP rows x xs
+  T* M = X + NH * NP * xs;                       // NH x NP x KS: exchange matrix, multipliers, then q
+  T* colbuf = M + NH * NP * KS;                  // 64
+  T* avec = colbuf + 64;                         // 64
+  T* wvec = avec + 64;                           // 64
+  int64_t* idxbuf = reinterpret_cast<int64_t*>(wvec + 64);  // 64 row offsets (elements)
+
+  const T* feat_q = static_cast<const T*>(a.feat_q);
+  const T* feat_nn = static_cast<const T*>(a.feat_nn);
+  const T* targets = static_cast<const T*>(a.targets);
+  const T* noise_dev = static_cast<const T*>(a.noise_dev);
+  const T* gmean = static_cast<const T*>(g.grad_mean);
+  const T* gvar = static_cast<const T*>(g.grad_var);
+  T* gq = static_cast<T*>(g.grad_feat_q);
+  T* gnn = static_cast<T*>(g.grad_feat_nn);
+  T* gtg = static_cast<T*>(g.grad_targets);
+  T* gls = static_cast<T*>(g.grad_ls);
+  T* gnz = static_cast<T*>(g.grad_noise);
+  const bool l2 = a.metric_id == MGP_METRIC_L2;
+  const T inv_l = T(1) / static_cast<const T*>(a.length_scale)[0];
+  const T post_scale = l2 ? inv_l : inv_l * inv_l;
+  constexpr int wp = DG * E;                     // padded feature count (a multiple of the distance loop's chunk)
+  static_assert(wp % CH == 0, "DG must be even");
+  const int dv = (d + E - 1) / E;
+  const int64_t ntasks = (a.b + NH - 1) / NH;
+
+  for (int64_t task = blockIdx.x; task < ntasks; task += gridDim.x) {
+    int lane = threadIdx.x;
+    asm volatile("" : "+v"(lane));
+    const int h = NH == 1 ? 0 : lane / NP;
+    const int i = lane & (NP - 1);
+    T* Xh = X + h * NP * xs;
+    T* Mh = M + h * NP * KS;
+    T* colh = colbuf + h * NP;
+    const int64_t nb = task * NH + h;
+    const bool live = nb < a.b;
+    const int64_t nbb = live ? nb : task * NH;
+
+    // ---- phase 0: indices, nugget, combined right-hand side -----------------------------------------
+    int64_t myidx = 0;
+    T myeps = T(0), myyt = T(0);
+    if (i < k) {
+      myidx = a.nn_idx[nbb * k + i];
+      if (a.noise_mode == MGP_NOISE_SCALAR) myeps = (T)a.noise_scalar;
+      else if (a.noise_mode == MGP_NOISE_TABLE) myeps = noise_dev[myidx];
+      else myeps = noise_dev[nbb * k + i];
+      if (gmean) {
+        const T* ty = targets + (a.targets_batch ? nbb * k + i : myidx) * (int64_t)R;
+        for (int r = 0; r < R; ++r) myyt += gmean[nbb * R + r] * ty[r];
+      }
+    } else if (i == k) {
+      myidx = a.batch_idx ? a.batch_idx[nbb] : nbb;
+    }
+    __syncthreads();
+    idxbuf[lane] = myidx * (int64_t)d;
+    __syncthreads();
+
+    // ---- phase 1: feature tile (rows 0 .. k of each half; other slots zero rows) ---------------------
+    {
+      constexpr int c16p = DG;
+      for (int t = lane; t < NH * NP * c16p; t += 64) {
+        const int row = t / c16p, c = t - row * c16p;
+        const int slot = row & (NP - 1);
+        V v = V(0);
+        if (slot <= k && c < dv) {
+          const T* src = (slot < k ? feat_nn : feat_q) + idxbuf[row] + c * E;
+          if (vec_ok) {
+            v = *reinterpret_cast<const V*>(src);
+          } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+              if (c * E + e < d) v[e] = src[e];
+          }
+        }
+        *reinterpret_cast<V*>(X + row * xs + c * E) = v;
+      }
+    }
+    __syncthreads();
+
+    // ---- phase 2: squared distances of the lane's NS pairs (kept: the derivative needs them) --------
+    ACC acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = ACC(0);
+#pragma unroll
+    for (int c0 = 0; c0 < wp; c0 += CH) {
+      V own0[BA], own1[BA];
+#pragma unroll
+      for (int j = 0; j < BA; ++j) {
+        const T* xj = Xh + ((i + own_offset(j)) & (NP - 1)) * xs + c0;
+        own0[j] = *reinterpret_cast<const V*>(xj);
+        own1[j] = *reinterpret_cast<const V*>(xj + E);
+      }
+#pragma unroll
+      for (int s = 1; s <= BP; ++s) {
+        const T* xo = Xh + ((i + s) & (NP - 1)) * xs + c0;
+        const V o0 = *reinterpret_cast<const V*>(xo);
+        const V o1 = *reinterpret_cast<const V*>(xo + E);
+#pragma unroll
+        for (int j = 0; j < BA; ++j) {
+          accum(acc[j * BP + s - 1], vsub(own0[j], o0));
+          accum(acc[j * BP + s - 1], vsub(own1[j], o1));
+        }
+      }
+    }
+
+    // ---- phase 3: covariances -> exchange matrix -> row per lane ---------------------------------------
+    {
+      T kv[NS];
+      kernel_dispatch(a.kernel_id, a.metric_id, [&](auto kid, auto mid) {
+        constexpr int KID = decltype(kid)::value, MID = decltype(mid)::value;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) kv[s] = cov_from_sqdist<T>(acc_total(acc[s]), KID, MID, post_scale);
+      });
+      const int dump = (NP - 1) * KS + NP;  // padding behind the last row
+#pragma unroll
+      for (int s = 1; s <= NS; ++s) {
+        const int r1 = (i + own_offset((s - 1) / BP)) & (NP - 1);
+        const int c = (i + (s - 1) % BP + 1) & (NP - 1);
+        const int hi = max(r1, c), lo = min(r1, c);
+        const bool real = lo < k && hi <= k;   // neighbour x neighbour, or neighbour x query
+        Mh[hi <= k ? hi * KS + lo : dump] = real ? kv[s - 1] : T(0);
+      }
+      Mh[i * KS + i] = i < k ? T(1) + myeps : T(1);
+    }
+    __syncthreads();
+    if (i < k) Mh[(k + 1) * KS + i] = myyt;      // the right-hand-side row (no pair store touches it)
+    else if (i <= k + 1) Mh[(k + 1) * KS + i] = i == k + 1 ? T(1) : T(0);
+    __syncthreads();
+    V A[NP / E];
+#pragma unroll
+    for (int c4 = 0; c4 < NP / E; ++c4)
+      A[c4] = i <= k + 1 ? *reinterpret_cast<const V*>(Mh + i * KS + c4 * E) : V(0);  // slots behind the rhs row: zero rows
+    __syncthreads();
+
+    // ---- phase 4: elimination, multipliers l_ij kept in the exchange matrix ---------------------------
+    __builtin_amdgcn_s_setprio(2);  // chains of short dependent steps go first
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < NP - 2; ++j) {
+      if (j < k) {
+        const T ajj = A[j / E][j % E];
+        colh[i] = ajj;
+        __syncthreads();
+        const V cp = *reinterpret_cast<const V*>(colh + (j / E) * E);
+        const T p = cp[j % E];
+        bad = bad || !(p > T(0));
+        const T t = ajj * pivot_rcp(p);
+        Mh[i * KS + j] = t;
+        const V nt = V(-t);
+        A[j / E] = cp * nt + A[j / E];
+        constexpr int GC = sizeof(T) == 4 ? 8 : 4;
+#pragma unroll
+        for (int c0 = j / E + 1; c0 < NP / E; c0 += GC) {
+          V cv[GC];
+#pragma unroll
+          for (int u = 0; u < GC; ++u)
+            if (c0 + u < NP / E) cv[u] = *reinterpret_cast<const V*>(colh + (c0 + u) * E);
+#pragma unroll
+          for (int u = 0; u < GC; ++u)
+            if (c0 + u < NP / E) A[c0 + u] = cv[u] * nt + A[c0 + u];
+        }
+        __syncthreads();
+      }
+    }
+
+    // ---- phase 5: back-substitution L^T [a w] = D^-1 L^-1 [c yt] ----------------------------------------
+    T xa = i < k ? Mh[k * KS + i] : T(0);
+    T xw = i < k ? Mh[(k + 1) * KS + i] : T(0);
+    for (int m = k - 1; m >= 1; --m) {
+      T am = lane_value(xa, m), wm = lane_value(xw, m);
+      if constexpr (NH == 2) {
+        const T am1 = lane_value(xa, m + NP), wm1 = lane_value(xw, m + NP);
+        am = h == 0 ? am : am1;
+        wm = h == 0 ? wm : wm1;
+      }
+      if (i < m) {
+        const T l = Mh[m * KS + i];
+        xa = fma_t(-l, am, xa);
+        xw = fma_t(-l, wm, xw);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __syncthreads();  // every lane is done with the multipliers: M becomes the q matrix
+    avec[lane] = i < k ? xa : T(0);
+    wvec[lane] = i < k ? xw : T(0);
+    __syncthreads();
+    const bool skip = bad || !live;  // cotangents of a non-SPD neighbourhood are left untouched
+
+    // ---- phase 6: pair cotangents q_ij = gK_ij dkappa/dacc_ij, symmetric, zero diagonal ---------------
+    const T gv = gvar ? gvar[nbb] : T(0);
+    T liso = T(0);
+    {
+      const T* ah = avec + h * NP;
+      const T* wh = wvec + h * NP;
+      const int dump = (NP - 1) * KS + NP;
+#pragma unroll
+      for (int s = 1; s <= NS; ++s) {
+        const int r1 = (i + own_offset((s - 1) / BP)) & (NP - 1);
+        const int c = (i + (s - 1) % BP + 1) & (NP - 1);
+        const int hi = max(r1, c), lo = min(r1, c);
+        const bool real = lo < k && hi <= k;
+        const T alo = ah[lo], wlo = wh[lo], ahi = ah[hi], whi = wh[hi];
+        const T gK = hi < k ? T(2) * gv * ahi * alo - (ahi * wlo + alo * whi) : wlo - T(2) * gv * alo;
+        const T x = metric_arg<T>(acc_total(acc[s - 1]), a.metric_id, post_scale);
+        const T kp = kernel_deriv<T>(a.kernel_id, x);
+        T dk_dacc;
+        if (l2) dk_dacc = x > T(0) ? kp * post_scale * post_scale / (T(2) * x) : T(0);
+        else dk_dacc = kp * post_scale;
+        const T q = real ? gK * dk_dacc : T(0);
+        // the pair at cyclic distance NP / 2 is met from both ends: count it once
+        const bool twice = ((r1 - c) & (NP - 1)) == NP / 2 && r1 < c;
+        if (real && !twice) liso += gK * kp * x;
+        Mh[hi <= k ? hi * KS + lo : dump] = q;
+        Mh[hi <= k ? lo * KS + hi : dump] = q;
+      }
+      Mh[i * KS + i] = T(0);
+    }
+    // per-neighbourhood outputs that need a and w only
+    if (!skip) {
+      if (gnz && i < k) gnz[nb * k + i] = gv * xa * xa - xa * xw;
+      if (gtg && gmean && i < k)
+        for (int r = 0; r < R; ++r) unsafeAtomicAdd(gtg + myidx * (int64_t)R + r, gmean[nb * R + r] * xa);
+    }
+    if (gls) {
+      // sum over the lanes of the half
+      T s = liso;
+      for (int off = NP / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+      if (!skip && i == 0) gls[nb] = -(l2 ? T(1) : T(2)) * inv_l * s;  // dx/dl = -x/l | -2x/l
+    }
+    __syncthreads();
+
+    // ---- phase 7: feature cotangents: gx_i = 2 sum_j q_ij (x_i - x_j) (the metric's 1/l^2 is in q) ------
+    if (gq || gnn) {
+      V xi[DG], sv[DG], qrow[NP / E];
+#pragma unroll
+      for (int c4 = 0; c4 < DG; ++c4) {
+        sv[c4] = V(0);
+        xi[c4] = *reinterpret_cast<const V*>(Xh + i * xs + c4 * E);
+      }
+#pragma unroll
+      for (int c4 = 0; c4 < NP / E; ++c4) qrow[c4] = *reinterpret_cast<const V*>(Mh + i * KS + c4 * E);
+#pragma unroll
+      for (int j = 0; j < NP - 1; ++j) {
+        if (j <= k) {  // uniform; the DG reads of a row are issued together
+          const V qv = V(qrow[j / E][j % E]);
+          const T* xj = Xh + j * xs;
+          V xr[DG];
+#pragma unroll
+          for (int c4 = 0; c4 < DG; ++c4) xr[c4] = *reinterpret_cast<const V*>(xj + c4 * E);
+#pragma unroll
+          for (int c4 = 0; c4 < DG; ++c4) sv[c4] = (xi[c4] - xr[c4]) * qv + sv[c4];
+        }
+      }
+      // out through the tile (every lane is done reading it): consecutive lanes then add consecutive
+      // features of a row -- a lane adding its own row's features one by one touches 62 different cache
+      // lines per instruction (measured: 57 ms of a 65 ms launch)
+      __syncthreads();
+#pragma unroll
+      for (int c4 = 0; c4 < DG; ++c4) *reinterpret_cast<V*>(Xh + i * xs + c4 * E) = (skip || i > k) ? V(0) : V(T(2)) * sv[c4];
+      __syncthreads();
+      // consecutive lanes add consecutive features (row-major over the rows of the task): an atomic
+      // instruction then touches 2-3 cache lines; (row, feature) advance incrementally, no division
+      {
+        int row = lane / d, f = lane - row * d;
+        for (int t = lane; t < NH * NP * d; t += 64) {
+          const int slot = row & (NP - 1);
+          if (slot <= k) {
+            T* dstp = slot < k ? gnn : gq;
+            const T v = X[row * xs + f];
+            if (dstp != nullptr && v != T(0)) unsafeAtomicAdd(dstp + idxbuf[row] + f, v);
+          }
+          f += 64;
+          while (f >= d) {
+            f -= d;
+            ++row;
+          }
+        }
+      }
+    }
+    if (bad && live && i == 0 && a.info) atomicAdd(a.info, 1);
+  }
+}
+
+template <typename T, int NP, int DG>
+static int launch_bwd_np(const BackwardArgs& g, hipStream_t stream) {
+  constexpr int NH = 64 / NP;
+  constexpr int E = v16<T>::N, KS = NP + E, xs = DG * E + E;
+  const uintptr_t align = (uintptr_t)g.f.feat_q | (uintptr_t)g.f.feat_nn;
+  const int vec_ok = (g.f.d % E == 0) && (align % 16 == 0);
+  const size_t lds = ((size_t)NH * NP * xs + (size_t)NH * NP * KS + 3 * 64) * sizeof(T) + 64 * sizeof(int64_t);
+  static Residency res;
+  int per_cu = 0, cus = 0;
+  const int rc = res.lookup(reinterpret_cast<const void*>(&backward_wave_kernel<T, NP, DG>), 64, lds, &per_cu, &cus);
+  if (rc != MGP_OK) return rc;
+  const int64_t ntasks = (g.f.b + NH - 1) / NH;
+  int64_t grid = (int64_t)cus * per_cu;
+  if (grid > ntasks) grid = ntasks;
+  hipLaunchKernelGGL((backward_wave_kernel<T, NP, DG>), dim3((unsigned)grid), dim3(64), lds, stream, g, vec_ok);
+  MGP_HIP_CHECK_LAUNCH();
+  return MGP_OK;
+}
+
+template <typename T, int NP>
+static int launch_bwd_dg(const BackwardArgs& g, hipStream_t stream) {
+  constexpr int E = v16<T>::N;
+  const int dv = (g.f.d + E - 1) / E;
+  if (dv <= 4) return launch_bwd_np<T, NP, 4>(g, stream);
+  if (dv <= 8) return launch_bwd_np<T, NP, 8>(g, stream);
+  if constexpr (sizeof(T) == 8) {
+    return MGP_EUNSUPPORTED;  // fp64 rows of more than 16 features: the sweep's registers spill
+  } else {
+    if (dv <= 12) return launch_bwd_np<T, NP, 12>(g, stream);
+    return launch_bwd_np<T, NP, 16>(g, stream);
+  }
+}
+
+// Isotropy, d <= 64 (fp32) / 16 (fp64), k + 2 <= 64 (fp32) / 32 (fp64); everything else: MGP_EUNSUPPORTED (the LDS workgroup kernel)
+template <typename T>
+int launch_backward_wave(const BackwardArgs& g, hipStream_t stream) {
+  const int rows = g.f.k + 2;
+  if (g.f.ls_count != 1 || g.f.d > 16 * (16 / (int)sizeof(T)) || rows > 64) return MGP_EUNSUPPORTED;
+  if (rows <= 32) return launch_bwd_dg<T, 32>(g, stream);
+  if constexpr (sizeof(T) == 8) return MGP_EUNSUPPORTED;  // 64 fp64 row registers + the sweep's: spills
+  else return launch_bwd_dg<T, 64>(g, stream);
+}
+
+template int launch_backward_wave<float>(const BackwardArgs&, hipStream_t);
+template int launch_backward_wave<double>(const BackwardArgs&, hipStream_t);
+
+}  // namespace mgp

@@ -1,5 +1,6 @@
 // extern "C" boundary: argument validation + dispatch to the kernels.  See
 // include/muygpys_hip.h for the contract and the reference functions each entry replaces.
+#include <cstdlib>
 #include <cstdio>
 
 #include "mgp_args.h"
@@ -99,6 +100,11 @@ int posterior_backward(const T* fq, const T* fn, int d, const int64_t* bi, const
   BackwardArgs g{{fq, fn, bi, ni, tg, nd, ls, nullptr, nullptr, nullptr, info, b, eps, d, k, R, noise_mode, kernel_id,
                   metric_id, ls_count, 0},
                  gmean, gvar, gfq, gfn, gtg, gls, gnz};
+  static const bool lds_only = getenv("MGP_BACKWARD_LDS") != nullptr;  // A/B switch (timing only)
+  if (!lds_only) {
+    const int rc = launch_backward_wave<T>(g, static_cast<hipStream_t>(stream));
+    if (rc != MGP_EUNSUPPORTED) return rc;
+  }
   return launch_backward<T>(g, static_cast<hipStream_t>(stream));
 }
 
