@@ -321,3 +321,49 @@ def test_register_kernels_ignore_stale_lds(k, R, dtype):
         if ref is None:
             ref = (mean.clone(), var.clone())
         assert torch.equal(mean, ref[0]) and torch.equal(var, ref[1])
+
+
+def _random_shapes():
+    rng = np.random.default_rng(20261003)
+    shapes = []
+    for _ in range(36):
+        k = int(rng.choice([3, 7, 12, 20, 29, 30, 31, 33, 47, 50, 61, 62, 63, 64, 65, 70, 90, 100, 111, 126]))
+        R = int(rng.choice([1, 1, 2, 3, 5, 16]))
+        if k + 1 + R > 128:
+            R = 1
+        d = int(rng.choice([1, 3, 4, 8, 10, 17, 24, 40, 64]))
+        dtype = str(rng.choice(["float32", "float64"]))
+        kernel = str(rng.choice(["rbf", "matern05", "matern15", "matern25", "maternInf"]))
+        aniso = bool(rng.integers(0, 2))
+        shapes.append((k, R, d, dtype, kernel, aniso))
+    return shapes
+
+
+@pytest.mark.parametrize("shape", _random_shapes(), ids=lambda s: f"k{s[0]}-R{s[1]}-d{s[2]}-{s[3]}-{s[4]}-{'aniso' if s[5] else 'iso'}")
+def test_dispatcher_agrees_with_the_lds_workgroup_kernel(shape):
+    """Random shapes across every dispatch boundary (32 / 64 / 128 slots, rhs columns, fp64 two-lane rows,
+    aligned and unaligned rows): whichever register kernel the dispatcher picks agrees with the
+    independent LDS workgroup kernel on the same inputs."""
+    from muygpys_amd import _lib
+    from muygpys_amd.fused import KernelSpec, posterior_mean_var
+
+    k, R, d, dtype, kernel, aniso = shape
+    td = getattr(torch, dtype)
+    rng = np.random.default_rng(k * 131 + R * 17 + d)
+    N, b = 3000, 777
+    X = torch.from_numpy(rng.normal(size=(N, d))).to("cuda", td)
+    Y = torch.from_numpy(np.sin(rng.normal(size=(N, R)))).to("cuda", td)
+    bi = torch.from_numpy(rng.integers(0, N, size=b)).cuda()
+    ni = torch.from_numpy(np.stack([rng.choice(N, size=k, replace=False) for _ in range(b)])).cuda()
+    metric = "F2" if kernel == "rbf" else "l2"
+    base = np.sqrt(2.0 * d) if metric == "l2" else np.sqrt(np.sqrt(2.0 * d))
+    ls = (base * rng.uniform(0.8, 1.3, size=d)).tolist() if aniso else float(base)
+    spec = KernelSpec(kernel, metric, ls, 1e-2)
+    Yt = Y[:, 0] if R == 1 else Y
+    m1, v1, y1 = posterior_mean_var(spec, X, X, bi, ni, Yt, want_ykinvy=True, path="auto", packed=False)
+    m2, v2, y2 = posterior_mean_var(spec, X, X, bi, ni, Yt, want_ykinvy=True, path="generic")
+    torch.cuda.synchronize()
+    rtol = 10 * RTOL[dtype] if dtype == "float32" else RTOL[dtype]  # two fp32 kernels against each other
+    assert_close(m1.cpu().numpy().reshape(b, R), m2.cpu().numpy().reshape(b, R), rtol, f"mean [{_lib.served_by(d, k, R, td, False, 'auto')}]")
+    assert_close(v1.cpu().numpy(), v2.cpu().numpy(), rtol, "var")
+    assert_close(y1.cpu().numpy().reshape(b, R), y2.cpu().numpy().reshape(b, R), rtol, "ykinvy")
