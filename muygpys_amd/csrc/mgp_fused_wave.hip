@@ -242,7 +242,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         }
 #pragma unroll
         for (int u = 0; u < GB; ++u)
-          if (n0 + u < SPR) glds16(src[u], reinterpret_cast<char*>(tile) + (n0 + u) * 1024);
+          if (n0 + u < SPR) glds16_lds(src[u], smem, (n0 + u) * 1024);  // the tile starts the dynamic LDS
       }
     }
     // response and nugget of the slot's row: unconditional single loads (idx_n is 0, a valid

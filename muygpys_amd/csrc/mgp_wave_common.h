@@ -196,6 +196,15 @@ __device__ __forceinline__ double lane_value(double x, int lane) {
 
 // 16 bytes per lane straight from global memory into LDS (no VGPR round trip): the LDS
 // destination is the wave-uniform pointer + lane * 16, the global source is per lane.
+// same, destination given as the (address-space-3) shared array itself + a byte offset: no generic ->
+// LDS pointer conversion (a null test and four scalar instructions per load) is left in the code
+template <typename SharedArray>
+__device__ __forceinline__ void glds16_lds(const void* gsrc, SharedArray& shared, int byte_offset) {
+  typedef __attribute__((address_space(3))) char lds_char;
+  lds_char* base = (lds_char*)(&shared[0]);
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)(base + byte_offset), 16, 0, 0);
+}
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
