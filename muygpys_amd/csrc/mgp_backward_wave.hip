@@ -141,8 +141,17 @@ __global__ __launch_bounds__(64, 2) void backward_wave_kernel(BackwardArgs g, in
       T kv[NS];
       kernel_dispatch(a.kernel_id, a.metric_id, [&](auto kid, auto mid) {
         constexpr int KID = decltype(kid)::value, MID = decltype(mid)::value;
+        if constexpr (sizeof(T) == 4) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) kv[s] = cov_from_sqdist<T>(acc_total(acc[s]), KID, MID, post_scale);
+          for (int s = 0; s < NS; s += 2) {  // two covariances per packed instruction
+            const f2 kk = cov_from_sqdist2(f2{acc_total(acc[s]), acc_total(acc[s + 1])}, KID, MID, post_scale);
+            kv[s] = kk.x;
+            kv[s + 1] = kk.y;
+          }
+        } else {
+#pragma unroll
+          for (int s = 0; s < NS; ++s) kv[s] = cov_from_sqdist<T>(acc_total(acc[s]), KID, MID, post_scale);
+        }
       });
       const int dump = (NP - 1) * KS + NP;  // padding behind the last row
 #pragma unroll
@@ -226,26 +235,38 @@ __global__ __launch_bounds__(64, 2) void backward_wave_kernel(BackwardArgs g, in
       const T* ah = avec + h * NP;
       const T* wh = wvec + h * NP;
       const int dump = (NP - 1) * KS + NP;
+      kernel_dispatch(a.kernel_id, a.metric_id, [&](auto kid, auto mid) {
+        constexpr int KID = decltype(kid)::value, MID = decltype(mid)::value;
 #pragma unroll
-      for (int s = 1; s <= NS; ++s) {
-        const int r1 = (i + own_offset((s - 1) / BP)) & (NP - 1);
-        const int c = (i + (s - 1) % BP + 1) & (NP - 1);
-        const int hi = max(r1, c), lo = min(r1, c);
-        const bool real = lo < k && hi <= k;
-        const T alo = ah[lo], wlo = wh[lo], ahi = ah[hi], whi = wh[hi];
-        const T gK = hi < k ? T(2) * gv * ahi * alo - (ahi * wlo + alo * whi) : wlo - T(2) * gv * alo;
-        const T x = metric_arg<T>(acc_total(acc[s - 1]), a.metric_id, post_scale);
-        const T kp = kernel_deriv<T>(a.kernel_id, x);
-        T dk_dacc;
-        if (l2) dk_dacc = x > T(0) ? kp * post_scale * post_scale / (T(2) * x) : T(0);
-        else dk_dacc = kp * post_scale;
-        const T q = real ? gK * dk_dacc : T(0);
-        // the pair at cyclic distance NP / 2 is met from both ends: count it once
-        const bool twice = ((r1 - c) & (NP - 1)) == NP / 2 && r1 < c;
-        if (real && !twice) liso += gK * kp * x;
-        Mh[hi <= k ? hi * KS + lo : dump] = q;
-        Mh[hi <= k ? lo * KS + hi : dump] = q;
-      }
+        for (int s = 1; s <= NS; ++s) {
+          const int r1 = (i + own_offset((s - 1) / BP)) & (NP - 1);
+          const int c = (i + (s - 1) % BP + 1) & (NP - 1);
+          const int hi = max(r1, c), lo = min(r1, c);
+          const bool real = lo < k && hi <= k;
+          const T alo = ah[lo], wlo = wh[lo], ahi = ah[hi], whi = wh[hi];
+          const T gK = hi < k ? T(2) * gv * ahi * alo - (ahi * wlo + alo * whi) : wlo - T(2) * gv * alo;
+          const T accv = acc_total(acc[s - 1]);
+          const T x = (MID == MGP_METRIC_L2 ? sqrt_fast(accv) : accv) * post_scale;
+          // d kappa / d x with the fast exponential of the forward kernels (mgp_device.h: kernel_deriv)
+          T kp;
+          if constexpr (KID == MGP_KERNEL_RBF) kp = T(-0.5) * exp_neg(x * T(0.5));
+          else if constexpr (KID == MGP_KERNEL_MATERN_05) kp = -exp_neg(x);
+          else if constexpr (KID == MGP_KERNEL_MATERN_15) kp = T(-3) * x * exp_neg(x * T(1.7320508075688772935));
+          else if constexpr (KID == MGP_KERNEL_MATERN_25) {
+            const T t = x * T(2.2360679774997896964);
+            kp = T(-5.0 / 3.0) * x * (T(1) + t) * exp_neg(t);
+          } else kp = -x * exp_neg(x * x * T(0.5));
+          T dk_dacc;
+          if constexpr (MID == MGP_METRIC_L2) dk_dacc = x > T(0) ? kp * post_scale * post_scale * pivot_rcp(T(2) * x) : T(0);
+          else dk_dacc = kp * post_scale;
+          const T q = real ? gK * dk_dacc : T(0);
+          // the pair at cyclic distance NP / 2 is met from both ends: count it once
+          const bool twice = ((r1 - c) & (NP - 1)) == NP / 2 && r1 < c;
+          if (real && !twice) liso += gK * kp * x;
+          Mh[hi <= k ? hi * KS + lo : dump] = q;
+          Mh[hi <= k ? lo * KS + hi : dump] = q;
+        }
+      });
       Mh[i * KS + i] = T(0);
     }
     // per-neighbourhood outputs that need a and w only
