@@ -363,6 +363,7 @@ static int launch_bwd_dg(const BackwardArgs& g, hipStream_t stream) {
   if constexpr (sizeof(T) == 8) {
     return MGP_EUNSUPPORTED;  // fp64 rows of more than 16 features: the sweep's registers spill
   } else {
+    if (dv <= 10) return launch_bwd_np<T, NP, 10>(g, stream);  // d = 40: 2 KB of LDS less than DG = 12, one more wave per CU
     if (dv <= 12) return launch_bwd_np<T, NP, 12>(g, stream);
     return launch_bwd_np<T, NP, 16>(g, stream);
   }
