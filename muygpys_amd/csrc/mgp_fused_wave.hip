@@ -76,6 +76,21 @@
 #ifndef MGP_LOOKAHEAD
 #define MGP_LOOKAHEAD 1
 #endif
+#ifndef MGP_CHOL_ONE_BLOCK
+#define MGP_CHOL_ONE_BLOCK 1
+#endif
+#ifndef MGP_MODM
+#define MGP_MODM 1
+#endif
+#ifndef MGP_GRAM
+#define MGP_GRAM 1
+#endif
+#ifndef MGP_DMA_ASM
+#define MGP_DMA_ASM 1
+#endif
+#ifndef MGP_DIST_ASM
+#define MGP_DIST_ASM 1
+#endif
 #ifndef MGP_F64_GC
 #define MGP_F64_GC 6
 #endif
@@ -97,15 +112,31 @@ struct WaveGeom {
 // PACKED: the tables are prepared tables (mgp_table_pack_*): rows of [features | responses | pad] at a
 //        64-byte multiple stride, so a row and its response arrive with the same two cache lines
 //        and no separate 4-byte response read (a whole line each) is issued.
-template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF = false, bool PACKED = false>
+// GRAM: (fp32, pipelined) squared distances as |a'|^2 + |b'|^2 - 2 a'.b' on rows centred on the query
+//        in place (a' = a - q, times the inverse length scales under Anisotropy): one packed FMA per
+//        two features of a pair instead of a packed subtract + a packed FMA.  See phase 1b / 2.
+template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF = false, bool PACKED = false,
+          bool GRAM = false>
 __global__ __launch_bounds__(64, (sizeof(T) == 4 ? (NP == 32 ? (KFIX == 30 && MGP_W4 ? 4 : 3) : 2) : (NP == 32 ? 2 : 2)))
 void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   static_assert(!PACKED || PIPED, "prepared tables are gathered by the direct-to-LDS pipeline");
+  static_assert(!GRAM || (sizeof(T) == 4 && PIPED && !COEFF), "Gram form: fp32, one feature stage");
   constexpr int NH = 64 / NP;     // neighbourhoods per wave
-  constexpr int NS = NP / 2;      // pairs per lane
-  constexpr int BA = 4;           // own rows per lane        } register blocking of the pair scheme,
-  constexpr int BP = NS / BA;     // partner rows per lane    } see phase 2
+  // Pair scheme.  Generic: the NP slots form the cycle, NP/2 pairs per lane (the half-way distance twice),
+  // pairs with a response or padding slot computed and discarded.  Static shapes whose feature rows
+  // 0 .. KFIX (neighbours + query) are an ODD count M and fill the slots up to the responses run the
+  // cycle modulo M instead: (M - 1)/2 pairs per lane, every pair exactly once, nothing discarded
+  // (k = 30: 15 instead of 16 pairs per lane, 3 x 5 blocking; lanes >= M repeat lane 0 and are dropped).
+  // (not with the Gram form: measured 1.89 vs 1.83 ms on the headline shape -- the wrap at M = 31 breaks the
+  // bank spread of the 176-byte tile rows, and the Gram form is shorter on arithmetic and longer on LDS)
+  constexpr bool MODM = MGP_MODM && !GRAM && KFIX > 0 && RFIX > 0 && DFIX > 0 && !COEFF && (KFIX + 1) % 2 == 1 && KFIX + 1 + RFIX == NP;
+  constexpr int M = MODM ? KFIX + 1 : NP;
+  constexpr int NS = MODM ? (M - 1) / 2 : NP / 2;            // pairs per lane
+  constexpr int BA = MODM ? (NS % 3 == 0 ? 3 : 5) : 4;        // own rows per lane        } register blocking of the pair scheme,
+  constexpr int BP = NS / BA;                                 // partner rows per lane    } see phase 2
+  static_assert(BA * BP == NS, "pair blocking");
   auto own_offset = [](int j) { return j == 0 ? 0 : (j + 1) * BP + 1; };
+  auto wrap = [](int r) { return MODM ? r % M : r & (NP - 1); };
   constexpr int E = v16<T>::N;    // elements per 16 bytes
   constexpr int CH = 2 * E;       // feature chunk per inner iteration (two 16-B reads per row)
   constexpr int KS = NP + E;      // row stride of the (square) exchange matrix: NP/E + 1 (odd) 16-B slots
@@ -242,7 +273,13 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         }
 #pragma unroll
         for (int u = 0; u < GB; ++u)
-          if (n0 + u < SPR) glds16_lds(src[u], smem, (n0 + u) * 1024);  // the tile starts the dynamic LDS
+          if (n0 + u < SPR) {  // the tile starts the dynamic LDS
+#if MGP_DMA_ASM
+            glds16_asm(src[u], smem, (n0 + u) * 1024);
+#else
+            glds16_lds(src[u], smem, (n0 + u) * 1024);
+#endif
+          }
       }
     }
     // response and nugget of the slot's row: unconditional single loads (idx_n is 0, a valid
@@ -281,10 +318,10 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     const int dump0 = TRI ? KMAT - E : (NP - 1) * KS + NP;
 #pragma unroll
     for (int s = 1; s <= NS; ++s) {
-      const int r1 = (i0 + own_offset((s - 1) / BP)) & (NP - 1);
-      const int c = (i0 + (s - 1) % BP + 1) & (NP - 1);
+      const int r1 = wrap(i0 + own_offset((s - 1) / BP));
+      const int c = wrap(i0 + (s - 1) % BP + 1);
       const int hi = max(r1, c), lo = min(r1, c);
-      xoff[s - 1] = hbase + (hi <= q ? rowoff(hi) + lo : dump0);
+      xoff[s - 1] = hbase + (hi <= q && i0 < M ? rowoff(hi) + lo : dump0);
       if (lo < k && (hi < k || hi == q)) xkeep |= 1u << (s - 1);
     }
   }
@@ -296,10 +333,11 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     const int i0 = threadIdx.x & (NP - 1);
     const int hb = (NH == 1 ? 0 : (int)threadIdx.x / NP) * NP * xs;
 #pragma unroll
-    for (int j = 0; j < BA; ++j) down[j] = hb + ((i0 + own_offset(j)) & (NP - 1)) * xs;
+    for (int j = 0; j < BA; ++j) down[j] = hb + wrap(i0 + own_offset(j)) * xs;
 #pragma unroll
-    for (int s2 = 1; s2 <= BP; ++s2) dpar[s2 - 1] = hb + ((i0 + s2) & (NP - 1)) * xs;
+    for (int s2 = 1; s2 <= BP; ++s2) dpar[s2 - 1] = hb + wrap(i0 + s2) * xs;
   }
+  static_assert(!MODM || (XPRE && DPRE), "the modulo-M pair scheme relies on the per-lane tables");
 
   for (int64_t task = task0; task < t_end; task += t_step) {
     // The lane id is made opaque per task: otherwise LICM hoists every per-lane address, mask
@@ -355,6 +393,9 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     for (int d0 = 0; d0 < d; d0 += dst) {
       const int w = min(dst, d - d0);
       const int wp = (w + CH - 1) / CH * CH;
+#if MGP_DMA_ASM
+      if (PIPE) lds_dma_wait();  // this task's tile (requested during the previous task's elimination) has landed
+#endif
       __syncthreads();
       if (PIPE) {
         if constexpr (PACKED) {
@@ -422,13 +463,114 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) acc[s] = ACC(0);
       }
+      if constexpr (GRAM) {
+        // ---- phase 1b: centre the rows on the query, in place; squared norms --------------------
+        // Row i becomes a' = (a - q) [x inverse length scales]; |a'|^2 goes to the first element of the
+        // row's padding slot (column dst), where the lanes that pair with the row pick it up.  The query
+        // row becomes exactly zero (norm 0), so a pair with the query is |a'|^2: the cross-covariances
+        // keep the difference form.  All reads of the query row are issued before any lane's writes (one
+        // wave, LDS executes in order).  Slots without features (responses, padding) are left alone:
+        // their pairs are dropped or masked.
+        if (MGP_PHASE(g, 2)) {
+          const bool has = i < k || i == q;
+          T* xrow = Xh + i * xs;
+          const T* qrow = Xh + q * xs;
+          constexpr int NCF = DFIX > 0 ? DSTFIX / E : 1;  // 16-byte groups per row (static shapes)
+          if constexpr (DFIX > 0) {
+            V x[NCF], qv[NCF];
+#pragma unroll
+            for (int c = 0; c < NCF; ++c) {
+              x[c] = *reinterpret_cast<const V*>(xrow + c * E);
+              qv[c] = *reinterpret_cast<const V*>(qrow + c * E);
+            }
+#pragma unroll
+            for (int c = 0; c < NCF; ++c) {
+              x[c] = vsub(x[c], qv[c]);  // (v_pk_add_f32 with neg modifiers; a plain vector subtract is split into v_sub_f32)
+              if (aniso) x[c] = x[c] * *reinterpret_cast<const V*>(ilbuf + c * E);
+            }
+            if (has) {
+#pragma unroll
+              for (int c = 0; c < NCF; ++c) *reinterpret_cast<V*>(xrow + c * E) = x[c];
+            }
+            // four independent partial sums (a single chain of 2 NCF dependent packed FMAs costs a wait state each)
+            f2 n4[4] = {f2{0.0f, 0.0f}, f2{0.0f, 0.0f}, f2{0.0f, 0.0f}, f2{0.0f, 0.0f}};
+#pragma unroll
+            for (int c = 0; c < NCF; ++c) {
+              n4[(2 * c) & 3] = x[c].xy * x[c].xy + n4[(2 * c) & 3];
+              n4[(2 * c + 1) & 3] = x[c].zw * x[c].zw + n4[(2 * c + 1) & 3];
+            }
+            const f2 n2 = (n4[0] + n4[1]) + (n4[2] + n4[3]);
+            if (has) xrow[dst] = n2.x + n2.y;
+          } else {
+            f2 n2 = f2{0.0f, 0.0f};
+            for (int c0 = 0; c0 < wp; c0 += CH) {
+              V x0 = *reinterpret_cast<const V*>(xrow + c0), x1 = *reinterpret_cast<const V*>(xrow + c0 + E);
+              const V q0 = *reinterpret_cast<const V*>(qrow + c0), q1 = *reinterpret_cast<const V*>(qrow + c0 + E);
+              x0 = vsub(x0, q0);
+              x1 = vsub(x1, q1);
+              if (aniso) {
+                x0 = x0 * *reinterpret_cast<const V*>(ilbuf + c0);
+                x1 = x1 * *reinterpret_cast<const V*>(ilbuf + c0 + E);
+              }
+              n2 = x0.xy * x0.xy + n2;
+              n2 = x0.zw * x0.zw + n2;
+              n2 = x1.xy * x1.xy + n2;
+              n2 = x1.zw * x1.zw + n2;
+              // (lane q writes zeros over the chunk every lane has just read; the next chunk's reads come
+              // after this store in program order)
+              if (has) {
+                *reinterpret_cast<V*>(xrow + c0) = x0;
+                *reinterpret_cast<V*>(xrow + c0 + E) = x1;
+              }
+            }
+            if (has) xrow[dst] = n2.x + n2.y;
+          }
+        }
+        __syncthreads();
+        // ---- phase 2 (Gram form): acc = a'.b' per pair ------------------------------------------
+        if (MGP_PHASE(g, 2)) {
+#pragma unroll
+          for (int c0 = 0; c0 < (DFIX > 0 ? DSTFIX : wp); c0 += CH) {
+            V own0[BA], own1[BA];
+#pragma unroll
+            for (int j = 0; j < BA; ++j) {
+              const T* xj = DPRE ? tile + down[DPRE ? j : 0] + c0 : Xh + wrap(i + own_offset(j)) * xs + c0;
+              own0[j] = *reinterpret_cast<const V*>(xj);
+              own1[j] = *reinterpret_cast<const V*>(xj + E);
+            }
+#pragma unroll
+            for (int s = 1; s <= BP; ++s) {
+              const T* xo = DPRE ? tile + dpar[DPRE ? s - 1 : 0] + c0 : Xh + wrap(i + s) * xs + c0;
+              const V o0 = *reinterpret_cast<const V*>(xo);
+              const V o1 = *reinterpret_cast<const V*>(xo + E);
+              gram_block<BA, BP>(&acc[s - 1], own0, o0);
+              gram_block<BA, BP>(&acc[s - 1], own1, o1);
+            }
+          }
+          // squared distance of a pair: |a'|^2 + |b'|^2 - 2 a'.b', clamped at zero; left in acc[].x
+          // (acc[].y = 0) so that the covariance stage below reads it like a difference-form sum
+          T nown[BA], npar[BP];
+#pragma unroll
+          for (int j = 0; j < BA; ++j) nown[j] = (DPRE ? tile + down[DPRE ? j : 0] : Xh + wrap(i + own_offset(j)) * xs)[dst];
+#pragma unroll
+          for (int s = 1; s <= BP; ++s) npar[s - 1] = (DPRE ? tile + dpar[DPRE ? s - 1 : 0] : Xh + wrap(i + s) * xs)[dst];
+#pragma unroll
+          for (int j = 0; j < BA; ++j)
+#pragma unroll
+            for (int s = 0; s < BP; ++s) {
+              const T gsum = acc[j * BP + s].x + acc[j * BP + s].y;
+              acc[j * BP + s].x = __builtin_fmaxf(__builtin_fmaf(-2.0f, gsum, nown[j] + npar[s]), 0.0f);
+              acc[j * BP + s].y = 0.0f;
+            }
+        }
+      } else
       if (MGP_PHASE(g, 2)) {
         if (aniso) {
           for (int c0 = 0; c0 < wp; c0 += CH) {
             V own0[BA], own1[BA];
 #pragma unroll
             for (int j = 0; j < BA; ++j) {
-              const T* xj = Xh + ((i + own_offset(j)) & (NP - 1)) * xs + c0;
+              const T* xj = Xh + wrap(i + own_offset(j)) * xs + c0;
               own0[j] = *reinterpret_cast<const V*>(xj);
               own1[j] = *reinterpret_cast<const V*>(xj + E);
             }
@@ -436,7 +578,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
             const V il1 = *reinterpret_cast<const V*>(ilbuf + c0 + E);
 #pragma unroll
             for (int s = 1; s <= BP; ++s) {
-              const T* xo = Xh + ((i + s) & (NP - 1)) * xs + c0;
+              const T* xo = Xh + wrap(i + s) * xs + c0;
               const V o0 = *reinterpret_cast<const V*>(xo);
               const V o1 = *reinterpret_cast<const V*>(xo + E);
 #pragma unroll
@@ -452,19 +594,26 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
             V own0[BA], own1[BA];
 #pragma unroll
             for (int j = 0; j < BA; ++j) {
-              const T* xj = DPRE ? tile + down[DPRE ? j : 0] + c0 : Xh + ((i + own_offset(j)) & (NP - 1)) * xs + c0;
+              const T* xj = DPRE ? tile + down[DPRE ? j : 0] + c0 : Xh + wrap(i + own_offset(j)) * xs + c0;
               own0[j] = *reinterpret_cast<const V*>(xj);
               own1[j] = *reinterpret_cast<const V*>(xj + E);
             }
 #pragma unroll
             for (int s = 1; s <= BP; ++s) {
-              const T* xo = DPRE ? tile + dpar[DPRE ? s - 1 : 0] + c0 : Xh + ((i + s) & (NP - 1)) * xs + c0;
+              const T* xo = DPRE ? tile + dpar[DPRE ? s - 1 : 0] + c0 : Xh + wrap(i + s) * xs + c0;
               const V o0 = *reinterpret_cast<const V*>(xo);
               const V o1 = *reinterpret_cast<const V*>(xo + E);
+              if constexpr (sizeof(T) == 4 && BA == 4 && MGP_DIST_ASM) {
+                dist_block4(acc[s - 1], acc[BP + s - 1], acc[2 * BP + s - 1], acc[3 * BP + s - 1], own0[0], own0[1],
+                            own0[2], own0[3], o0);
+                dist_block4(acc[s - 1], acc[BP + s - 1], acc[2 * BP + s - 1], acc[3 * BP + s - 1], own1[0], own1[1],
+                            own1[2], own1[3], o1);
+              } else {
 #pragma unroll
-              for (int j = 0; j < BA; ++j) {
-                accum(acc[j * BP + s - 1], vsub(own0[j], o0));
-                accum(acc[j * BP + s - 1], vsub(own1[j], o1));
+                for (int j = 0; j < BA; ++j) {
+                  accum(acc[j * BP + s - 1], vsub(own0[j], o0));
+                  accum(acc[j * BP + s - 1], vsub(own1[j], o1));
+                }
               }
             }
           }
@@ -491,12 +640,18 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         kernel_dispatch(a.kernel_id, a.metric_id, [&](auto kid, auto mid) {
           constexpr int KID = decltype(kid)::value, MID = decltype(mid)::value;
           if constexpr (sizeof(T) == 4) {
+            // (Gram form: the squared distance already sits in acc[].x)
+            auto sq = [&](int s) {
+              if constexpr (GRAM) return acc[s].x;
+              else return acc_total(acc[s]);
+            };
 #pragma unroll
-            for (int s = 0; s < NS; s += 2) {
-              const f2 kk = cov_from_sqdist2(f2{acc_total(acc[s]), acc_total(acc[s + 1])}, KID, MID, post_scale);
+            for (int s = 0; s + 1 < NS; s += 2) {
+              const f2 kk = cov_from_sqdist2(f2{sq(s), sq(s + 1)}, KID, MID, post_scale);
               kv[s] = kk.x;
               kv[s + 1] = kk.y;
             }
+            if constexpr (NS % 2 == 1) kv[NS - 1] = cov_from_sqdist<T>(sq(NS - 1), KID, MID, post_scale);
           } else {
 #pragma unroll
             for (int s = 1; s <= NS; ++s) kv[s - 1] = cov_from_sqdist<T>(acc_total(acc[s - 1]), KID, MID, post_scale);
@@ -511,8 +666,8 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
             if (!nopad) v = (xkeep >> (s - 1)) & 1u ? v : T(0);
             tile[xoff[s - 1]] = v;
           } else {
-            const int r1 = (i3 + own_offset((s - 1) / BP)) & (NP - 1);
-            const int c = (i3 + (s - 1) % BP + 1) & (NP - 1);
+            const int r1 = wrap(i3 + own_offset((s - 1) / BP));
+            const int c = wrap(i3 + (s - 1) % BP + 1);
             const int hi = max(r1, c), lo = min(r1, c);
             if (!nopad) v = (lo < k && (hi < k || hi == q)) ? v : T(0);
             Kh3[hi <= q ? rowoff(hi) + lo : dump] = v;
@@ -566,9 +721,16 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         piv = *reinterpret_cast<const V*>(colh);
       }
     }
+    // ONE test of the phase bit around the whole elimination (not one per step): with a test per step every
+    // step is its own basic block -- two taken branches per step, and the wait-count pass, which starts
+    // each block pessimistic, puts `s_waitcnt lgkmcnt(0)` in front of the trailing update, i.e. waits for
+    // the look-ahead pivot it has just requested.  In one block the waits are counted.
+#if MGP_CHOL_ONE_BLOCK
+    if (MGP_PHASE(g, 8))
+#endif
 #pragma unroll
     for (int j = 0; j < NP - 2; ++j) {
-      if (j < k && MGP_PHASE(g, 8)) {
+      if (j < k && (MGP_CHOL_ONE_BLOCK || MGP_PHASE(g, 8))) {
         const T ajj = A[j / E][j % E];
         if constexpr (!LOOK) colh[i] = ajj;
         if constexpr (sizeof(T) == 8) {
@@ -719,8 +881,9 @@ int g_grid_per_cu = 0;  // override of resident workgroups per CU
 int g_lds_pad = 0;      // extra dynamic LDS bytes per workgroup
 #endif
 
-template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF = false, bool PACKED = false>
-static int launch_np(const FusedArgs& a, hipStream_t stream) {
+template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF = false, bool PACKED = false,
+          bool GRAM = false>
+static int launch_np_impl(const FusedArgs& a, hipStream_t stream) {
   constexpr int NH = 64 / NP;
   constexpr int E = v16<T>::N;
   constexpr int CH = 2 * E;
@@ -759,7 +922,8 @@ static int launch_np(const FusedArgs& a, hipStream_t stream) {
   static Residency res;
   int per_cu = 0, cus = 0;
   const int rrc = res.lookup(
-      reinterpret_cast<const void*>(&fused_wave_kernel<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF, PACKED>), 64, lds, &per_cu, &cus);
+      reinterpret_cast<const void*>(&fused_wave_kernel<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF, PACKED, GRAM>), 64, lds, &per_cu,
+      &cus);
   if (rrc != MGP_OK) return rrc;
 #ifdef MGP_DEBUG_HOOKS
   if (g_grid_per_cu > 0) per_cu = g_grid_per_cu;
@@ -769,13 +933,26 @@ static int launch_np(const FusedArgs& a, hipStream_t stream) {
   if (grid > g.ntasks) grid = (g.ntasks + 7) / 8 * 8;
   static const bool trace = getenv("MGP_TRACE") != nullptr;  // which instantiation served a call
   if (trace)
-    fprintf(stderr, "mgp: fused_wave_kernel<%s,%d,%d,%d,%d,%s%s> b=%lld k=%d d=%d R=%d grid=%lld lds=%zu\n",
+    fprintf(stderr, "mgp: fused_wave_kernel<%s,%d,%d,%d,%d,%s%s%s> b=%lld k=%d d=%d R=%d grid=%lld lds=%zu\n",
             sizeof(T) == 4 ? "float" : "double", NP, KFIX, RFIX, DFIX, PIPED ? "pipe" : "stage", PACKED ? ",packed" : "",
+            GRAM ? ",gram" : "",
             (long long)a.b, a.k, a.d, a.R, (long long)grid, lds);
-  hipLaunchKernelGGL((fused_wave_kernel<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF, PACKED>), dim3((unsigned)grid), dim3(64), lds,
-                     stream, a, g);
+  hipLaunchKernelGGL((fused_wave_kernel<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF, PACKED, GRAM>), dim3((unsigned)grid), dim3(64),
+                     lds, stream, a, g);
   MGP_HIP_CHECK_LAUNCH();
   return MGP_OK;
+}
+
+// fp32 pipelined kernels compute the squared distances in the Gram form, except for the Matern-1/2
+// kernel: exp(-r) has a kink at r = 0, so the absolute error a cancelling Gram form leaves in a tiny
+// squared distance (duplicated training points) would show up at first order there.
+template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF = false, bool PACKED = false>
+static int launch_np(const FusedArgs& a, hipStream_t stream) {
+  if constexpr (sizeof(T) == 4 && PIPED && !COEFF && MGP_GRAM) {
+    if (a.kernel_id != MGP_KERNEL_MATERN_05)
+      return launch_np_impl<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF, PACKED, true>(a, stream);
+  }
+  return launch_np_impl<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF, PACKED, false>(a, stream);
 }
 
 template <typename T>
@@ -789,6 +966,9 @@ int launch_fused_wave(const FusedArgs& a, hipStream_t stream) {
   }
   if (a.packed_nn != nullptr) {  // prepared tables: the pipelined kernels only
     if (a.k == 30 && a.R == 1 && a.d == 40) return launch_np<T, 32, 30, 1, 40, true, false, true>(a, stream);
+#ifdef MGP_TEST_D32
+    if (a.k == 30 && a.R == 1 && a.d == 32 && sizeof(T) == 4) return launch_np<float, 32, 30, 1, 32, true, false, true>(a, stream);
+#endif
     if (a.k == 50 && a.R == 1 && a.d == 8) return launch_np<T, 64, 50, 1, 8, true, false, true>(a, stream);
     if (rows <= 32) return launch_np<T, 32, 0, 0, 0, true, false, true>(a, stream);
     if (rows <= 64) return launch_np<T, 64, 0, 0, 0, true, false, true>(a, stream);

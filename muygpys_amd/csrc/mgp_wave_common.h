@@ -79,7 +79,113 @@ __device__ __forceinline__ void accum(double& a, const v16<double>::type& df) {
   a = __builtin_fma(df.x, df.x, a);
   a = __builtin_fma(df.y, df.y, a);
 }
+// One partner 16-byte group against FOUR own rows: acc_j += (w_j - o).xy^2 + (w_j - o).zw^2, as one
+// hand-ordered block of 16 packed instructions.  gfx950 needs one wait state between a packed-f32
+// instruction and an instruction that reads its result; left to the compiler's scheduler, which
+// does not model that, every second instruction of this stream was followed by an `s_nop 0`
+// (~300 per task).  Here no instruction reads the result of its predecessor: 4 differences, then
+// squares-and-adds interleaved with the second half's differences.  Same operation order per
+// accumulator as accum(acc, vsub(w, o)) -- results are bit-identical.
+__device__ __forceinline__ void dist_block4(f2& a0, f2& a1, f2& a2, f2& a3, const v16<float>::type& w0,
+                                            const v16<float>::type& w1, const v16<float>::type& w2,
+                                            const v16<float>::type& w3, const v16<float>::type& o) {
+  f2 t0, t1, t2, t3;
+#ifdef MGP_FAKE_GRAM
+  asm volatile(
+      "v_pk_fma_f32 %0, %8, %16, %0\n\t"
+      "v_pk_fma_f32 %1, %10, %16, %1\n\t"
+      "v_pk_fma_f32 %2, %12, %16, %2\n\t"
+      "v_pk_fma_f32 %3, %14, %16, %3\n\t"
+      "v_pk_fma_f32 %0, %9, %17, %0\n\t"
+      "v_pk_fma_f32 %1, %11, %17, %1\n\t"
+      "v_pk_fma_f32 %2, %13, %17, %2\n\t"
+      "v_pk_fma_f32 %3, %15, %17, %3"
+      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "v"(w0.xy), "v"(w0.zw), "v"(w1.xy), "v"(w1.zw), "v"(w2.xy), "v"(w2.zw), "v"(w3.xy), "v"(w3.zw), "v"(o.xy),
+        "v"(o.zw));
+  return;
+#endif
+  asm volatile(
+      "v_pk_add_f32 %4, %8, %16 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %5, %10, %16 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %6, %12, %16 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %7, %14, %16 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_fma_f32 %0, %4, %4, %0\n\t"
+      "v_pk_add_f32 %4, %9, %17 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_fma_f32 %1, %5, %5, %1\n\t"
+      "v_pk_add_f32 %5, %11, %17 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_fma_f32 %2, %6, %6, %2\n\t"
+      "v_pk_add_f32 %6, %13, %17 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_fma_f32 %3, %7, %7, %3\n\t"
+      "v_pk_add_f32 %7, %15, %17 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_fma_f32 %0, %4, %4, %0\n\t"
+      "v_pk_fma_f32 %1, %5, %5, %1\n\t"
+      "v_pk_fma_f32 %2, %6, %6, %2\n\t"
+      "v_pk_fma_f32 %3, %7, %7, %3"
+      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "v"(w0.xy), "v"(w0.zw), "v"(w1.xy), "v"(w1.zw), "v"(w2.xy), "v"(w2.zw), "v"(w3.xy), "v"(w3.zw), "v"(o.xy),
+        "v"(o.zw));
+}
+__device__ __forceinline__ void dist_block4(double&, double&, double&, double&, const v16<double>::type&,
+                                            const v16<double>::type&, const v16<double>::type&,
+                                            const v16<double>::type&, const v16<double>::type&) {}  // fp32 only
+// Gram form: one partner 16-byte group against BA own rows, acc[j * BP] += w_j.xy * o.xy + w_j.zw * o.zw,
+// ordered so that no packed instruction reads its predecessor's result (see dist_block4).
+template <int BA, int BP>
+__device__ __forceinline__ void gram_block(f2* acc, const v16<float>::type (&w)[BA], const v16<float>::type& o) {
+  if constexpr (BA == 3) {
+    asm volatile(
+        "v_pk_fma_f32 %0, %3, %9, %0\n\t"
+        "v_pk_fma_f32 %1, %5, %9, %1\n\t"
+        "v_pk_fma_f32 %2, %7, %9, %2\n\t"
+        "v_pk_fma_f32 %0, %4, %10, %0\n\t"
+        "v_pk_fma_f32 %1, %6, %10, %1\n\t"
+        "v_pk_fma_f32 %2, %8, %10, %2"
+        : "+v"(acc[0]), "+v"(acc[BP]), "+v"(acc[2 * BP])
+        : "v"(w[0].xy), "v"(w[0].zw), "v"(w[1].xy), "v"(w[1].zw), "v"(w[2].xy), "v"(w[2].zw), "v"(o.xy), "v"(o.zw));
+  } else if constexpr (BA == 4) {
+    asm volatile(
+        "v_pk_fma_f32 %0, %4, %12, %0\n\t"
+        "v_pk_fma_f32 %1, %6, %12, %1\n\t"
+        "v_pk_fma_f32 %2, %8, %12, %2\n\t"
+        "v_pk_fma_f32 %3, %10, %12, %3\n\t"
+        "v_pk_fma_f32 %0, %5, %13, %0\n\t"
+        "v_pk_fma_f32 %1, %7, %13, %1\n\t"
+        "v_pk_fma_f32 %2, %9, %13, %2\n\t"
+        "v_pk_fma_f32 %3, %11, %13, %3"
+        : "+v"(acc[0]), "+v"(acc[BP]), "+v"(acc[2 * BP]), "+v"(acc[3 * BP])
+        : "v"(w[0].xy), "v"(w[0].zw), "v"(w[1].xy), "v"(w[1].zw), "v"(w[2].xy), "v"(w[2].zw), "v"(w[3].xy), "v"(w[3].zw),
+          "v"(o.xy), "v"(o.zw));
+  } else if constexpr (BA == 5) {
+    asm volatile(
+        "v_pk_fma_f32 %0, %5, %15, %0\n\t"
+        "v_pk_fma_f32 %1, %7, %15, %1\n\t"
+        "v_pk_fma_f32 %2, %9, %15, %2\n\t"
+        "v_pk_fma_f32 %3, %11, %15, %3\n\t"
+        "v_pk_fma_f32 %4, %13, %15, %4\n\t"
+        "v_pk_fma_f32 %0, %6, %16, %0\n\t"
+        "v_pk_fma_f32 %1, %8, %16, %1\n\t"
+        "v_pk_fma_f32 %2, %10, %16, %2\n\t"
+        "v_pk_fma_f32 %3, %12, %16, %3\n\t"
+        "v_pk_fma_f32 %4, %14, %16, %4"
+        : "+v"(acc[0]), "+v"(acc[BP]), "+v"(acc[2 * BP]), "+v"(acc[3 * BP]), "+v"(acc[4 * BP])
+        : "v"(w[0].xy), "v"(w[0].zw), "v"(w[1].xy), "v"(w[1].zw), "v"(w[2].xy), "v"(w[2].zw), "v"(w[3].xy), "v"(w[3].zw),
+          "v"(w[4].xy), "v"(w[4].zw), "v"(o.xy), "v"(o.zw));
+  } else {
+#pragma unroll
+    for (int j = 0; j < BA; ++j) acc[j * BP] = w[j].xy * o.xy + acc[j * BP];
+#pragma unroll
+    for (int j = 0; j < BA; ++j) acc[j * BP] = w[j].zw * o.zw + acc[j * BP];
+  }
+}
+template <int BA, int BP, typename A, typename W>
+__device__ __forceinline__ void gram_block(A*, const W&, const v16<double>::type&) {}  // fp32 only
+
+#ifdef MGP_FAKE_GRAM
+__device__ __forceinline__ float acc_total(const v16<float>::acc& a) { return __builtin_fabsf(a.x + a.y) * 4.0f + 20.0f; }
+#else
 __device__ __forceinline__ float acc_total(const v16<float>::acc& a) { return a.x + a.y; }
+#endif
 __device__ __forceinline__ double acc_total(const double& a) { return a; }
 
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
@@ -205,6 +311,21 @@ __device__ __forceinline__ void glds16_lds(const void* gsrc, SharedArray& shared
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)(base + byte_offset), 16, 0, 0);
 }
+// Same transfer issued as inline assembly.  The compiler books `global_load_lds` as a FLAT operation
+// that touches both memory and LDS; while one is pending, its wait-count pass turns EVERY LDS wait
+// into `s_waitcnt lgkmcnt(0)` (and every memory wait into vmcnt(0)) -- for a kernel that keeps the
+// next tile in flight during the whole elimination that means no counted waits at all: each step
+// waited for the pivot group it had just requested for the NEXT step.  Issued from here the compiler
+// does not see the transfer; the consumer must wait for it itself (lds_dma_wait) before reading the
+// tile.  M0 carries the LDS byte address of lane 0's 16 bytes (one wait state between the write of
+// M0 and the transfer); the compiler keeps nothing in M0 across statements on gfx950.
+template <typename SharedArray>
+__device__ __forceinline__ void glds16_asm(const void* gsrc, SharedArray& shared, int byte_offset) {
+  typedef __attribute__((address_space(3))) char lds_char;
+  const unsigned lds = (unsigned)(size_t)(lds_char*)(&shared[0]) + (unsigned)byte_offset;
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds) : "memory");
+}
+__device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
