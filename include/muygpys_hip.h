@@ -160,7 +160,9 @@ int mgp_posterior_kernel_name(int elem_size, int d, int k, int R, int packed, in
  * response from two separate arrays; at d = 40 fp32 that is two 128-byte lines
  * for the row plus one whole line for the response.  A prepared table stores
  *     row i = [ features (d) | responses (R) | zero pad ]   at stride mgp_packed_row_bytes(d, R, s)
- * (a multiple of 64 bytes), so row and responses arrive together.  The tables
+ * (a multiple of 64 bytes that always covers d * s + max(16, R * s): the 16-byte slot behind the
+ * features is read with every row, also of a table packed with R = 0), so row and responses
+ * arrive together.  The tables
  * are constant across all objective evaluations of a hyper-parameter search
  * (the reference rebuilds its difference tensors never, its kernels every
  * evaluation: optimize/objective.py:95-103), so the table is packed once.

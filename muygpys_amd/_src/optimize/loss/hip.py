@@ -78,12 +78,13 @@ class _MseMean(torch.autograd.Function):
     def forward(ctx, predictions, targets):
         ctx.save_for_backward(predictions, targets)
         sums, count = _sums_and_count(predictions.detach(), targets)
+        ctx.count = float(count)  # the GLOBAL element count under sharded reductions
         return (sums[0] / count).to(predictions.dtype)
 
     @staticmethod
     def backward(ctx, g):
         p, t = ctx.saved_tensors
-        return g * 2.0 * (p - t.to(p.dtype).reshape(p.shape)) / p.numel(), None
+        return g * 2.0 * (p - t.to(p.dtype).reshape(p.shape)) / ctx.count, None
 
 
 def _cross_entropy_fn(predictions, targets, **kwargs):

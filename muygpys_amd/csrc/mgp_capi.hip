@@ -31,7 +31,9 @@ int posterior(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t*
   if (b == 0) return MGP_OK;  // empty shard: nothing to read or write (outputs may be NULL)
   const bool packed = packed_nn != nullptr;
   if (packed) {
-    if (!packed_q || q_stride < (int64_t)(d * sizeof(T)) || nn_stride < (int64_t)((d + R) * sizeof(T))) return MGP_EINVAL;
+    // both strides cover the features and the 16-byte response slot the gather reads with every row
+    const int64_t need = (int64_t)(d * sizeof(T)) + 16;
+    if (!packed_q || q_stride < need || nn_stride < need || nn_stride < (int64_t)((d + R) * sizeof(T))) return MGP_EINVAL;
   } else if (!fq || !fn || !tg) {
     return MGP_EINVAL;
   }
@@ -153,7 +155,10 @@ int mgp_posterior_kernel_name(int elem_size, int d, int k, int R, int packed, in
 }
 int64_t mgp_packed_row_bytes(int d, int R, int elem_size) {
   if (d < 1 || R < 0 || (elem_size != 4 && elem_size != 8)) return MGP_EINVAL;
-  return (((int64_t)(d + R) * elem_size) + 63) / 64 * 64;
+  // the gather always reads the 16-byte slot behind the features (the responses), also from a table
+  // packed without responses (a query table): the stride reserves it, so the read stays inside the row
+  const int64_t resp = (int64_t)R * elem_size > 16 ? (int64_t)R * elem_size : 16;
+  return ((int64_t)d * elem_size + resp + 63) / 64 * 64;
 }
 #ifdef MGP_DEBUG_HOOKS
 /* timing-ablation hooks of debug builds (tools/kbench.py, tools/bwdbench.py); absent from the shipped library */

@@ -10,35 +10,50 @@
 
 namespace mgp {
 
-// Resident workgroups per CU of one kernel instantiation at one LDS size, per device.  Queried once
-// per (instantiation, device, LDS size) under a mutex: the entry points stay re-entrant and a
-// second device gets its own CU count.
+// Resident workgroups per CU of one kernel instantiation, per device and per (LDS size, thread count):
+// the run-time-shape instantiations change their LDS size with d, so a few recent geometries are kept
+// (alternating shapes do not re-run the occupancy query); the CU count is read once per device.
+// Queried under a mutex: the entry points stay re-entrant and a second device gets its own numbers.
 struct Residency {
+  static constexpr int WAYS = 8;
   std::mutex mu;
-  struct Entry { int lds = -1, per_cu = 0, cus = 0; } dev[MGP_MAX_DEVICES];
+  struct Entry { int lds = -1, threads = 0, per_cu = 0; };
+  struct Dev { int cus = 0, next = 0; Entry e[WAYS]; } dev[MGP_MAX_DEVICES];
   // -> MGP_OK and (per_cu, cus), or an error status
   int lookup(const void* kernel, int threads, size_t lds, int* per_cu, int* cus) {
     int d = 0;
     if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MGP_MAX_DEVICES) return MGP_EHIP;
     std::lock_guard<std::mutex> lock(mu);
-    Entry& e = dev[d];
-    if (e.lds != (int)lds) {
+    Dev& v = dev[d];
+    if (v.cus == 0) {
       int n = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDeviceProperties(&prop, d) != hipSuccess) return MGP_EHIP;
-      hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lds);
-      if (err != hipSuccess) return -(1000 + (int)err);
-      if (n < 1) return MGP_EUNSUPPORTED;
-      // the occupancy query over-reports for LDS-bound shapes: measured on gfx950, LDS is handed out
-      // in 1280-byte granules of the CU's 160 KiB (13 x 12192 B is refused, 12 x 12704 B fits)
-      const int by_lds = lds == 0 ? n : (int)((160 * 1024) / (((lds + 1279) / 1280) * 1280));
-      e.per_cu = n < by_lds ? n : by_lds;
-      if (e.per_cu < 1) return MGP_EUNSUPPORTED;
-      e.cus = prop.multiProcessorCount;
-      e.lds = (int)lds;
+      if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n < 1) return MGP_EHIP;
+      v.cus = n;
     }
+    for (int w = 0; w < WAYS; ++w)
+      if (v.e[w].lds == (int)lds && v.e[w].threads == threads) {
+        *per_cu = v.e[w].per_cu;
+        *cus = v.cus;
+        return MGP_OK;
+      }
+    int n = 0;
+    hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lds);
+    if (err != hipSuccess) return -(1000 + (int)err);
+    if (n < 1) return MGP_EUNSUPPORTED;
+    // the occupancy query over-reports for LDS-bound shapes: measured on gfx950, LDS is handed out
+    // in 1280-byte granules of the CU's 160 KiB (13 x 12192 B is refused, 12 x 12704 B fits)
+    const int by_lds = lds == 0 ? n : (int)((160 * 1024) / (((lds + 1279) / 1280) * 1280));
+    Entry& e = v.e[v.next];
+    v.next = (v.next + 1) % WAYS;
+    e.per_cu = n < by_lds ? n : by_lds;
+    if (e.per_cu < 1) {
+      e.lds = -1;
+      return MGP_EUNSUPPORTED;
+    }
+    e.lds = (int)lds;
+    e.threads = threads;
     *per_cu = e.per_cu;
-    *cus = e.cus;
+    *cus = v.cus;
     return MGP_OK;
   }
 };

@@ -104,6 +104,11 @@ def reductions_active() -> bool:
     return bool(_ACTIVE["on"]) and _world(_ACTIVE["group"])[1] > 1
 
 
+def active_group():
+    """The process group of the enclosing :class:`sharded_reductions` block (None: the default group)."""
+    return _ACTIVE["group"]
+
+
 def reduce_if_sharded_(sums: torch.Tensor) -> torch.Tensor:
     """All-reduce a vector of partial sums when the sharded-reduction mode is on (else a no-op)."""
     if reductions_active():
@@ -118,7 +123,8 @@ def broadcast_scalar(value: float, group=None, root: int = 0) -> float:
 
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
         return float(value)
-    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    # nccl (= RCCL) needs a device tensor: this rank's current device (ranks set it from LOCAL_RANK)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
     t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
     dist.broadcast(t, src=root, group=group)
     return float(t.item())

@@ -116,8 +116,15 @@ class PackedTable:
         return (d * es) % 16 == 0 and R * es <= 16 and k + 1 + R <= 64
 
 
+# Prepared tables are kept per (features, targets) identity: at most _PACK_CACHE_SIZE entries and
+# _PACK_CACHE_BYTES bytes of packed copies (an entry also keeps its source tensors alive -- see
+# clear_caches()).  A table packed WITHOUT responses (the query side of a prediction on a separate test
+# table: every row is read once per neighbourhood, so its pack is pure overhead kept small, not an
+# investment) gets a single slot of its own and never evicts a training table.
 _PACK_CACHE: "OrderedDict[tuple, PackedTable]" = OrderedDict()
 _PACK_CACHE_SIZE = 4
+_PACK_CACHE_BYTES = 8 << 30
+_QUERY_PACK: "OrderedDict[tuple, PackedTable]" = OrderedDict()
 
 
 def _tensor_key(t: Optional[torch.Tensor]):
@@ -128,14 +135,17 @@ def pack_table(features: torch.Tensor, targets: Optional[torch.Tensor] = None) -
     """The prepared table of ``(features, targets)``, cached on the tensors' identity and version
     (an in-place edit of either tensor invalidates the entry)."""
     key = (_tensor_key(features), _tensor_key(targets))
-    hit = _PACK_CACHE.get(key)
+    cache = _QUERY_PACK if targets is None else _PACK_CACHE
+    hit = cache.get(key)
     if hit is None:
         hit = PackedTable(features, targets)
-        _PACK_CACHE[key] = hit
-        if len(_PACK_CACHE) > _PACK_CACHE_SIZE:
-            _PACK_CACHE.popitem(last=False)
+        if targets is None:
+            cache.clear()
+        cache[key] = hit
+        while len(cache) > 1 and (len(cache) > _PACK_CACHE_SIZE or sum(t.data.numel() for t in cache.values()) > _PACK_CACHE_BYTES):
+            cache.popitem(last=False)
     else:
-        _PACK_CACHE.move_to_end(key)
+        cache.move_to_end(key)
     return hit
 
 
@@ -143,6 +153,7 @@ def clear_caches() -> None:
     """Drop the cached prepared tables (and with them the references to their source tensors) and the
     cached device-resident length scales."""
     _PACK_CACHE.clear()
+    _QUERY_PACK.clear()
     _LS_CACHE.clear()
 
 
@@ -252,7 +263,9 @@ def posterior_mean_var(
     if use_packed and packed == "auto":
         # a pack is one pass over the table; worth it once the batch gathers a comparable number of rows
         key = (_tensor_key(train_features), _tensor_key(train_targets))
-        use_packed = key in _PACK_CACHE or b * (k + 1) >= fn.shape[0] // 4
+        # (a separate test table is packed too -- one more pass over ITS rows -- so it counts as table size)
+        rows = fn.shape[0] + (0 if test_features is train_features else fq.shape[0])
+        use_packed = key in _PACK_CACHE or b * (k + 1) >= rows // 4
     if use_packed:
         pn = pack_table(train_features, train_targets)
         pq = pn if test_features is train_features else pack_table(test_features, None)
@@ -328,7 +341,9 @@ def loocv_partials(
     use_packed = packed is not False and PackedTable.supported(d, 1, k, dtype) and b > 0
     if use_packed and packed == "auto":
         key = (_tensor_key(train_features), _tensor_key(train_targets))
-        use_packed = key in _PACK_CACHE or b * (k + 1) >= fn.shape[0] // 4
+        # (a separate test table is packed too -- one more pass over ITS rows -- so it counts as table size)
+        rows = fn.shape[0] + (0 if test_features is train_features else fq.shape[0])
+        use_packed = key in _PACK_CACHE or b * (k + 1) >= rows // 4
     if use_packed:
         pn = pack_table(train_features, train_targets)
         rc = _lib.fn("loocv_packed", dtype)(_lib.ptr(pn.data), pn.stride, d, _lib.ptr(bi), _lib.ptr(ni), b, k, *tail)

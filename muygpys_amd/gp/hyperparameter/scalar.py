@@ -36,10 +36,12 @@ class Parameter:
             new = float(np.exp(np.random.uniform(low=np.log(lo), high=np.log(hi))))
         else:
             raise ValueError(f"Unsupported string hyperparameter value {val}.")
-        # every rank of a multi-GPU job starts from rank 0's draw (scalar.py:145-146: bcast(root=0))
-        from muygpys_amd.distributed import broadcast_scalar
+        # under sharded reductions (the mpi-backend layout) every rank starts from rank 0's draw
+        # (scalar.py:145-146: bcast(root=0) when _is_mpi_mode()); a plain torch.distributed job that
+        # samples on some ranks only is left alone
+        from muygpys_amd import distributed as _D
 
-        return broadcast_scalar(new)
+        return _D.broadcast_scalar(new, _D.active_group()) if _D.reductions_active() else new
 
     def _set_val(self, val) -> None:
         if isinstance(val, str):

@@ -141,8 +141,10 @@ def _opt_worker(rank, world, port, q):
         X, y = torch.from_numpy(g["features"]), torch.from_numpy(g["targets"])
         bi, ni = torch.from_numpy(g["batch_idx"]), torch.from_numpy(g["nn_idx"])
         # "sample": drawn on rank 0 and broadcast (scalar.py:145-146); ranks seed differently on purpose
+        # (opt-in like the reference's _is_mpi_mode(): only inside a sharded_reductions block)
         np.random.seed(100 + rank)
-        ls = Parameter("sample", (0.5, 8.0))
+        with D.sharded_reductions():
+            ls = Parameter("sample", (0.5, 8.0))
         model = MuyGPS(Matern(smoothness=Parameter(1.5), deformation=Isotropy(l2, length_scale=ls)),
                        noise=HomoscedasticNoise(g["meta"]["noise"]))
         start = model.kernel.deformation.length_scale()

@@ -75,6 +75,46 @@ def test_prepared_tables_give_identical_bits(dtype):
         assert torch.equal(a, c)
 
 
+def test_query_table_stride_keeps_the_response_slot_inside_the_row():
+    """Round-2 advisor finding: the gather reads the 16-byte slot behind the features with EVERY row,
+    also of a query table packed without responses.  With d * s a multiple of 64 (d = 16, fp32) the
+    old stride ended at the features, so that read ran 16 bytes past the last row of the table.  The
+    stride now reserves the slot; the library refuses a stride without it."""
+    from muygpys_amd import _lib
+    from muygpys_amd.fused import KernelSpec, PackedTable, posterior_mean_var
+
+    lib = _lib.load()
+    for d, es in ((16, 4), (32, 4), (8, 8), (40, 4)):
+        for R in (0, 1):
+            assert lib.mgp_packed_row_bytes(d, R, es) >= d * es + 16
+            assert lib.mgp_packed_row_bytes(d, R, es) % 64 == 0
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    N, M, d, k = 4096, 1 << 14, 16, 30
+    X = torch.randn(N, d, device="cuda", generator=gen)
+    Q = torch.randn(M, d, device="cuda", generator=gen)
+    y = torch.randn(N, device="cuda", generator=gen)
+    bi = torch.arange(M - 512, M, device="cuda")  # the last rows of the query table, the very last included
+    ni = torch.randint(0, N, (bi.numel(), k), device="cuda", generator=gen)
+    spec = KernelSpec("matern15", "l2", float(np.sqrt(2 * d)), 1e-3)
+    ref = posterior_mean_var(spec, Q, X, bi, ni, y, packed=False)
+    got = posterior_mean_var(spec, Q, X, bi, ni, y, packed=True)
+    torch.cuda.synchronize()
+    assert PackedTable(Q).stride >= d * 4 + 16
+    for a, c in zip(ref, got):
+        assert torch.equal(a, c)
+    # a caller-made query table without the slot is refused (MGP_EINVAL), not read out of bounds
+    pn = PackedTable(X, y)
+    mean = torch.empty((bi.numel(), 1), device="cuda")
+    var = torch.empty((bi.numel(),), device="cuda")
+    ls = torch.tensor([5.0], device="cuda")
+    rc = _lib.fn("posterior_packed", torch.float32)(
+        _lib.ptr(Q), d * 4, _lib.ptr(pn.data), pn.stride, d, _lib.ptr(bi), _lib.ptr(ni), bi.numel(), k, 1,
+        0, 1e-3, None, spec.kernel_id(), spec.metric_id(), _lib.ptr(ls), 1,
+        _lib.ptr(mean), _lib.ptr(var), None, None, _lib.stream_ptr(),
+    )
+    assert rc == -1  # MGP_EINVAL
+
+
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_fused_random_large(dtype):
     """BASELINE config-2 shape at a size the oracle finishes in seconds."""
