@@ -79,6 +79,12 @@
 #ifndef MGP_CHOL_ONE_BLOCK
 #define MGP_CHOL_ONE_BLOCK 1
 #endif
+#ifndef MGP_F64_COV_BATCH
+#define MGP_F64_COV_BATCH 5
+#endif
+#ifndef MGP_C4_W3
+#define MGP_C4_W3 0
+#endif
 #ifndef MGP_MODM
 #define MGP_MODM 1
 #endif
@@ -106,6 +112,36 @@ struct WaveGeom {
   int mask;      // debug: phases to execute (bit0 gather, 1 distances, 2 kernel+exchange, 3 factor)
 };
 
+// Sizes shared by the kernel and its launcher.
+template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool COEFF>
+struct WaveShape {
+  static constexpr int E = v16<T>::N;
+  static constexpr int CH = 2 * E;
+  static constexpr int NH = 64 / NP;
+  static constexpr bool STAT = KFIX > 0 && RFIX > 0 && DFIX > 0 && !COEFF;  // all shapes static
+  static constexpr int NPL = STAT ? KFIX + 1 + RFIX : NP;                    // live slots
+  static constexpr int NG = (NPL + E - 1) / E;                               // 16-byte groups of a lane's row
+  static constexpr int KS = NP + E;
+  static constexpr bool TRI = NP == 64 && !COEFF;
+  // elements per exchange matrix (packed: up to the last live row, the NG groups a lane reads from
+  // there, a dump slot)
+  static constexpr int KMAT =
+      TRI ? E * ((NPL - 1) / E + 1) * (E * ((NPL - 1) / E) / 2 + (NPL - 1) % E) + NG * E + E : NP * KS;
+  // rows of the feature tile: all NP slots of every neighbourhood of the wave, or -- one static
+  // neighbourhood per wave -- the live slots only (the direct-to-LDS gather stops after the query row;
+  // its last 1-KiB piece may run into the first response row, which holds no features)
+  static constexpr int tile_rows(int xs) {
+    if (!(STAT && NH == 1)) return NH * NP;
+    const int spr = xs / E, pieces = ((KFIX + 1) * spr + 63) / 64;
+    const int covered = (pieces * 64 + spr - 1) / spr;
+    return covered > NPL ? covered : NPL;
+  }
+  static constexpr int gather_pieces(int xs) {
+    const int spr = xs / E;
+    return (STAT && NH == 1) ? ((KFIX + 1) * spr + 63) / 64 : spr;
+  }
+};
+
 // KFIX / RFIX / DFIX > 0: nn_count / response_count / feature_count known at compile time.
 // PIPED: software-pipelined direct-to-LDS gather (one feature stage, 16-byte aligned rows).
 // COEFF: also emit K^-1 y (the fast-posterior-mean coefficients): multipliers kept, back-substitution.
@@ -117,7 +153,7 @@ struct WaveGeom {
 //        two features of a pair instead of a packed subtract + a packed FMA.  See phase 1b / 2.
 template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF = false, bool PACKED = false,
           bool GRAM = false>
-__global__ __launch_bounds__(64, (sizeof(T) == 4 ? (NP == 32 ? (KFIX == 30 && MGP_W4 ? 4 : 3) : 2) : (NP == 32 ? 2 : 2)))
+__global__ __launch_bounds__(64, (sizeof(T) == 4 ? (NP == 32 ? (KFIX == 30 && MGP_W4 ? 4 : 3) : 2) : (NP == 32 ? 2 : (KFIX > 0 && MGP_C4_W3 ? 3 : 2))))
 void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   static_assert(!PACKED || PIPED, "prepared tables are gathered by the direct-to-LDS pipeline");
   static_assert(!GRAM || (sizeof(T) == 4 && PIPED && !COEFF), "Gram form: fp32, one feature stage");
@@ -129,7 +165,15 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   // (k = 30: 15 instead of 16 pairs per lane, 3 x 5 blocking; lanes >= M repeat lane 0 and are dropped).
   // (not with the Gram form: measured 1.89 vs 1.83 ms on the headline shape -- the wrap at M = 31 breaks the
   // bank spread of the 176-byte tile rows, and the Gram form is shorter on arithmetic and longer on LDS)
-  constexpr bool MODM = MGP_MODM && !GRAM && KFIX > 0 && RFIX > 0 && DFIX > 0 && !COEFF && (KFIX + 1) % 2 == 1 && KFIX + 1 + RFIX == NP;
+  constexpr bool MODM = MGP_MODM && !GRAM && KFIX > 0 && RFIX > 0 && DFIX > 0 && !COEFF && (KFIX + 1) % 2 == 1;
+  // Static shapes put the query and the responses directly behind the k neighbours (q = k): NPL live
+  // slots, lanes NPL .. NP-1 idle.  Everything downstream is sized by NPL, not NP -- the row a lane
+  // holds (NG 16-byte groups), the exchange matrix, the elimination's trailing update, the gather
+  // (k = 50, R = 1: 52 of 64 slots; 26 instead of 32 register groups of fp64 per row).
+  using WS = WaveShape<T, NP, KFIX, RFIX, DFIX, COEFF>;
+  constexpr bool STAT = WS::STAT;
+  constexpr int NPL = WS::NPL;
+  static_assert(NPL <= NP, "live slots");
   constexpr int M = MODM ? KFIX + 1 : NP;
   constexpr int NS = MODM ? (M - 1) / 2 : NP / 2;            // pairs per lane
   constexpr int BA = MODM ? (NS % 3 == 0 ? 3 : 5) : 4;        // own rows per lane        } register blocking of the pair scheme,
@@ -154,7 +198,8 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       return r * KS;
     }
   };
-  constexpr int KMAT = TRI ? E * (NP / E + 1) * (E * (NP / E) / 2) + NP + E : NP * KS;  // elements per matrix
+  constexpr int NG = WS::NG;      // 16-byte groups of a lane's row
+  constexpr int KMAT = WS::KMAT;  // elements per exchange matrix
   constexpr int DPADFIX = (DFIX + CH - 1) / CH * CH;
   constexpr int DSTFIX = DFIX > 0 ? (DPADFIX < 64 ? DPADFIX : 64) : CH;
   using V = typename v16<T>::type;
@@ -164,10 +209,11 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   const int k = KFIX > 0 ? KFIX : a.k;
   const int R = RFIX > 0 ? RFIX : a.R;
   const int d = DFIX > 0 ? DFIX : a.d;
-  const int q = RFIX > 0 ? NP - 1 - RFIX : g.q;
+  const int q = STAT ? KFIX : (RFIX > 0 ? NP - 1 - RFIX : g.q);
   const int dst = DFIX > 0 ? DSTFIX : g.dst;
   const int xs = DFIX > 0 ? DSTFIX + E : g.xs;
-  const int tile_elems = NH * (NP * xs > KMAT ? NP * xs : KMAT);
+  const int tile_rows = WS::tile_rows(xs);
+  const int tile_elems = tile_rows * xs > NH * KMAT ? tile_rows * xs : NH * KMAT;
   T* tile = reinterpret_cast<T*>(smem);               // feature tile, later the exchange matrix
   // Plain kernels: [tile][colbuf 64][ilbuf dst][idxbuf 64 x int64].  Pipelined kernels keep LDS
   // at tile + 256 bytes (9 allocation granules of 1280 B -> 14 workgroups per CU): the 32-bit row
@@ -176,7 +222,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   // (a response slot: it has no features, and its distances are never used).
   constexpr bool PIPE_ = PIPED;
   T* colbuf = tile + tile_elems;                      // 64 entries
-  T* ilbuf = PIPE_ ? tile + (NP - 1) * xs : colbuf + 64;  // dst entries (Anisotropy)
+  T* ilbuf = PIPE_ ? tile + (NPL - 1) * xs : colbuf + 64;  // dst entries (Anisotropy)
   int64_t* idxbuf = reinterpret_cast<int64_t*>(ilbuf + dst + (dst & 1));  // 64 entries (plain kernels)
   const T** rowaddr = reinterpret_cast<const T**>(colbuf);  // 64 row pointers (pipelined; overlays colbuf + 256 B)
 
@@ -259,11 +305,12 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       // 16-byte slot sigma = 64 n + lane of the tile: row = sigma / SPR, column = sigma % SPR
       // (unsigned 32-bit arithmetic throughout; padding slots re-read the last data slot, the
       // ones inside the padded feature range are zeroed when the tile is consumed)
-      for (int n0 = 0; n0 < SPR; n0 += GB) {
+      const int NPC = WS::gather_pieces(xs);  // 1-KiB pieces per task (SPR when all 64 rows are gathered)
+      for (int n0 = 0; n0 < NPC; n0 += GB) {
         const T* src[GB];
 #pragma unroll
         for (int u = 0; u < GB; ++u) {
-          if (n0 + u < SPR) {  // uniform; folded for the static shapes
+          if (n0 + u < NPC) {  // uniform; folded for the static shapes
             const unsigned sigma = 64u * (unsigned)(n0 + u) + (unsigned)lane_;
             const unsigned row = (sigma * spr_magic) >> 20;
             // prepared tables: the slot after the features holds the responses
@@ -273,7 +320,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         }
 #pragma unroll
         for (int u = 0; u < GB; ++u)
-          if (n0 + u < SPR) {  // the tile starts the dynamic LDS
+          if (n0 + u < NPC) {  // the tile starts the dynamic LDS
 #if MGP_DMA_ASM
             glds16_asm(src[u], smem, (n0 + u) * 1024);
 #else
@@ -310,7 +357,11 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   // kernel instead of once per task (8 integer instructions per pair: 9 % of the headline kernel's
   // VALU work).  NS registers: the 32-slot kernels and the static shapes have them to spare.
   constexpr bool XPRE = (NP == 32 || KFIX > 0) && !COEFF;
-  int xoff[XPRE ? NS : 1];
+  // (more than 16 pairs per lane: two 16-bit element offsets per register -- the 25 offsets of the
+  // k = 50 kernel are what stands between it and a third wave per SIMD)
+  constexpr bool XPK = XPRE && NS > 16;
+  static_assert(!XPK || NH * KMAT < 65536, "packed exchange offsets are 16-bit");
+  int xoff[XPRE ? (XPK ? (NS + 1) / 2 : NS) : 1];
   unsigned xkeep = 0;
   if constexpr (XPRE) {
     const int i0 = threadIdx.x & (NP - 1);
@@ -321,7 +372,13 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       const int r1 = wrap(i0 + own_offset((s - 1) / BP));
       const int c = wrap(i0 + (s - 1) % BP + 1);
       const int hi = max(r1, c), lo = min(r1, c);
-      xoff[s - 1] = hbase + (hi <= q && i0 < M ? rowoff(hi) + lo : dump0);
+      const int xo = hbase + (hi <= q && i0 < M ? rowoff(hi) + lo : dump0);
+      if constexpr (XPK) {
+        if ((s - 1) % 2 == 0) xoff[(s - 1) / 2] = xo;
+        else xoff[(s - 1) / 2] |= xo << 16;
+      } else {
+        xoff[s - 1] = xo;
+      }
       if (lo < k && (hi < k || hi == q)) xkeep |= 1u << (s - 1);
     }
   }
@@ -337,7 +394,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 #pragma unroll
     for (int s2 = 1; s2 <= BP; ++s2) dpar[s2 - 1] = hb + wrap(i0 + s2) * xs;
   }
-  static_assert(!MODM || (XPRE && DPRE), "the modulo-M pair scheme relies on the per-lane tables");
+  static_assert(!MODM || XPRE, "the modulo-M pair scheme relies on the per-lane exchange offsets");
 
   for (int64_t task = task0; task < t_end; task += t_step) {
     // The lane id is made opaque per task: otherwise LICM hoists every per-lane address, mask
@@ -400,12 +457,12 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       if (PIPE) {
         if constexpr (PACKED) {
           // the slot behind the features carries the row's responses (before it is zeroed as padding)
-          myyv = *reinterpret_cast<const V*>(Xh + i * xs + d);
+          myyv = *reinterpret_cast<const V*>(Xh + (NPL == NP ? i : min(i, NPL - 1)) * xs + d);
           myy0 = i < k ? myyv[0] : T(0);
         }
         // feature columns w .. wp-1 of the staged rows are padding of the 8-wide inner loop: the
         // direct-to-LDS gather filled them with a repeat of the last data slot
-        if (wp > w) *reinterpret_cast<V*>(Xh + i * xs + w) = V(0);
+        if (wp > w && (NPL == NP || i < NPL)) *reinterpret_cast<V*>(Xh + i * xs + w) = V(0);
       } else if (!MGP_PHASE(g, 1)) {
       } else if (DFIX > 0 || g.vec_ok) {
         // c16p consecutive lanes walk one row; rpr rows per round; all rounds of a task in flight
@@ -566,29 +623,20 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       } else
       if (MGP_PHASE(g, 2)) {
         if (aniso) {
-          for (int c0 = 0; c0 < wp; c0 += CH) {
-            V own0[BA], own1[BA];
-#pragma unroll
-            for (int j = 0; j < BA; ++j) {
-              const T* xj = Xh + wrap(i + own_offset(j)) * xs + c0;
-              own0[j] = *reinterpret_cast<const V*>(xj);
-              own1[j] = *reinterpret_cast<const V*>(xj + E);
-            }
-            const V il0 = *reinterpret_cast<const V*>(ilbuf + c0);
-            const V il1 = *reinterpret_cast<const V*>(ilbuf + c0 + E);
-#pragma unroll
-            for (int s = 1; s <= BP; ++s) {
-              const T* xo = Xh + wrap(i + s) * xs + c0;
-              const V o0 = *reinterpret_cast<const V*>(xo);
-              const V o1 = *reinterpret_cast<const V*>(xo + E);
-#pragma unroll
-              for (int j = 0; j < BA; ++j) {
-                accum(acc[j * BP + s - 1], vsub(own0[j], o0) * il0);
-                accum(acc[j * BP + s - 1], vsub(own1[j], o1) * il1);
-              }
+          // Anisotropy: every row is scaled by the inverse length scales ONCE, in place (x / l), so that
+          // the pair loop below is the isotropic one: one multiply per row element instead of one per
+          // pair element (k = 50, d = 8: 8 instead of 200 multiplies per lane and neighbourhood).
+          if (i < k || i == q) {  // rows with features (the pipelined kernels keep ilbuf in a response slot's row)
+            T* xrow = Xh + i * xs;
+            for (int c0 = 0; c0 < wp; c0 += E) {
+              V x = *reinterpret_cast<const V*>(xrow + c0);
+              x = x * *reinterpret_cast<const V*>(ilbuf + c0);
+              *reinterpret_cast<V*>(xrow + c0) = x;
             }
           }
-        } else {
+          __syncthreads();
+        }
+        {
 #pragma unroll
           for (int c0 = 0; c0 < (DFIX > 0 ? DSTFIX : wp); c0 += CH) {
             V own0[BA], own1[BA];
@@ -633,13 +681,30 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       asm volatile("" : "+v"(i3));
       T* Kh3 = tile + (NH == 1 ? 0 : (lane / NP) * KMAT);
       if (MGP_PHASE(g, 4)) {
-        // All NS covariances first (independent chains the scheduler can interleave), then the
+        // fp32: all NS covariances first (independent chains the scheduler can interleave), then the
         // stores -- unconditional: an entry whose row is a response slot (hi > q) goes to the
         // unused padding column of the last row instead of being branched around.
-        T kv[NS];
+        // fp64 evaluates exp and sqrt in software (~40 instructions and a dozen temporaries per chain):
+        // interleaving all NS chains is what the register file cannot hold, so they go in batches of CB,
+        // each batch stored before the next starts.
+        const int dump = TRI ? KMAT - E : (NP - 1) * KS + NP;  // padding behind the last row / columns NP .. KS-1
+        auto put = [&](int s, T v) {  // s = 1 .. NS: pair j * BP + p - 1 = (own row j, partner p)
+          if constexpr (XPRE) {
+            if (!nopad) v = (xkeep >> (s - 1)) & 1u ? v : T(0);
+            if constexpr (XPK) tile[(s - 1) % 2 == 0 ? (xoff[(s - 1) / 2] & 0xFFFF) : ((unsigned)xoff[(s - 1) / 2] >> 16)] = v;
+            else tile[xoff[s - 1]] = v;
+          } else {
+            const int r1 = wrap(i3 + own_offset((s - 1) / BP));
+            const int c = wrap(i3 + (s - 1) % BP + 1);
+            const int hi = max(r1, c), lo = min(r1, c);
+            if (!nopad) v = (lo < k && (hi < k || hi == q)) ? v : T(0);
+            Kh3[hi <= q ? rowoff(hi) + lo : dump] = v;
+          }
+        };
         kernel_dispatch(a.kernel_id, a.metric_id, [&](auto kid, auto mid) {
           constexpr int KID = decltype(kid)::value, MID = decltype(mid)::value;
           if constexpr (sizeof(T) == 4) {
+            T kv[NS];
             // (Gram form: the squared distance already sits in acc[].x)
             auto sq = [&](int s) {
               if constexpr (GRAM) return acc[s].x;
@@ -652,29 +717,25 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
               kv[s + 1] = kk.y;
             }
             if constexpr (NS % 2 == 1) kv[NS - 1] = cov_from_sqdist<T>(sq(NS - 1), KID, MID, post_scale);
-          } else {
 #pragma unroll
-            for (int s = 1; s <= NS; ++s) kv[s - 1] = cov_from_sqdist<T>(acc_total(acc[s - 1]), KID, MID, post_scale);
+            for (int s = 1; s <= NS; ++s) put(s, kv[s - 1]);
+          } else {
+            constexpr int CB = MGP_F64_COV_BATCH;
+#pragma unroll
+            for (int s0 = 0; s0 < NS; s0 += CB) {
+              T kv[CB];
+#pragma unroll
+              for (int u = 0; u < CB; ++u)
+                if (s0 + u < NS) kv[u] = cov_from_sqdist<T>(acc_total(acc[s0 + u]), KID, MID, post_scale);
+#pragma unroll
+              for (int u = 0; u < CB; ++u)
+                if (s0 + u < NS) put(s0 + u + 1, kv[u]);
+              __builtin_amdgcn_sched_barrier(0);  // keep the batches apart
+            }
           }
         });
-        const int dump = TRI ? KMAT - E : (NP - 1) * KS + NP;  // padding behind the last row / columns NP .. KS-1
-#pragma unroll
-        for (int s = 1; s <= NS; ++s) {
-          // pair j * BP + p - 1: (own row j, partner p)
-          T v = kv[s - 1];
-          if constexpr (XPRE) {
-            if (!nopad) v = (xkeep >> (s - 1)) & 1u ? v : T(0);
-            tile[xoff[s - 1]] = v;
-          } else {
-            const int r1 = wrap(i3 + own_offset((s - 1) / BP));
-            const int c = wrap(i3 + (s - 1) % BP + 1);
-            const int hi = max(r1, c), lo = min(r1, c);
-            if (!nopad) v = (lo < k && (hi < k || hi == q)) ? v : T(0);
-            Kh3[hi <= q ? rowoff(hi) + lo : dump] = v;
-          }
-        }
       }
-      Kh3[rowoff(i3) + i3] = i3 < k ? T(1) + myeps : (i3 <= q ? T(1) : T(0));
+      if (NPL == NP || i3 < NPL) Kh3[rowoff(i3) + i3] = i3 < k ? T(1) + myeps : (i3 <= q ? T(1) : T(0));
       // response rows: lower-triangle columns only (a packed row ends at its diagonal)
       if (!TRI || i3 <= q + 1) Kh3[rowoff(q + 1) + i3] = myy0;
       if constexpr (PACKED) {
@@ -690,9 +751,12 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 #if MGP_CHOL_PRIO && MGP_PRIO_EARLY_RAISE
     __builtin_amdgcn_s_setprio(MGP_CHOL_PRIO);  // row read-back and the next task's gather already at elimination priority
 #endif
-    V A[NP / E];
+    V A[NG];
+    {
+      const T* myrow = Kh + rowoff(NPL == NP ? i : min(i, NPL - 1));  // (idle lanes re-read the last live row)
 #pragma unroll
-    for (int c4 = 0; c4 < NP / E; ++c4) A[c4] = *reinterpret_cast<const V*>(Kh + rowoff(i) + c4 * E);
+      for (int c4 = 0; c4 < NG; ++c4) A[c4] = *reinterpret_cast<const V*>(myrow + c4 * E);
+    }
 
     // the next task's rows are requested now: their latency hides behind the factorisation, and
     // the registers they land in are not live during the (register-hungry) distance phase
@@ -729,7 +793,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     if (MGP_PHASE(g, 8))
 #endif
 #pragma unroll
-    for (int j = 0; j < NP - 2; ++j) {
+    for (int j = 0; j < (STAT ? KFIX : NP - 2); ++j) {
       if (j < k && (MGP_CHOL_ONE_BLOCK || MGP_PHASE(g, 8))) {
         const T ajj = A[j / E][j % E];
         if constexpr (!LOOK) colh[i] = ajj;
@@ -747,25 +811,25 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
           // single wave needs ~8 outstanding 16-byte reads to cover the LDS latency with FMAs)
           constexpr int GC = MGP_F64_GC;
 #pragma unroll
-          for (int c0 = j / E + 1; c0 < NP / E; c0 += GC) {
+          for (int c0 = j / E + 1; c0 < NG; c0 += GC) {
             V cv[GC];
 #pragma unroll
             for (int u = 0; u < GC; ++u)
-              if (c0 + u < NP / E) cv[u] = *reinterpret_cast<const V*>(colh + (c0 + u) * E);
+              if (c0 + u < NG) cv[u] = *reinterpret_cast<const V*>(colh + (c0 + u) * E);
 #pragma unroll
             for (int u = 0; u < GC; ++u)
-              if (c0 + u < NP / E) A[c0 + u] = cv[u] * nt + A[c0 + u];
+              if (c0 + u < NG) A[c0 + u] = cv[u] * nt + A[c0 + u];
           }
         } else if constexpr (LOOK) {
-          V col[NP / E];
+          V col[NG];
           col[j / E] = piv;
 #pragma unroll
-          for (int c4 = j / E + 1; c4 < NP / E; ++c4) col[c4] = *reinterpret_cast<const V*>(colh + c4 * E);
+          for (int c4 = j / E + 1; c4 < NG; ++c4) col[c4] = *reinterpret_cast<const V*>(colh + c4 * E);
           const T p = piv[j % E];
           bad = bad || !(p > T(0));
           const V nt = V(-ajj * pivot_rcp(p));
           if constexpr (COEFF) Kh[i * KS + j] = -nt[0];  // multiplier l_ij, kept for the back-substitution
-          constexpr int JL = NP - 3;                       // last step of the loop
+          constexpr int JL = (STAT ? KFIX : NP - 2) - 1;    // last step of the loop
           const int g1 = (j < JL ? j + 1 : j) / E;         // compile-time after unrolling
           A[g1] = col[g1] * nt + A[g1];
           if (j < JL && j + 1 < k) {
@@ -773,18 +837,18 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
             piv = *reinterpret_cast<const V*>(colh + g1 * E);
           }
 #pragma unroll
-          for (int c4 = j / E; c4 < NP / E; ++c4)
+          for (int c4 = j / E; c4 < NG; ++c4)
             if (c4 != g1) A[c4] = col[c4] * nt + A[c4];
         } else {
-          V col[NP / E];
+          V col[NG];
 #pragma unroll
-          for (int c4 = j / E; c4 < NP / E; ++c4) col[c4] = *reinterpret_cast<const V*>(colh + c4 * E);
+          for (int c4 = j / E; c4 < NG; ++c4) col[c4] = *reinterpret_cast<const V*>(colh + c4 * E);
           const T p = col[j / E][j % E];
           bad = bad || !(p > T(0));
           const V nt = V(-ajj * pivot_rcp(p));
           if constexpr (COEFF) Kh[i * KS + j] = -nt[0];  // multiplier l_ij, kept for the back-substitution
 #pragma unroll
-          for (int c4 = j / E; c4 < NP / E; ++c4) A[c4] = col[c4] * nt + A[c4];
+          for (int c4 = j / E; c4 < NG; ++c4) A[c4] = col[c4] * nt + A[c4];
         }
       }
     }
@@ -823,7 +887,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       if (live && bad && i == q && a.info) atomicAdd(a.info, 1);  // mean / variance are not emitted
     } else if (RFIX == 1) {
       // q = NP-2 and the response row NP-1 are compile-time: the Schur block sits in fixed registers
-      constexpr int QF = NP - 2, YF = NP - 1;
+      constexpr int QF = STAT ? KFIX : NP - 2, YF = QF + 1;
       const T sq = A[QF / E][QF % E], sy = A[YF / E][YF % E];
       if (live) {
         if (i == QF) {
@@ -841,7 +905,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       // of the registers by a compare-select sweep instead of a round trip through LDS.
       T aq = T(0), aii = T(0);
 #pragma unroll
-      for (int c = 0; c < NP; ++c) {
+      for (int c = 0; c < NG * E; ++c) {
         const T v = A[c / E][c % E];
         aq = c == q ? v : aq;
         aii = c == i ? v : aii;
@@ -859,7 +923,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     } else {
       __syncthreads();
 #pragma unroll
-      for (int c4 = 0; c4 < NP / E; ++c4) *reinterpret_cast<V*>(Kh + i * KS + c4 * E) = A[c4];
+      for (int c4 = 0; c4 < NG; ++c4) *reinterpret_cast<V*>(Kh + i * KS + c4 * E) = A[c4];
       __syncthreads();
       if (live) {
         if (i == q) {
@@ -884,12 +948,11 @@ int g_lds_pad = 0;      // extra dynamic LDS bytes per workgroup
 template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF = false, bool PACKED = false,
           bool GRAM = false>
 static int launch_np_impl(const FusedArgs& a, hipStream_t stream) {
-  constexpr int NH = 64 / NP;
-  constexpr int E = v16<T>::N;
-  constexpr int CH = 2 * E;
-  constexpr int KS = NP + E;
-  constexpr bool TRI = NP == 64 && !COEFF;
-  constexpr int KMAT = TRI ? E * (NP / E + 1) * (E * (NP / E) / 2) + NP + E : NP * KS;
+  using WS = WaveShape<T, NP, KFIX, RFIX, DFIX, COEFF>;
+  constexpr int NH = WS::NH;
+  constexpr int E = WS::E;
+  constexpr int CH = WS::CH;
+  constexpr int KMAT = WS::KMAT;
   WaveGeom g;
 #ifdef MGP_DEBUG_HOOKS
   g.mask = g_phase_mask;
@@ -907,7 +970,8 @@ static int launch_np_impl(const FusedArgs& a, hipStream_t stream) {
   if ((DFIX > 0 || PIPED) && !g.vec_ok) return MGP_EUNSUPPORTED;
   if (PIPED && a.d > g.dst) return MGP_EUNSUPPORTED;  // more than one feature stage
   g.ntasks = (a.b + NH - 1) / NH;
-  const size_t tile_elems = (size_t)NH * ((size_t)NP * g.xs > (size_t)KMAT ? (size_t)NP * g.xs : (size_t)KMAT);
+  const size_t tile_feat = (size_t)WS::tile_rows(g.xs) * g.xs, tile_mat = (size_t)NH * KMAT;
+  const size_t tile_elems = tile_feat > tile_mat ? tile_feat : tile_mat;
   constexpr bool PIPE = PIPED;
   size_t lds = PIPE ? tile_elems * sizeof(T) + 64 * sizeof(void*)
                     : (tile_elems + 64 + g.dst + (g.dst & 1)) * sizeof(T) + 64 * sizeof(int64_t);

@@ -341,9 +341,7 @@ def loocv_partials(
     use_packed = packed is not False and PackedTable.supported(d, 1, k, dtype) and b > 0
     if use_packed and packed == "auto":
         key = (_tensor_key(train_features), _tensor_key(train_targets))
-        # (a separate test table is packed too -- one more pass over ITS rows -- so it counts as table size)
-        rows = fn.shape[0] + (0 if test_features is train_features else fq.shape[0])
-        use_packed = key in _PACK_CACHE or b * (k + 1) >= rows // 4
+        use_packed = key in _PACK_CACHE or b * (k + 1) >= fn.shape[0] // 4
     if use_packed:
         pn = pack_table(train_features, train_targets)
         rc = _lib.fn("loocv_packed", dtype)(_lib.ptr(pn.data), pn.stride, d, _lib.ptr(bi), _lib.ptr(ni), b, k, *tail)

@@ -1,5 +1,8 @@
 mkdir -p gpurun_out/r03
-python3 tools/abtime.py --variants vC,default --rounds 3 > gpurun_out/r03/ab5.log 2>&1
-cat gpurun_out/r03/ab5.log
-python3 -m pytest tests -m gpu -q -x 2>&1 | tail -8
-python3 bench.py --cpu-sample 0 --steps 10 2>&1 | tail -1 > gpurun_out/r03/bench_c2.json; cat gpurun_out/r03/bench_c2.json | cut -c1-600
+python3 -m pytest tests/test_gpu_fused.py tests/test_gpu_properties.py tests/test_gpu_functor_layer.py tests/test_gpu_backend.py -m gpu -q -x 2>&1 | tail -4
+python3 tools/abtime.py --variants vC,default --k 50 --d 8 --dtype f64 --aniso 1 --rounds 2 --iters 6 > gpurun_out/r03/ab7.log 2>&1
+python3 tools/abtime.py --variants vC,default --k 30 --d 40 --dtype f32 --aniso 1 --rounds 2 --iters 6 >> gpurun_out/r03/ab7.log 2>&1
+python3 tools/abtime.py --variants vC,default --k 30 --d 40 --dtype f64 --rounds 2 --iters 6 >> gpurun_out/r03/ab7.log 2>&1
+python3 tools/abtime.py --variants vC,default --k 20 --d 32 --dtype f32 --rounds 2 --iters 6 >> gpurun_out/r03/ab7.log 2>&1
+python3 tools/abtime.py --variants vC,default --k 40 --d 40 --dtype f32 --rounds 2 --iters 6 >> gpurun_out/r03/ab7.log 2>&1
+cat gpurun_out/r03/ab7.log
