@@ -39,8 +39,9 @@ import numpy as np
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_VECTOR_TFLOPS = 157.3  # same guide: peak FP32 (vector)
 FP64_VECTOR_TFLOPS = 78.6   # half the fp32 vector rate (v_fma_f64 at the v_pk_fma_f32 issue cost, tools/ubench)
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_wave_pmc_traffic.json")
-TRAFFIC45_JSON = os.path.join(ROOT, "profiles", "r02_c45_pmc_traffic.json")
+# committed PMC passes, newest first (each names the shape(s) it was taken on)
+TRAFFIC_FILES = [(os.path.join(ROOT, "profiles", f), f) for f in (
+    "r03_wave_pmc_traffic.json", "r03_c45_pmc_traffic.json", "r02_wave_pmc_traffic.json", "r02_c45_pmc_traffic.json")]
 
 # BASELINE.json configs: shape, model and what one step does
 CONFIGS = {
@@ -60,21 +61,22 @@ CONFIGS = {
 
 
 def measured_traffic(b: int, k: int, d: int, dtype: str):
-    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
-    collected separately, gfx950 correction applied; see profiles/).  The counters were taken on
-    the headline shape; scaled by neighbourhood count, else null."""
-    if not (k == 30 and d == 40 and dtype == "f32" and os.path.exists(TRAFFIC_JSON)):
-        # configs 4 / 5: their own PMC passes (profiles/r02_c45_pmc_traffic.json)
-        if os.path.exists(TRAFFIC45_JSON):
-            with open(TRAFFIC45_JSON) as f:
-                t = json.load(f)["configs"]
-            for c, shape in (("4", (50, 8, "f64")), ("5", (64, 40, "f32"))):
-                if shape == (k, d, dtype) and c in t:
-                    return t[c]["hbm_bytes_per_launch_corrected"] / t[c]["neighbourhoods_per_launch"] * b
-        return None
-    with open(TRAFFIC_JSON) as f:
-        t = json.load(f)
-    return t["hbm_bytes_per_launch_corrected"] / t["neighbourhoods_per_launch"] * b
+    """(HBM-side bytes per launch, where they come from): the committed rocprofv3 PMC passes (FETCH_SIZE /
+    WRITE_SIZE collected separately, gfx950 correction applied; see profiles/), scaled by neighbourhood
+    count -- NOT measured in this run; (None, None) for shapes without a pass."""
+    for path, key in TRAFFIC_FILES:
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            t = json.load(f)
+        legacy = {"2": (30, 40, "f32"), "4": (50, 8, "f64"), "5": (64, 40, "f32")}  # files without a "shape" entry
+        for cid, c in (t.get("configs") or {"2": t}).items():
+            shape = c.get("shape")
+            shape = (shape["k"], shape["d"], shape["dtype"]) if shape else legacy.get(cid)
+            if shape == (k, d, dtype):
+                per = c["hbm_bytes_per_launch_corrected"] / c["neighbourhoods_per_launch"]
+                return per * b, os.path.relpath(path, ROOT) + " (rocprofv3 --pmc, committed; not measured in this run)"
+    return None, None
 
 
 def algorithmic_bytes(k: int, d: int, R: int, s: int, loocv: bool = False) -> int:
@@ -217,12 +219,198 @@ def launch_ranks(n: int, argv) -> int:
     return rc
 
 
+def build_workload(cfg, dev, rank: int, knn: bool):
+    """Synthetic tables + neighbourhood indices of one config, resident in HBM."""
+    import torch
+
+    td = torch.float32 if cfg["dtype"] == "f32" else torch.float64
+    n, k, d, R = cfg["points"], cfg["k"], cfg["d"], cfg["R"]
+    b = min(cfg["batch"], n)
+    X, y = synth(n, d, 20241008, R)  # same table on every rank (replicated)
+    Xd = torch.from_numpy(X).to(dev, td)
+    yd = torch.from_numpy(y).to(dev, td)
+    del X, y
+    if knn:
+        bi_np = np.random.default_rng(1 + rank).permutation(n)[:b].astype(np.int64)
+        bi = torch.from_numpy(bi_np).to(dev)
+        ni = knn_neighbors(Xd.float(), bi, k)
+    else:
+        bi_np, ni_np = random_neighbors(n, b, k, 1 + rank)
+        bi, ni = torch.from_numpy(bi_np).to(dev), torch.from_numpy(ni_np).to(dev)
+    ell = float(np.sqrt(d / 40.0) * 5.0)
+    if cfg["metric"] == "F2":
+        ell = 5.0
+    if cfg["aniso"]:
+        ls = list(np.exp(np.random.default_rng(2).uniform(np.log(0.5), np.log(2.0), size=d)) * ell)
+    else:
+        ls = ell
+    return dict(td=td, n=n, k=k, d=d, R=R, b=b, X=Xd, y=yd, bi=bi, ni=ni, ls=ls,
+                mean=torch.empty((b, R), device=dev, dtype=td), var=torch.empty((b,), device=dev, dtype=td),
+                info=torch.zeros(1, dtype=torch.int32, device=dev))
+
+
+def make_step(cfg, w, route: str, path: str, use_packed: bool):
+    """The callable one timed step runs.
+
+    route "fused":  muygpys_amd.fused.posterior_mean_var / distributed.sharded_loocv (one library call).
+    route "dropin": the call sequence ``integration.install()`` binds into the reference's functor layer
+                    (gp/muygps.py:406-551 -> gp/kernels/matern.py:148-168 -> gp/muygps.py:164-259):
+                    _crosswise_tensor / _pairwise_tensor -> metric -> / length scale -> kernel fn -> perturb
+                    -> train_targets[nn_indices] -> _muygps_posterior_mean + _muygps_diagonal_variance,
+                    on lazy handles.  "dropin_plain": the same with the responses in a plain torch tensor,
+                    so that the reference's gather materialises (b, k)."""
+    from muygpys_amd import distributed as D
+    from muygpys_amd.fused import KernelSpec, posterior_mean_var
+
+    spec = KernelSpec(cfg["kernel"], cfg["metric"], w["ls"], cfg["noise"])
+    if route == "fused":
+        if cfg["objective"]:
+            return lambda: D.sharded_loocv(spec, w["X"], w["y"], w["bi"], w["ni"], loss="lool", presharded=True,
+                                           packed=use_packed)
+        return lambda: posterior_mean_var(spec, w["X"], w["X"], w["bi"], w["ni"], w["y"], out_mean=w["mean"],
+                                          out_var=w["var"], info=w["info"], path=path, packed=use_packed)
+    import torch
+
+    from muygpys_amd import integration
+    from muygpys_amd._src.gp.kernels import hip as K
+    from muygpys_amd._src.gp.muygps import hip as M
+    from muygpys_amd._src.gp.noise import hip as N
+    from muygpys_amd._src.gp.tensors import hip as T
+    from muygpys_amd.config import config
+
+    config.state.lazy_tensors = True  # what integration.install() switches on
+    kfn = {"rbf": K._rbf_fn, "matern05": K._matern_05_fn, "matern15": K._matern_15_fn, "matern25": K._matern_25_fn,
+           "matern_inf": K._matern_inf_fn}[cfg["kernel"]]
+    metric = T._l2 if cfg["metric"] == "l2" else T._F2
+    ytab = integration.table(w["y"]) if route == "dropin" else w["y"].as_subclass(torch.Tensor)
+    ls = w["ls"]
+
+    def deform(diffs):
+        if cfg["aniso"]:  # Anisotropy.__call__: metric(diffs / length_scales)
+            return metric(diffs / torch.as_tensor(ls, device=w["X"].device, dtype=w["td"]))
+        dist = metric(diffs)  # Isotropy.__call__: metric(diffs) / l (l2) or / l^2 (F2)
+        return dist / (ls if cfg["metric"] == "l2" else ls**2)
+
+    def step():
+        cross = T._crosswise_tensor(w["X"], w["X"], w["bi"], w["ni"])
+        pair = T._pairwise_tensor(w["X"], w["ni"])
+        y_nn = ytab[w["ni"]]
+        Kcross, Kin = kfn(deform(cross)), kfn(deform(pair))
+        Kin = N._homoscedastic_perturb(Kin, cfg["noise"])
+        mean = M._muygps_posterior_mean(Kin, Kcross, y_nn)
+        var = M._muygps_diagonal_variance(Kin, Kcross, 1.0)
+        return mean, var
+
+    return step
+
+
+def time_steps(step, warmup: int, steps: int, dist, backend: str, dev):
+    """W untimed steps, then K steps bracketed by barrier + synchronize; MAX over ranks.  Per-step HIP
+    events on the launch stream (torch's current stream is the one every library call is given)."""
+    import torch
+
+    last = None
+    for _ in range(warmup):
+        last = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(steps):
+        last = step()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kern_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+    ranks_seen = 1
+    if dist is not None:
+        cdev = dev if backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        ones = torch.ones(1, device=cdev, dtype=torch.float64)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)  # every rank took part in a collective
+        ranks_seen = int(ones.item())
+    return elapsed, kern_ms, ranks_seen, last
+
+
+def roofline_of(cfg, w, avg_ms: float, kernel_name: str, objective: bool):
+    s = 4 if cfg["dtype"] == "f32" else 8
+    k, d, R, b = w["k"], w["d"], w["R"], w["b"]
+    B = algorithmic_bytes(k, d, R, s, loocv=objective)
+    F = algorithmic_flops(k, d, R, loocv=objective)
+    achieved = B * b / (avg_ms * 1e-3) / 1e9
+    tflops = F * b / (avg_ms * 1e-3) / 1e12
+    vpeak = FP32_VECTOR_TFLOPS if cfg["dtype"] == "f32" else FP64_VECTOR_TFLOPS
+    traffic, source = measured_traffic(b, k, d, cfg["dtype"])
+    return {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
+        "kernel": kernel_name,
+        "algorithmic_bytes_per_neighbourhood": B, "algorithmic_bytes_per_launch": B * b,
+        "kernel_ms": avg_ms,
+        "valu": {"achieved": tflops, "peak": vpeak, "unit": "TFLOP/s", "frac": tflops / vpeak,
+                 "algorithmic_flops_per_neighbourhood": F},
+    }
+
+
+def secondary_line(name: str, cfg_id: int, route: str, args, dev, steps: int = 5):
+    """A short run of another BASELINE config (or of the drop-in route on the headline config) for
+    the driver's one line: value, ms_per_step, roofline / VALU fraction, kernel."""
+    import gc
+
+    import torch
+
+    from muygpys_amd import _lib
+    from muygpys_amd.fused import PackedTable, clear_caches, pack_table
+
+    cfg = dict(CONFIGS[cfg_id])
+    w = build_workload(cfg, dev, 0, False)
+    gathered_route = route == "dropin_plain"
+    use_packed = PackedTable.supported(w["d"], w["R"], w["k"], w["td"])
+    if use_packed and route == "fused":
+        pack_table(w["X"], w["y"])
+    step = make_step(cfg, w, route, "auto", use_packed if route == "fused" else "auto")
+    elapsed, kern_ms, _, last = time_steps(step, 2, steps, None, "", dev)
+    if route == "fused" and cfg["objective"]:
+        assert np.isfinite(last["lool"]) and np.isfinite(last["sigma_sq"]), f"{name}: non-finite objective"
+    avg_ms = float(np.mean(kern_ms))
+    roof = roofline_of(cfg, w, avg_ms, _lib.served_by(w["d"], w["k"], w["R"], w["td"], bool(use_packed), "auto"),
+                       cfg["objective"])
+    out = {
+        "baseline_config": cfg_id, "route": route, "what": cfg["what"], "dtype": cfg["dtype"],
+        "value": w["b"] * steps / elapsed, "unit": "neighborhoods/s", "steps": steps, "ms_per_step": elapsed / steps * 1e3,
+        "batch": w["b"], "points": w["n"], "nn_count": w["k"], "feature_count": w["d"], "response_count": w["R"],
+        "roofline": {"frac": roof["frac"], "achieved": roof["achieved"], "traffic": roof["traffic"],
+                     "traffic_source": roof["traffic_source"], "kernel_ms": avg_ms},
+        "valu": {"frac": roof["valu"]["frac"], "achieved": roof["valu"]["achieved"], "unit": "TFLOP/s"},
+        "kernel": roof["kernel"],
+    }
+    if gathered_route:
+        out["note"] = ("responses in a plain torch tensor: the reference's own train_targets[nn_indices] materialises "
+                       "(b, k) per step (a torch gather inside the timed step); features from the prepared table")
+    del w, step, last
+    gc.collect()
+    clear_caches()
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json config")
+    ap.add_argument("--route", default="fused", choices=["fused", "dropin", "dropin_plain"],
+                    help="fused: one library call per step; dropin: the family-level call sequence "
+                         "integration.install() binds (lazy handles); dropin_plain: the same, plain response tensor")
     ap.add_argument("--points", type=int, default=0, help="training points N (replicated per GPU; 0 = the config's)")
     ap.add_argument("--batch", type=int, default=0, help="neighbourhoods per GPU per step (0 = the config's)")
     ap.add_argument("--k", type=int, default=0)
@@ -235,6 +423,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=32768, help="0 disables the CPU baseline leg")
     ap.add_argument("--path", default="auto", choices=["auto", "generic", "rhs"], help="kernel family to time")
     ap.add_argument("--no-prepared-tables", action="store_true", help="read the plain feature / target tables")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the short runs of configs 3 / 4 / 5 and of the drop-in route attached as `secondary`")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for self-tests)")
     ap.add_argument("--one-device", action="store_true",
                     help="self-test only: every rank uses cuda:0 (exercises the N>1 logic on a 1-GPU box)")
@@ -269,8 +459,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    from muygpys_amd import distributed as D
-    from muygpys_amd.fused import KernelSpec, PackedTable, pack_table, posterior_mean_var
+    from muygpys_amd import _lib
+    from muygpys_amd.fused import PackedTable, pack_table
 
     cfg = dict(CONFIGS[args.config])
     for key, val in (("points", args.points), ("batch", args.batch), ("k", args.k), ("d", args.d),
@@ -279,102 +469,49 @@ def main():
             cfg[key] = val
     if args.objective:
         cfg["objective"] = True
-    td = torch.float32 if cfg["dtype"] == "f32" else torch.float64
-    n, k, d, R = cfg["points"], cfg["k"], cfg["d"], cfg["R"]
-    b = min(cfg["batch"], n)
-    X, y = synth(n, d, 20241008, R)  # same table on every rank (replicated)
-    Xd = torch.from_numpy(X).to(dev, td)
-    yd = torch.from_numpy(y).to(dev, td)
-    del X, y
-    if args.knn:
-        bi_np = np.random.default_rng(1 + rank).permutation(n)[:b].astype(np.int64)
-        bi = torch.from_numpy(bi_np).to(dev)
-        ni = knn_neighbors(Xd.float(), bi, k)
-    else:
-        bi_np, ni_np = random_neighbors(n, b, k, 1 + rank)
-        bi, ni = torch.from_numpy(bi_np).to(dev), torch.from_numpy(ni_np).to(dev)
-    ell = float(np.sqrt(d / 40.0) * 5.0)
-    if cfg["metric"] == "F2":
-        ell = 5.0
-    if cfg["aniso"]:
-        ls = list(np.exp(np.random.default_rng(2).uniform(np.log(0.5), np.log(2.0), size=d)) * ell)
-    else:
-        ls = ell
-    spec = KernelSpec(cfg["kernel"], cfg["metric"], ls, cfg["noise"])
-    mean = torch.empty((b, R), device=dev, dtype=td)
-    var = torch.empty((b,), device=dev, dtype=td)
-    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    if args.route != "fused" and cfg["objective"]:
+        raise SystemExit("bench.py: --route dropin times the prediction call sequence (configs 2 / 5)")
+    w = build_workload(cfg, dev, rank, args.knn)
+    td, n, k, d, R, b = w["td"], w["n"], w["k"], w["d"], w["R"], w["b"]
     # the prepared tables are built once, outside the timed loop (they are constant across all
     # objective evaluations / prediction batches of a model; DESIGN.md sec. 5 gives the pack time)
     use_packed = (not args.no_prepared_tables) and args.path == "auto" and PackedTable.supported(d, R, k, td)
-    t_pack = None
+    pack_ms = None
     if use_packed:
+        pack_table(w["X"], w["y"])  # the cached table the timed steps use
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        pack_table(Xd, yd)
+        e0.record()
+        spare = PackedTable(w["X"], w["y"])  # one more pack, timed on the stream: what a pack per step would add
+        e1.record()
         torch.cuda.synchronize()
-        t_pack = time.perf_counter() - t0
-
-    if cfg["objective"]:
-        def step():
-            return D.sharded_loocv(spec, Xd, yd, bi, ni, loss="lool", presharded=True, packed=use_packed)
-    else:
-        def step():
-            posterior_mean_var(spec, Xd, Xd, bi, ni, yd, out_mean=mean, out_var=var, info=info, path=args.path,
-                               packed=use_packed)
-
-    last = None
-    for _ in range(args.warmup):
-        last = step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
-    ev[0].record()
-    for i in range(args.steps):
-        last = step()
-        ev[i + 1].record()  # same stream the kernel is enqueued on (torch's current stream)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    kern_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
-    ranks_seen = 1
-    if dist is not None:
-        cdev = dev if args.backend == "nccl" else "cpu"
-        t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        ones = torch.ones(1, device=cdev, dtype=torch.float64)
-        dist.all_reduce(ones, op=dist.ReduceOp.SUM)  # every rank took part in a collective
-        ranks_seen = int(ones.item())
-    non_spd = int(info.item())
+        pack_ms = e0.elapsed_time(e1)
+        del spare
+    step = make_step(cfg, w, args.route, args.path, use_packed if args.route == "fused" else "auto")
+    elapsed, kern_ms, ranks_seen, last = time_steps(step, args.warmup, args.steps, dist, args.backend, dev)
+    non_spd = int(w["info"].item())
     if cfg["objective"]:
         assert np.isfinite(last["lool"]) and np.isfinite(last["sigma_sq"]), "non-finite objective"
+    elif args.route == "fused":
+        assert torch.isfinite(w["mean"]).all() and torch.isfinite(w["var"]).all(), "non-finite outputs"
     else:
-        assert torch.isfinite(mean).all() and torch.isfinite(var).all(), "non-finite outputs"
+        assert torch.isfinite(last[0]).all() and torch.isfinite(last[1]).all(), "non-finite outputs"
 
     if rank == 0:
-        from muygpys_amd import _lib
-
-        s = 4 if cfg["dtype"] == "f32" else 8
-        B = algorithmic_bytes(k, d, R, s, loocv=cfg["objective"])
-        F = algorithmic_flops(k, d, R, loocv=cfg["objective"])
         avg_ms = float(np.mean(kern_ms))
-        achieved = B * b / (avg_ms * 1e-3) / 1e9
-        tflops = F * b / (avg_ms * 1e-3) / 1e12
-        vpeak = FP32_VECTOR_TFLOPS if cfg["dtype"] == "f32" else FP64_VECTOR_TFLOPS
-        kernel_name = _lib.served_by(d, k, R, td, use_packed, args.path)
+        kernel_name = _lib.served_by(d, k, R, td, bool(use_packed), args.path)
+        roof = roofline_of(cfg, w, avg_ms, kernel_name, cfg["objective"])
+        if pack_ms is not None:
+            roof["prepared_table_pack_kernel_ms"] = pack_ms
+            roof["frac_with_pack_per_step"] = roof["frac"] * avg_ms / (avg_ms + pack_ms)
         out = {
             "metric": "neighborhoods/sec (posterior mean+var)" if not cfg["objective"]
                       else "neighborhoods/sec (LOOCV objective evaluation)",
             "value": world * b * args.steps / elapsed,
             "unit": "neighborhoods/s",
             "n_gpus": world,
-            "rccl_ranks_seen": ranks_seen,
+            "ranks_seen": ranks_seen,
+            "collective_backend": None if dist is None else ("rccl" if args.backend == "nccl" else args.backend),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -388,27 +525,41 @@ def main():
                             f"points, d={d}, nn_count={k}, responses={R}, {b} neighbourhoods per GPU per step, "
                             f"{'exact kNN' if args.knn else 'random'} neighbour rows, "
                             f"{'Anisotropy' if cfg['aniso'] else 'Isotropy'}/{cfg['metric']}, noise={cfg['noise']}",
-                "baseline_config": args.config,
+                "baseline_config": args.config, "route": args.route,
                 "points": n, "batch_per_gpu": b, "nn_count": k, "feature_count": d, "response_count": R,
                 "kernel_path": args.path, "prepared_tables": bool(use_packed),
-                "prepared_table_pack_ms": None if t_pack is None else t_pack * 1e3,
+                "prepared_table_pack_ms": pack_ms,
                 "non_spd_neighbourhoods": non_spd,
             },
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(b, k, d, cfg["dtype"]),
-                "kernel": kernel_name,
-                "algorithmic_bytes_per_neighbourhood": B, "algorithmic_bytes_per_launch": B * b,
-                "kernel_ms": avg_ms,
-                "valu": {"achieved": tflops, "peak": vpeak, "unit": "TFLOP/s", "frac": tflops / vpeak,
-                         "algorithmic_flops_per_neighbourhood": F},
-            },
+            "roofline": roof,
         }
         if cfg["objective"]:
             out["config"]["lool"] = last["lool"]
             out["config"]["sigma_sq"] = last["sigma_sq"]
             out["roofline"]["note"] = ("kernel_ms is the whole step (fused launch + fp64 loss reductions + host finish "
                                        "+ all-reduce), so achieved is a lower bound for the fused kernel alone")
+        if args.route != "fused":
+            out["roofline"]["note"] = ("kernel_ms is the whole family-level call sequence of one prediction batch "
+                                       "(handles, one fused launch, its host glue)")
+        if world == 1 and not args.no_secondary:
+            # the other BASELINE configs and the drop-in route, 5 steps each (the headline keys above are
+            # unaffected: these run after the timed region, on their own tables)
+            del w, step, last
+            from muygpys_amd.fused import clear_caches
+
+            clear_caches()
+            torch.cuda.empty_cache()
+            sec = {}
+            plan = [("dropin", 2, "dropin"), ("dropin_plain", 2, "dropin_plain"), ("c3", 3, "fused"), ("c4", 4, "fused"),
+                    ("c5", 5, "fused")]
+            for name, cid, route in plan:
+                if cid == args.config and route == args.route:
+                    continue
+                try:
+                    sec[name] = secondary_line(name, cid, route, args, dev)
+                except Exception as exc:  # a secondary line must never take the headline down
+                    sec[name] = {"error": f"{type(exc).__name__}: {exc}"}
+            out["secondary"] = sec
         if args.cpu_sample > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(k, d, args.cpu_sample, 20241008)
         print(json.dumps(out), flush=True)

@@ -192,6 +192,24 @@ int mgp_posterior_packed_f64(const void* packed_q, int64_t q_stride_bytes, const
                              int noise_mode, double noise_scalar, const double* noise_dev,
                              int kernel_id, int metric_id, const double* length_scale, int ls_count,
                              double* mean, double* var, double* ykinvy, int* info, void* stream);
+/* The same with the neighbour responses ALREADY GATHERED, nn_targets (b, k, R) = targets[nn_idx]: what the
+ * reference's functor layer hands to posterior_mean (MuyGPS.make_predict_tensors gathers them itself,
+ * gp/muygps.py:474,543).  The feature rows still come from the prepared tables (two cache lines per
+ * neighbour); the table may be packed without responses (R = 0).  Any R the kernels support. */
+int mgp_posterior_packed_gathered_f32(const void* packed_q, int64_t q_stride_bytes, const void* packed_nn,
+                                      int64_t nn_stride_bytes, int d,
+                                      const int64_t* batch_idx, const int64_t* nn_idx, int64_t b, int k,
+                                      const float* nn_targets, int R,
+                                      int noise_mode, double noise_scalar, const float* noise_dev,
+                                      int kernel_id, int metric_id, const float* length_scale, int ls_count,
+                                      float* mean, float* var, float* ykinvy, int* info, void* stream);
+int mgp_posterior_packed_gathered_f64(const void* packed_q, int64_t q_stride_bytes, const void* packed_nn,
+                                      int64_t nn_stride_bytes, int d,
+                                      const int64_t* batch_idx, const int64_t* nn_idx, int64_t b, int k,
+                                      const double* nn_targets, int R,
+                                      int noise_mode, double noise_scalar, const double* noise_dev,
+                                      int kernel_id, int metric_id, const double* length_scale, int ls_count,
+                                      double* mean, double* var, double* ykinvy, int* info, void* stream);
 
 /* ---------------------------------------------------------------------------
  * One LOOCV objective evaluation of a shard in one call: mgp_posterior_* with

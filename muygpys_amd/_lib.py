@@ -65,6 +65,7 @@ _SIGS = {
     "posterior_rhs": [_p, _p, _i, _p, _p, _l, _i, _p, _i, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p],
     "posterior_gathered": [_p, _p, _i, _p, _p, _l, _i, _p, _i, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p],
     "posterior_packed": [_p, _l, _p, _l, _i, _p, _p, _l, _i, _i, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p],
+    "posterior_packed_gathered": [_p, _l, _p, _l, _i, _p, _p, _l, _i, _p, _i, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p],
     "table_pack": [_p, _p, _l, _i, _i, _p, _l, _p],
     "loocv": [_p, _i, _p, _p, _l, _i, _p, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p, _p, _d, _p, _p, _p],
     "loocv_packed": [_p, _l, _i, _p, _p, _l, _i, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p, _p, _d, _p, _p, _p],

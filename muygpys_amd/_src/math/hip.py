@@ -72,8 +72,30 @@ def _as_tensor(x, dtype):
     return torch.as_tensor(x, dtype=dtype, device=_device())
 
 
+class TableTensor(torch.Tensor):
+    """What the float constructors of this facade return: a ``torch.Tensor`` (``isinstance`` holds, same
+    storage, every torch function works) whose gather by a 2-D integer index tensor --
+    ``train_targets[batch_nn_indices]``, the one line of the reference's functor layer that is NOT a
+    backend function (gp/muygps.py:474,543) -- yields the lazy handle :class:`muygpys_amd.lazy.LazyTargets`
+    while ``config.state.lazy_tensors`` is on (``integration.install()``).  The handle remembers
+    (table, indices); the fused launch then reads the responses with the neighbour rows from the
+    prepared table (``mgp_posterior_packed_*``) instead of from a materialised ``(b, k, R)`` copy.  Any
+    other use of the handle materialises it.  A plain tensor is wrapped, without a copy, by
+    ``muygpys_amd.integration.table(t)``."""
+
+    def __getitem__(self, item):
+        if (
+            config.state.lazy_tensors and isinstance(item, torch.Tensor) and item.ndim == 2
+            and item.dtype in (torch.int64, torch.int32) and self.ndim in (1, 2) and self.is_floating_point()
+        ):
+            from muygpys_amd import lazy
+
+            return lazy.LazyTargets(self.as_subclass(torch.Tensor), item)
+        return super().__getitem__(item)
+
+
 def farray(x, **kwargs):
-    return _as_tensor(x, kwargs.get("dtype", ftype))
+    return _as_tensor(x, kwargs.get("dtype", ftype)).as_subclass(TableTensor)
 
 
 def iarray(x, **kwargs):

@@ -33,7 +33,9 @@ int posterior(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t*
   if (packed) {
     // both strides cover the features and the 16-byte response slot the gather reads with every row
     const int64_t need = (int64_t)(d * sizeof(T)) + 16;
-    if (!packed_q || q_stride < need || nn_stride < need || nn_stride < (int64_t)((d + R) * sizeof(T))) return MGP_EINVAL;
+    if (!packed_q || q_stride < need || nn_stride < need) return MGP_EINVAL;
+    // the neighbour table carries the responses, unless they come already gathered (b, k, R)
+    if (targets_batch ? tg == nullptr : nn_stride < (int64_t)((d + R) * sizeof(T))) return MGP_EINVAL;
   } else if (!fq || !fn || !tg) {
     return MGP_EINVAL;
   }
@@ -209,6 +211,14 @@ int mgp_posterior_f64(const double* fq, const double* fn, int d, const int64_t* 
                                  T* yk, int* info, void* st) {                                                       \
     return posterior<T>(nullptr, nullptr, d, bi, ni, b, k, nullptr, R, nm, eps, nd, kid, mid, ls, lsc, mean, var,   \
                         yk, info, st, PATH_AUTO, packed_q, q_stride, packed_nn, nn_stride);                          \
+  }                                                                                                                  \
+  int mgp_posterior_packed_gathered_##SUF(const void* packed_q, int64_t q_stride, const void* packed_nn,            \
+                                          int64_t nn_stride, int d, const int64_t* bi, const int64_t* ni, int64_t b, \
+                                          int k, const T* nn_tg, int R, int nm, double eps, const T* nd, int kid,    \
+                                          int mid, const T* ls, int lsc, T* mean, T* var, T* yk, int* info,          \
+                                          void* st) {                                                                \
+    return posterior<T>(nullptr, nullptr, d, bi, ni, b, k, nn_tg, R, nm, eps, nd, kid, mid, ls, lsc, mean, var, yk, \
+                        info, st, PATH_AUTO, packed_q, q_stride, packed_nn, nn_stride, 1);                           \
   }                                                                                                                  \
   int mgp_loocv_##SUF(const T* feat, int d, const int64_t* bi, const int64_t* ni, int64_t b, int k, const T* tg,     \
                       int nm, double eps, const T* nd, int kid, int mid, const T* ls, int lsc, T* mean, T* var,      \

@@ -336,7 +336,8 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       const int hh = (NH > 1 && nb0 + h >= a.b) ? 0 : h;
       pre_tg = a.targets_batch ? (nb0 + hh) * k + (i < k ? i : 0) : idx_n;
     }
-    if constexpr (!PACKED) pre_y = targets[pre_tg * (int64_t)R];  // prepared tables: read from the tile
+    // (prepared tables: the responses arrive in the tile, unless the caller hands them over gathered)
+    if (!PACKED || a.targets_batch) pre_y = targets[pre_tg * (int64_t)R];
     pre_eps = (T)a.noise_scalar;
     if (a.noise_mode != MGP_NOISE_SCALAR) {
       const int64_t nb0 = task_n * NH;
@@ -457,8 +458,10 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       if (PIPE) {
         if constexpr (PACKED) {
           // the slot behind the features carries the row's responses (before it is zeroed as padding)
-          myyv = *reinterpret_cast<const V*>(Xh + (NPL == NP ? i : min(i, NPL - 1)) * xs + d);
-          myy0 = i < k ? myyv[0] : T(0);
+          if (!a.targets_batch) {
+            myyv = *reinterpret_cast<const V*>(Xh + (NPL == NP ? i : min(i, NPL - 1)) * xs + d);
+            myy0 = i < k ? myyv[0] : T(0);
+          }
         }
         // feature columns w .. wp-1 of the staged rows are padding of the 8-wide inner loop: the
         // direct-to-LDS gather filled them with a repeat of the last data slot
@@ -738,7 +741,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       if (NPL == NP || i3 < NPL) Kh3[rowoff(i3) + i3] = i3 < k ? T(1) + myeps : (i3 <= q ? T(1) : T(0));
       // response rows: lower-triangle columns only (a packed row ends at its diagonal)
       if (!TRI || i3 <= q + 1) Kh3[rowoff(q + 1) + i3] = myy0;
-      if constexpr (PACKED) {
+      if (PACKED && !a.targets_batch) {
 #pragma unroll
         for (int r = 1; r < E; ++r)
           if (r < R && (!TRI || i3 <= q + 1 + r)) Kh3[rowoff(q + 1 + r) + i3] = i3 < k ? myyv[r] : T(0);
@@ -966,7 +969,7 @@ static int launch_np_impl(const FusedArgs& a, hipStream_t stream) {
   const uintptr_t align = PACKED ? ((uintptr_t)a.packed_q | (uintptr_t)a.packed_nn | (uintptr_t)a.q_stride | (uintptr_t)a.nn_stride)
                                  : ((uintptr_t)a.feat_q | (uintptr_t)a.feat_nn);
   g.vec_ok = (a.d % E == 0) && (align % 16 == 0);
-  if (PACKED && a.R > E) return MGP_EUNSUPPORTED;  // the responses ride in one 16-byte slot
+  if (PACKED && a.R > E && !a.targets_batch) return MGP_EUNSUPPORTED;  // the responses ride in one 16-byte slot
   if ((DFIX > 0 || PIPED) && !g.vec_ok) return MGP_EUNSUPPORTED;
   if (PIPED && a.d > g.dst) return MGP_EUNSUPPORTED;  // more than one feature stage
   g.ntasks = (a.b + NH - 1) / NH;
@@ -1070,8 +1073,10 @@ int describe_fused_wave(int elem_size, int d, int k, int R, int packed, char* bu
   if (k == 30 && R == 1 && d == 40) kf = 30, rf = 1, df = 40, np = 32, piped = true;
   else if (k == 50 && R == 1 && d == 8) kf = 50, rf = 1, df = 8, np = 64, piped = true;
   if (np == 0 || (packed && (!piped || R > E))) return snprintf(buf, len, "%s", "");
-  return snprintf(buf, len, "mgp::fused_wave_kernel<%s,%d,%d,%d,%d,%s,false,%s>", t, np, kf, rf, df,
-                  piped ? "true" : "false", packed ? "true" : "false");
+  // (the Gram-form instantiation serves fp32 pipelined shapes for every kernel except Matern-1/2)
+  const bool gram = elem_size == 4 && piped && MGP_GRAM;
+  return snprintf(buf, len, "mgp::fused_wave_kernel<%s,%d,%d,%d,%d,%s,false,%s,%s>", t, np, kf, rf, df,
+                  piped ? "true" : "false", packed ? "true" : "false", gram ? "true" : "false");
 }
 
 template int launch_fused_wave<float>(const FusedArgs&, hipStream_t);

@@ -131,15 +131,16 @@ def _tensor_key(t: Optional[torch.Tensor]):
     return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), t.dtype, t.device)
 
 
-def pack_table(features: torch.Tensor, targets: Optional[torch.Tensor] = None) -> PackedTable:
+def pack_table(features: torch.Tensor, targets: Optional[torch.Tensor] = None, query: Optional[bool] = None) -> PackedTable:
     """The prepared table of ``(features, targets)``, cached on the tensors' identity and version
-    (an in-place edit of either tensor invalidates the entry)."""
+    (an in-place edit of either tensor invalidates the entry).  ``query``: the table serves the query
+    side only (default: a table without responses does)."""
     key = (_tensor_key(features), _tensor_key(targets))
-    cache = _QUERY_PACK if targets is None else _PACK_CACHE
+    cache = _QUERY_PACK if (targets is None if query is None else query) else _PACK_CACHE
     hit = cache.get(key)
     if hit is None:
         hit = PackedTable(features, targets)
-        if targets is None:
+        if cache is _QUERY_PACK:
             cache.clear()
         cache[key] = hit
         while len(cache) > 1 and (len(cache) > _PACK_CACHE_SIZE or sum(t.data.numel() for t in cache.values()) > _PACK_CACHE_BYTES):
@@ -240,7 +241,6 @@ def posterior_mean_var(
         squeeze = train_targets.ndim == 2
         tg = train_targets.reshape(b, k, -1).contiguous()
         R = tg.shape[2]
-        packed = False
     else:
         squeeze = train_targets.ndim == 1
         tg = (train_targets[:, None] if squeeze else train_targets).contiguous()
@@ -259,14 +259,24 @@ def posterior_mean_var(
     if path not in ("auto", "generic", "rhs"):
         raise ValueError(f"unknown kernel path {path!r}")
     rc = -2
-    use_packed = path == "auto" and packed is not False and PackedTable.supported(d, R, k, dtype) and b > 0
+    # gathered responses: the FEATURE rows still come from a prepared table (packed without responses)
+    use_packed = (path == "auto" and packed is not False and b > 0
+                  and PackedTable.supported(d, 0 if gathered else R, k + (R if gathered else 0), dtype))
     if use_packed and packed == "auto":
         # a pack is one pass over the table; worth it once the batch gathers a comparable number of rows
-        key = (_tensor_key(train_features), _tensor_key(train_targets))
+        key = (_tensor_key(train_features), None if gathered else _tensor_key(train_targets))
         # (a separate test table is packed too -- one more pass over ITS rows -- so it counts as table size)
         rows = fn.shape[0] + (0 if test_features is train_features else fq.shape[0])
         use_packed = key in _PACK_CACHE or b * (k + 1) >= rows // 4
-    if use_packed:
+    if use_packed and gathered:
+        pn = pack_table(train_features, None, query=False)
+        pq = pn if test_features is train_features else pack_table(test_features, None)
+        rc = _lib.fn("posterior_packed_gathered", dtype)(
+            _lib.ptr(pq.data), pq.stride, _lib.ptr(pn.data), pn.stride, d, _lib.ptr(bi), _lib.ptr(ni), b, k,
+            _lib.ptr(tg), R, mode, eps, _lib.ptr(nz), spec.kernel_id(), spec.metric_id(), _lib.ptr(ls), ls.numel(),
+            _lib.ptr(mean), _lib.ptr(var), _lib.ptr(yk), _lib.ptr(info), _lib.stream_ptr(),
+        )
+    elif use_packed:
         pn = pack_table(train_features, train_targets)
         pq = pn if test_features is train_features else pack_table(test_features, None)
         rc = _lib.fn("posterior_packed", dtype)(

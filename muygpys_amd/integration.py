@@ -62,3 +62,14 @@ def install(package: str = "MuyGPyS", require_device: bool = True, lazy: bool = 
     # 3. select it (the enum validator only knows the four stock names, so set the state mirror)
     ref.config.state.backend = "hip"
     ref.config.state.ftype = hip_config.state.ftype
+
+
+def table(t):
+    """Wrap a device tensor (no copy) so that ``t[batch_nn_indices]`` -- the reference's own response
+    gather, gp/muygps.py:474 -- stays a lazy handle and the fused launch reads the responses from the
+    prepared table.  Tensors made by the facade's constructors (``mm.array`` ...) already are."""
+    import torch
+
+    from muygpys_amd._src.math.hip import TableTensor
+
+    return t if isinstance(t, TableTensor) else torch.as_tensor(t).as_subclass(TableTensor)

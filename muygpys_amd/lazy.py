@@ -271,7 +271,7 @@ class LazyTargets(_Lazy):
         return len(self.shape)
 
     def materialize(self) -> torch.Tensor:
-        return self.targets[self.nn_indices]
+        return torch.Tensor.__getitem__(self.targets.as_subclass(torch.Tensor), self.nn_indices)
 
 
 def is_lazy(x) -> bool:

@@ -205,13 +205,17 @@ def test_empty_inputs_through_the_new_entry_points():
     assert coeffs.shape == (0, 10) and nn_fast.shape == (0, 10)
 
 
+@pytest.mark.parametrize("responses", ["plain_tensor", "facade_table"])
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_family_level_lazy_route_matches_golden(golden, dtype):
+def test_family_level_lazy_route_matches_golden(golden, dtype, responses):
     """The call sequence of the reference's functor layer written against the family functions
     (what integration.install() binds): with config.state.lazy_tensors the tensor family returns
     handles, the metric / deformation / kernel / noise steps decorate them, and posterior mean,
-    variance and sigma^2 come out of ONE fused launch on gathered responses
-    (mgp_posterior_gathered_*) -- same numbers as the fixtures."""
+    variance and sigma^2 come out of ONE fused launch -- on gathered responses when the response
+    table is a plain tensor (the reference's own ``train_targets[nn_indices]`` materialises (b, k);
+    mgp_posterior_packed_gathered_* / mgp_posterior_gathered_*), on the prepared table when it is a
+    tensor of the facade (the gather stays a handle; mgp_posterior_packed_*) -- same numbers as the
+    fixtures either way."""
     from muygpys_amd import lazy
     from muygpys_amd._src.gp import kernels as K
     from muygpys_amd._src.gp import muygps as M
@@ -243,7 +247,14 @@ def test_family_level_lazy_route_matches_golden(golden, dtype):
             dp, dc = metric(pair) / div, metric(cross) / div
         Kin, Kc = kfn(dp), kfn(dc)
         assert isinstance(Kin, lazy.LazyCov) and tuple(Kin.shape) == tuple(ni.shape) + (ni.shape[1],)
-        ynn = y[ni]
+        if responses == "facade_table":
+            from muygpys_amd import integration
+
+            ynn = integration.table(y)[ni]  # gp/muygps.py:474 on a tensor of the facade
+            assert isinstance(ynn, lazy.LazyTargets) and tuple(ynn.shape) == tuple(ni.shape) + tuple(y.shape[1:])
+        else:
+            ynn = y[ni]
+            assert isinstance(ynn, torch.Tensor)
         if meta.get("hetero"):
             Kp = N._heteroscedastic_perturb(Kin, T._make_heteroscedastic_tensor(to_dev(g["noise_table"], td), ni))
         else:

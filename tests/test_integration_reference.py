@@ -79,32 +79,41 @@ from MuyGPyS.optimize.loss import lool_fn
 rng = np.random.default_rng(0)
 X = torch.from_numpy(rng.normal(size=(200, 6))); y = torch.from_numpy(rng.normal(size=200))
 bi = torch.arange(0, 40); ni = torch.from_numpy(rng.integers(40, 200, size=(40, 8)))
-for deformation, probe in (
+# the response table as the caller holds it: a tensor of the facade (mm.array / integration.table: the
+# reference's own gather train_targets[batch_nn_indices] then stays a handle and the launch is the
+# prepared-table one, responses included), or a plain torch tensor (the reference gathers (b, k); the
+# FEATURE rows still come from a prepared table)
+for y_tab, entry in ((hip_backend.table(y), "posterior_packed"), (y, "posterior_packed_gathered")):
+  for deformation, probe in (
     (Isotropy(l2, length_scale=Parameter(2.0, (0.1, 10.0))), {"length_scale": 1.5}),
     (Anisotropy(l2, length_scale=VectorParameter(*[Parameter(1.0 + 0.1 * i, (0.1, 10.0)) for i in range(6)])),
      {f"length_scale{i}": 2.0 for i in range(6)}),
-):
+  ):
     calls.clear()
     m = MuyGPS(kernel=Matern(smoothness=Parameter(1.5), deformation=deformation),
                noise=HomoscedasticNoise(1e-3), scale=AnalyticScale())
-    cross, pair, y_b, y_nn = m.make_train_tensors(bi, ni, X, y)
+    cross, pair, y_b, y_nn = m.make_train_tensors(bi, ni, X, y_tab)
     assert type(pair).__name__ == "LazyDiffs" and type(cross).__name__ == "LazyDiffs", (type(pair), type(cross))
-    assert tuple(pair.shape)[:3] == (40, 8, 8)
+    assert (type(y_nn).__name__ == "LazyTargets") == (entry == "posterior_packed"), type(y_nn)
+    assert tuple(pair.shape)[:3] == (40, 8, 8) and tuple(y_nn.shape) == (40, 8)
     assert not calls, calls                             # building the tensors launches nothing
     obj = L_BFGS_B_optimize.make_obj_fn(m, y_b, y_nn, cross, pair, loss_fn=lool_fn)
-    for rep in range(2):
+    packs = 0
+    for rep in range(3):
         calls.clear()
         obj(**probe)
-        assert calls["posterior_gathered"] == 1, dict(calls)   # ONE fused launch per objective evaluation
-        assert set(calls) <= {"posterior_gathered", "loss_sums", "column_sums"}, dict(calls)
+        assert calls[entry] == 1, dict(calls)           # ONE fused launch per objective evaluation ...
+        assert set(calls) <= {entry, "table_pack", "loss_sums", "column_sums"}, dict(calls)
+        packs += calls["table_pack"]
+    assert packs <= 1, packs                            # ... from a table prepared at most once
     # prediction-style calls share one launch too
     calls.clear()
     Kin, Kc = m.kernel(pair), m.kernel(cross)
     m.posterior_mean(Kin, Kc, y_nn); m.posterior_variance(Kin, Kc)
-    assert calls["posterior_gathered"] == 1 and "solve" not in calls and "pairwise_diffs" not in calls, dict(calls)
+    assert calls[entry] == 1 and "solve" not in calls and "pairwise_diffs" not in calls, dict(calls)
     calls.clear()
     m.optimize_scale(pair, y_nn)
-    assert calls["posterior_gathered"] == 1 and "solve" not in calls, dict(calls)
+    assert calls[entry] == 1 and "solve" not in calls, dict(calls)
 print("lazy-ok")
 """
 
@@ -113,7 +122,8 @@ print("lazy-ok")
 def test_reference_functor_layer_reaches_the_fused_launch():
     """integration.install() + the reference's OWN MuyGPS / Matern / Isotropy / Anisotropy /
     make_loo_crossval_fn: the tensor family hands out lazy handles and every objective evaluation is
-    exactly one mgp_posterior_gathered_* call (recorded; the build container has no GPU)."""
+    exactly one prepared-table launch -- mgp_posterior_packed_* when the response table is a tensor of the
+    facade, mgp_posterior_packed_gathered_* for a plain tensor (recorded; the build container has no GPU)."""
     env = dict(os.environ, PYTHONPATH=REF + os.pathsep + ROOT, PYTHONDONTWRITEBYTECODE="1", MUYGPYS_BACKEND="numpy")
     r = subprocess.run([sys.executable, "-c", LAZY_SCRIPT], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "lazy-ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
