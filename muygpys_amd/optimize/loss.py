@@ -1,62 +1,74 @@
-"""Loss functors and predict-and-loss closures (reference contract:
-src/MuyGPyS/optimize/loss.py:26-396).
+"""Loss objects of the optimisation layer.
 
-``LossFn(loss_fn, make_predict_and_loss_fn)`` pairs a backend loss with the recipe that
-evaluates it inside the objective: *raw* losses (mse, pseudo-Huber, cross-entropy) need only
-the posterior mean; *variance* losses (lool, looph) also need the unscaled posterior variance
-and the analytic sigma^2.  Every closure returns MINUS the loss (loss.py:94,174) because the
-Bayesian optimiser maximises.
+Contract (src/MuyGPyS/optimize/loss.py:26-396): a loss object is callable like its backend function and
+offers ``make_predict_and_loss_fn(mean_fn, var_fn, scale_fn, batch_nn_targets, batch_targets, **loss_kwargs)``,
+which returns ``f(Kin, Kcross, **kwargs) -> -loss``.  Minus, because the Bayesian driver maximises
+(loss.py:94,174).
+
+Here the catalogue is one table.  Each entry names the backend function and which posterior
+quantities its objective needs:
+
+* ``"mean"`` -- the loss compares posterior means with the batch targets (mse, pseudo-Huber,
+  cross-entropy);
+* ``"mean+var"`` -- it also takes the unscaled posterior variance and the analytic sigma^2 (lool,
+  looph).  The three are requested in the reference's order (mean, scale, variance); on lazy handles
+  they are one fused launch (``muygpys_amd.lazy_eval``).
+
+One closure builder serves both kinds.
 """
 
 from __future__ import annotations
 
-from typing import Callable, Optional
+from typing import Callable, Dict, Tuple
 
-from muygpys_amd._src.optimize.loss import (
-    _cross_entropy_fn,
-    _looph_fn,
-    _lool_fn,
-    _lool_fn_unscaled,
-    _mse_fn,
-    _pseudo_huber_fn,
-)
+from muygpys_amd._src.optimize import loss as _backend
+
+_CATALOGUE: Dict[str, Tuple[str, str]] = {
+    # public name        backend function        what the objective evaluates
+    "cross_entropy_fn": ("_cross_entropy_fn", "mean"),
+    "mse_fn": ("_mse_fn", "mean"),
+    "pseudo_huber_fn": ("_pseudo_huber_fn", "mean"),
+    "lool_fn": ("_lool_fn", "mean+var"),
+    "lool_fn_unscaled": ("_lool_fn_unscaled", "mean+var"),
+    "looph_fn": ("_looph_fn", "mean+var"),
+}
 
 
-def make_raw_predict_and_loss_fn(
-    loss_fn: Callable, mean_fn: Callable, var_fn: Callable, scale_fn: Callable, batch_nn_targets, batch_targets,
-    target_mask=None, **loss_kwargs,
-) -> Callable:
-    """loss.py:26-96."""
+def _objective_closure(needs: str, loss: Callable, mean_fn, var_fn, scale_fn, batch_nn_targets, batch_targets,
+                       target_mask=None, **loss_kwargs) -> Callable:
+    """``f(Kin, Kcross, **kwargs) -> -loss`` for one batch.  ``target_mask`` selects response columns of
+    the mean (and the matching diagonal block of a full covariance)."""
+    with_variance = needs == "mean+var"
 
-    def predict_and_loss_fn(Kin, Kcross, *args, **kwargs):
-        predictions = mean_fn(Kin, Kcross, batch_nn_targets, **kwargs)
+    def negative_loss(Kin, Kcross, *unused, **kwargs):
+        operands = [mean_fn(Kin, Kcross, batch_nn_targets, **kwargs), batch_targets]
+        if with_variance:
+            scale = scale_fn(Kin, batch_nn_targets, **kwargs)
+            operands += [var_fn(Kin, Kcross, **kwargs), scale]
         if target_mask is not None:
-            predictions = predictions[:, target_mask]
-        return -loss_fn(predictions, batch_targets, **loss_kwargs)
+            operands[0] = operands[0][:, target_mask]
+            if with_variance:
+                operands[2] = operands[2][:, target_mask, target_mask]
+        return -loss(*operands, **loss_kwargs)
 
-    return predict_and_loss_fn
+    return negative_loss
 
 
-def make_var_predict_and_loss_fn(
-    loss_fn: Callable, mean_fn: Callable, var_fn: Callable, scale_fn: Callable, batch_nn_targets, batch_targets,
-    target_mask=None, **loss_kwargs,
-) -> Callable:
-    """loss.py:99-178.  Evaluation order as in the reference: mean, scale, variance -- under
-    the hip backend the three share one fused launch when the tensors are lazy handles."""
+def make_raw_predict_and_loss_fn(loss_fn: Callable, *args, **kwargs) -> Callable:
+    """The reference's builder name for mean-only losses (loss.py:26-96)."""
+    return _objective_closure("mean", loss_fn, *args, **kwargs)
 
-    def predict_and_loss_fn(Kin, Kcross, *args, **kwargs):
-        predictions = mean_fn(Kin, Kcross, batch_nn_targets, **kwargs)
-        scale = scale_fn(Kin, batch_nn_targets, **kwargs)
-        variances = var_fn(Kin, Kcross, **kwargs)
-        if target_mask is not None:
-            predictions = predictions[:, target_mask]
-            variances = variances[:, target_mask, target_mask]
-        return -loss_fn(predictions, batch_targets, variances, scale, **loss_kwargs)
 
-    return predict_and_loss_fn
+def make_var_predict_and_loss_fn(loss_fn: Callable, *args, **kwargs) -> Callable:
+    """The reference's builder name for losses that take variance and scale (loss.py:99-178)."""
+    return _objective_closure("mean+var", loss_fn, *args, **kwargs)
 
 
 class LossFn:
+    """A backend loss plus the recipe that evaluates it inside an objective.  The second argument is a
+    builder ``(loss_fn, mean_fn, var_fn, scale_fn, batch_nn_targets, batch_targets, ...) -> closure``
+    (the two above, or a caller's own)."""
+
     def __init__(self, loss_fn: Callable, make_predict_and_loss_fn: Callable):
         self._fn = loss_fn
         self._make_predict_and_loss_fn = make_predict_and_loss_fn
@@ -64,13 +76,19 @@ class LossFn:
     def __call__(self, *args, **kwargs):
         return self._fn(*args, **kwargs)
 
-    def make_predict_and_loss_fn(self, *args, **kwargs):
+    def make_predict_and_loss_fn(self, *args, **kwargs) -> Callable:
         return self._make_predict_and_loss_fn(self._fn, *args, **kwargs)
 
 
-cross_entropy_fn = LossFn(_cross_entropy_fn, make_raw_predict_and_loss_fn)
-mse_fn = LossFn(_mse_fn, make_raw_predict_and_loss_fn)
-lool_fn = LossFn(_lool_fn, make_var_predict_and_loss_fn)
-lool_fn_unscaled = LossFn(_lool_fn_unscaled, make_var_predict_and_loss_fn)
-pseudo_huber_fn = LossFn(_pseudo_huber_fn, make_raw_predict_and_loss_fn)
-looph_fn = LossFn(_looph_fn, make_var_predict_and_loss_fn)
+_BUILDERS = {"mean": make_raw_predict_and_loss_fn, "mean+var": make_var_predict_and_loss_fn}
+globals().update(
+    {name: LossFn(getattr(_backend, fn), _BUILDERS[needs]) for name, (fn, needs) in _CATALOGUE.items()}
+)
+# (spelled out for readers and static tools)
+cross_entropy_fn: LossFn
+mse_fn: LossFn
+pseudo_huber_fn: LossFn
+lool_fn: LossFn
+lool_fn_unscaled: LossFn
+looph_fn: LossFn
+__all__ = ["LossFn", "make_raw_predict_and_loss_fn", "make_var_predict_and_loss_fn", *_CATALOGUE]
