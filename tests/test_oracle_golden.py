@@ -177,3 +177,20 @@ def test_oracle_general_matern_matches_reference():
             mean, var = orc.posterior_mean_var(spec, g["features"], g["features"], g["batch_idx"], g["nn_idx"], g["targets"])
             np.testing.assert_allclose(mean, g["mean"], rtol=1e-8, atol=1e-10)
             np.testing.assert_allclose(var, g["var_unscaled"], rtol=1e-8)
+
+
+def test_fp32_reference_fixture_covers_every_forward_fixture():
+    """tests/golden/fp32_reference.npz (make_golden_fp32.py: the reference's torch backend at
+    MUYGPYS_FTYPE=32) calibrates the fp32 acceptance band of the HIP kernels: one (mean32, var32) pair
+    per forward fixture, same shapes as the fp64 results, and never better than fp32 can be."""
+    from tests.conftest import golden_names, load_golden
+    from tests.util import fp32_reference
+
+    for name in golden_names():
+        g = load_golden(name)
+        mean32, var32 = fp32_reference(name)
+        assert mean32 is not None, name
+        assert mean32.dtype == np.float32 and var32.dtype == np.float32
+        assert mean32.size == g["mean"].size and var32.shape == g["var_unscaled"].shape, name
+        rel = np.abs(var32.astype(np.float64) - g["var_unscaled"]) / np.abs(g["var_unscaled"])
+        assert np.all(np.isfinite(rel)), name
