@@ -63,7 +63,7 @@ def synth(n, d, true_ls, gen, noise_std=0.03, features=2048, chunk=1 << 20):
 
 
 def run(points=1_000_000, test_points=100_000, batch=1_000_000, d=8, k=50, optimizer="bayes", seed=0, n_iter=20,
-        init_points=5, verbose=True):
+        init_points=5, verbose=True, x0=1.0, bounds=(0.1, 10.0)):
     clock = Clock()
     gen = torch.Generator(device="cuda").manual_seed(seed)
     rng = np.random.default_rng(2)
@@ -80,7 +80,7 @@ def run(points=1_000_000, test_points=100_000, batch=1_000_000, d=8, k=50, optim
     model = MuyGPS(
         kernel=Matern(
             smoothness=Parameter(1.5),
-            deformation=Anisotropy(l2, length_scale=VectorParameter(*[Parameter(1.0, (0.1, 10.0)) for _ in range(d)])),
+            deformation=Anisotropy(l2, length_scale=VectorParameter(*[Parameter(float(x0), tuple(bounds)) for _ in range(d)])),
         ),
         noise=HomoscedasticNoise(1e-3),  # ~ the planted noise variance (0.03^2)
         scale=AnalyticScale(),

@@ -8,9 +8,12 @@ These are host-side loops around the (GPU) objective, one scalar per evaluation:
   ``bayesian-optimization`` (>= 1.4.2, pyproject.toml:43), which is not vendored and not
   installed in the build image.  What follows is a self-contained restatement of that
   package's published default algorithm -- probe x0, ``init_points`` uniform samples, then
-  ``n_iter`` rounds of: fit a GP (Matern nu=2.5, alpha=1e-6, normalised targets, 5 optimiser
-  restarts) to the evaluations and maximise the UCB acquisition (kappa = 2.576) by 10 000
-  random candidates refined with L-BFGS-B from the best ten.  PARITY UNPINNED: no reference
+  ``n_iter`` rounds of: fit a GP (Matern nu=2.5, alpha=1e-6, normalised targets) to the
+  evaluations and maximise the UCB acquisition (kappa = 2.576) by 10 000 random candidates
+  refined with L-BFGS-B from the best ten.  The surrogate is written out in numpy
+  (``_SurrogateGP``: one restart of the length-scale fit, Cholesky reused, candidates and
+  gradients vectorised) so that a suggestion costs milliseconds, not the ~200 ms of
+  scikit-learn's regressor, next to a 3 ms objective.  PARITY UNPINNED: no reference
   test pins a Bayes-opt trajectory or value; only behaviour (recovers
   planted hyper-parameters within the reference's statistical tolerances) is checked.
 """
@@ -69,21 +72,124 @@ def _scipy_optimize(muygps, obj_fn: Callable, verbose: bool = False, **kwargs):
     return _new_muygps(muygps, x0_names, bounds, {n: optres.x[i] for i, n in enumerate(x0_names)})
 
 
+class _SurrogateGP:
+    """The surrogate of the Bayes driver: a zero-mean GP with a Matern-5/2 kernel of one length scale on
+    the evaluated points, nugget 1e-6, targets standardised (the published defaults of the
+    ``bayesian-optimization`` package's scikit-learn regressor).  Written out in numpy because the
+    driver is host-bound otherwise: scikit-learn's regressor with five restarts and a per-point
+    ``predict`` made a suggestion cost ~200 ms against a 3 ms objective.  Here the length scale is the
+    one free parameter (log-marginal likelihood maximised by L-BFGS-B with its analytic derivative from
+    the previous optimum and ONE random restart), the Cholesky factor is kept, and mean / deviation /
+    their gradients are closed forms evaluated for all candidates at once."""
+
+    ALPHA = 1e-6
+    S5 = 5.0 ** 0.5
+
+    def __init__(self, rng):
+        self.rng = rng
+        self.log_ell = 0.0
+
+    @classmethod
+    def _kernel(cls, r, ell):
+        t = cls.S5 * r / ell
+        return (1.0 + t + t * t / 3.0) * np.exp(-t)
+
+    def _neg_lml(self, log_ell, R, y):
+        from scipy.linalg import cho_factor, cho_solve
+
+        ell = float(np.exp(np.asarray(log_ell).reshape(-1)[0]))
+        t = self.S5 * R / ell
+        e = np.exp(-t)
+        K = (1.0 + t + t * t / 3.0) * e
+        K[np.diag_indices_from(K)] += self.ALPHA
+        try:
+            c = cho_factor(K, lower=True)
+        except np.linalg.LinAlgError:
+            return 1e25, np.zeros(1)
+        a = cho_solve(c, y)
+        lml = -0.5 * float(y @ a) - float(np.log(np.diag(c[0])).sum()) - 0.5 * len(y) * np.log(2 * np.pi)
+        dK = (t * t / 3.0) * (1.0 + t) * e  # dK / d log(ell)
+        g = 0.5 * float(a @ dK @ a) - 0.5 * float(np.trace(cho_solve(c, dK)))
+        return -lml, np.array([-g])
+
+    def fit(self, X, y):
+        from scipy.linalg import cho_factor, cho_solve
+        from scipy.optimize import minimize
+
+        self.X = np.asarray(X, dtype=np.float64)
+        y = np.asarray(y, dtype=np.float64)
+        self.mu, self.sd = float(y.mean()), float(y.std()) or 1.0
+        yn = (y - self.mu) / self.sd
+        R = np.sqrt(np.maximum(((self.X[:, None, :] - self.X[None, :, :]) ** 2).sum(-1), 0.0))
+        best = None
+        for start in (self.log_ell, float(self.rng.uniform(np.log(1e-2), np.log(1e2)))):
+            res = minimize(self._neg_lml, [start], args=(R, yn), jac=True, method="L-BFGS-B",
+                           bounds=[(np.log(1e-5), np.log(1e5))])
+            if best is None or res.fun < best.fun:
+                best = res
+        self.log_ell = float(best.x[0])
+        self.ell = float(np.exp(self.log_ell))
+        K = self._kernel(R, self.ell)
+        K[np.diag_indices_from(K)] += self.ALPHA
+        self.chol = cho_factor(K, lower=True)
+        self.alpha = cho_solve(self.chol, yn)
+        return self
+
+    def ucb(self, Xc, kappa, want_grad=False):
+        """UCB (and its gradient) of the candidates Xc (m, p), in the units of the objective."""
+        from scipy.linalg import cho_solve
+
+        Xc = np.atleast_2d(Xc)
+        if not want_grad:
+            return self._ucb_many(Xc, kappa)
+        diff = Xc[:, None, :] - self.X[None, :, :]                      # (m, n, p): a handful of points
+        r = np.sqrt(np.maximum((diff ** 2).sum(-1), 0.0))               # (m, n)
+        t = self.S5 * r / self.ell
+        e = np.exp(-t)
+        k = (1.0 + t + t * t / 3.0) * e
+        mean = k @ self.alpha
+        v = cho_solve(self.chol, k.T)                                   # (n, m)
+        var = np.maximum(1.0 - np.einsum("mn,nm->m", k, v), 1e-18)
+        std = np.sqrt(var)
+        val = self.mu + self.sd * (mean + kappa * std)
+        # dk/dx = -(5 / (3 ell^2)) (1 + t) e^{-t} (x - x_i)
+        w = -(5.0 / (3.0 * self.ell**2)) * (1.0 + t) * e                # (m, n)
+        dk = w[:, :, None] * diff                                       # (m, n, p)
+        dmean = np.einsum("mnp,n->mp", dk, self.alpha)
+        dvar = -2.0 * np.einsum("mnp,nm->mp", dk, v)
+        grad = self.sd * (dmean + kappa * dvar / (2.0 * std[:, None]))
+        return val, grad
+
+
+    def _ucb_many(self, Xc, kappa):
+        """The thousands of random candidates of one suggestion, scored in one pass of torch tensor
+        operations (on the ROCm device when there is one): pairwise distances, kernel, one triangular
+        solve (k^T K^-1 k = |L^-1 k|^2).  fp64 throughout."""
+        import torch
+
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        to = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)  # noqa: E731
+        r = torch.cdist(to(Xc), to(self.X))
+        t = self.S5 * r / self.ell
+        k = (1.0 + t + t * t / 3.0) * torch.exp(-t)
+        L = torch.tril(to(self.chol[0]))
+        u = torch.linalg.solve_triangular(L, k.T, upper=False)
+        var = (1.0 - (u * u).sum(0)).clamp_min(1e-18)
+        val = self.mu + self.sd * (k @ to(self.alpha) + kappa * var.sqrt())
+        return val.cpu().numpy()
+
+
 class _UCBBayesOpt:
     """Minimal GP-UCB maximiser over a box (see the module docstring for provenance)."""
 
     def __init__(self, f: Callable, names: List[str], bounds: np.ndarray, random_state=None, verbose: int = 0):
-        from sklearn.gaussian_process import GaussianProcessRegressor
-        from sklearn.gaussian_process.kernels import Matern
-
         self.f, self.names, self.bounds = f, names, bounds
         self.rng = np.random.RandomState(random_state) if not isinstance(random_state, np.random.RandomState) else random_state
         self.verbose = verbose
         self.X: List[np.ndarray] = []
         self.y: List[float] = []
-        self.gp = GaussianProcessRegressor(
-            kernel=Matern(nu=2.5), alpha=1e-6, normalize_y=True, n_restarts_optimizer=5, random_state=self.rng
-        )
+        self.gp = _SurrogateGP(self.rng)
+        self.suggest_seconds = 0.0
 
     def probe(self, x: np.ndarray) -> float:
         val = _as_float(self.f(**{n: float(x[i]) for i, n in enumerate(self.names)}))
@@ -97,25 +203,25 @@ class _UCBBayesOpt:
         return self.rng.uniform(self.bounds[:, 0], self.bounds[:, 1], size=(n, len(self.names)))
 
     def _suggest(self, kappa: float) -> np.ndarray:
-        import warnings
+        import time
 
         from scipy.optimize import minimize
 
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            self.gp.fit(np.array(self.X), np.array(self.y))
-
-        def ucb(x):
-            mean, std = self.gp.predict(np.atleast_2d(x), return_std=True)
-            return mean + kappa * std
-
+        t0 = time.perf_counter()
+        self.gp.fit(np.array(self.X), np.array(self.y))
         cand = self._sample(10000)
-        vals = ucb(cand)
+        vals = self.gp.ucb(cand, kappa)          # all candidates in one pass
         best_x, best_v = cand[int(np.argmax(vals))], float(np.max(vals))
+
+        def neg(x):
+            v, g = self.gp.ucb(x, kappa, want_grad=True)
+            return -float(v[0]), -g[0]
+
         for seed in cand[np.argsort(vals)[-10:]]:
-            res = minimize(lambda x: -float(ucb(x)[0]), seed, bounds=self.bounds, method="L-BFGS-B")
+            res = minimize(neg, seed, jac=True, bounds=self.bounds, method="L-BFGS-B")
             if res.success and -res.fun > best_v:
                 best_x, best_v = res.x, -res.fun
+        self.suggest_seconds += time.perf_counter() - t0
         return np.clip(best_x, self.bounds[:, 0], self.bounds[:, 1])
 
     def maximize(self, init_points: int = 5, n_iter: int = 20, kappa: float = 2.576, **ignored) -> Dict:

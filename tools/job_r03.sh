@@ -1,1 +1,1 @@
-python3 -m pytest tests/test_gpu_fused.py -m gpu -q -x 2>&1 | tail -12
+python3 tools/scratch_bayes.py 2>&1 | grep -v Warn | tail -8
