@@ -176,6 +176,23 @@ int mgp_posterior_kernel_name(int elem_size, int d, int k, int R, int packed, in
  *       mgp_posterior_* (same kernels, same arithmetic).
  * ------------------------------------------------------------------------- */
 int64_t mgp_packed_row_bytes(int d, int R, int elem_size);
+
+/* ---------------------------------------------------------------------------
+ * Run-time specialisation.  mgp_posterior_* / mgp_loocv_* serve a shape (k, R, d) with a kernel whose
+ * loops are compiled for exactly that shape: built into the library for the BASELINE shapes, compiled
+ * on first use (hiprtc, ~1 s, cached on disk next to the library) for any other shape with
+ * k + 1 + R <= 64, 16-byte rows and d <= 64 (fp32) / 32 (fp64) -- when the call has at least
+ * MUYGPYS_HIP_JIT_MIN_BATCH neighbourhoods (default 65536).  MUYGPYS_HIP_JIT=0 turns it off (the
+ * run-time-shape kernels serve every call), =force applies it to every call.  Results do not depend
+ * on which kernel served a call beyond the rounding of a different summation order.
+ *   mgp_jit_prepare: compile one shape into the disk cache ahead of time (no GPU needed);
+ *                    MGP_OK, or MGP_EUNSUPPORTED (shape outside the static kernels, or no hiprtc).
+ *   mgp_jit_mode:    0 off, 1 automatic, 2 forced.
+ *   mgp_jit_loaded_count: run-time compiled kernels loaded in this process so far.
+ * ------------------------------------------------------------------------- */
+int mgp_jit_prepare(int elem_size, int k, int R, int d, int packed, int kernel_id);
+int mgp_jit_mode(void);
+int mgp_jit_loaded_count(void);
 int mgp_table_pack_f32(const float* features, const float* targets, int64_t n, int d, int R, void* packed,
                        int64_t stride_bytes, void* stream);
 int mgp_table_pack_f64(const double* features, const double* targets, int64_t n, int d, int R, void* packed,

@@ -110,6 +110,12 @@ def load():
     lib.mgp_reduce_scratch_doubles.restype = _i
     lib.mgp_matern_gen_constants.argtypes = [_d, C.POINTER(C.c_double)]
     lib.mgp_matern_gen_constants.restype = _i
+    lib.mgp_jit_prepare.argtypes = [_i, _i, _i, _i, _i, _i]
+    lib.mgp_jit_prepare.restype = _i
+    lib.mgp_jit_mode.argtypes = []
+    lib.mgp_jit_mode.restype = _i
+    lib.mgp_jit_loaded_count.argtypes = []
+    lib.mgp_jit_loaded_count.restype = _i
     lib.mgp_packed_row_bytes.argtypes = [_i, _i, _i]
     lib.mgp_packed_row_bytes.restype = _l
     for base, sig in _SIGS.items():

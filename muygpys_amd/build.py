@@ -76,7 +76,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + out)
         if verbose and out.strip():
             print(out, file=sys.stderr)
-    link = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB + ".tmp", *objs]
+    link = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB + ".tmp", *objs, "-ldl"]
     r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed: " + " ".join(link) + "\n" + r.stdout)
@@ -84,5 +84,45 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+# Static shapes compiled into the run-time-specialisation cache at build time (csrc/mgp_jit.hip; hiprtc
+# needs no GPU): the nn_count x feature_count grid of profiles/r03_shape_sweep.md, prepared and plain
+# tables in fp32, prepared tables in fp64.  Any other shape is compiled on first use (~1 s).
+PREWARM_K = (10, 20, 25, 30, 40, 50)
+PREWARM_D = (8, 16, 32, 40, 64)
+
+
+def _prewarm_one(job):
+    import ctypes
+
+    es, k, d, packed = job
+    lib = ctypes.CDLL(LIB)
+    lib.mgp_jit_prepare.argtypes = [ctypes.c_int] * 6
+    lib.mgp_jit_prepare.restype = ctypes.c_int
+    return job, lib.mgp_jit_prepare(es, k, 1, d, packed, 2)  # kernel id 2 = Matern-3/2 (any Gram-form kernel)
+
+
+def prewarm(verbose: bool = False) -> int:
+    """Fill muygpys_amd/lib/jit/ for the common shapes (objects already there are kept: the file name
+    carries a hash of the kernel sources).  Returns the number of shapes available."""
+    import multiprocessing as mp
+
+    jobs = [(4, k, d, p) for k in PREWARM_K for d in PREWARM_D for p in (1, 0)]
+    jobs += [(8, k, d, 1) for k in PREWARM_K for d in PREWARM_D if d <= 32]
+    with mp.get_context("spawn").Pool(min(8, os.cpu_count() or 1)) as pool:
+        done = pool.map(_prewarm_one, jobs)
+    ok = sum(1 for _, rc in done if rc == 0)
+    if verbose:
+        print(f"run-time specialisation cache: {ok} of {len(jobs)} shapes ready", file=sys.stderr)
+    # drop objects of older builds (their hash no longer matches any source)
+    jit = os.path.join(LIBDIR, "jit")
+    if os.path.isdir(jit):
+        newest = max((os.path.getmtime(os.path.join(jit, f)) for f in os.listdir(jit)), default=0)
+        for f in os.listdir(jit):
+            if os.path.getmtime(os.path.join(jit, f)) < newest - 6 * 3600:
+                os.remove(os.path.join(jit, f))
+    return ok
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    prewarm(verbose=True)

@@ -31,6 +31,7 @@ struct FusedArgs {
   int64_t q_stride = 0, nn_stride = 0;
 };
 
+#ifndef __HIPCC_RTC__  // the rest is host side: other argument blocks and the launcher declarations
 #define MGP_MAX_DEVICES 64
 
 struct SolveArgs {
@@ -99,6 +100,13 @@ template <typename T> int launch_solve_generic(const SolveArgs&, hipStream_t);
 template <typename T> int launch_solve_wave(const SolveArgs&, hipStream_t);  // k + 1 + R <= 64, no coefficients
 // register-resident wave-per-neighbourhood kernels; MGP_EUNSUPPORTED when the shape is not covered
 template <typename T> int launch_fused_wave(const FusedArgs&, hipStream_t);
+// run-time specialisation of the wave kernel (mgp_jit.hip)
+int jit_wave_function(int es, int np, int k, int R, int d, bool packed, bool gram, hipFunction_t* fn);
+int jit_wave_prepare(int es, int np, int k, int R, int d, bool packed, bool gram);
+int jit_mode();
+int jit_loaded_count();
+int64_t jit_min_batch();
+int prepare_fused_wave(int elem_size, int d, int k, int R, int packed, int kernel_id);  // compile into the disk cache
 // k <= 64 with up to 16 responses carried as right-hand-side columns (mgp_fused_rhs.hip)
 template <typename T> int launch_fused_rhs(const FusedArgs&, hipStream_t);
 // 64 < k + 1 + R <= 128, fp32: two waves per neighbourhood, rows in registers (mgp_fused_wide.hip)
@@ -130,5 +138,7 @@ template <typename T> int launch_table_pack(const T*, const T*, int64_t, int, in
 template <typename T>
 int launch_fast_mean(const void*, const void*, int, const int64_t*, const int64_t*, int64_t, int, const void*,
                      const int64_t*, int, int, int, const void*, int, void*, hipStream_t);
+
+#endif  // !__HIPCC_RTC__
 
 }  // namespace mgp

@@ -155,6 +155,12 @@ int mgp_posterior_kernel_name(int elem_size, int d, int k, int R, int packed, in
     snprintf(buf, len, "mgp::fused_generic_kernel<%s>", t);
   return MGP_OK;
 }
+int mgp_jit_prepare(int elem_size, int k, int R, int d, int packed, int kernel_id) {
+  if ((elem_size != 4 && elem_size != 8) || k < 1 || R < 1 || d < 1 || !valid_kernel(kernel_id)) return MGP_EINVAL;
+  return prepare_fused_wave(elem_size, d, k, R, packed, kernel_id);
+}
+int mgp_jit_mode(void) { return jit_mode(); }
+int mgp_jit_loaded_count(void) { return jit_loaded_count(); }
 int64_t mgp_packed_row_bytes(int d, int R, int elem_size) {
   if (d < 1 || R < 0 || (elem_size != 4 && elem_size != 8)) return MGP_EINVAL;
   // the gather always reads the 16-byte slot behind the features (the responses), also from a table

@@ -2,10 +2,20 @@
 // Wave size is 64 on CDNA4; every cross-lane idiom below is written for that.
 #pragma once
 
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/muygpys_hip.h"
+#else
+// run-time compile (hiprtc): no libc headers; the few names of the C header the kernels use
+typedef long long int64_t;
+typedef unsigned long long uint64_t;
+typedef unsigned long uintptr_t;
+enum { MGP_KERNEL_RBF = 0, MGP_KERNEL_MATERN_05 = 1, MGP_KERNEL_MATERN_15 = 2, MGP_KERNEL_MATERN_25 = 3, MGP_KERNEL_MATERN_INF = 4 };
+enum { MGP_METRIC_L2 = 0, MGP_METRIC_F2 = 1 };
+enum { MGP_NOISE_SCALAR = 0, MGP_NOISE_TABLE = 1, MGP_NOISE_BATCH = 2 };
+#endif
 
 #define MGP_WAVE 64
 

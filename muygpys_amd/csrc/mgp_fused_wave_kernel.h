@@ -1,0 +1,979 @@
+// Register-resident wave-per-neighbourhood fused kernel (the roofline path).
+//
+// One wavefront (64 lanes, one workgroup) owns NH = 64/NP neighbourhoods at a time; a
+// neighbourhood is a set of NP "slots", one per lane:
+//
+//     slot 0 .. k-1      neighbour rows            (features gathered by nn_idx)
+//     slot k .. q-1      padding (identity rows)    q = NP-1-R
+//     slot q             the query point            (features gathered by batch_idx)
+//     slot q+1 .. NP-1   the R response rows        (no features)
+//
+// Phase 0  indices (prefetched one task ahead), responses and nugget of the neighbours.
+// Phase 1  gather: the (k+1) feature rows are staged once in LDS with coalesced 16-byte
+//          loads (d/4 consecutive lanes walk one row, all loads of a task in flight together;
+//          rows padded to an odd number of 16-B slots so that ds_read_b128 of a column of
+//          rows is bank-conflict free).
+// Phase 2  distances, difference form sum((x-y)^2) (never the Gram trick: fp32 parity),
+//          each unordered pair ONCE, NP/2 pairs per lane in registers (v_pk_add_f32 /
+//          v_pk_fma_f32).  LDS read bandwidth is what this phase is short of (measured: halving
+//          the partner reads at equal VALU work saves 21 % of the kernel), so the pairs are
+//          register-blocked BA x BP (BA = 4 own rows, BP = NP/8 partner rows per lane): lane i
+//          keeps own rows i + o_j, o_0 = 0, o_j = (j+1) BP + 1, and every partner row i+p
+//          (p = 1..BP) it reads serves all of them -- pair {i+p, i+o_j} has cyclic distance
+//          p for j = 0 and o_j - p in (j BP, (j+1) BP] otherwise, so the BA x BP pairs of all
+//          lanes cover the distances 1..NP/2 exactly like the one-row scheme, with 8 instead
+//          of 17 row reads at NP = 32.
+// Phase 3  kernel function + nugget, exchanged through a small LDS matrix so that lane i
+//          ends up holding row i of the augmented system
+//                [ K+eps  .   . ]
+//                [ c^T    1   . ]     (lower triangle; see mgp_lds_factor.h for the algebra)
+//                [ Y^T    0   0 ]
+//          in NP registers.
+// Phase 4  right-looking Cholesky, row per lane, all in registers: step j broadcasts
+//          column j through a 64-entry LDS buffer (one ds_write_b32, a few uniform
+//          ds_read_b128), then packed FMAs on the trailing registers.  After k steps the
+//          Schur complement of the (query, responses) block holds
+//          var = S[q][q],  mean_r = -S[q+1+r][q],  y_r^T K^-1 y_r = -S[q+1+r][q+1+r].
+//
+// No inter-wave communication, no barrier that waits on another wave (one wave per
+// workgroup: __syncthreads() is a compiler / wait-count fence only).  The kernel is
+// VALU-issue bound, so the code below spends its effort on instruction
+// count: packed f32 math, compile-time shapes for the headline configuration
+// (KFIX/RFIX/DFIX), and a grid sized to exactly the resident capacity.
+// (This header is the DEVICE side: the kernel template and its compile-time knobs.  It is compiled into
+// the library for the shapes instantiated in mgp_fused_wave.hip and, at run time, by hiprtc for any
+// other static shape -- mgp_jit.hip -- so it includes nothing a device-only compile cannot see.)
+#pragma once
+
+#include "mgp_wave_common.h"
+
+// Phase tests: WaveGeom::mask is a kernel argument, always 0xF in the shipped library (only builds
+// with -DMGP_DEBUG_HOOKS export a setter, for the timing ablations of tools/kbench.py).  The test
+// stays a run-time one on purpose: with the phases fused into one straight-line region the
+// compiler hoists per-lane addresses of all phases to the top of the task loop and the static
+// shapes spill (168 VGPRs + 164 B scratch instead of 134 and none; 2.78 instead of 2.22 ms).
+#define MGP_PHASE(g, bit) ((g).mask & (bit))
+
+#ifndef MGP_F64_SAME_PRIO
+#define MGP_F64_SAME_PRIO 0
+#endif
+#ifndef MGP_DIST_PRIO
+#define MGP_DIST_PRIO 1
+#endif
+#ifndef MGP_PRIO_EARLY_RAISE
+#define MGP_PRIO_EARLY_RAISE 0
+#endif
+#ifndef MGP_W4
+#define MGP_W4 0
+#endif
+#ifndef MGP_PRIO_LATE_DROP
+#define MGP_PRIO_LATE_DROP 0
+#endif
+#ifndef MGP_XCHG_PRIO
+#define MGP_XCHG_PRIO 0
+#endif
+#ifndef MGP_CHOL_PRIO
+#define MGP_CHOL_PRIO 2
+#endif
+#ifndef MGP_LOOKAHEAD
+#define MGP_LOOKAHEAD 1
+#endif
+#ifndef MGP_CHOL_ONE_BLOCK
+#define MGP_CHOL_ONE_BLOCK 1
+#endif
+#ifndef MGP_F64_COV_BATCH
+#define MGP_F64_COV_BATCH 5
+#endif
+#ifndef MGP_C4_W3
+#define MGP_C4_W3 0
+#endif
+#ifndef MGP_MODM
+#define MGP_MODM 1
+#endif
+#ifndef MGP_GRAM
+#define MGP_GRAM 1
+#endif
+#ifndef MGP_DMA_ASM
+#define MGP_DMA_ASM 1
+#endif
+#ifndef MGP_DIST_ASM
+#define MGP_DIST_ASM 1
+#endif
+#ifndef MGP_F64_GC
+#define MGP_F64_GC 6
+#endif
+
+namespace mgp {
+
+struct WaveGeom {
+  int q;         // query slot
+  int dst;       // feature stage width (elements, multiple of the chunk)
+  int xs;        // LDS row stride of the feature tile (elements)
+  int vec_ok;    // 16-byte gathers allowed (d % (16/sizeof T) == 0, bases aligned)
+  int64_t ntasks;
+  int mask;      // debug: phases to execute (bit0 gather, 1 distances, 2 kernel+exchange, 3 factor)
+};
+
+// Sizes shared by the kernel and its launchers.  Plain constexpr functions of the shape (element size es,
+// slots NP, and the static k / R / d or 0), so that the precompiled instantiations (template arguments)
+// and the run-time compiled ones (mgp_fused_wave.hip, launch_jit: the same numbers at run time) cannot
+// drift apart.
+struct WaveDims {
+  int E, CH, NH, NPL, NG, KS, KMAT, BA, BP, NS, M;
+  bool STAT, TRI, MODM;
+};
+constexpr WaveDims wave_dims(int es, int NP, int KFIX, int RFIX, int DFIX, bool COEFF, bool GRAM) {
+  WaveDims w{};
+  w.E = 16 / es;
+  w.CH = 2 * w.E;
+  w.NH = 64 / NP;
+  w.STAT = KFIX > 0 && RFIX > 0 && DFIX > 0 && !COEFF;  // all shapes static
+  w.NPL = w.STAT ? KFIX + 1 + RFIX : NP;                 // live slots
+  w.NG = (w.NPL + w.E - 1) / w.E;                        // 16-byte groups of a lane's row
+  w.KS = NP + w.E;
+  w.TRI = NP == 64 && !COEFF;
+  // elements per exchange matrix (packed: up to the last live row, the NG groups a lane reads from
+  // there, a dump slot)
+  w.KMAT = w.TRI ? w.E * ((w.NPL - 1) / w.E + 1) * (w.E * ((w.NPL - 1) / w.E) / 2 + (w.NPL - 1) % w.E) + w.NG * w.E + w.E
+                 : NP * w.KS;
+  // Pair scheme.  Generic: the NP slots form the cycle, NP/2 pairs per lane in 4 x NP/8 blocks (the
+  // half-way distance twice; pairs with a response or padding slot computed and discarded).  Static
+  // shapes run the cycle modulo the feature-row count M = k + 1 instead when that is shorter: cyclic
+  // distances 1 .. M/2, BA own rows x BP partner rows per lane with BA x BP >= M/2 (BA of 3, 4 or 5,
+  // whichever wastes least; a distance computed twice -- t and M - t, or the surplus of the blocking --
+  // writes the same value to the same slot).  k = 30: 15 pairs (3 x 5) instead of 16; k = 50: 25
+  // (5 x 5) instead of 32; k = 10: 5 instead of 16.  With the Gram form the modulo scheme must save at
+  // least two pairs per lane: the wrap at M breaks the bank spread of the tile rows, measured 1.89 vs
+  // 1.83 ms at k = 30.
+  w.M = NP;
+  w.BA = 4;
+  w.BP = NP / 8;
+  w.MODM = false;
+  if (MGP_MODM && w.STAT) {
+    const int need = (KFIX + 1) / 2;
+    int ba = 4, bp = (need + 3) / 4;
+    for (int c = 3; c <= 5; c += 2) {
+      const int q = (need + c - 1) / c;
+      if (c * q < ba * bp) ba = c, bp = q;
+    }
+    if (ba * bp + (GRAM ? 2 : 1) <= NP / 2) {
+      w.MODM = true;
+      w.M = KFIX + 1;
+      w.BA = ba;
+      w.BP = bp;
+    }
+  }
+  w.NS = w.BA * w.BP;
+  return w;
+}
+// rows of the feature tile: all NP slots of every neighbourhood of the wave, or -- one static
+// neighbourhood per wave -- the live slots only (the direct-to-LDS gather stops after the query row;
+// its last 1-KiB piece may run into the first response row, which holds no features)
+constexpr int wave_tile_rows(const WaveDims& w, int NP, int KFIX, int xs) {
+  if (!(w.STAT && w.NH == 1)) return w.NH * NP;
+  const int spr = xs / w.E, pieces = ((KFIX + 1) * spr + 63) / 64;
+  const int covered = (pieces * 64 + spr - 1) / spr;
+  return covered > w.NPL ? covered : w.NPL;
+}
+constexpr int wave_gather_pieces(const WaveDims& w, int KFIX, int xs) {
+  const int spr = xs / w.E;
+  return (w.STAT && w.NH == 1) ? ((KFIX + 1) * spr + 63) / 64 : spr;
+}
+// waves per SIMD the register allocation is held to
+constexpr int wave_min_waves(int es, int NP, int KFIX) {
+  return es == 4 ? (NP <= 32 ? (KFIX == 30 && MGP_W4 ? 4 : 3) : 2) : (NP <= 32 ? 2 : (KFIX > 0 && MGP_C4_W3 ? 3 : 2));
+}
+
+// KFIX / RFIX / DFIX > 0: nn_count / response_count / feature_count known at compile time.
+// PIPED: software-pipelined direct-to-LDS gather (one feature stage, 16-byte aligned rows).
+// COEFF: also emit K^-1 y (the fast-posterior-mean coefficients): multipliers kept, back-substitution.
+// PACKED: the tables are prepared tables (mgp_table_pack_*): rows of [features | responses | pad] at a
+//        64-byte multiple stride, so a row and its response arrive with the same two cache lines
+//        and no separate 4-byte response read (a whole line each) is issued.
+// GRAM: (fp32, pipelined) squared distances as |a'|^2 + |b'|^2 - 2 a'.b' on rows centred on the query
+//        in place (a' = a - q, times the inverse length scales under Anisotropy): one packed FMA per
+//        two features of a pair instead of a packed subtract + a packed FMA.  See phase 1b / 2.
+template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF = false, bool PACKED = false,
+          bool GRAM = false>
+__global__ __launch_bounds__(64, wave_min_waves(sizeof(T), NP, KFIX))
+void fused_wave_kernel(FusedArgs a, WaveGeom g) {
+  static_assert(!PACKED || PIPED, "prepared tables are gathered by the direct-to-LDS pipeline");
+  static_assert(!GRAM || (sizeof(T) == 4 && PIPED && !COEFF), "Gram form: fp32, one feature stage");
+  constexpr WaveDims WD = wave_dims(sizeof(T), NP, KFIX, RFIX, DFIX, COEFF, GRAM);
+  constexpr int NH = WD.NH;       // neighbourhoods per wave
+  constexpr bool STAT = WD.STAT;  // all shapes static: q = k, NPL live slots, lanes NPL .. NP-1 idle; everything
+  constexpr int NPL = WD.NPL;     // downstream is sized by NPL (k = 50, R = 1: 52 of 64 slots, 26 of 32 fp64 groups)
+  static_assert(NPL <= NP, "live slots");
+  constexpr bool MODM = WD.MODM;  // pair scheme modulo M feature rows (wave_dims)
+  constexpr int M = WD.M;
+  constexpr int NS = WD.NS;       // pairs per lane
+  constexpr int BA = WD.BA;       // own rows per lane        } register blocking of the pair scheme,
+  constexpr int BP = WD.BP;       // partner rows per lane    } see phase 2
+  auto own_offset = [](int j) { return j == 0 ? 0 : (j + 1) * BP + 1; };
+  auto wrap = [](int r) { return MODM ? r % M : r & (NP - 1); };
+  constexpr int E = v16<T>::N;    // elements per 16 bytes
+  constexpr int CH = 2 * E;       // feature chunk per inner iteration (two 16-B reads per row)
+  constexpr int KS = NP + E;      // row stride of the (square) exchange matrix: NP/E + 1 (odd) 16-B slots
+  // 64-slot neighbourhoods keep the exchange matrix PACKED lower-triangular: row r holds its r + 1
+  // entries, padded to whole 16-byte groups, at rowoff(r) = E (a + 1) (E a / 2 + r % E), a = r / E --
+  // 17 KB instead of 34 KB in fp64, so LDS no longer holds these shapes at one wave per SIMD.  A lane
+  // reads NP entries from the start of its row; what lies beyond its diagonal belongs to later rows
+  // (upper-triangle garbage the elimination never uses).
+  constexpr bool TRI = NP == 64 && !COEFF;
+  auto rowoff = [](int r) {
+    if constexpr (TRI) {
+      const int a = r / E;
+      return E * (a + 1) * (E * a / 2 + r % E);
+    } else {
+      return r * KS;
+    }
+  };
+  constexpr int NG = WD.NG;      // 16-byte groups of a lane's row
+  constexpr int KMAT = WD.KMAT;  // elements per exchange matrix
+  constexpr int DPADFIX = (DFIX + CH - 1) / CH * CH;
+  constexpr int DSTFIX = DFIX > 0 ? (DPADFIX < 64 ? DPADFIX : 64) : CH;
+  using V = typename v16<T>::type;
+  using ACC = typename v16<T>::acc;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int k = KFIX > 0 ? KFIX : a.k;
+  const int R = RFIX > 0 ? RFIX : a.R;
+  const int d = DFIX > 0 ? DFIX : a.d;
+  const int q = STAT ? KFIX : (RFIX > 0 ? NP - 1 - RFIX : g.q);
+  const int dst = DFIX > 0 ? DSTFIX : g.dst;
+  const int xs = DFIX > 0 ? DSTFIX + E : g.xs;
+  const int tile_rows = wave_tile_rows(WD, NP, KFIX, xs);
+  const int tile_elems = tile_rows * xs > NH * KMAT ? tile_rows * xs : NH * KMAT;
+  T* tile = reinterpret_cast<T*>(smem);               // feature tile, later the exchange matrix
+  // Plain kernels: [tile][colbuf 64][ilbuf dst][idxbuf 64 x int64].  Pipelined kernels keep LDS
+  // at tile + 256 bytes (9 allocation granules of 1280 B -> 14 workgroups per CU): the 32-bit row
+  // indices live in the column buffer (only read while the gather is issued, before the
+  // factorisation writes there) and the inverse length scales in the tile row of the last slot
+  // (a response slot: it has no features, and its distances are never used).
+  constexpr bool PIPE_ = PIPED;
+  T* colbuf = tile + tile_elems;                      // 64 entries
+  T* ilbuf = PIPE_ ? tile + (NPL - 1) * xs : colbuf + 64;  // dst entries (Anisotropy)
+  int64_t* idxbuf = reinterpret_cast<int64_t*>(ilbuf + dst + (dst & 1));  // 64 entries (plain kernels)
+  const T** rowaddr = reinterpret_cast<const T**>(colbuf);  // 64 row pointers (pipelined; overlays colbuf + 256 B)
+
+  const T* feat_q = static_cast<const T*>(a.feat_q);
+  const T* feat_nn = static_cast<const T*>(a.feat_nn);
+  const T* targets = static_cast<const T*>(a.targets);
+  const T* noise_dev = static_cast<const T*>(a.noise_dev);
+  const T* ls = static_cast<const T*>(a.length_scale);
+  const bool aniso = a.ls_count > 1;
+  T post_scale = T(1);
+  if (!aniso) {
+    const T l = ls[0];
+    post_scale = a.metric_id == MGP_METRIC_L2 ? T(1) / l : T(1) / (l * l);
+  }
+  const bool nopad = k == q;  // every slot below q is a real neighbour
+
+  // XCD-aware task order: workgroups b and b+8 share an XCD (round-robin dispatch), so give
+  // each XCD one contiguous eighth of the neighbourhoods -> neighbouring neighbourhoods
+  // (which share rows under a spatially sorted kNN) meet in the same L2.
+  const int64_t ntasks = g.ntasks;
+  const int64_t per_xcd = (ntasks + 7) / 8;
+  const int xcd = blockIdx.x & 7;
+  const int64_t t_hi = (xcd + 1) * per_xcd;
+  const int64_t t_end = t_hi < ntasks ? t_hi : ntasks;
+  const int64_t t_step = gridDim.x >> 3;
+
+  // Index prefetch: the (dependent) index load of task t+1 is issued at the top of task t.
+  // The row of the index tensor is addressed as uniform 64-bit base + 32-bit lane offset.
+  // Branch-free on purpose: ONE load instruction per call whatever the slot, so that the value
+  // can stay in flight across the task (loads under divergent branches that write the same
+  // register make the compiler wait for the first before issuing the second).  Slots without
+  // an index read a valid dummy element and are zeroed when the value is consumed.
+  auto load_index = [&](int64_t task, int h, int i) -> int64_t {
+    const int64_t nb0 = task * NH;                       // uniform
+    const int hh = (NH > 1 && nb0 + h >= a.b) ? 0 : h;   // odd tail: replay the first half
+    const int64_t* row = a.nn_idx + nb0 * k;
+    const int64_t* p = row + (hh * k + (i < k ? i : 0));
+    if (a.batch_idx != nullptr && i == q) p = a.batch_idx + nb0 + hh;
+    return *p;
+  };
+  auto fix_index = [&](int64_t raw, int64_t task, int h, int i) -> int64_t {
+    const int64_t nb0 = task * NH;
+    const int hh = (NH > 1 && nb0 + h >= a.b) ? 0 : h;
+    if (i < k) return raw;
+    if (i == q) return a.batch_idx != nullptr ? raw : nb0 + hh;
+    return 0;
+  };
+
+  const int64_t task0 = xcd * per_xcd + (blockIdx.x >> 3);
+  int64_t next_idx = 0;
+  if (task0 < t_end) next_idx = load_index(task0, NH == 1 ? 0 : (int)threadIdx.x / NP, threadIdx.x & (NP - 1));
+
+  // Software-pipelined gather (static shapes, one feature stage): the feature tile of task
+  // t+1 is requested right before the factorisation of task t -- by then the tile region of
+  // LDS is free (row i of the system sits in registers) -- with direct global->LDS loads, so it
+  // costs no registers and its latency hides behind the Cholesky.  One load instruction fills
+  // 64 consecutive 16-byte slots of the tile (SPR slots per row, the last one padding).
+  constexpr bool PIPE = PIPED;
+  static_assert(!PIPED || DFIX <= 64, "the pipelined gather stages all features at once");
+  const int SPR = xs / E;                                   // 16-byte slots per staged row (NH * NP = 64 rows
+  const int C16V = d / E;                                   //  -> SPR loads per task); C16V of them hold data
+  constexpr int GB = 11;                                    // loads issued per batch (= SPR at d = 40, fp32)
+  const unsigned spr_magic = (1u << 20) / (unsigned)SPR + 1u;  // sigma / SPR for sigma < 64 * 33
+  T pre_y = T(0), pre_eps = T(0);
+  int64_t pre_idx = 0, pre_tg = 0;  // pre_tg: row of the response tensor (table row, or b * k + slot when gathered)
+  auto pipe_issue = [&](int64_t task_n, int64_t idx_n, int lane_) {
+    const int h = NH == 1 ? 0 : lane_ / NP;
+    const int i = lane_ & (NP - 1);
+    // pointer to this slot's feature row; slots without one (idx_n = 0) point at row 0 -- any
+    // valid row will do, their tile rows are never used
+    if constexpr (PACKED)
+      rowaddr[lane_] = reinterpret_cast<const T*>(
+          (i == q ? static_cast<const char*>(a.packed_q) + idx_n * a.q_stride
+                  : static_cast<const char*>(a.packed_nn) + idx_n * a.nn_stride));
+    else
+      rowaddr[lane_] = (i == q ? feat_q : feat_nn) + idx_n * (int64_t)d;
+    pre_idx = idx_n;
+    __syncthreads();
+    if (MGP_PHASE(g, 1)) {
+      // 16-byte slot sigma = 64 n + lane of the tile: row = sigma / SPR, column = sigma % SPR
+      // (unsigned 32-bit arithmetic throughout; padding slots re-read the last data slot, the
+      // ones inside the padded feature range are zeroed when the tile is consumed)
+      const int NPC = wave_gather_pieces(WD, KFIX, xs);  // 1-KiB pieces per task (SPR when all 64 rows are gathered)
+      for (int n0 = 0; n0 < NPC; n0 += GB) {
+        const T* src[GB];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+          if (n0 + u < NPC) {  // uniform; folded for the static shapes
+            const unsigned sigma = 64u * (unsigned)(n0 + u) + (unsigned)lane_;
+            const unsigned row = (sigma * spr_magic) >> 20;
+            // prepared tables: the slot after the features holds the responses
+            const unsigned c = min(sigma - row * (unsigned)SPR, (unsigned)(PACKED ? C16V : C16V - 1));
+            src[u] = rowaddr[row] + c * E;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < GB; ++u)
+          if (n0 + u < NPC) {  // the tile starts the dynamic LDS
+#if MGP_DMA_ASM
+            glds16_asm(src[u], smem, (n0 + u) * 1024);
+#else
+            glds16_lds(src[u], smem, (n0 + u) * 1024);
+#endif
+          }
+      }
+    }
+    // response and nugget of the slot's row: unconditional single loads (idx_n is 0, a valid
+    // row, for slots without one; the values are masked where they are consumed)
+    {
+      const int64_t nb0 = task_n * NH;
+      const int hh = (NH > 1 && nb0 + h >= a.b) ? 0 : h;
+      // (only neighbour slots index the response / noise tables: the query slot's row number belongs to
+      // the QUERY table, which may be the longer one)
+      pre_tg = a.targets_batch ? (nb0 + hh) * k + (i < k ? i : 0) : (i < k ? idx_n : 0);
+    }
+    // (prepared tables: the responses arrive in the tile, unless the caller hands them over gathered)
+    if (!PACKED || a.targets_batch) pre_y = targets[pre_tg * (int64_t)R];
+    pre_eps = (T)a.noise_scalar;
+    if (a.noise_mode != MGP_NOISE_SCALAR) {
+      const int64_t nb0 = task_n * NH;
+      const int hh = (NH > 1 && nb0 + h >= a.b) ? 0 : h;
+      const T* pn = a.noise_mode == MGP_NOISE_TABLE ? noise_dev + (i < k ? idx_n : 0) : noise_dev + nb0 * k + (hh * k + (i < k ? i : 0));
+      pre_eps = *pn;
+    }
+  };
+  if (PIPE && task0 < t_end) {
+    pipe_issue(task0, fix_index(next_idx, task0, NH == 1 ? 0 : (int)threadIdx.x / NP, threadIdx.x & (NP - 1)),
+               threadIdx.x);
+    if (task0 + t_step < t_end)
+      next_idx = load_index(task0 + t_step, NH == 1 ? 0 : (int)threadIdx.x / NP, threadIdx.x & (NP - 1));
+  }
+
+  // Exchange-matrix slot of each of the lane's NS pairs (phase 3) and which of them are real
+  // (both rows neighbours, or neighbour x query): functions of the lane only, so computed once per
+  // kernel instead of once per task (8 integer instructions per pair: 9 % of the headline kernel's
+  // VALU work).  NS registers: the 32-slot kernels and the static shapes have them to spare.
+  constexpr bool XPRE = (NP <= 32 || KFIX > 0) && !COEFF;
+  // (more than 16 pairs per lane: two 16-bit element offsets per register -- the 25 offsets of the
+  // k = 50 kernel are what stands between it and a third wave per SIMD)
+  constexpr bool XPK = XPRE && NS > 16;
+  static_assert(!XPK || NH * KMAT < 65536, "packed exchange offsets are 16-bit");
+  int xoff[XPRE ? (XPK ? (NS + 1) / 2 : NS) : 1];
+  unsigned xkeep = 0;
+  if constexpr (XPRE) {
+    const int i0 = threadIdx.x & (NP - 1);
+    const int hbase = (NH == 1 ? 0 : (int)threadIdx.x / NP) * KMAT;
+    const int dump0 = TRI ? KMAT - E : (NP - 1) * KS + NP;
+#pragma unroll
+    for (int s = 1; s <= NS; ++s) {
+      const int r1 = wrap(i0 + own_offset((s - 1) / BP));
+      const int c = wrap(i0 + (s - 1) % BP + 1);
+      const int hi = max(r1, c), lo = min(r1, c);
+      // (dropped: a response / padding slot, a lane that repeats another, and -- tiny M -- a surplus
+      // distance that wraps onto the row itself)
+      const int xo = hbase + (hi <= q && hi != lo && i0 < M ? rowoff(hi) + lo : dump0);
+      if constexpr (XPK) {
+        if ((s - 1) % 2 == 0) xoff[(s - 1) / 2] = xo;
+        else xoff[(s - 1) / 2] |= xo << 16;
+      } else {
+        xoff[s - 1] = xo;
+      }
+      if (lo < k && (hi < k || hi == q)) xkeep |= 1u << (s - 1);
+    }
+  }
+
+  // feature-tile rows of the lane's own and partner rows (phase 2), static shapes: lane-only as well
+  constexpr bool DPRE = XPRE && DFIX > 0 && NP <= 32;  // (the 64-slot static kernels have no registers left for it)
+  int down[DPRE ? BA : 1], dpar[DPRE ? BP : 1];
+  if constexpr (DPRE) {
+    const int i0 = threadIdx.x & (NP - 1);
+    const int hb = (NH == 1 ? 0 : (int)threadIdx.x / NP) * NP * xs;
+#pragma unroll
+    for (int j = 0; j < BA; ++j) down[j] = hb + wrap(i0 + own_offset(j)) * xs;
+#pragma unroll
+    for (int s2 = 1; s2 <= BP; ++s2) dpar[s2 - 1] = hb + wrap(i0 + s2) * xs;
+  }
+  static_assert(!MODM || XPRE, "the modulo-M pair scheme relies on the per-lane exchange offsets");
+
+  for (int64_t task = task0; task < t_end; task += t_step) {
+    // The lane id is made opaque per task: otherwise LICM hoists every per-lane address, mask
+    // and index of the unrolled phases out of this loop and the kernel runs out of registers.
+    int lane = threadIdx.x;
+    asm volatile("" : "+v"(lane));
+    const int h = NH == 1 ? 0 : lane / NP;
+    const int i = lane & (NP - 1);
+    T* Xh = tile + h * NP * xs;
+    T* Kh = tile + h * KMAT;
+    T* colh = colbuf + h * NP;
+    int64_t* idxh = idxbuf + h * NP;
+    const int64_t nb0 = task * NH;
+    const bool live = nb0 + h < a.b;
+    const int hh = live ? h : 0;
+
+    // ---- phase 0: indices, responses, nugget -------------------------------------------
+    int64_t myidx = 0, mytg = 0;
+    T myeps = T(0), myy0 = T(0);
+    V myyv = V(0);  // prepared tables: the row's responses, taken from the tile
+    if (PIPE) {
+      // the tile of this task was requested during the previous task's factorisation; the
+      // barrier at the top of the stage loop below waits for it (vmcnt) before anyone reads it
+      myidx = pre_idx;
+      mytg = pre_tg;
+      myy0 = i < k ? pre_y : T(0);
+      myeps = pre_eps;
+    } else {
+      myidx = fix_index(next_idx, task, h, i);
+      if (task + t_step < t_end) next_idx = load_index(task + t_step, h, i);
+      __syncthreads();  // previous task's LDS reads are complete
+      idxh[i] = myidx * (int64_t)d;  // element offset of the row
+      mytg = a.targets_batch ? (nb0 + hh) * k + (i < k ? i : 0) : myidx;
+      if (i < k) {
+        myy0 = targets[mytg * (int64_t)R];
+        if (a.noise_mode == MGP_NOISE_SCALAR) myeps = (T)a.noise_scalar;
+        else if (a.noise_mode == MGP_NOISE_TABLE) myeps = noise_dev[myidx];
+        else myeps = (noise_dev + nb0 * k)[hh * k + i];
+      }
+    }
+
+    ACC acc[NS];
+#if MGP_CHOL_PRIO && MGP_PRIO_LATE_DROP
+    __builtin_amdgcn_s_setprio(0);  // the distance phase: long independent streams, lowest priority
+#endif
+#if MGP_DIST_PRIO
+    // fp32: elimination (2) > distances (1) > covariances / exchange (0); fp64 (software exp in the
+    // covariances, few distance instructions at small d): elimination (2) > exchange (1) > distances (0)
+    __builtin_amdgcn_s_setprio(sizeof(T) == 4 || MGP_F64_SAME_PRIO ? MGP_DIST_PRIO : MGP_XCHG_PRIO);
+#endif
+
+    // ---- phases 1+2: stage features, accumulate squared distances ---------------------
+    for (int d0 = 0; d0 < d; d0 += dst) {
+      const int w = min(dst, d - d0);
+      const int wp = (w + CH - 1) / CH * CH;
+#if MGP_DMA_ASM
+      if (PIPE) lds_dma_wait();  // this task's tile (requested during the previous task's elimination) has landed
+#endif
+      __syncthreads();
+      if (PIPE) {
+        if constexpr (PACKED) {
+          // the slot behind the features carries the row's responses (before it is zeroed as padding)
+          if (!a.targets_batch) {
+            myyv = *reinterpret_cast<const V*>(Xh + (NPL == NP ? i : min(i, NPL - 1)) * xs + d);
+            myy0 = i < k ? myyv[0] : T(0);
+          }
+        }
+        // feature columns w .. wp-1 of the staged rows are padding of the 8-wide inner loop: the
+        // direct-to-LDS gather filled them with a repeat of the last data slot
+        if (wp > w && (NPL == NP || i < NPL)) *reinterpret_cast<V*>(Xh + i * xs + w) = V(0);
+      } else if (!MGP_PHASE(g, 1)) {
+      } else if (DFIX > 0 || g.vec_ok) {
+        // c16p consecutive lanes walk one row; rpr rows per round; all rounds of a task in flight
+        const int c16 = w / E, c16p = wp / E;
+        const int rpr = NP / c16p;
+        const int sub = DFIX > 0 ? i / c16p : (int)(((unsigned)i * ((1u << 16) / (unsigned)c16p + 1u)) >> 16);
+        const int c = i - sub * c16p;
+        const bool lane_on = sub < rpr;
+        constexpr int RPRFIX = NP / (DSTFIX / E);
+        constexpr int U = (KFIX > 0 && DFIX > 0) ? (KFIX + RPRFIX - 1) / RPRFIX : 6;
+        const int64_t* idxl = idxh + sub;
+        T* xdst = Xh + sub * xs + c * E;
+        for (int r0 = 0; r0 < k; r0 += U * rpr) {
+          V v[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int row = r0 + u * rpr + sub;
+            v[u] = V(0);
+            if (lane_on && row < k && c < c16)
+              v[u] = *reinterpret_cast<const V*>(feat_nn + idxl[r0 + u * rpr] + d0 + c * E);
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int row = r0 + u * rpr + sub;
+            if (lane_on && row < k) *reinterpret_cast<V*>(xdst + (r0 + u * rpr) * xs) = v[u];
+          }
+        }
+        // the query row, and zero rows for the padding slots (their distances are masked later,
+        // zeros only keep them finite)
+        if (i < c16p) {
+          V vq = V(0);
+          if (i < c16) vq = *reinterpret_cast<const V*>(feat_q + idxh[q] + d0 + i * E);
+          *reinterpret_cast<V*>(Xh + q * xs + i * E) = vq;
+        }
+        if (!nopad)
+          for (int t = i; t < (q - k) * c16p; t += NP) {
+            const int row = k + t / c16p;
+            *reinterpret_cast<V*>(Xh + row * xs + (t % c16p) * E) = V(0);
+          }
+      } else {
+        const unsigned magic = (1u << 20) / (unsigned)wp + 1u;
+        for (int t = i; t < NP * wp; t += NP) {
+          const int row = (int)(((unsigned)t * magic) >> 20);
+          const int c = t - row * wp;
+          T v = T(0);
+          if (c < w && (row < k || row == q)) v = ((row < k ? feat_nn : feat_q) + idxh[row] + d0)[c];
+          Xh[row * xs + c] = v;
+        }
+      }
+      if (aniso)
+        for (int c = lane; c < wp; c += 64) ilbuf[c] = c < w ? T(1) / ls[d0 + c] : T(0);
+      __syncthreads();
+
+      if (d0 == 0) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s] = ACC(0);
+      }
+      if constexpr (GRAM) {
+        // ---- phase 1b: centre the rows on the query, in place; squared norms --------------------
+        // Row i becomes a' = (a - q) [x inverse length scales]; |a'|^2 goes to the first element of the
+        // row's padding slot (column dst), where the lanes that pair with the row pick it up.  The query
+        // row becomes exactly zero (norm 0), so a pair with the query is |a'|^2: the cross-covariances
+        // keep the difference form.  All reads of the query row are issued before any lane's writes (one
+        // wave, LDS executes in order).  Slots without features (responses, padding) are left alone:
+        // their pairs are dropped or masked.
+        if (MGP_PHASE(g, 2)) {
+          const bool has = i < k || i == q;
+          T* xrow = Xh + i * xs;
+          const T* qrow = Xh + q * xs;
+          constexpr int NCF = DFIX > 0 ? DSTFIX / E : 1;  // 16-byte groups per row (static shapes)
+          if constexpr (DFIX > 0) {
+            V x[NCF], qv[NCF];
+#pragma unroll
+            for (int c = 0; c < NCF; ++c) {
+              x[c] = *reinterpret_cast<const V*>(xrow + c * E);
+              qv[c] = *reinterpret_cast<const V*>(qrow + c * E);
+            }
+#pragma unroll
+            for (int c = 0; c < NCF; ++c) {
+              x[c] = vsub(x[c], qv[c]);  // (v_pk_add_f32 with neg modifiers; a plain vector subtract is split into v_sub_f32)
+              if (aniso) x[c] = x[c] * *reinterpret_cast<const V*>(ilbuf + c * E);
+            }
+            if (has) {
+#pragma unroll
+              for (int c = 0; c < NCF; ++c) *reinterpret_cast<V*>(xrow + c * E) = x[c];
+            }
+            // four independent partial sums (a single chain of 2 NCF dependent packed FMAs costs a wait state each)
+            f2 n4[4] = {f2{0.0f, 0.0f}, f2{0.0f, 0.0f}, f2{0.0f, 0.0f}, f2{0.0f, 0.0f}};
+#pragma unroll
+            for (int c = 0; c < NCF; ++c) {
+              n4[(2 * c) & 3] = x[c].xy * x[c].xy + n4[(2 * c) & 3];
+              n4[(2 * c + 1) & 3] = x[c].zw * x[c].zw + n4[(2 * c + 1) & 3];
+            }
+            const f2 n2 = (n4[0] + n4[1]) + (n4[2] + n4[3]);
+            if (has) xrow[dst] = n2.x + n2.y;
+          } else {
+            f2 n2 = f2{0.0f, 0.0f};
+            for (int c0 = 0; c0 < wp; c0 += CH) {
+              V x0 = *reinterpret_cast<const V*>(xrow + c0), x1 = *reinterpret_cast<const V*>(xrow + c0 + E);
+              const V q0 = *reinterpret_cast<const V*>(qrow + c0), q1 = *reinterpret_cast<const V*>(qrow + c0 + E);
+              x0 = vsub(x0, q0);
+              x1 = vsub(x1, q1);
+              if (aniso) {
+                x0 = x0 * *reinterpret_cast<const V*>(ilbuf + c0);
+                x1 = x1 * *reinterpret_cast<const V*>(ilbuf + c0 + E);
+              }
+              n2 = x0.xy * x0.xy + n2;
+              n2 = x0.zw * x0.zw + n2;
+              n2 = x1.xy * x1.xy + n2;
+              n2 = x1.zw * x1.zw + n2;
+              // (lane q writes zeros over the chunk every lane has just read; the next chunk's reads come
+              // after this store in program order)
+              if (has) {
+                *reinterpret_cast<V*>(xrow + c0) = x0;
+                *reinterpret_cast<V*>(xrow + c0 + E) = x1;
+              }
+            }
+            if (has) xrow[dst] = n2.x + n2.y;
+          }
+        }
+        __syncthreads();
+        // ---- phase 2 (Gram form): acc = a'.b' per pair ------------------------------------------
+        if (MGP_PHASE(g, 2)) {
+#pragma unroll
+          for (int c0 = 0; c0 < (DFIX > 0 ? DSTFIX : wp); c0 += CH) {
+            V own0[BA], own1[BA];
+#pragma unroll
+            for (int j = 0; j < BA; ++j) {
+              const T* xj = DPRE ? tile + down[DPRE ? j : 0] + c0 : Xh + wrap(i + own_offset(j)) * xs + c0;
+              own0[j] = *reinterpret_cast<const V*>(xj);
+              own1[j] = *reinterpret_cast<const V*>(xj + E);
+            }
+#pragma unroll
+            for (int s = 1; s <= BP; ++s) {
+              const T* xo = DPRE ? tile + dpar[DPRE ? s - 1 : 0] + c0 : Xh + wrap(i + s) * xs + c0;
+              const V o0 = *reinterpret_cast<const V*>(xo);
+              const V o1 = *reinterpret_cast<const V*>(xo + E);
+              gram_block<BA, BP>(&acc[s - 1], own0, o0);
+              gram_block<BA, BP>(&acc[s - 1], own1, o1);
+            }
+          }
+          // squared distance of a pair: |a'|^2 + |b'|^2 - 2 a'.b', clamped at zero; left in acc[].x
+          // (acc[].y = 0) so that the covariance stage below reads it like a difference-form sum
+          T nown[BA], npar[BP];
+#pragma unroll
+          for (int j = 0; j < BA; ++j) nown[j] = (DPRE ? tile + down[DPRE ? j : 0] : Xh + wrap(i + own_offset(j)) * xs)[dst];
+#pragma unroll
+          for (int s = 1; s <= BP; ++s) npar[s - 1] = (DPRE ? tile + dpar[DPRE ? s - 1 : 0] : Xh + wrap(i + s) * xs)[dst];
+#pragma unroll
+          for (int j = 0; j < BA; ++j)
+#pragma unroll
+            for (int s = 0; s < BP; ++s) {
+              const T gsum = acc[j * BP + s].x + acc[j * BP + s].y;
+              acc[j * BP + s].x = __builtin_fmaxf(__builtin_fmaf(-2.0f, gsum, nown[j] + npar[s]), 0.0f);
+              acc[j * BP + s].y = 0.0f;
+            }
+        }
+      } else
+      if (MGP_PHASE(g, 2)) {
+        if (aniso) {
+          // Anisotropy: every row is scaled by the inverse length scales ONCE, in place (x / l), so that
+          // the pair loop below is the isotropic one: one multiply per row element instead of one per
+          // pair element (k = 50, d = 8: 8 instead of 200 multiplies per lane and neighbourhood).
+          if (i < k || i == q) {  // rows with features (the pipelined kernels keep ilbuf in a response slot's row)
+            T* xrow = Xh + i * xs;
+            for (int c0 = 0; c0 < wp; c0 += E) {
+              V x = *reinterpret_cast<const V*>(xrow + c0);
+              x = x * *reinterpret_cast<const V*>(ilbuf + c0);
+              *reinterpret_cast<V*>(xrow + c0) = x;
+            }
+          }
+          __syncthreads();
+        }
+        {
+#pragma unroll
+          for (int c0 = 0; c0 < (DFIX > 0 ? DSTFIX : wp); c0 += CH) {
+            V own0[BA], own1[BA];
+#pragma unroll
+            for (int j = 0; j < BA; ++j) {
+              const T* xj = DPRE ? tile + down[DPRE ? j : 0] + c0 : Xh + wrap(i + own_offset(j)) * xs + c0;
+              own0[j] = *reinterpret_cast<const V*>(xj);
+              own1[j] = *reinterpret_cast<const V*>(xj + E);
+            }
+#pragma unroll
+            for (int s = 1; s <= BP; ++s) {
+              const T* xo = DPRE ? tile + dpar[DPRE ? s - 1 : 0] + c0 : Xh + wrap(i + s) * xs + c0;
+              const V o0 = *reinterpret_cast<const V*>(xo);
+              const V o1 = *reinterpret_cast<const V*>(xo + E);
+              if constexpr (sizeof(T) == 4 && BA == 4 && MGP_DIST_ASM) {
+                dist_block4(acc[s - 1], acc[BP + s - 1], acc[2 * BP + s - 1], acc[3 * BP + s - 1], own0[0], own0[1],
+                            own0[2], own0[3], o0);
+                dist_block4(acc[s - 1], acc[BP + s - 1], acc[2 * BP + s - 1], acc[3 * BP + s - 1], own1[0], own1[1],
+                            own1[2], own1[3], o1);
+              } else {
+#pragma unroll
+                for (int j = 0; j < BA; ++j) {
+                  accum(acc[j * BP + s - 1], vsub(own0[j], o0));
+                  accum(acc[j * BP + s - 1], vsub(own1[j], o1));
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+
+    // ---- phase 3: covariances, nugget, responses -> exchange matrix -> row per lane ----
+#if MGP_XCHG_PRIO || MGP_DIST_PRIO
+    __builtin_amdgcn_s_setprio(sizeof(T) == 4 || MGP_F64_SAME_PRIO ? MGP_XCHG_PRIO : MGP_DIST_PRIO);
+#endif
+    __syncthreads();  // every lane is done reading the feature tile (Kh aliases it)
+    {
+      // re-materialise the slot index here so that the per-offset masks/addresses of this phase
+      // are computed now and not kept alive (or spilled) across the distance loop
+      int i3 = i;
+      asm volatile("" : "+v"(i3));
+      T* Kh3 = tile + (NH == 1 ? 0 : (lane / NP) * KMAT);
+      if (MGP_PHASE(g, 4)) {
+        // fp32: all NS covariances first (independent chains the scheduler can interleave), then the
+        // stores -- unconditional: an entry whose row is a response slot (hi > q) goes to the
+        // unused padding column of the last row instead of being branched around.
+        // fp64 evaluates exp and sqrt in software (~40 instructions and a dozen temporaries per chain):
+        // interleaving all NS chains is what the register file cannot hold, so they go in batches of CB,
+        // each batch stored before the next starts.
+        const int dump = TRI ? KMAT - E : (NP - 1) * KS + NP;  // padding behind the last row / columns NP .. KS-1
+        auto put = [&](int s, T v) {  // s = 1 .. NS: pair j * BP + p - 1 = (own row j, partner p)
+          if constexpr (XPRE) {
+            if (!nopad) v = (xkeep >> (s - 1)) & 1u ? v : T(0);
+            if constexpr (XPK) tile[(s - 1) % 2 == 0 ? (xoff[(s - 1) / 2] & 0xFFFF) : ((unsigned)xoff[(s - 1) / 2] >> 16)] = v;
+            else tile[xoff[s - 1]] = v;
+          } else {
+            const int r1 = wrap(i3 + own_offset((s - 1) / BP));
+            const int c = wrap(i3 + (s - 1) % BP + 1);
+            const int hi = max(r1, c), lo = min(r1, c);
+            if (!nopad) v = (lo < k && (hi < k || hi == q)) ? v : T(0);
+            Kh3[hi <= q && hi != lo ? rowoff(hi) + lo : dump] = v;
+          }
+        };
+        kernel_dispatch(a.kernel_id, a.metric_id, [&](auto kid, auto mid) {
+          constexpr int KID = decltype(kid)::value, MID = decltype(mid)::value;
+          if constexpr (sizeof(T) == 4) {
+            T kv[NS];
+            // (Gram form: the squared distance already sits in acc[].x)
+            auto sq = [&](int s) {
+              if constexpr (GRAM) return acc[s].x;
+              else return acc_total(acc[s]);
+            };
+#pragma unroll
+            for (int s = 0; s + 1 < NS; s += 2) {
+              const f2 kk = cov_from_sqdist2(f2{sq(s), sq(s + 1)}, KID, MID, post_scale);
+              kv[s] = kk.x;
+              kv[s + 1] = kk.y;
+            }
+            if constexpr (NS % 2 == 1) kv[NS - 1] = cov_from_sqdist<T>(sq(NS - 1), KID, MID, post_scale);
+#pragma unroll
+            for (int s = 1; s <= NS; ++s) put(s, kv[s - 1]);
+          } else {
+            constexpr int CB = MGP_F64_COV_BATCH;
+#pragma unroll
+            for (int s0 = 0; s0 < NS; s0 += CB) {
+              T kv[CB];
+#pragma unroll
+              for (int u = 0; u < CB; ++u)
+                if (s0 + u < NS) kv[u] = cov_from_sqdist<T>(acc_total(acc[s0 + u]), KID, MID, post_scale);
+#pragma unroll
+              for (int u = 0; u < CB; ++u)
+                if (s0 + u < NS) put(s0 + u + 1, kv[u]);
+              __builtin_amdgcn_sched_barrier(0);  // keep the batches apart
+            }
+          }
+        });
+      }
+      if (NPL == NP || i3 < NPL) Kh3[rowoff(i3) + i3] = i3 < k ? T(1) + myeps : (i3 <= q ? T(1) : T(0));
+      // response rows: lower-triangle columns only (a packed row ends at its diagonal)
+      if (!TRI || i3 <= q + 1) Kh3[rowoff(q + 1) + i3] = myy0;
+      if (PACKED && !a.targets_batch) {
+#pragma unroll
+        for (int r = 1; r < E; ++r)
+          if (r < R && (!TRI || i3 <= q + 1 + r)) Kh3[rowoff(q + 1 + r) + i3] = i3 < k ? myyv[r] : T(0);
+      } else {
+        for (int r = 1; r < R; ++r)
+          if (!TRI || i3 <= q + 1 + r) Kh3[rowoff(q + 1 + r) + i3] = i3 < k ? targets[mytg * (int64_t)R + r] : T(0);
+      }
+    }
+    __syncthreads();
+#if MGP_CHOL_PRIO && MGP_PRIO_EARLY_RAISE
+    __builtin_amdgcn_s_setprio(MGP_CHOL_PRIO);  // row read-back and the next task's gather already at elimination priority
+#endif
+    V A[NG];
+    {
+      const T* myrow = Kh + rowoff(NPL == NP ? i : min(i, NPL - 1));  // (idle lanes re-read the last live row)
+#pragma unroll
+      for (int c4 = 0; c4 < NG; ++c4) A[c4] = *reinterpret_cast<const V*>(myrow + c4 * E);
+    }
+
+    // the next task's rows are requested now: their latency hides behind the factorisation, and
+    // the registers they land in are not live during the (register-hungry) distance phase
+    if (PIPE && task + t_step < t_end) {
+      pipe_issue(task + t_step, fix_index(next_idx, task + t_step, h, i), lane);
+      if (task + 2 * t_step < t_end) next_idx = load_index(task + 2 * t_step, h, i);
+    }
+
+    // ---- phase 4: Cholesky, row per lane, column broadcast through LDS ----------------
+    // Whole 16-byte groups are updated from the pivot's group on: entries of columns <= j
+    // inside that group are dead by then (right-looking: column j is never read again).
+    bool bad = false;
+#if MGP_CHOL_PRIO
+    // the elimination is a chain of short dependent steps: let its instructions go first, the other
+    // waves' distance phases (long independent streams) fill the gaps
+    __builtin_amdgcn_s_setprio(MGP_CHOL_PRIO);
+#endif
+    // fp32: LOOK-AHEAD.  Step j first finishes the register group that holds column j + 1, posts that
+    // column and requests the 16 bytes with its pivot; the rest of the row is updated while that LDS round
+    // trip is under way, so the reciprocal of the next step does not wait for it.
+    constexpr bool LOOK = sizeof(T) == 4 && KFIX > 0 && MGP_LOOKAHEAD;  // (the run-time shapes gain nothing measurable and one of them spills)
+    V piv = V(0);
+    if constexpr (LOOK) {
+      if (MGP_PHASE(g, 8)) {
+        colh[i] = A[0][0];
+        piv = *reinterpret_cast<const V*>(colh);
+      }
+    }
+    // ONE test of the phase bit around the whole elimination (not one per step): with a test per step every
+    // step is its own basic block -- two taken branches per step, and the wait-count pass, which starts
+    // each block pessimistic, puts `s_waitcnt lgkmcnt(0)` in front of the trailing update, i.e. waits for
+    // the look-ahead pivot it has just requested.  In one block the waits are counted.
+#if MGP_CHOL_ONE_BLOCK
+    if (MGP_PHASE(g, 8))
+#endif
+#pragma unroll
+    for (int j = 0; j < (STAT ? KFIX : NP - 2); ++j) {
+      if (j < k && (MGP_CHOL_ONE_BLOCK || MGP_PHASE(g, 8))) {
+        const T ajj = A[j / E][j % E];
+        if constexpr (!LOOK) colh[i] = ajj;
+        if constexpr (sizeof(T) == 8) {
+          // fp64: the pivot first (one group), then the trailing groups streamed: load, FMA,
+          // next -- no full copy of the column is held, which keeps the 128-register rows of
+          // the big shapes out of the spill zone (2 waves/SIMD instead of 1)
+          const V cp = *reinterpret_cast<const V*>(colh + (j / E) * E);
+          const T p = cp[j % E];
+          bad = bad || !(p > T(0));
+          const V nt = V(-ajj * pivot_rcp(p));
+          if constexpr (COEFF) Kh[i * KS + j] = -nt[0];
+          A[j / E] = cp * nt + A[j / E];
+          // trailing groups GC at a time: the GC loads are in flight together, then the 2 GC FMAs (a
+          // single wave needs ~8 outstanding 16-byte reads to cover the LDS latency with FMAs)
+          constexpr int GC = MGP_F64_GC;
+#pragma unroll
+          for (int c0 = j / E + 1; c0 < NG; c0 += GC) {
+            V cv[GC];
+#pragma unroll
+            for (int u = 0; u < GC; ++u)
+              if (c0 + u < NG) cv[u] = *reinterpret_cast<const V*>(colh + (c0 + u) * E);
+#pragma unroll
+            for (int u = 0; u < GC; ++u)
+              if (c0 + u < NG) A[c0 + u] = cv[u] * nt + A[c0 + u];
+          }
+        } else if constexpr (LOOK) {
+          V col[NG];
+          col[j / E] = piv;
+#pragma unroll
+          for (int c4 = j / E + 1; c4 < NG; ++c4) col[c4] = *reinterpret_cast<const V*>(colh + c4 * E);
+          const T p = piv[j % E];
+          bad = bad || !(p > T(0));
+          const V nt = V(-ajj * pivot_rcp(p));
+          if constexpr (COEFF) Kh[i * KS + j] = -nt[0];  // multiplier l_ij, kept for the back-substitution
+          constexpr int JL = (STAT ? KFIX : NP - 2) - 1;    // last step of the loop
+          const int g1 = (j < JL ? j + 1 : j) / E;         // compile-time after unrolling
+          A[g1] = col[g1] * nt + A[g1];
+          if (j < JL && j + 1 < k) {
+            colh[i] = A[g1][(j + 1) % E];
+            piv = *reinterpret_cast<const V*>(colh + g1 * E);
+          }
+#pragma unroll
+          for (int c4 = j / E; c4 < NG; ++c4)
+            if (c4 != g1) A[c4] = col[c4] * nt + A[c4];
+        } else {
+          V col[NG];
+#pragma unroll
+          for (int c4 = j / E; c4 < NG; ++c4) col[c4] = *reinterpret_cast<const V*>(colh + c4 * E);
+          const T p = col[j / E][j % E];
+          bad = bad || !(p > T(0));
+          const V nt = V(-ajj * pivot_rcp(p));
+          if constexpr (COEFF) Kh[i * KS + j] = -nt[0];  // multiplier l_ij, kept for the back-substitution
+#pragma unroll
+          for (int c4 = j / E; c4 < NG; ++c4) A[c4] = col[c4] * nt + A[c4];
+        }
+      }
+    }
+
+#if MGP_CHOL_PRIO && !MGP_PRIO_LATE_DROP
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    // ---- phase 4b (COEFF): x = K^-1 y by back-substitution -------------------------------
+    // K = L D L^T with unit lower L; the forward sweep formed l_ij (j < i) in lane i, and the
+    // response row's multipliers are w_j = (D^-1 L^-1 y)_j.  Solve L^T x = w: the multipliers are
+    // written to the (by then free) exchange matrix as they are formed, so lane j can read column j
+    // of L; then for m = k-1 .. 1 the finished x_m is read from lane m (v_readlane) and every lane
+    // j < m takes l_mj x_m off.
+    if constexpr (COEFF) {
+      static_assert(!PIPED, "coefficient variant: register-staged gather (the tile must be free)");
+      __syncthreads();
+      T x = Kh[(q + 1) * KS + i];  // w_i, from the response row
+#pragma unroll
+      for (int m = NP - 3; m >= 1; --m) {
+        if (m < k) {
+          const T lmj = Kh[m * KS + i];  // l_mi
+          T xm = lane_value(x, m);
+          if constexpr (NH == 2) xm = h == 0 ? xm : lane_value(x, m + NP);
+          if (i < m) x = fma_t(-lmj, xm, x);
+        }
+      }
+      if (live && i < k) static_cast<T*>(a.coeffs)[(nb0 + h) * (int64_t)k + i] = bad ? num<T>::nan() : x;
+    }
+
+    // ---- phase 5: Schur block -> outputs ----------------------------------------------
+    T* mean = static_cast<T*>(a.mean);
+    T* var = static_cast<T*>(a.var);
+    T* yk = static_cast<T*>(a.ykinvy);
+    const int64_t nb = nb0 + h;
+    if constexpr (COEFF) {
+      if (live && bad && i == q && a.info) atomicAdd(a.info, 1);  // mean / variance are not emitted
+    } else if (RFIX == 1) {
+      // q = NP-2 and the response row NP-1 are compile-time: the Schur block sits in fixed registers
+      constexpr int QF = STAT ? KFIX : NP - 2, YF = QF + 1;
+      const T sq = A[QF / E][QF % E], sy = A[YF / E][YF % E];
+      if (live) {
+        if (i == QF) {
+          var[nb] = bad ? num<T>::nan() : sq;
+          if (bad && a.info) atomicAdd(a.info, 1);
+        } else if (i == YF) {
+          mean[nb] = bad ? num<T>::nan() : -sq;
+          if (yk) yk[nb] = bad ? num<T>::nan() : -sy;
+        }
+      }
+    } else if constexpr (PIPED || TRI) {
+      // The tile (which the exchange matrix aliases) already receives the next task's rows (and a
+      // packed exchange matrix has no room for whole rows), so
+      // the two entries a lane emits -- column q and the diagonal of its own row -- are picked out
+      // of the registers by a compare-select sweep instead of a round trip through LDS.
+      T aq = T(0), aii = T(0);
+#pragma unroll
+      for (int c = 0; c < NG * E; ++c) {
+        const T v = A[c / E][c % E];
+        aq = c == q ? v : aq;
+        aii = c == i ? v : aii;
+      }
+      if (live) {
+        if (i == q) {
+          var[nb] = bad ? num<T>::nan() : aq;
+          if (bad && a.info) atomicAdd(a.info, 1);
+        } else if (i > q && i <= q + R) {  // (static shapes: lanes behind the last response row are idle)
+          const int r = i - q - 1;
+          mean[nb * R + r] = bad ? num<T>::nan() : -aq;
+          if (yk) yk[nb * R + r] = bad ? num<T>::nan() : -aii;
+        }
+      }
+    } else {
+      __syncthreads();
+#pragma unroll
+      for (int c4 = 0; c4 < NG; ++c4) *reinterpret_cast<V*>(Kh + i * KS + c4 * E) = A[c4];
+      __syncthreads();
+      if (live) {
+        if (i == q) {
+          var[nb] = bad ? num<T>::nan() : Kh[q * KS + q];
+          if (bad && a.info) atomicAdd(a.info, 1);
+        } else if (i > q && i <= q + R) {  // (static shapes: lanes behind the last response row are idle)
+          const int r = i - q - 1;
+          mean[nb * R + r] = bad ? num<T>::nan() : -Kh[i * KS + q];
+          if (yk) yk[nb * R + r] = bad ? num<T>::nan() : -Kh[i * KS + i];
+        }
+      }
+    }
+  }
+}
+
+}  // namespace mgp

@@ -3,24 +3,38 @@
 // reciprocal, squared distance -> covariance, direct-to-LDS load, compile-time kernel dispatch.
 #pragma once
 
+#ifndef __HIPCC_RTC__
 #include <mutex>
 #include <utility>
+#endif
 
 #include "mgp_args.h"
 
 namespace mgp {
+
+#ifndef __HIPCC_RTC__  // host side (a run-time compile of the kernels sees the device helpers only)
 
 // Resident workgroups per CU of one kernel instantiation, per device and per (LDS size, thread count):
 // the run-time-shape instantiations change their LDS size with d, so a few recent geometries are kept
 // (alternating shapes do not re-run the occupancy query); the CU count is read once per device.
 // Queried under a mutex: the entry points stay re-entrant and a second device gets its own numbers.
 struct Residency {
-  static constexpr int WAYS = 8;
+  static constexpr int WAYS = 16;
   std::mutex mu;
-  struct Entry { int lds = -1, threads = 0, per_cu = 0; };
+  struct Entry { int lds = -1, threads = 0, per_cu = 0; uintptr_t who = 0; };
   struct Dev { int cus = 0, next = 0; Entry e[WAYS]; } dev[MGP_MAX_DEVICES];
   // -> MGP_OK and (per_cu, cus), or an error status
   int lookup(const void* kernel, int threads, size_t lds, int* per_cu, int* cus) {
+    return lookup_by([&](int* n) { return hipOccupancyMaxActiveBlocksPerMultiprocessor(n, kernel, threads, lds); }, 0, threads,
+                     lds, per_cu, cus);
+  }
+  // (a kernel of a run-time compiled module: one Residency serves them all, so the function is part of the key)
+  int lookup(hipFunction_t fn, int threads, size_t lds, int* per_cu, int* cus) {
+    return lookup_by([&](int* n) { return hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(n, fn, threads, lds); },
+                     reinterpret_cast<uintptr_t>(fn), threads, lds, per_cu, cus);
+  }
+  template <typename Query>
+  int lookup_by(Query&& query, uintptr_t who, int threads, size_t lds, int* per_cu, int* cus) {
     int d = 0;
     if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MGP_MAX_DEVICES) return MGP_EHIP;
     std::lock_guard<std::mutex> lock(mu);
@@ -31,13 +45,13 @@ struct Residency {
       v.cus = n;
     }
     for (int w = 0; w < WAYS; ++w)
-      if (v.e[w].lds == (int)lds && v.e[w].threads == threads) {
+      if (v.e[w].lds == (int)lds && v.e[w].threads == threads && v.e[w].who == who) {
         *per_cu = v.e[w].per_cu;
         *cus = v.cus;
         return MGP_OK;
       }
     int n = 0;
-    hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lds);
+    hipError_t err = query(&n);
     if (err != hipSuccess) return -(1000 + (int)err);
     if (n < 1) return MGP_EUNSUPPORTED;
     // the occupancy query over-reports for LDS-bound shapes: measured on gfx950, LDS is handed out
@@ -52,11 +66,14 @@ struct Residency {
     }
     e.lds = (int)lds;
     e.threads = threads;
+    e.who = who;
     *per_cu = e.per_cu;
     *cus = v.cus;
     return MGP_OK;
   }
 };
+
+#endif  // !__HIPCC_RTC__
 
 template <typename T> struct v16;
 template <> struct v16<float> {
@@ -365,6 +382,7 @@ __device__ __forceinline__ void kernel_dispatch(int kernel_id, int metric_id, F&
   else kernel_dispatch_m<MGP_METRIC_F2>(kernel_id, f);
 }
 
+#ifndef __HIPCC_RTC__
 // f(ic<0>{}), f(ic<1>{}), ... f(ic<N-1>{}): a loop whose index is a compile-time constant in every
 // iteration (a `#pragma unroll` the compiler declines leaves the 128-register row indexed at run
 // time, i.e. in scratch memory)
@@ -376,5 +394,7 @@ template <int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
+
+#endif  // !__HIPCC_RTC__
 
 }  // namespace mgp

@@ -1,1 +1,1 @@
-python3 tools/scratch_bayes.py 2>&1 | grep -v Warn | tail -8
+python3 -m pytest tests -m gpu -q -x 2>&1 | grep -v "^Extension\|^  File" | tail -6
