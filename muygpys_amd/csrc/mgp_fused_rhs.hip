@@ -182,11 +182,19 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
             constexpr int s = decltype(sc)::value + 1;
             const T* xo = tile + ((i + s) & (NP - 1)) * xs + c0;
             const V o0 = *reinterpret_cast<const V*>(xo), o1 = *reinterpret_cast<const V*>(xo + E);
-            static_for<BA>([&](auto jc) {
-              constexpr int j = decltype(jc)::value;
-              accum(acc[j * BP + s - 1], vsub(own0[j], o0));
-              accum(acc[j * BP + s - 1], vsub(own1[j], o1));
-            });
+            if constexpr (sizeof(T) == 4 && BA == 4) {
+              // hand-ordered packed blocks: no instruction reads its predecessor's result (mgp_wave_common.h)
+              dist_block4(acc[s - 1], acc[BP + s - 1], acc[2 * BP + s - 1], acc[3 * BP + s - 1], own0[0], own0[1], own0[2],
+                          own0[3], o0);
+              dist_block4(acc[s - 1], acc[BP + s - 1], acc[2 * BP + s - 1], acc[3 * BP + s - 1], own1[0], own1[1], own1[2],
+                          own1[3], o1);
+            } else {
+              static_for<BA>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                accum(acc[j * BP + s - 1], vsub(own0[j], o0));
+                accum(acc[j * BP + s - 1], vsub(own1[j], o1));
+              });
+            }
           });
         }
       }

@@ -127,6 +127,11 @@ static int launch_jit(const FusedArgs& a, hipStream_t stream) {
   int per_cu = 0, cus = 0;
   const int rrc = res.lookup(fn, 64, lds, &per_cu, &cus);
   if (rrc != MGP_OK) return rrc;
+#ifdef MGP_DEBUG_HOOKS
+  if (g_grid_per_cu > 0) per_cu = g_grid_per_cu;
+#endif
+  static const int env_per_cu = getenv("MGP_JIT_PER_CU") ? atoi(getenv("MGP_JIT_PER_CU")) : 0;  // occupancy experiments
+  if (env_per_cu > 0 && env_per_cu < per_cu) per_cu = env_per_cu;
   int64_t grid = (int64_t)cus * per_cu / 8 * 8;
   if (grid < 8) grid = 8;
   if (grid > g.ntasks) grid = (g.ntasks + 7) / 8 * 8;

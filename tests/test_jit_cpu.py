@@ -1,0 +1,77 @@
+"""CPU-side checks of the run-time specialisation (csrc/mgp_jit.hip) and of the pair scheme the static
+kernels use (csrc/mgp_fused_wave_kernel.h, wave_dims): no GPU needed -- hiprtc compiles for gfx950
+without a device, and the scheme is arithmetic."""
+
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+PREPARE = r"""
+import ctypes, os, sys, time
+sys.path.insert(0, %(root)r)
+from muygpys_amd import _lib
+lib = _lib.load()
+assert lib.mgp_jit_mode() == 1
+t0 = time.time(); rc = lib.mgp_jit_prepare(4, 17, 2, 24, 1, 2); t1 = time.time()
+assert rc == 0, rc
+files = sorted(os.listdir(os.environ["MUYGPYS_HIP_JIT_CACHE"]))
+assert len(files) == 1 and files[0].startswith("wave_f32_np32_k17_r2_d24_p1_g1_") and files[0].endswith(".hsaco"), files
+blob = open(os.path.join(os.environ["MUYGPYS_HIP_JIT_CACHE"], files[0]), "rb").read()
+assert blob.startswith(b"MGPJIT1\n_ZN3mgp17fused_wave_kernel") and b"\x7fELF" in blob[:200]
+t2 = time.time(); assert lib.mgp_jit_prepare(4, 17, 2, 24, 1, 2) == 0; t3 = time.time()
+assert t3 - t2 < 0.5 * (t1 - t0) + 0.05, "the second request must come from the disk cache"
+assert lib.mgp_jit_prepare(4, 30, 1, 40, 1, 2) == 0          # built into the library: nothing to compile
+assert len(os.listdir(os.environ["MUYGPYS_HIP_JIT_CACHE"])) == 1
+assert lib.mgp_jit_prepare(4, 70, 1, 8, 1, 2) == -2           # more than 64 slots
+assert lib.mgp_jit_prepare(4, 20, 1, 30, 1, 2) == -2          # rows not 16-byte multiples
+assert lib.mgp_jit_prepare(4, 20, 8, 16, 1, 2) == -2          # a prepared table carries at most four fp32 responses
+assert lib.mgp_jit_prepare(2, 20, 1, 16, 1, 2) == -1
+print("prepared in %%.2f s" %% (t1 - t0))
+"""
+
+
+def test_shape_is_compiled_without_a_gpu_and_cached_on_disk(tmp_path):
+    env = dict(os.environ, MUYGPYS_HIP_JIT_CACHE=str(tmp_path), PYTHONDONTWRITEBYTECODE="1")
+    env.pop("MUYGPYS_HIP_JIT", None)
+    r = subprocess.run([sys.executable, "-c", PREPARE % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "prepared in" in r.stdout, r.stdout[-500:] + r.stderr[-2000:]
+
+
+def _wave_dims(np_, k, gram):
+    """The pair-scheme part of wave_dims() (csrc/mgp_fused_wave_kernel.h), restated."""
+    need = (k + 1) // 2
+    ba, bp = 4, (need + 3) // 4
+    for c in (3, 5):
+        q = (need + c - 1) // c
+        if c * q < ba * bp:
+            ba, bp = c, q
+    if ba * bp + (2 if gram else 1) <= np_ // 2:
+        return True, k + 1, ba, bp
+    return False, np_, 4, np_ // 8
+
+
+@pytest.mark.parametrize("gram", [False, True])
+def test_every_pair_of_feature_rows_is_computed_by_some_lane(gram):
+    """Lane i keeps own rows i + o_j (o_0 = 0, o_j = (j + 1) BP + 1) and reads partner rows i + p, p = 1 .. BP,
+    all modulo M: over the lanes 0 .. M-1 the BA x BP pairs per lane must cover every unordered pair of the
+    M feature rows, and a pair of a row with itself must never be kept."""
+    for k in range(1, 63):
+        np_ = 16 if k + 2 <= 16 else (32 if k + 2 <= 32 else 64)
+        modm, M, ba, bp = _wave_dims(np_, k, gram)
+        own = [0] + [(j + 1) * bp + 1 for j in range(1, ba)]
+        seen = set()
+        for i in range(M if modm else np_):
+            for o in own:
+                for p in range(1, bp + 1):
+                    r1, c = (i + o) % M, (i + p) % M
+                    if r1 != c:
+                        seen.add((min(r1, c), max(r1, c)))
+        rows = k + 1  # neighbours + query (the generic scheme also visits response / padding slots)
+        want = {(a, b) for a in range(rows) for b in range(a + 1, rows)}
+        assert want <= seen, (k, np_, modm, ba, bp, sorted(want - seen)[:5])
+        if modm:
+            assert ba * bp < np_ // 2 and ba * bp >= (k + 1) // 2
