@@ -84,6 +84,9 @@
 #ifndef MGP_F64_COV_BATCH
 #define MGP_F64_COV_BATCH 5
 #endif
+#ifndef MGP_OWN_REG
+#define MGP_OWN_REG 0
+#endif
 #ifndef MGP_C4_W3
 #define MGP_C4_W3 0
 #endif
@@ -565,13 +568,18 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         // keep the difference form.  All reads of the query row are issued before any lane's writes (one
         // wave, LDS executes in order).  Slots without features (responses, padding) are left alone:
         // their pairs are dropped or masked.
+        // (-DMGP_OWN_REG=1: the centred row of the lane's own slot stays in registers -- it is own row 0 of
+        // the pair scheme, so the Gram loop below need not read it back: 10 of 330 LDS instructions at
+        // d = 40 for 38 more VGPRs.  Measured 1.826 vs 1.819 ms: nothing; off.)
+        constexpr int NCF = DFIX > 0 ? DSTFIX / E : 1;  // 16-byte groups per row (static shapes)
+        constexpr bool OWNREG = MGP_OWN_REG && DFIX > 0;
+        V x[DFIX > 0 ? NCF : 1];
         if (MGP_PHASE(g, 2)) {
           const bool has = i < k || i == q;
-          T* xrow = Xh + i * xs;
+          T* xrow = Xh + (MODM ? wrap(i) : i) * xs;  // (modulo scheme: idle lanes repeat a live one; they store nothing)
           const T* qrow = Xh + q * xs;
-          constexpr int NCF = DFIX > 0 ? DSTFIX / E : 1;  // 16-byte groups per row (static shapes)
           if constexpr (DFIX > 0) {
-            V x[NCF], qv[NCF];
+            V qv[NCF];
 #pragma unroll
             for (int c = 0; c < NCF; ++c) {
               x[c] = *reinterpret_cast<const V*>(xrow + c * E);
@@ -628,6 +636,11 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
             V own0[BA], own1[BA];
 #pragma unroll
             for (int j = 0; j < BA; ++j) {
+              if (OWNREG && j == 0) {  // own row 0 is the lane's own slot (o_0 = 0): still in registers
+                own0[0] = x[OWNREG ? c0 / E : 0];
+                own1[0] = x[OWNREG ? c0 / E + 1 : 0];
+                continue;
+              }
               const T* xj = DPRE ? tile + down[DPRE ? j : 0] + c0 : Xh + wrap(i + own_offset(j)) * xs + c0;
               own0[j] = *reinterpret_cast<const V*>(xj);
               own1[j] = *reinterpret_cast<const V*>(xj + E);
