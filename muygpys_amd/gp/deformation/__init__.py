@@ -1,4 +1,4 @@
-from .deformation_fn import Anisotropy, DeformationFn, Isotropy
+from .deformation_fn import Anisotropy, DeformationFn, DifferenceIsotropy, Isotropy
 from .metric import F2, MetricFn, l2
 
-__all__ = ["Anisotropy", "DeformationFn", "F2", "Isotropy", "MetricFn", "l2"]
+__all__ = ["Anisotropy", "DeformationFn", "DifferenceIsotropy", "F2", "Isotropy", "MetricFn", "l2"]

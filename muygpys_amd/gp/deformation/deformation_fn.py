@@ -70,6 +70,33 @@ class Isotropy(DeformationFn):
         return self.metric.crosswise_distances(data, nn_data, data_indices, nn_indices)
 
 
+class DifferenceIsotropy(Isotropy):
+    """One length scale, applied to feature-wise DIFFERENCES before the metric: ``metric(diffs / l)``
+    (isotropy.py:165-260; what the reference's experimental kernels build on).  For the stock metrics it
+    is the same function of the points as :class:`Isotropy` -- ``l2(diffs / l) = l2(diffs) / l``,
+    ``F2(diffs / l) = F2(diffs) / l^2`` -- so on lazy handles it ends in the same fused launch; what
+    differs is the tensor the deformation hands out: differences ``(b, k[, k], d)``."""
+
+    def __call__(self, dists, length_scale: Optional[float] = None, **kwargs):
+        if length_scale is None:
+            length_scale = self.length_scale(**kwargs)
+        if isinstance(dists, _lazy.LazyDiffs):
+            return dists.with_length_scale(float(length_scale)).reduce(self._metric_name())
+        return self.metric(dists / length_scale)
+
+    def pairwise_tensor(self, data, nn_indices, lazy: bool = False, **kwargs):
+        """isotropy.py:214-237: (b, k, k, d) differences."""
+        if lazy:
+            return _lazy.LazyDiffs("pairwise", None, False, data, nn_indices)
+        return self.metric.pairwise_differences(data, nn_indices)
+
+    def crosswise_tensor(self, data, nn_data, data_indices, nn_indices, lazy: bool = False, **kwargs):
+        """isotropy.py:240-276: (b, k, d) differences."""
+        if lazy:
+            return _lazy.LazyDiffs("crosswise", None, False, nn_data, nn_indices, data, data_indices)
+        return self.metric.crosswise_differences(data, nn_data, data_indices, nn_indices)
+
+
 class Anisotropy(DeformationFn):
     def __init__(self, metric: MetricFn, length_scale: VectorParam):
         if not isinstance(length_scale, VectorParam):

@@ -184,3 +184,34 @@ def test_free_smoothness_model_matches_reference(dtype, materialize):
         obj = L_BFGS_B_optimize.make_obj_fn(m, y_b, y_nn, cross, pair, loss_fn=loss)
         got = [float(obj(smoothness=p)) for p in meta["probes"]]
         assert_close(got, want, rtol, "objective at smoothness probes")
+
+
+@pytest.mark.parametrize("name", ["m15_iso_l2_k10_d8", "rbf_iso_F2_k10_d1", "m25_iso_l2_k30_d40"])
+@pytest.mark.parametrize("lazy", [True, False])
+def test_difference_isotropy_is_isotropy_on_differences(name, lazy):
+    """DifferenceIsotropy (gp/deformation/isotropy.py:165-276): ``metric(diffs / l)`` on difference tensors.
+    For the stock metrics it is the same function of the points as Isotropy, so an isotropic fixture must be
+    reproduced -- through the lazy route (one fused launch) and on materialised (b, k, k, d) differences."""
+    from muygpys_amd.gp import MuyGPS
+    from muygpys_amd.gp.deformation import F2, DifferenceIsotropy, l2
+    from muygpys_amd.gp.hyperparameter import AnalyticScale, Parameter
+    from muygpys_amd.gp.kernels import RBF, Matern
+    from muygpys_amd.gp.noise import HomoscedasticNoise
+    from tests.conftest import load_golden
+
+    g = load_golden(name)
+    meta = g["meta"]
+    td = torch.float64
+    deformation = DifferenceIsotropy(l2 if meta["metric"] == "l2" else F2, Parameter(meta["length_scale"]))
+    kernel = RBF(deformation=deformation) if meta["kernel"] == "rbf" else Matern(
+        smoothness=Parameter(NU[meta["kernel"]]), deformation=deformation)
+    m = MuyGPS(kernel=kernel, noise=HomoscedasticNoise(meta["noise"]), scale=AnalyticScale())
+    X, y = to_dev(g["features"], td), to_dev(g["targets"], td)
+    bi, ni = to_dev(g["batch_idx"]), to_dev(g["nn_idx"])
+    cross, pair, y_b, y_nn = m.make_train_tensors(bi, ni, X, y, materialize=not lazy)
+    assert tuple(pair.shape) == tuple(ni.shape) + (ni.shape[1], meta["d"])  # differences, not distances
+    Kin, Kc = m.kernel(pair), m.kernel(cross)
+    mean = m.posterior_mean(Kin, Kc, y_nn)
+    var = m.get_opt_var_fn()(Kin, Kc)
+    assert_close(torch.as_tensor(mean).cpu().numpy().reshape(g["mean"].shape), g["mean"], 1e-5, "mean")
+    assert_close(torch.as_tensor(var).cpu().numpy(), g["var_unscaled"], 1e-5, "var")
