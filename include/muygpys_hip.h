@@ -40,7 +40,9 @@ enum mgp_kernel {
   MGP_KERNEL_MATERN_05 = 1,  /* exp(-r),    r = l2 / l               :16-17 */
   MGP_KERNEL_MATERN_15 = 2,  /* (1+s3 r) exp(-s3 r)                  :20-22 */
   MGP_KERNEL_MATERN_25 = 3,  /* (1+s5 r+5r^2/3) exp(-s5 r)           :25-27 */
-  MGP_KERNEL_MATERN_INF = 4  /* exp(-r^2/2)                          :30-31 */
+  MGP_KERNEL_MATERN_INF = 4, /* exp(-r^2/2)                          :30-31 */
+  MGP_KERNEL_MATERN_GEN = 5  /* 2^(1-nu)/Gamma(nu) x^nu K_nu(x), x = sqrt(2 nu) r :34-43; only the entry points
+                                that take a smoothness accept it (mgp_posterior_gen_*, mgp_matern_gen_*) */
 };
 
 /* metric ids -- _src/gp/tensors/numpy.py:89-94, gp/deformation/metric.py:237-265 */
@@ -176,6 +178,32 @@ int mgp_posterior_kernel_name(int elem_size, int d, int k, int R, int packed, in
  *       mgp_posterior_* (same kernels, same arithmetic).
  * ------------------------------------------------------------------------- */
 int64_t mgp_packed_row_bytes(int d, int R, int elem_size);
+
+/* ---------------------------------------------------------------------------
+ * General-smoothness Matern on the fused path (K3: _matern_gen_fn, _src/gp/kernels/numpy.py:34-43, selected
+ * by gp/kernels/matern.py:61-81 whenever the smoothness is not one of 1/2, 3/2, 5/2, inf -- e.g. while it
+ * is being optimised).  One entry point for every table form: plain tables (feat_q / feat_nn / targets;
+ * packed_* NULL) or prepared tables (packed_q / packed_nn with strides; feat_* NULL), responses from the
+ * table or already gathered (targets_batch != 0: targets = (b, k, R)).  The covariance is evaluated inside
+ * the fused kernel (trapezoidal rule on the integral representation of K_nu, csrc/mgp_wave_common.h), so a
+ * free-smoothness objective evaluation is ONE launch with nothing materialised.  fp32 tables,
+ * k + 1 + R <= 32 or a shape the static kernels serve, nu <= 30; MGP_EUNSUPPORTED otherwise (the caller
+ * falls back to mgp_*_dists_* + mgp_matern_gen_* + mgp_solve_*).
+ * ------------------------------------------------------------------------- */
+int mgp_posterior_gen_f32(const float* feat_q, const float* feat_nn, const void* packed_q, int64_t q_stride_bytes,
+                          const void* packed_nn, int64_t nn_stride_bytes, int d,
+                          const int64_t* batch_idx, const int64_t* nn_idx, int64_t b, int k,
+                          const float* targets, int R, int targets_batch,
+                          int noise_mode, double noise_scalar, const float* noise_dev,
+                          double smoothness, int metric_id, const float* length_scale, int ls_count,
+                          float* mean, float* var, float* ykinvy, int* info, void* stream);
+int mgp_posterior_gen_f64(const double* feat_q, const double* feat_nn, const void* packed_q, int64_t q_stride_bytes,
+                          const void* packed_nn, int64_t nn_stride_bytes, int d,
+                          const int64_t* batch_idx, const int64_t* nn_idx, int64_t b, int k,
+                          const double* targets, int R, int targets_batch,
+                          int noise_mode, double noise_scalar, const double* noise_dev,
+                          double smoothness, int metric_id, const double* length_scale, int ls_count,
+                          double* mean, double* var, double* ykinvy, int* info, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Run-time specialisation.  mgp_posterior_* / mgp_loocv_* serve a shape (k, R, d) with a kernel whose

@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MUYGPYS_HIP_LIB") or os.path.join(HERE, "lib", "libmuygpys_hip.so")
 HEADER = os.path.join(HERE, "..", "include", "muygpys_hip.h")
 
-KERNEL_IDS = {"rbf": 0, "matern05": 1, "matern15": 2, "matern25": 3, "maternInf": 4}
+KERNEL_IDS = {"rbf": 0, "matern05": 1, "matern15": 2, "matern25": 3, "maternInf": 4, "matern_gen": 5}
 METRIC_IDS = {"l2": 0, "F2": 1}
 NOISE_SCALAR, NOISE_TABLE, NOISE_BATCH = 0, 1, 2
 
@@ -66,6 +66,7 @@ _SIGS = {
     "posterior_gathered": [_p, _p, _i, _p, _p, _l, _i, _p, _i, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p],
     "posterior_packed": [_p, _l, _p, _l, _i, _p, _p, _l, _i, _i, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p],
     "posterior_packed_gathered": [_p, _l, _p, _l, _i, _p, _p, _l, _i, _p, _i, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p],
+    "posterior_gen": [_p, _p, _p, _l, _p, _l, _i, _p, _p, _l, _i, _p, _i, _i, _i, _d, _p, _d, _i, _p, _i, _p, _p, _p, _p, _p],
     "table_pack": [_p, _p, _l, _i, _i, _p, _l, _p],
     "loocv": [_p, _i, _p, _p, _l, _i, _p, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p, _p, _d, _p, _p, _p],
     "loocv_packed": [_p, _l, _i, _p, _p, _l, _i, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p, _p, _d, _p, _p, _p],

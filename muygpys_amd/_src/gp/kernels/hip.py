@@ -52,14 +52,16 @@ def _matern_gen_fn(dists, smoothness, **kwargs):
     with zeros replaced by eps -- ``mgp_matern_gen_*`` evaluates the modified Bessel function on the
     device in fp64 (the reference calls scipy.special.kv).  The input is left untouched (the
     reference overwrites it)."""
-    if isinstance(dists, lazy.LazyDiffs):
-        # not one of the fused kernels' closed forms: the distances are materialised here and the
-        # posterior goes through mgp_solve_* on the materialised tensors
-        dists = dists.scaled_distances()
-    _lib.require_cuda(dists)
     nu = float(smoothness.detach().reshape(-1)[0]) if isinstance(smoothness, torch.Tensor) else float(smoothness)
     if not nu > 0.0:
         raise ValueError(f"Matern smoothness must be positive, got {nu}")
+    if isinstance(dists, lazy.LazyDiffs):
+        if dists.reduced:
+            # a handle: the fused launch evaluates the kernel itself where it can (fp32 tables,
+            # mgp_posterior_gen_*); where it cannot, the handle materialises through this function
+            return lazy.LazyCov(dists, "matern_gen", smoothness=nu)
+        dists = dists.scaled_distances()
+    _lib.require_cuda(dists)
     x = dists.contiguous()
     out = torch.empty_like(x)
     rc = _lib.fn("matern_gen", x.dtype)(_lib.ptr(x), x.numel(), 1.0, nu, _lib.ptr(out), _lib.stream_ptr())

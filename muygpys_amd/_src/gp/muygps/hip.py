@@ -41,7 +41,9 @@ def _solve(Kin, Kcross, Y, kout=1.0, want=("mean",)):
 def _muygps_posterior_mean(Kin, Kcross, nn_targets, **kwargs):
     """numpy.py:17-41: Kcross^T Kin^-1 Y -> (b,) for (b,k) targets, (b,R) for (b,k,R)."""
     if lazy.fused_triple(Kin, Kcross, nn_targets):
-        return lazy_eval.fused(Kin, Kcross, nn_targets)[0]
+        out = lazy_eval.fused(Kin, Kcross, nn_targets)
+        if out is not None:
+            return out[0]
     Kin, Kcross, nn_targets = lazy.force(Kin), lazy.force(Kcross), lazy.force(nn_targets)
     mean, _, _, _ = _solve(Kin, Kcross, nn_targets, want=("mean",))
     b = Kin.shape[0]

@@ -29,6 +29,7 @@ struct FusedArgs {
   const void* packed_q = nullptr;
   const void* packed_nn = nullptr;
   int64_t q_stride = 0, nn_stride = 0;
+  double smoothness = 0.0;  // kernel_id == MGP_KERNEL_MATERN_GEN: the Matern smoothness nu
 };
 
 #ifndef __HIPCC_RTC__  // the rest is host side: other argument blocks and the launcher declarations

@@ -132,6 +132,39 @@ int solve(const T* Kin, const T* Kc, const T* Y, int64_t b, int k, int R, double
 using namespace mgp;
 #define S_(x) static_cast<hipStream_t>(x)
 
+// General-smoothness Matern through the fused wave kernels (fp32, k + 1 + R <= 32 or a static shape);
+// MGP_EUNSUPPORTED elsewhere: the caller evaluates mgp_matern_gen_* on materialised distances instead.
+template <typename T>
+static int posterior_gen(const T* fq, const T* fn, const void* packed_q, int64_t q_stride, const void* packed_nn,
+                         int64_t nn_stride, int d, const int64_t* bi, const int64_t* ni, int64_t b, int k, const T* tg,
+                         int R, int targets_batch, int noise_mode, double eps, const T* nd, double smoothness,
+                         int metric_id, const T* ls, int ls_count, T* mean, T* var, T* yk, int* info, void* stream) {
+  if (b < 0 || k < 1 || d < 1 || R < 1 || !(smoothness > 0.0)) return MGP_EINVAL;
+  if (b == 0) return MGP_OK;
+  const bool packed = packed_nn != nullptr;
+  if (packed) {
+    const int64_t need = (int64_t)(d * sizeof(T)) + 16;
+    if (!packed_q || q_stride < need || nn_stride < need) return MGP_EINVAL;
+    if (targets_batch ? tg == nullptr : nn_stride < (int64_t)((d + R) * sizeof(T))) return MGP_EINVAL;
+  } else if (!fq || !fn || !tg) {
+    return MGP_EINVAL;
+  }
+  if (!ni || !ls || !mean || !var || !valid_metric(metric_id)) return MGP_EINVAL;
+  if (noise_mode < MGP_NOISE_SCALAR || noise_mode > MGP_NOISE_BATCH) return MGP_EINVAL;
+  if (noise_mode != MGP_NOISE_SCALAR && !nd) return MGP_EINVAL;
+  if (ls_count != 1 && ls_count != d) return MGP_EINVAL;
+  if (sizeof(T) != 4 || smoothness > 30.0) return MGP_EUNSUPPORTED;  // fp32 tables; beyond nu = 30 the RBF limit is the better model anyway
+  FusedArgs a{fq, fn, bi, ni, tg, nd, ls, mean, var, yk, info, b, eps, d, k, R, noise_mode, MGP_KERNEL_MATERN_GEN, metric_id,
+              ls_count, 0};
+  a.targets_batch = targets_batch;
+  a.packed_q = packed_q;
+  a.packed_nn = packed_nn;
+  a.q_stride = q_stride;
+  a.nn_stride = nn_stride;
+  a.smoothness = smoothness;
+  return launch_fused_wave<T>(a, static_cast<hipStream_t>(stream));
+}
+
 extern "C" {
 
 const char* mgp_version(void) { return "muygpys_amd-hip 0.1 (gfx950)"; }
@@ -225,6 +258,14 @@ int mgp_posterior_f64(const double* fq, const double* fn, int d, const int64_t* 
                                           void* st) {                                                                \
     return posterior<T>(nullptr, nullptr, d, bi, ni, b, k, nn_tg, R, nm, eps, nd, kid, mid, ls, lsc, mean, var, yk, \
                         info, st, PATH_AUTO, packed_q, q_stride, packed_nn, nn_stride, 1);                           \
+  }                                                                                                                  \
+  int mgp_posterior_gen_##SUF(const T* fq, const T* fn, const void* packed_q, int64_t q_stride,                     \
+                              const void* packed_nn, int64_t nn_stride, int d, const int64_t* bi, const int64_t* ni, \
+                              int64_t b, int k, const T* tg, int R, int targets_batch, int nm, double eps,          \
+                              const T* nd, double smoothness, int mid, const T* ls, int lsc, T* mean, T* var,       \
+                              T* yk, int* info, void* st) {                                                          \
+    return posterior_gen<T>(fq, fn, packed_q, q_stride, packed_nn, nn_stride, d, bi, ni, b, k, tg, R, targets_batch, \
+                            nm, eps, nd, smoothness, mid, ls, lsc, mean, var, yk, info, st);                         \
   }                                                                                                                  \
   int mgp_loocv_##SUF(const T* feat, int d, const int64_t* bi, const int64_t* ni, int64_t b, int k, const T* tg,     \
                       int nm, double eps, const T* nd, int kid, int mid, const T* ls, int lsc, T* mean, T* var,      \

@@ -12,7 +12,7 @@
 typedef long long int64_t;
 typedef unsigned long long uint64_t;
 typedef unsigned long uintptr_t;
-enum { MGP_KERNEL_RBF = 0, MGP_KERNEL_MATERN_05 = 1, MGP_KERNEL_MATERN_15 = 2, MGP_KERNEL_MATERN_25 = 3, MGP_KERNEL_MATERN_INF = 4 };
+enum { MGP_KERNEL_RBF = 0, MGP_KERNEL_MATERN_05 = 1, MGP_KERNEL_MATERN_15 = 2, MGP_KERNEL_MATERN_25 = 3, MGP_KERNEL_MATERN_INF = 4, MGP_KERNEL_MATERN_GEN = 5 };
 enum { MGP_METRIC_L2 = 0, MGP_METRIC_F2 = 1 };
 enum { MGP_NOISE_SCALAR = 0, MGP_NOISE_TABLE = 1, MGP_NOISE_BATCH = 2 };
 #endif

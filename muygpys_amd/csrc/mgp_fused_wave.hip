@@ -13,6 +13,20 @@ int g_grid_per_cu = 0;  // override of resident workgroups per CU
 int g_lds_pad = 0;      // extra dynamic LDS bytes per workgroup
 #endif
 
+// general-smoothness Matern: the node table (2 x MGP_GEN_NODES floats) goes behind everything else in
+// LDS; spacing and the log2 of h 2^(1-nu)/Gamma(nu) are launch constants
+static void gen_geometry(const FusedArgs& a, WaveGeom* g, size_t* lds) {
+  g->gen_tab = 0;
+  g->gen_h = 0.5f;
+  g->gen_lc = 0.0f;
+  if (a.kernel_id != MGP_KERNEL_MATERN_GEN) return;
+  const double nu = a.smoothness, h = gen_step(nu);
+  g->gen_tab = (int)*lds;
+  g->gen_h = (float)h;
+  g->gen_lc = (float)((log(h) + (1.0 - nu) * log(2.0) - lgamma(nu)) / log(2.0));
+  *lds += 2 * MGP_GEN_NODES * sizeof(float);
+}
+
 template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF = false, bool PACKED = false,
           bool GRAM = false>
 static int launch_np_impl(const FusedArgs& a, hipStream_t stream) {
@@ -44,6 +58,8 @@ static int launch_np_impl(const FusedArgs& a, hipStream_t stream) {
   size_t lds = PIPE ? tile_elems * sizeof(T) + 64 * sizeof(void*)
                     : (tile_elems + 64 + g.dst + (g.dst & 1)) * sizeof(T) + 64 * sizeof(int64_t);
   lds = (lds + 15) & ~(size_t)15;
+  if (a.kernel_id == MGP_KERNEL_MATERN_GEN && !(sizeof(T) == 4 && (NP <= 32 || KFIX > 0) && !COEFF)) return MGP_EUNSUPPORTED;
+  gen_geometry(a, &g, &lds);
 #ifdef MGP_DEBUG_HOOKS
   lds += (size_t)g_lds_pad;
 #endif
@@ -76,13 +92,17 @@ static int launch_np_impl(const FusedArgs& a, hipStream_t stream) {
 }
 
 // fp32 pipelined kernels compute the squared distances in the Gram form, except for the Matern-1/2
-// kernel: exp(-r) has a kink at r = 0, so the absolute error a cancelling Gram form leaves in a tiny
-// squared distance (duplicated training points) would show up at first order there.
+// kernel (and the general Matern below nu = 1): exp(-r) has a kink at r = 0, so the absolute error a
+// cancelling Gram form leaves in a tiny squared distance (duplicated training points) would show up at
+// first order there.
+static bool gram_allowed(const FusedArgs& a) {
+  return a.kernel_id != MGP_KERNEL_MATERN_05 && !(a.kernel_id == MGP_KERNEL_MATERN_GEN && a.smoothness < 1.0);
+}
+
 template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF = false, bool PACKED = false>
 static int launch_np(const FusedArgs& a, hipStream_t stream) {
   if constexpr (sizeof(T) == 4 && PIPED && !COEFF && MGP_GRAM) {
-    if (a.kernel_id != MGP_KERNEL_MATERN_05)
-      return launch_np_impl<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF, PACKED, true>(a, stream);
+    if (gram_allowed(a)) return launch_np_impl<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF, PACKED, true>(a, stream);
   }
   return launch_np_impl<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF, PACKED, false>(a, stream);
 }
@@ -106,7 +126,8 @@ static int launch_jit(const FusedArgs& a, hipStream_t stream) {
   const uintptr_t align = packed ? ((uintptr_t)a.packed_q | (uintptr_t)a.packed_nn | (uintptr_t)a.q_stride | (uintptr_t)a.nn_stride)
                                  : ((uintptr_t)a.feat_q | (uintptr_t)a.feat_nn);
   if (align % 16 != 0) return MGP_EUNSUPPORTED;
-  const bool gram = sizeof(T) == 4 && MGP_GRAM && a.kernel_id != MGP_KERNEL_MATERN_05;
+  if (a.kernel_id == MGP_KERNEL_MATERN_GEN && sizeof(T) != 4) return MGP_EUNSUPPORTED;
+  const bool gram = sizeof(T) == 4 && MGP_GRAM && gram_allowed(a);
   hipFunction_t fn = nullptr;
   const int jrc = jit_wave_function(sizeof(T), NP, a.k, a.R, a.d, packed, gram, &fn);
   if (jrc != MGP_OK) return jrc;
@@ -123,6 +144,7 @@ static int launch_jit(const FusedArgs& a, hipStream_t stream) {
   const size_t tile_elems = tile_feat > tile_mat ? tile_feat : tile_mat;
   size_t lds = tile_elems * sizeof(T) + 64 * sizeof(void*);
   lds = (lds + 15) & ~(size_t)15;
+  gen_geometry(a, &g, &lds);
   static Residency res;
   int per_cu = 0, cus = 0;
   const int rrc = res.lookup(fn, 64, lds, &per_cu, &cus);

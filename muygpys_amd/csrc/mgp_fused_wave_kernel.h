@@ -115,6 +115,10 @@ struct WaveGeom {
   int vec_ok;    // 16-byte gathers allowed (d % (16/sizeof T) == 0, bases aligned)
   int64_t ntasks;
   int mask;      // debug: phases to execute (bit0 gather, 1 distances, 2 kernel+exchange, 3 factor)
+  // general-smoothness Matern (kernel_id == MGP_KERNEL_MATERN_GEN, fp32): byte offset of the node table
+  // in LDS (2 x MGP_GEN_NODES floats), node spacing, log2(h 2^(1-nu) / Gamma(nu))
+  int gen_tab;
+  float gen_h, gen_lc;
 };
 
 // Sizes shared by the kernel and its launchers.  Plain constexpr functions of the shape (element size es,
@@ -258,6 +262,10 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   T* ilbuf = PIPE_ ? tile + (NPL - 1) * xs : colbuf + 64;  // dst entries (Anisotropy)
   int64_t* idxbuf = reinterpret_cast<int64_t*>(ilbuf + dst + (dst & 1));  // 64 entries (plain kernels)
   const T** rowaddr = reinterpret_cast<const T**>(colbuf);  // 64 row pointers (pipelined; overlays colbuf + 256 B)
+
+  const float* gtab = reinterpret_cast<const float*>(smem + g.gen_tab);
+  if (a.kernel_id == MGP_KERNEL_MATERN_GEN)  // node table of the launch's smoothness, once per workgroup
+    gen_build_table(reinterpret_cast<float*>(smem + g.gen_tab), (float)a.smoothness, g.gen_h, (int)threadIdx.x);
 
   const T* feat_q = static_cast<const T*>(a.feat_q);
   const T* feat_nn = static_cast<const T*>(a.feat_nn);
@@ -751,9 +759,25 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
             Kh3[hi <= q && hi != lo ? rowoff(hi) + lo : dump] = v;
           }
         };
-        kernel_dispatch(a.kernel_id, a.metric_id, [&](auto kid, auto mid) {
+        kernel_dispatch_gen(a.kernel_id, a.metric_id, [&](auto kid, auto mid) {
           constexpr int KID = decltype(kid)::value, MID = decltype(mid)::value;
-          if constexpr (sizeof(T) == 4) {
+          if constexpr (KID == MGP_KERNEL_MATERN_GEN) {
+            // general smoothness (fp32 kernels with per-lane pair tables; the launcher admits nothing else):
+            // metric arguments of all pairs, then the node loop shared by the wave (mgp_wave_common.h)
+            if constexpr (sizeof(T) == 4 && XPRE) {
+              float kv[NS];
+#pragma unroll
+              for (int s = 0; s < NS; ++s) {
+                float sqd;
+                if constexpr (GRAM) sqd = acc[s].x;
+                else sqd = acc_total(acc[s]);
+                kv[s] = (MID == MGP_METRIC_L2 ? sqrt_fast(sqd) : sqd) * post_scale;
+              }
+              matern_gen_eval<NS>(kv, xkeep, gtab, (float)a.smoothness, g.gen_h, g.gen_lc);
+#pragma unroll
+              for (int s = 1; s <= NS; ++s) put(s, kv[s - 1]);
+            }
+          } else if constexpr (sizeof(T) == 4) {
             T kv[NS];
             // (Gram form: the squared distance already sits in acc[].x)
             auto sq = [&](int s) {

@@ -321,6 +321,82 @@ __device__ __forceinline__ f2 cov_from_sqdist2(f2 acc, int kernel_id, int metric
   }
 }
 
+// ---- general-smoothness Matern inside the fused kernels (fp32) ------------------------------------------
+// k(r) = 2^(1-nu)/Gamma(nu) x^nu K_nu(x), x = sqrt(2 nu) r (_src/gp/kernels/numpy.py:34-43).  nu is uniform
+// per launch, so K_nu(x) = int_0^inf exp(-x cosh t) cosh(nu t) dt is evaluated by the trapezoidal rule on
+// nodes t_n = n h that every lane shares: the rule converges exponentially for this entire integrand
+// (error ~ exp(-pi^2 / h) at moderate nu; h shrinks with nu, gen_step()), and with everything kept in the
+// log domain,
+//     term_n = exp2( nu log2 x + lc + l_n - x c_n ),   c_n = cosh(t_n) log2 e,  l_n = log2 cosh(nu t_n) [- 1 at n = 0],
+// no term exceeds the result (<= 1), whatever nu.  The node table (-c_n, l_n) is built once per workgroup
+// in LDS (gen_build_table); a covariance costs N(x) nodes x (one packed add, one packed FMA, one v_exp_f32,
+// one packed add per TWO covariances), N = 5..13 for x in [0.5, 10] -- against ~10^3 fp64 instructions of
+// the Temme / Steed evaluation the per-function kernel uses (mgp_tensor_ops.hip).  Checked against scipy
+// in tests/test_matern_gen_cpu.py (the same arithmetic restated in numpy float32): <= 4e-6 absolute for
+// nu <= 4, <= 3e-5 up to nu = 25, x in [1e-5, 80].
+#define MGP_GEN_NODES 128
+__host__ __device__ inline float gen_step(double nu) { return nu <= 2.0 ? 0.5f : (nu <= 4.0 ? 0.4f : (nu <= 10.0 ? 0.3f : 0.22f)); }
+
+__device__ __forceinline__ void gen_build_table(float* tab, float nu, float h, int lane) {
+  for (int n = lane; n < MGP_GEN_NODES; n += 64) {
+    const float t = n * h, a = nu * t;
+    tab[2 * n] = -coshf(t) * 1.44269504088896f;
+    tab[2 * n + 1] = (a + log1pf(expf(-2.0f * a)) - 0.693147180559945f) * 1.44269504088896f - (n == 0 ? 1.0f : 0.0f);
+  }
+}
+
+// in: r[s] = metric argument (scaled distance) of the lane's NS pairs; out: the covariances.  `live`: bit s
+// set for pairs whose value is used (the others are evaluated at x = 1: their distance may be garbage and
+// must not drive the node count).  lc = log2(h 2^(1-nu) / Gamma(nu)).
+template <int NS>
+__device__ __forceinline__ void matern_gen_eval(float (&r)[NS], unsigned live, const float* tab, float nu, float h, float lc) {
+  constexpr int NP2 = (NS + 1) / 2;
+  f2 x2[NP2], L2[NP2], acc2[NP2];
+  const float s2nu = __builtin_amdgcn_sqrtf(2.0f * nu);
+  float nmaxf = 1.0f;
+  unsigned zero = 0;
+#pragma unroll
+  for (int s = 0; s < NP2 * 2; ++s) {
+    float x = 1.0f;
+    if (s < NS && ((live >> s) & 1u)) {
+      if (!(r[s] > 0.0f)) zero |= 1u << s;  // identical rows: k(0) = 1 (the reference nudges zeros to eps)
+      x = __builtin_fminf(__builtin_fmaxf(r[s] * s2nu, 1e-6f), 3.0e4f);
+    }
+    const float lx = __builtin_amdgcn_logf(x);  // log2
+    // nodes until x cosh t - nu t > ~22: T = ln(2 (22 + nu max(1, ln(44 / x))) / x)
+    const float inner = 22.0f + nu * __builtin_fmaxf(1.0f, (5.4594316f - lx) * 0.693147181f);
+    const float T = (__builtin_amdgcn_logf(2.0f * inner) - lx) * 0.693147181f;
+    nmaxf = __builtin_fmaxf(nmaxf, T);
+    const float Ls = __builtin_fmaf(nu, lx, lc);
+    if (s & 1) {
+      x2[s / 2].y = x;
+      L2[s / 2].y = Ls;
+    } else {
+      x2[s / 2].x = x;
+      L2[s / 2].x = Ls;
+    }
+  }
+  int N = (int)(nmaxf / h) + 3;
+  N = N < MGP_GEN_NODES ? N : MGP_GEN_NODES;
+#pragma unroll
+  for (int p = 0; p < NP2; ++p) acc2[p] = f2{0.0f, 0.0f};
+  for (int n = 0; n < MGP_GEN_NODES; ++n) {
+    if (__builtin_amdgcn_ballot_w64(n < N) == 0) break;  // (uniform: the longest tail of the wave)
+    const f2 cl = *reinterpret_cast<const f2*>(tab + 2 * n);  // uniform LDS read: (-c_n, l_n)
+    const f2 negc = {cl.x, cl.x}, l = {cl.y, cl.y};
+#pragma unroll
+    for (int p = 0; p < NP2; ++p) {
+      const f2 arg = x2[p] * negc + (L2[p] + l);
+      f2 e;
+      e.x = __builtin_amdgcn_exp2f(arg.x);
+      e.y = __builtin_amdgcn_exp2f(arg.y);
+      acc2[p] = acc2[p] + e;
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s) r[s] = (zero >> s) & 1u ? 1.0f : (s & 1 ? acc2[s / 2].y : acc2[s / 2].x);
+}
+
 // value of x in a given (wave-uniform) lane
 __device__ __forceinline__ float lane_value(float x, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane));
@@ -380,6 +456,17 @@ template <typename F>
 __device__ __forceinline__ void kernel_dispatch(int kernel_id, int metric_id, F&& f) {
   if (metric_id == MGP_METRIC_L2) kernel_dispatch_m<MGP_METRIC_L2>(kernel_id, f);
   else kernel_dispatch_m<MGP_METRIC_F2>(kernel_id, f);
+}
+
+// the same with the general-smoothness Matern as a sixth kernel id (the wave kernels, fp32)
+template <typename F>
+__device__ __forceinline__ void kernel_dispatch_gen(int kernel_id, int metric_id, F&& f) {
+  if (kernel_id == MGP_KERNEL_MATERN_GEN) {
+    if (metric_id == MGP_METRIC_L2) f(ic<MGP_KERNEL_MATERN_GEN>{}, ic<MGP_METRIC_L2>{});
+    else f(ic<MGP_KERNEL_MATERN_GEN>{}, ic<MGP_METRIC_F2>{});
+  } else {
+    kernel_dispatch(kernel_id, metric_id, f);
+  }
 }
 
 #ifndef __HIPCC_RTC__

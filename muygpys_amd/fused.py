@@ -26,7 +26,9 @@ class KernelSpec:
     """Hyper-parameters of one local-GP model, in the reference's vocabulary.
 
     kernel: "rbf" | "matern05" | "matern15" | "matern25" | "maternInf"
-        (_src/gp/kernels/numpy.py:12-31; Matern with fixed nu, gp/kernels/matern.py:61-81)
+        (_src/gp/kernels/numpy.py:12-31; Matern with fixed nu, gp/kernels/matern.py:61-81), or
+        "matern_gen" with ``smoothness`` = nu (numpy.py:34-43: any nu > 0; fp32 tables only on the fused
+        path -- :class:`FusedUnsupported` otherwise, and the caller materialises)
     metric: "l2" | "F2"  (gp/deformation/metric.py:237-265)
     length_scale: scalar -> Isotropy (isotropy.py:60-89); sequence of d -> Anisotropy
         (anisotropy.py:43-70)
@@ -39,6 +41,7 @@ class KernelSpec:
     metric: str = "l2"
     length_scale: Union[Number, Sequence[Number], torch.Tensor] = 1.0
     noise: Union[Number, torch.Tensor] = 0.0
+    smoothness: Optional[float] = None
 
     def kernel_id(self) -> int:
         try:
@@ -51,6 +54,11 @@ class KernelSpec:
             return _lib.METRIC_IDS[self.metric]
         except KeyError:
             raise ValueError(f"unknown metric {self.metric!r}; expected 'l2' or 'F2'")
+
+
+class FusedUnsupported(RuntimeError):
+    """The fused kernels do not serve this model / shape (general-smoothness Matern on fp64 tables, more than
+    32 slots in a small batch ...): evaluate through the per-function kernels instead."""
 
 
 # device-resident length scales of host-valued hyper-parameters, keyed by (values, device, dtype): an
@@ -258,6 +266,37 @@ def posterior_mean_var(
     yk = torch.empty((b, R), device=fn.device, dtype=dtype) if want_ykinvy else None
     if path not in ("auto", "generic", "rhs"):
         raise ValueError(f"unknown kernel path {path!r}")
+    if spec.kernel == "matern_gen":
+        if path != "auto":
+            raise ValueError("the general-smoothness Matern goes through the dispatcher (path='auto')")
+        if spec.smoothness is None or not float(spec.smoothness) > 0.0:
+            raise ValueError(f"kernel 'matern_gen' needs a positive smoothness, got {spec.smoothness}")
+        # one entry point for every table form (mgp_posterior_gen_*): prepared tables when they pay off
+        use_packed = (packed is not False and b > 0
+                      and PackedTable.supported(d, 0 if gathered else R, k + (R if gathered else 0), dtype))
+        if use_packed and packed == "auto":
+            key = (_tensor_key(train_features), None if gathered else _tensor_key(train_targets))
+            rows = fn.shape[0] + (0 if test_features is train_features else fq.shape[0])
+            use_packed = key in _PACK_CACHE or b * (k + 1) >= rows // 4
+        pn = pq = None
+        if use_packed:
+            pn = pack_table(train_features, None if gathered else train_targets, query=False)
+            pq = pn if test_features is train_features else pack_table(test_features, None)
+        rc = _lib.fn("posterior_gen", dtype)(
+            None if use_packed else _lib.ptr(fq), None if use_packed else _lib.ptr(fn),
+            _lib.ptr(pq.data) if use_packed else None, pq.stride if use_packed else 0,
+            _lib.ptr(pn.data) if use_packed else None, pn.stride if use_packed else 0,
+            d, _lib.ptr(bi), _lib.ptr(ni), b, k, _lib.ptr(tg), R, 1 if gathered else 0, mode, eps, _lib.ptr(nz),
+            float(spec.smoothness), spec.metric_id(), _lib.ptr(ls), ls.numel(),
+            _lib.ptr(mean), _lib.ptr(var), _lib.ptr(yk), _lib.ptr(info), _lib.stream_ptr(),
+        )
+        if rc == -2:
+            raise FusedUnsupported(f"general-smoothness Matern: no fused kernel for {dtype}, k={k}, R={R}, d={d}")
+        _lib.check(rc, "mgp_posterior_gen")
+        mean_out = mean.reshape(b) if squeeze else mean.reshape(b, R)
+        if want_ykinvy:
+            return mean_out, var, (yk.reshape(b) if squeeze else yk)
+        return mean_out, var
     rc = -2
     # gathered responses: the FEATURE rows still come from a prepared table (packed without responses)
     use_packed = (path == "auto" and packed is not False and b > 0

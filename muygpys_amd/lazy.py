@@ -217,6 +217,7 @@ class LazyCov(_Lazy):
     kernel: str
     noise: Any = None          # attached by the noise model's perturb(): float or tensor
     cache: Dict = field(default_factory=dict, repr=False, compare=False)
+    smoothness: Optional[float] = None  # kernel "matern_gen": the Matern smoothness nu
 
     @property
     def shape(self):
@@ -238,7 +239,7 @@ class LazyCov(_Lazy):
     def perturbed(self, noise) -> "LazyCov":
         # the cache dict is shared on purpose: mean, variance and scale of one evaluation
         # see differently decorated copies of the same Kin
-        return LazyCov(self.diffs, self.kernel, noise, self.cache)
+        return LazyCov(self.diffs, self.kernel, noise, self.cache, self.smoothness)
 
     def materialize(self) -> torch.Tensor:
         """kernel(metric(diffs / length_scale)) [+ nugget] through the per-function kernels."""
@@ -246,7 +247,10 @@ class LazyCov(_Lazy):
         from muygpys_amd._src.gp.noise import hip as N
 
         d = self.diffs
-        out = K._apply(d.scaled_distances(), self.kernel, 1.0)
+        if self.kernel == "matern_gen":
+            out = K._matern_gen_fn(d.scaled_distances(), self.smoothness)
+        else:
+            out = K._apply(d.scaled_distances(), self.kernel, 1.0)
         if self.noise is not None and d.kind == "pairwise":
             if isinstance(self.noise, torch.Tensor) and self.noise.ndim >= 1:
                 out = N._heteroscedastic_perturb(out, self.noise)
@@ -305,6 +309,7 @@ def fused_triple(Kin, Kcross, nn_targets) -> bool:
         return False
     return (
         a.kind == "pairwise" and c.kind == "crosswise" and a.reduced and c.reduced and Kin.kernel == Kcross.kernel
+        and Kin.smoothness == Kcross.smoothness
         and _same_tensor(a.nn_indices, c.nn_indices) and _same_tensor(a.nn_data, c.nn_data)
         and a.metric == c.metric and a.metric in ("l2", "F2") and _same_ls(a.length_scale, c.length_scale)
     )

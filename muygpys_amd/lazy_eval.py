@@ -69,13 +69,15 @@ def _spec(Kin: lazy.LazyCov):
     a = Kin.diffs
     return KernelSpec(
         kernel=Kin.kernel, metric=a.metric, length_scale=1.0 if a.length_scale is None else a.length_scale,
-        noise=0.0 if Kin.noise is None else Kin.noise,
+        noise=0.0 if Kin.noise is None else Kin.noise, smoothness=Kin.smoothness,
     )
 
 
 def fused(Kin: lazy.LazyCov, Kcross: lazy.LazyCov, nn_targets, differentiable: Optional[bool] = None):
     """(mean, var_unscaled_with_Kout_1, ykinvy, info) of a lazy triple, computed once per
-    (noise, Kcross, responses) and cached on the shared Kin cache.
+    (noise, Kcross, responses) and cached on the shared Kin cache -- or None when no fused kernel serves
+    the model (:class:`muygpys_amd.fused.FusedUnsupported`: the general-smoothness Matern on fp64 tables
+    or in an oversized small batch); the caller then materialises.
 
     ``nn_targets``: a :class:`lazy.LazyTargets` handle (responses gathered inside the kernel) or the
     already gathered (b, k[, R]) tensor (``mgp_posterior_gathered_*``).  When a feature table, the
@@ -84,9 +86,11 @@ def fused(Kin: lazy.LazyCov, Kcross: lazy.LazyCov, nn_targets, differentiable: O
     whose backward is the HIP vector-Jacobian kernel; that entry carries no ``ykinvy`` (the scale is a
     constant of the layer, as in the reference)."""
     from . import _lib
-    from .fused import posterior_mean_var
+    from .fused import FusedUnsupported, posterior_mean_var
 
     a, c = Kin.diffs, Kcross.diffs
+    if Kin.cache.get("unsupported"):
+        return None
     tg = _targets_tensor(nn_targets)
     gathered = not isinstance(nn_targets, lazy.LazyTargets)
     if differentiable is None:
@@ -96,6 +100,8 @@ def fused(Kin: lazy.LazyCov, Kcross: lazy.LazyCov, nn_targets, differentiable: O
         if e.differentiable == bool(differentiable) and e.noise_matches(nk) and e.cross is c and e.targets_match(tg):
             return e.value
     spec = _spec(Kin)
+    if differentiable and Kin.kernel == "matern_gen":
+        return None  # (the backward kernels know the closed-form kernels only)
     if differentiable:
         from .autograd import posterior
 
@@ -104,9 +110,13 @@ def fused(Kin: lazy.LazyCov, Kcross: lazy.LazyCov, nn_targets, differentiable: O
         _entries(Kin).append(_Entry(nk, c, tg, True, value))
         return value
     info = torch.zeros(1, dtype=torch.int32, device=a.device)
-    value = posterior_mean_var(
-        spec, c.data, a.nn_data, c.data_indices, a.nn_indices, tg, want_ykinvy=True, info=info, gathered=gathered,
-    ) + (info,)
+    try:
+        value = posterior_mean_var(
+            spec, c.data, a.nn_data, c.data_indices, a.nn_indices, tg, want_ykinvy=True, info=info, gathered=gathered,
+        ) + (info,)
+    except FusedUnsupported:
+        Kin.cache["unsupported"] = True  # (shared by the decorated copies of this Kin: asked once)
+        return None
     _lib.raise_if_not_spd(info, "fused posterior")
     # one evaluation at a time: the hyper-parameters changed -> older plain entries are dead
     Kin.cache["entries"] = [e for e in _entries(Kin) if e.differentiable]
@@ -125,7 +135,8 @@ def variance(Kin: lazy.LazyCov, Kcross: lazy.LazyCov):
     a = Kin.diffs
     dummy = lazy.LazyTargets(torch.zeros((a.nn_data.shape[0],), device=Kin.device, dtype=Kin.dtype), a.nn_indices)
     if lazy.fused_triple(Kin, Kcross, dummy):
-        return fused(Kin, Kcross, dummy, differentiable=False)[1]
+        out = fused(Kin, Kcross, dummy, differentiable=False)
+        return None if out is None else out[1]
     return None
 
 
@@ -166,9 +177,12 @@ def analytic_scale(Kin: lazy.LazyCov, nn_targets):
         stand_in = lazy.LazyCov(
             lazy.LazyDiffs("crosswise", a.metric, True, a.nn_data, a.nn_indices, a.nn_data,
                            a.nn_indices[:, 0].contiguous(), a.length_scale),
-            Kin.kernel,
+            Kin.kernel, smoothness=Kin.smoothness,
         )
-        yk = fused(Kin, stand_in, nn_targets, differentiable=False)[2]
+        out = fused(Kin, stand_in, nn_targets, differentiable=False)
+        if out is None:
+            return None
+        yk = out[2]
     from .config import config
 
     out = _lib.column_sums(yk.reshape(b, -1).contiguous())

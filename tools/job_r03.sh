@@ -1,1 +1,2 @@
-python3 -m pytest tests/test_gpu_functor_layer.py -m gpu -q -x -k "difference_isotropy" 2>&1 | tail -8
+python3 -m pytest tests/test_gpu_matern_gen.py -m gpu -q -x 2>&1 | tail -15
+python3 -m pytest tests/test_gpu_functor_layer.py tests/test_gpu_backend.py -m gpu -q -x 2>&1 | tail -4
