@@ -95,14 +95,18 @@ static int launch_np_impl(const FusedArgs& a, hipStream_t stream) {
 // kernel (and the general Matern below nu = 1): exp(-r) has a kink at r = 0, so the absolute error a
 // cancelling Gram form leaves in a tiny squared distance (duplicated training points) would show up at
 // first order there.
+// In fp64 the Gram form is used for every kernel: its absolute error in a squared distance, ~1e-16 r^2, is
+// eleven orders below the 1e-5 the results are held to.
+template <typename T>
 static bool gram_allowed(const FusedArgs& a) {
+  if (sizeof(T) == 8) return MGP_GRAM64 != 0;
   return a.kernel_id != MGP_KERNEL_MATERN_05 && !(a.kernel_id == MGP_KERNEL_MATERN_GEN && a.smoothness < 1.0);
 }
 
 template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF = false, bool PACKED = false>
 static int launch_np(const FusedArgs& a, hipStream_t stream) {
-  if constexpr (sizeof(T) == 4 && PIPED && !COEFF && MGP_GRAM) {
-    if (gram_allowed(a)) return launch_np_impl<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF, PACKED, true>(a, stream);
+  if constexpr (PIPED && !COEFF && MGP_GRAM && (sizeof(T) == 4 || MGP_GRAM64)) {
+    if (gram_allowed<T>(a)) return launch_np_impl<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF, PACKED, true>(a, stream);
   }
   return launch_np_impl<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF, PACKED, false>(a, stream);
 }
@@ -127,7 +131,7 @@ static int launch_jit(const FusedArgs& a, hipStream_t stream) {
                                  : ((uintptr_t)a.feat_q | (uintptr_t)a.feat_nn);
   if (align % 16 != 0) return MGP_EUNSUPPORTED;
   if (a.kernel_id == MGP_KERNEL_MATERN_GEN && sizeof(T) != 4) return MGP_EUNSUPPORTED;
-  const bool gram = sizeof(T) == 4 && MGP_GRAM && gram_allowed(a);
+  const bool gram = MGP_GRAM && gram_allowed<T>(a);
   hipFunction_t fn = nullptr;
   const int jrc = jit_wave_function(sizeof(T), NP, a.k, a.R, a.d, packed, gram, &fn);
   if (jrc != MGP_OK) return jrc;
@@ -231,7 +235,7 @@ int describe_fused_wave(int elem_size, int d, int k, int R, int packed, char* bu
     kf = k, rf = R, df = d, np = static_slots(elem_size, d, k, R, packed != 0, false), piped = true;
   if (np == 0 || (packed && (!piped || R > E))) return snprintf(buf, len, "%s", "");
   // (the Gram-form instantiation serves fp32 pipelined shapes for every kernel except Matern-1/2)
-  const bool gram = elem_size == 4 && piped && MGP_GRAM;
+  const bool gram = piped && MGP_GRAM && (elem_size == 4 || MGP_GRAM64);
   return snprintf(buf, len, "mgp::fused_wave_kernel<%s,%d,%d,%d,%d,%s,false,%s,%s>", t, np, kf, rf, df,
                   piped ? "true" : "false", packed ? "true" : "false", gram ? "true" : "false");
 }
@@ -241,7 +245,7 @@ int prepare_fused_wave(int elem_size, int d, int k, int R, int packed, int kerne
   if (R == 1 && ((k == 30 && d == 40) || (k == 50 && d == 8))) return MGP_OK;  // built into the library
   const int np = static_slots(elem_size, d, k, R, packed != 0, false);
   if (np == 0) return MGP_EUNSUPPORTED;
-  const bool gram = elem_size == 4 && MGP_GRAM && kernel_id != MGP_KERNEL_MATERN_05;
+  const bool gram = MGP_GRAM && (elem_size == 8 ? MGP_GRAM64 != 0 : kernel_id != MGP_KERNEL_MATERN_05);
   return jit_wave_prepare(elem_size, np, k, R, d, packed != 0, gram);
 }
 

@@ -96,6 +96,12 @@
 #ifndef MGP_GRAM
 #define MGP_GRAM 1
 #endif
+// (the Gram form in fp64: precision is no concern there, and the code path exists -- but the fp64 kernels are
+// bound by the elimination, not by the distances: config 4 114.8 vs 114.9 M/s, fp64 headline 241.6 vs 245.2,
+// k = 20 / d = 16 340 vs 332.  Off.)
+#ifndef MGP_GRAM64
+#define MGP_GRAM64 0
+#endif
 #ifndef MGP_DMA_ASM
 #define MGP_DMA_ASM 1
 #endif
@@ -197,7 +203,7 @@ constexpr int wave_min_waves(int es, int NP, int KFIX) {
 // PACKED: the tables are prepared tables (mgp_table_pack_*): rows of [features | responses | pad] at a
 //        64-byte multiple stride, so a row and its response arrive with the same two cache lines
 //        and no separate 4-byte response read (a whole line each) is issued.
-// GRAM: (fp32, pipelined) squared distances as |a'|^2 + |b'|^2 - 2 a'.b' on rows centred on the query
+// GRAM: (pipelined kernels) squared distances as |a'|^2 + |b'|^2 - 2 a'.b' on rows centred on the query
 //        in place (a' = a - q, times the inverse length scales under Anisotropy): one packed FMA per
 //        two features of a pair instead of a packed subtract + a packed FMA.  See phase 1b / 2.
 template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF = false, bool PACKED = false,
@@ -205,7 +211,7 @@ template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COE
 __global__ __launch_bounds__(64, wave_min_waves(sizeof(T), NP, KFIX))
 void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   static_assert(!PACKED || PIPED, "prepared tables are gathered by the direct-to-LDS pipeline");
-  static_assert(!GRAM || (sizeof(T) == 4 && PIPED && !COEFF), "Gram form: fp32, one feature stage");
+  static_assert(!GRAM || (PIPED && !COEFF), "Gram form: one feature stage");
   constexpr WaveDims WD = wave_dims(sizeof(T), NP, KFIX, RFIX, DFIX, COEFF, GRAM);
   constexpr int NH = WD.NH;       // neighbourhoods per wave
   constexpr bool STAT = WD.STAT;  // all shapes static: q = k, NPL live slots, lanes NPL .. NP-1 idle; everything
@@ -603,16 +609,13 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
               for (int c = 0; c < NCF; ++c) *reinterpret_cast<V*>(xrow + c * E) = x[c];
             }
             // four independent partial sums (a single chain of 2 NCF dependent packed FMAs costs a wait state each)
-            f2 n4[4] = {f2{0.0f, 0.0f}, f2{0.0f, 0.0f}, f2{0.0f, 0.0f}, f2{0.0f, 0.0f}};
+            ACC n4[4] = {ACC(0), ACC(0), ACC(0), ACC(0)};
 #pragma unroll
-            for (int c = 0; c < NCF; ++c) {
-              n4[(2 * c) & 3] = x[c].xy * x[c].xy + n4[(2 * c) & 3];
-              n4[(2 * c + 1) & 3] = x[c].zw * x[c].zw + n4[(2 * c + 1) & 3];
-            }
-            const f2 n2 = (n4[0] + n4[1]) + (n4[2] + n4[3]);
-            if (has) xrow[dst] = n2.x + n2.y;
+            for (int c = 0; c < NCF; ++c) norm_accum(n4[c & 3], x[c]);
+            const ACC n2 = (n4[0] + n4[1]) + (n4[2] + n4[3]);
+            if (has) xrow[dst] = acc_total(n2);
           } else {
-            f2 n2 = f2{0.0f, 0.0f};
+            ACC n2 = ACC(0);
             for (int c0 = 0; c0 < wp; c0 += CH) {
               V x0 = *reinterpret_cast<const V*>(xrow + c0), x1 = *reinterpret_cast<const V*>(xrow + c0 + E);
               const V q0 = *reinterpret_cast<const V*>(qrow + c0), q1 = *reinterpret_cast<const V*>(qrow + c0 + E);
@@ -622,10 +625,8 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
                 x0 = x0 * *reinterpret_cast<const V*>(ilbuf + c0);
                 x1 = x1 * *reinterpret_cast<const V*>(ilbuf + c0 + E);
               }
-              n2 = x0.xy * x0.xy + n2;
-              n2 = x0.zw * x0.zw + n2;
-              n2 = x1.xy * x1.xy + n2;
-              n2 = x1.zw * x1.zw + n2;
+              norm_accum(n2, x0);
+              norm_accum(n2, x1);
               // (lane q writes zeros over the chunk every lane has just read; the next chunk's reads come
               // after this store in program order)
               if (has) {
@@ -633,7 +634,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
                 *reinterpret_cast<V*>(xrow + c0 + E) = x1;
               }
             }
-            if (has) xrow[dst] = n2.x + n2.y;
+            if (has) xrow[dst] = acc_total(n2);
           }
         }
         __syncthreads();
@@ -672,11 +673,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 #pragma unroll
           for (int j = 0; j < BA; ++j)
 #pragma unroll
-            for (int s = 0; s < BP; ++s) {
-              const T gsum = acc[j * BP + s].x + acc[j * BP + s].y;
-              acc[j * BP + s].x = __builtin_fmaxf(__builtin_fmaf(-2.0f, gsum, nown[j] + npar[s]), 0.0f);
-              acc[j * BP + s].y = 0.0f;
-            }
+            for (int s = 0; s < BP; ++s) gram_finish(acc[j * BP + s], nown[j] + npar[s]);
         }
       } else
       if (MGP_PHASE(g, 2)) {
@@ -769,7 +766,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 #pragma unroll
               for (int s = 0; s < NS; ++s) {
                 float sqd;
-                if constexpr (GRAM) sqd = acc[s].x;
+                if constexpr (GRAM) sqd = gram_sq(acc[s]);
                 else sqd = acc_total(acc[s]);
                 kv[s] = (MID == MGP_METRIC_L2 ? sqrt_fast(sqd) : sqd) * post_scale;
               }
@@ -781,7 +778,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
             T kv[NS];
             // (Gram form: the squared distance already sits in acc[].x)
             auto sq = [&](int s) {
-              if constexpr (GRAM) return acc[s].x;
+              if constexpr (GRAM) return gram_sq(acc[s]);
               else return acc_total(acc[s]);
             };
 #pragma unroll
@@ -800,7 +797,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
               T kv[CB];
 #pragma unroll
               for (int u = 0; u < CB; ++u)
-                if (s0 + u < NS) kv[u] = cov_from_sqdist<T>(acc_total(acc[s0 + u]), KID, MID, post_scale);
+                if (s0 + u < NS) kv[u] = cov_from_sqdist<T>(GRAM ? gram_sq(acc[s0 + u]) : acc_total(acc[s0 + u]), KID, MID, post_scale);
 #pragma unroll
               for (int u = 0; u < CB; ++u)
                 if (s0 + u < NS) put(s0 + u + 1, kv[u]);

@@ -210,8 +210,30 @@ __device__ __forceinline__ void gram_block(f2* acc, const v16<float>::type (&w)[
     for (int j = 0; j < BA; ++j) acc[j * BP] = w[j].zw * o.zw + acc[j * BP];
   }
 }
-template <int BA, int BP, typename A, typename W>
-__device__ __forceinline__ void gram_block(A*, const W&, const v16<double>::type&) {}  // fp32 only
+// fp64: the same block as plain FMAs (no packed fp64; two accumulators' worth of independent chains per row)
+template <int BA, int BP>
+__device__ __forceinline__ void gram_block(double* acc, const v16<double>::type (&w)[BA], const v16<double>::type& o) {
+#pragma unroll
+  for (int j = 0; j < BA; ++j) acc[j * BP] = __builtin_fma(w[j].x, o.x, acc[j * BP]);
+#pragma unroll
+  for (int j = 0; j < BA; ++j) acc[j * BP] = __builtin_fma(w[j].y, o.y, acc[j * BP]);
+}
+// |x|^2 of one 16-byte group into a partial sum; squared distance out of a Gram accumulator
+__device__ __forceinline__ void norm_accum(f2& n, const v16<float>::type& x) {
+  n = x.xy * x.xy + n;
+  n = x.zw * x.zw + n;
+}
+__device__ __forceinline__ void norm_accum(double& n, const v16<double>::type& x) {
+  n = __builtin_fma(x.x, x.x, n);
+  n = __builtin_fma(x.y, x.y, n);
+}
+__device__ __forceinline__ void gram_finish(f2& a, float nsum) {  // |a'|^2 + |b'|^2 - 2 a'.b', clamped; left in a.x
+  a.x = __builtin_fmaxf(__builtin_fmaf(-2.0f, a.x + a.y, nsum), 0.0f);
+  a.y = 0.0f;
+}
+__device__ __forceinline__ void gram_finish(double& a, double nsum) { a = __builtin_fmax(__builtin_fma(-2.0, a, nsum), 0.0); }
+__device__ __forceinline__ float gram_sq(const f2& a) { return a.x; }
+__device__ __forceinline__ double gram_sq(const double& a) { return a; }
 
 #ifdef MGP_FAKE_GRAM
 __device__ __forceinline__ float acc_total(const v16<float>::acc& a) { return __builtin_fabsf(a.x + a.y) * 4.0f + 20.0f; }
