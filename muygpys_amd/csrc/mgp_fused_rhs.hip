@@ -32,6 +32,10 @@
 #define MGP_RHS_XCHG_PRIO 2
 #endif
 
+#ifndef MGP_RHS_BACK
+#define MGP_RHS_BACK 1
+#endif
+
 namespace mgp {
 
 struct RhsGeom {
@@ -39,7 +43,14 @@ struct RhsGeom {
   int64_t ntasks;
 };
 
-template <typename T, int RC>  // RC: compiled number of response columns (run-time R <= RC)
+// BACK (prediction: no y^T K^-1 y requested, more than one response): only the cross-covariance column is
+// carried through the elimination; the multipliers are kept (one coalesced ds_write_b32 per step into
+// the by then free exchange matrix, row = step, odd stride -> the transposed reads of the back-
+// substitution are conflict-free), w = K^-1 c follows from L^T w = D^-1 L^-1 c in k - 1 v_readlane + FMA
+// steps, and mean_r = w . y_r are R plain dot products.  Per elimination step that is 1 instead of 1 + R
+// v_readlane_b32 and 1 instead of (1 + R) / 2 packed FMAs on the right-hand sides: at R = 16, 24 of ~90
+// instructions per step.
+template <typename T, int RC, bool BACK = false>  // RC: compiled number of response columns (run-time R <= RC)
 __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel(FusedArgs a, RhsGeom g) {
   constexpr int NP = 64;
   constexpr int NS = NP / 2;
@@ -262,11 +273,14 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
     // the column are requested at once (the reads stay in flight together: serialised read -> wait ->
     // FMA pairs cost an LDS round trip per group), and lane j's 1 + R right-hand sides are broadcast
     // through SGPRs (v_readlane, j is a compile-time lane) instead of a second LDS round trip.
-    V rv[NRV];
+    constexpr int NRE = BACK ? 1 : NRV;  // right-hand-side groups carried through the elimination
+    constexpr int LS = NP + 1;           // (BACK) row stride of the multiplier matrix: odd
+    T* Lm = tile;                        // (BACK) multipliers l_ij at Lm[j * LS + i]; the exchange matrix is free by now
+    V rv[NRE];
 #pragma unroll
-    for (int r4 = 0; r4 < NRV; ++r4)
+    for (int r4 = 0; r4 < NRE; ++r4)
 #pragma unroll
-      for (int e = 0; e < E; ++e) rv[r4][e] = r4 * E + e < NR ? rhs[r4 * E + e] : T(0);
+      for (int e = 0; e < E; ++e) rv[r4][e] = r4 * E + e < (BACK ? 1 : NR) ? rhs[r4 * E + e] : T(0);
     bool bad = false;
     T mypiv = T(1);
     // unused slots (k .. 63) are identity rows: eliminating them changes nothing, so the k test is
@@ -287,11 +301,11 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
 #pragma unroll
       for (int j = jb; j < jb + JB; ++j) {
         const T ajj = A[j / E][j % E];
-        V bj[NRV];
+        V bj[NRE];
 #pragma unroll
-        for (int r4 = 0; r4 < NRV; ++r4)
+        for (int r4 = 0; r4 < NRE; ++r4)
 #pragma unroll
-          for (int e = 0; e < E; ++e) bj[r4][e] = r4 * E + e < NR ? lane_value(rv[r4][e], j) : T(0);
+          for (int e = 0; e < E; ++e) bj[r4][e] = r4 * E + e < (BACK ? 1 : NR) ? lane_value(rv[r4][e], j) : T(0);
         if constexpr (sizeof(T) == 4) {
           V col[NP / E];
           col[j / E] = piv;
@@ -302,6 +316,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
           if (i == j) mypiv = p;
           const T t = i > j ? ajj * pivot_rcp(p) : T(0);  // rows <= j are finished: leave them alone
           const V nt = V(-t);
+          if constexpr (BACK) Lm[j * LS + i] = t;
           constexpr int JN = NP - 1;
           const int g1 = (j < JN ? j + 1 : j) / E;  // group of the next column (compile-time after unrolling)
           A[g1] = col[g1] * nt + A[g1];
@@ -313,7 +328,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
           for (int c4 = j / E; c4 < NP / E; ++c4)
             if (c4 != g1) A[c4] = col[c4] * nt + A[c4];
 #pragma unroll
-          for (int r4 = 0; r4 < NRV; ++r4) rv[r4] = bj[r4] * nt + rv[r4];
+          for (int r4 = 0; r4 < NRE; ++r4) rv[r4] = bj[r4] * nt + rv[r4];
         } else {
           // fp64: a full copy of the column would not fit beside the 128-register row; streamed
           colbuf[i] = ajj;
@@ -323,6 +338,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
           if (i == j) mypiv = p;
           const T t = i > j ? ajj * pivot_rcp(p) : T(0);
           const V nt = V(-t);
+          if constexpr (BACK) Lm[j * LS + i] = t;
           A[j / E] = cp * nt + A[j / E];
 #pragma unroll
           for (int c4 = j / E + 1; c4 < NP / E; ++c4) {
@@ -330,12 +346,12 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
             A[c4] = cv * nt + A[c4];
           }
 #pragma unroll
-          for (int r4 = 0; r4 < NRV; ++r4) rv[r4] = bj[r4] * nt + rv[r4];
+          for (int r4 = 0; r4 < NRE; ++r4) rv[r4] = bj[r4] * nt + rv[r4];
         }
       }
     }
 #pragma unroll
-    for (int r = 0; r < NR; ++r) rhs[r] = rv[r / E][r % E];
+    for (int r = 0; r < (BACK ? 1 : NR); ++r) rhs[r] = rv[r / E][r % E];
 
 #if MGP_RHS_PRIO
     __builtin_amdgcn_s_setprio(0);
@@ -352,6 +368,25 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
       var[nb] = bad ? num<T>::nan() : T(1) - sv;
       if (bad && a.info) atomicAdd(a.info, 1);
     }
+    if constexpr (BACK) {
+      // w = K^-1 c: L^T w = D^-1 u, from the last row up; lane j takes l_mj w_m off for every m > j
+      T w = u * inv_d;
+#pragma unroll
+      for (int m = NP - 1; m >= 1; --m) {
+        if (m < k) {  // (uniform)
+          const T lmj = Lm[i * LS + m];  // multiplier of row m at step i (junk for i >= m: masked below)
+          const T wm = lane_value(w, m);
+          if (i < m) w = fma_t(-lmj, wm, w);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < RC; ++r) {
+        if (r < R) {
+          const T sm = wave_sum_lane63(w * rhs[1 + r]);  // (rows >= k carry zero responses and w = 0)
+          if (i == NP - 1) mean[nb * R + r] = bad ? num<T>::nan() : sm;
+        }
+      }
+    } else {
 #pragma unroll
     for (int r = 0; r < RC; ++r) {
       if (r < R) {
@@ -363,10 +398,11 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
         }
       }
     }
+    }
   }
 }
 
-template <typename T, int RC>
+template <typename T, int RC, bool BACK = false>
 static int launch_rhs(const FusedArgs& a, hipStream_t stream) {
   constexpr int NP = 64;
   constexpr int E = v16<T>::N;
@@ -385,11 +421,11 @@ static int launch_rhs(const FusedArgs& a, hipStream_t stream) {
   lds = (lds + 15) & ~(size_t)15;
   static Residency res;
   int per_cu = 0, cus = 0;
-  const int rc = res.lookup(reinterpret_cast<const void*>(&fused_rhs_kernel<T, RC>), 64, lds, &per_cu, &cus);
+  const int rc = res.lookup(reinterpret_cast<const void*>(&fused_rhs_kernel<T, RC, BACK>), 64, lds, &per_cu, &cus);
   if (rc != MGP_OK) return rc;
   int64_t grid = (int64_t)cus * per_cu;
   if (grid > g.ntasks) grid = g.ntasks;
-  hipLaunchKernelGGL((fused_rhs_kernel<T, RC>), dim3((unsigned)grid), dim3(64), lds, stream, a, g);
+  hipLaunchKernelGGL((fused_rhs_kernel<T, RC, BACK>), dim3((unsigned)grid), dim3(64), lds, stream, a, g);
   MGP_HIP_CHECK_LAUNCH();
   return MGP_OK;
 }
@@ -398,6 +434,8 @@ template <typename T>
 int launch_fused_rhs(const FusedArgs& a, hipStream_t stream) {
   if (a.k > 64 || a.packed_nn != nullptr) return MGP_EUNSUPPORTED;
   if (a.R <= 4) return launch_rhs<T, 4>(a, stream);
+  // many responses without y^T K^-1 y (prediction): one right-hand side + back-substitution
+  if (a.R <= 16 && a.ykinvy == nullptr && MGP_RHS_BACK) return launch_rhs<T, 16, true>(a, stream);
   if (a.R <= 16) return launch_rhs<T, 16>(a, stream);
   return MGP_EUNSUPPORTED;
 }
