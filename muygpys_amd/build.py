@@ -113,13 +113,16 @@ def prewarm(verbose: bool = False) -> int:
     ok = sum(1 for _, rc in done if rc == 0)
     if verbose:
         print(f"run-time specialisation cache: {ok} of {len(jobs)} shapes ready", file=sys.stderr)
-    # drop objects of older builds (their hash no longer matches any source)
+    # drop objects of older builds: the file name ends in the hash of the kernel sources, and the newest
+    # object carries the current one
     jit = os.path.join(LIBDIR, "jit")
-    if os.path.isdir(jit):
-        newest = max((os.path.getmtime(os.path.join(jit, f)) for f in os.listdir(jit)), default=0)
-        for f in os.listdir(jit):
-            if os.path.getmtime(os.path.join(jit, f)) < newest - 6 * 3600:
-                os.remove(os.path.join(jit, f))
+    if ok and os.path.isdir(jit):
+        files = [f for f in os.listdir(jit) if f.endswith(".hsaco")]
+        if files:
+            current = max(files, key=lambda f: os.path.getmtime(os.path.join(jit, f))).rsplit("_", 1)[-1]
+            for f in files:
+                if f.rsplit("_", 1)[-1] != current:
+                    os.remove(os.path.join(jit, f))
     return ok
 
 
