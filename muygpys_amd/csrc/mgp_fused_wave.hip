@@ -55,7 +55,8 @@ static int launch_np_impl(const FusedArgs& a, hipStream_t stream) {
   const size_t tile_feat = (size_t)wave_tile_rows(WD, NP, KFIX, g.xs) * g.xs, tile_mat = (size_t)NH * KMAT;
   const size_t tile_elems = tile_feat > tile_mat ? tile_feat : tile_mat;
   constexpr bool PIPE = PIPED;
-  size_t lds = PIPE ? tile_elems * sizeof(T) + 64 * sizeof(void*)
+  size_t lds = PIPE ? tile_elems * sizeof(T) +
+                          wave_colbuf_bytes(sizeof(T), NP, wave_fold(sizeof(T), NP, KFIX, RFIX, DFIX, PIPED, COEFF, GRAM))
                     : (tile_elems + 64 + g.dst + (g.dst & 1)) * sizeof(T) + 64 * sizeof(int64_t);
   lds = (lds + 15) & ~(size_t)15;
   if (a.kernel_id == MGP_KERNEL_MATERN_GEN && !(sizeof(T) == 4 && (NP <= 32 || KFIX > 0) && !COEFF)) return MGP_EUNSUPPORTED;
@@ -146,7 +147,7 @@ static int launch_jit(const FusedArgs& a, hipStream_t stream) {
   g.ntasks = (a.b + WD.NH - 1) / WD.NH;
   const size_t tile_feat = (size_t)wave_tile_rows(WD, NP, a.k, g.xs) * g.xs, tile_mat = (size_t)WD.NH * WD.KMAT;
   const size_t tile_elems = tile_feat > tile_mat ? tile_feat : tile_mat;
-  size_t lds = tile_elems * sizeof(T) + 64 * sizeof(void*);
+  size_t lds = tile_elems * sizeof(T) + wave_colbuf_bytes(sizeof(T), NP, wave_fold(sizeof(T), NP, a.k, a.R, a.d, true, false, gram));
   lds = (lds + 15) & ~(size_t)15;
   gen_geometry(a, &g, &lds);
   static Residency res;

@@ -211,6 +211,20 @@ constexpr int wave_min_waves(int es, int NP, int KFIX) {
   return es == 4 ? (NP <= 32 ? (KFIX == 30 && MGP_W4 ? 4 : 3) : 2) : (NP <= 32 ? 2 : (KFIX > 0 && MGP_C4_W3 ? 3 : 2));
 }
 
+// Folded elimination (phase 4F): which instantiations use it, and the bytes of column buffers behind the tile
+// (one per neighbourhood in flight; never less than the 64 row addresses of the gather that share the space).
+#ifndef MGP_FOLD64
+#define MGP_FOLD64 1
+#endif
+constexpr bool wave_fold(int es, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF, bool GRAM) {
+  return MGP_FOLD && PIPED && KFIX > 0 && RFIX == 1 && DFIX > 0 && !COEFF && KFIX >= NP / 2 &&
+         es == 4 && ((NP == 32 && GRAM) || (NP == 64 && MGP_FOLD64));  // (fp64, 64 slots: 168 parked VGPRs -- spills)
+}
+constexpr int wave_colbuf_bytes(int es, int NP, bool fold) {
+  const int need = fold ? (64 / (NP / 2)) * NP * es : 64 * es;
+  return need > 512 ? need : 512;
+}
+
 // KFIX / RFIX / DFIX > 0: nn_count / response_count / feature_count known at compile time.
 // PIPED: software-pipelined direct-to-LDS gather (one feature stage, 16-byte aligned rows).
 // COEFF: also emit K^-1 y (the fast-posterior-mean coefficients): multipliers kept, back-substitution.
@@ -242,7 +256,11 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   // covariance ONCE per pair and the rows are assembled as in the VALU kernels.  -DMGP_MFMA=2: no exchange,
   // v_permlane32_swap leaves every lane its whole row and it evaluates all 32 entries itself (twice the
   // transcendental work: measured slower, 1.90 vs 1.81 ms on the headline shape).
-  constexpr bool FOLD = MGP_FOLD && GRAM && sizeof(T) == 4 && NP == 32 && STAT && !COEFF && KFIX >= 16 && RFIX == 1;
+  // (32 slots, fp32, Gram form; or -- MGP_FOLD64 -- 64 slots: one neighbourhood per half-wave.  The query and
+  // response rows must be among the long rows: k >= NP / 2)
+  constexpr bool FOLD = wave_fold(sizeof(T), NP, KFIX, RFIX, DFIX, PIPED, COEFF, GRAM);
+  constexpr int HALF = NP / 2;    // (FOLD) lanes per neighbourhood; lane l owns rows l and HALF + l
+  constexpr int NGS = HALF / WD.E;  // (FOLD) 16-byte groups of a short row
   constexpr bool MFROW = MF && MGP_MFMA == 2 && !FOLD;
   constexpr bool MFX = MF && !MFROW;
   constexpr int BA = WD.BA;       // own rows per lane        } register blocking of the pair scheme,
@@ -483,7 +501,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 
   // (FOLD) the folded rows: FS = row l (columns 0 .. 15), FL = row 16 + l, of the neighbourhood of the lane's
   // quarter; quarters 0 / 1 belong to the first task of a pair, 2 / 3 to the second
-  V FL[FOLD ? NG : 1], FS[FOLD ? 4 : 1];
+  V FL[FOLD ? NG : 1], FS[FOLD ? NGS : 1];
   int fold_sub = 0;
   int64_t fold_task_a = 0;
   for (int64_t task = task0; task < t_end; task += t_step) {
@@ -1074,12 +1092,12 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     if constexpr (FOLD) {
       // the half-wave of this task of the pair picks its rows up, sixteen lanes per neighbourhood
       if ((lane >> 5) == fold_sub) {
-        const T* Kq = tile + ((lane >> 4) & 1) * KMAT;
-        const int l16 = lane & 15;
+        const T* Kq = tile + (NH == 1 ? 0 : (lane / HALF) & 1) * KMAT;
+        const int lh = lane & (HALF - 1);
 #pragma unroll
-        for (int c4 = 0; c4 < 4; ++c4) FS[c4] = *reinterpret_cast<const V*>(Kq + rowoff(l16) + c4 * E);
+        for (int c4 = 0; c4 < NGS; ++c4) FS[c4] = *reinterpret_cast<const V*>(Kq + rowoff(lh) + c4 * E);
 #pragma unroll
-        for (int c4 = 0; c4 < NG; ++c4) FL[c4] = *reinterpret_cast<const V*>(Kq + rowoff(16 + l16) + c4 * E);
+        for (int c4 = 0; c4 < NG; ++c4) FL[c4] = *reinterpret_cast<const V*>(Kq + rowoff(HALF + lh) + c4 * E);
       }
     } else if constexpr (!MFROW) {
       const T* myrow = Kh + rowoff(NPL == NP ? i : min(i, NPL - 1));  // (idle lanes re-read the last live row)
@@ -1116,42 +1134,75 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       __builtin_amdgcn_s_setprio(MGP_CHOL_PRIO);
 #endif
       if (MGP_PHASE(g, 8)) {
-        const int l16 = lane & 15;
-        T* colq = colbuf + (lane >> 4) * NP;  // the quarter's column buffer (the four overlay the row-address array)
-        colq[16 + l16] = FL[0][0];
-        colq[l16] = FS[0][0];
-        V piv = *reinterpret_cast<const V*>(colq);
+        const int lh = lane & (HALF - 1);
+        T* colq = colbuf + (lane / HALF) * NP;  // the neighbourhood's column buffer (together: the row-address array's space)
+        if constexpr (sizeof(T) == 4) {
+          colq[HALF + lh] = FL[0][0];
+          colq[lh] = FS[0][0];
+          V piv = *reinterpret_cast<const V*>(colq);
 #pragma unroll
-        for (int j = 0; j < KFIX; ++j) {
-          constexpr int dummy = 0;
-          (void)dummy;
-          const int g0 = j / E, e0 = j % E;
-          const bool sh = j < 16;  // (compile-time after unrolling) the short rows are still being eliminated
-          const T aL = FL[g0][e0];
-          const T aS = sh ? FS[g0 < 4 ? g0 : 0][e0] : T(0);
-          V col[NG];
-          col[g0] = piv;
+          for (int j = 0; j < KFIX; ++j) {
+            const int g0 = j / E, e0 = j % E;
+            const bool sh = j < HALF;  // (compile-time after unrolling) the short rows are still being eliminated
+            const T aL = FL[g0][e0];
+            const T aS = sh ? FS[g0 < NGS ? g0 : 0][e0] : T(0);
+            V col[NG];
+            col[g0] = piv;
 #pragma unroll
-          for (int c4 = g0 + 1; c4 < NG; ++c4) col[c4] = *reinterpret_cast<const V*>(colq + c4 * E);
-          const T p = piv[e0];
-          bad = bad || !(p > T(0));
-          const T rp = pivot_rcp(p);
-          const V ntL = V(-aL * rp), ntS = V(-aS * rp);
-          const int g1 = (j + 1 < KFIX ? j + 1 : j) / E;
-          FL[g1] = col[g1] * ntL + FL[g1];
-          if (sh && g1 < 4) FS[g1] = col[g1] * ntS + FS[g1];
-          if (j + 1 < KFIX) {  // look-ahead: column j + 1 is complete, post it and ask for its pivot group
-            colq[16 + l16] = FL[g1][(j + 1) % E];
-            if (j + 1 < 16) colq[l16] = FS[g1][(j + 1) % E];
-            piv = *reinterpret_cast<const V*>(colq + g1 * E);
+            for (int c4 = g0 + 1; c4 < NG; ++c4) col[c4] = *reinterpret_cast<const V*>(colq + c4 * E);
+            const T p = piv[e0];
+            bad = bad || !(p > T(0));
+            const T rp = pivot_rcp(p);
+            const V ntL = V(-aL * rp), ntS = V(-aS * rp);
+            const int g1 = (j + 1 < KFIX ? j + 1 : j) / E;
+            FL[g1] = col[g1] * ntL + FL[g1];
+            if (sh && g1 < NGS) FS[g1] = col[g1] * ntS + FS[g1];
+            if (j + 1 < KFIX) {  // look-ahead: column j + 1 is complete, post it and ask for its pivot group
+              colq[HALF + lh] = FL[g1][(j + 1) % E];
+              if (j + 1 < HALF) colq[lh] = FS[g1][(j + 1) % E];
+              piv = *reinterpret_cast<const V*>(colq + g1 * E);
+            }
+#pragma unroll
+            for (int c4 = g0; c4 < NG; ++c4)
+              if (c4 != g1) FL[c4] = col[c4] * ntL + FL[c4];
+            if (sh) {
+#pragma unroll
+              for (int c4 = g0; c4 < NGS; ++c4)
+                if (c4 != g1) FS[c4] = col[c4] * ntS + FS[c4];
+            }
           }
+        } else {
+          // fp64: no look-ahead, the column streamed GC groups at a time (as in phase 4), each group serving
+          // the long and -- while it has one -- the short row
 #pragma unroll
-          for (int c4 = g0; c4 < NG; ++c4)
-            if (c4 != g1) FL[c4] = col[c4] * ntL + FL[c4];
-          if (sh) {
+          for (int j = 0; j < KFIX; ++j) {
+            const int g0 = j / E, e0 = j % E;
+            const bool sh = j < HALF;
+            const T aL = FL[g0][e0];
+            const T aS = sh ? FS[g0 < NGS ? g0 : 0][e0] : T(0);
+            colq[HALF + lh] = aL;
+            if (sh) colq[lh] = aS;
+            const V cp = *reinterpret_cast<const V*>(colq + g0 * E);
+            const T p = cp[e0];
+            bad = bad || !(p > T(0));
+            const T rp = pivot_rcp(p);
+            const V ntL = V(-aL * rp), ntS = V(-aS * rp);
+            FL[g0] = cp * ntL + FL[g0];
+            if (sh) FS[g0 < NGS ? g0 : 0] = cp * ntS + FS[g0 < NGS ? g0 : 0];
+            constexpr int GC = MGP_F64_GC;
 #pragma unroll
-            for (int c4 = g0; c4 < 4; ++c4)
-              if (c4 != g1) FS[c4] = col[c4] * ntS + FS[c4];
+            for (int c0 = g0 + 1; c0 < NG; c0 += GC) {
+              V cv[GC];
+#pragma unroll
+              for (int u = 0; u < GC; ++u)
+                if (c0 + u < NG) cv[u] = *reinterpret_cast<const V*>(colq + (c0 + u) * E);
+#pragma unroll
+              for (int u = 0; u < GC; ++u)
+                if (c0 + u < NG) {
+                  FL[c0 + u] = cv[u] * ntL + FL[c0 + u];
+                  if (sh && c0 + u < NGS) FS[c0 + u] = cv[u] * ntS + FS[c0 + u];
+                }
+            }
           }
         }
       }
@@ -1161,19 +1212,19 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       // Schur block: the query row KFIX and the response row KFIX + 1 are rows 16 + l of lanes KFIX - 16, KFIX - 15
       {
         constexpr int QF = KFIX, YF = KFIX + 1;
-        const int l16 = lane & 15;
+        const int l16 = lane & (HALF - 1);
         const bool second = (lane >> 5) != 0;
-        const int64_t nbq = (second ? task : fold_task_a) * NH + ((lane >> 4) & 1);
+        const int64_t nbq = (second ? task : fold_task_a) * NH + (NH == 1 ? 0 : (lane / HALF) & 1);
         const bool liveq = nbq < a.b && (!second || have_b);
         T* mean = static_cast<T*>(a.mean);
         T* var = static_cast<T*>(a.var);
         T* yk = static_cast<T*>(a.ykinvy);
         const T sq = FL[QF / E][QF % E], sy = FL[YF / E][YF % E];
         if (liveq) {
-          if (l16 == QF - 16) {
+          if (l16 == QF - HALF) {
             var[nbq] = bad ? num<T>::nan() : sq;
             if (bad && a.info) atomicAdd(a.info, 1);
-          } else if (l16 == YF - 16) {
+          } else if (l16 == YF - HALF) {
             mean[nbq] = bad ? num<T>::nan() : -sq;
             if (yk) yk[nbq] = bad ? num<T>::nan() : -sy;
           }
