@@ -26,7 +26,9 @@ PER_FILE_FLAGS = {
     # the 64-step elimination must unroll completely (the fp64 / 16-response body exceeds the default
     # pragma-unroll budget, and a rolled loop indexes the 128-register row at run time = in scratch)
     "mgp_fused_rhs.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
-    "mgp_fused_wave.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
+    # (+ the register report of every instantiation -> lib/kernel_resources.json: the headline kernels sit at
+    # the 168-register cap of three waves per SIMD, and a spill there costs 30 %)
+    "mgp_fused_wave.hip": ["-mllvm", "-pragma-unroll-threshold=1000000", "-Rpass-analysis=kernel-resource-usage"],
     "mgp_solve_wave.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
     "mgp_backward.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
     "mgp_backward_wave.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
@@ -70,18 +72,44 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    resources = {}
     for cmd, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + out)
+        if "-Rpass-analysis=kernel-resource-usage" in cmd:
+            resources.update(_parse_resource_remarks(out))
+            out = "\n".join(ln for ln in out.splitlines() if "kernel-resource-usage" not in ln and "remark:" not in ln)
         if verbose and out.strip():
             print(out, file=sys.stderr)
+    if resources:
+        import json
+
+        with open(os.path.join(LIBDIR, "kernel_resources.json"), "w") as f:
+            json.dump(resources, f, indent=1, sort_keys=True)
     link = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB + ".tmp", *objs, "-ldl"]
     r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed: " + " ".join(link) + "\n" + r.stdout)
     os.replace(LIB + ".tmp", LIB)
     return LIB
+
+
+def _parse_resource_remarks(text: str) -> dict:
+    """{mangled kernel name: {"VGPRs": n, "VGPRs Spill": n, ...}} from -Rpass-analysis=kernel-resource-usage."""
+    import re
+
+    out, cur = {}, None
+    for ln in text.splitlines():
+        m = re.search(r"remark:\s+Function Name: (\S+)", ln)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z][A-Za-z /\[\]]*?): (\S+) \[-Rpass-analysis", ln)
+        if m and cur is not None:
+            v = m.group(2)
+            cur[m.group(1).strip()] = int(v) if v.isdigit() else v
+    return out
 
 
 # Static shapes compiled into the run-time-specialisation cache at build time (csrc/mgp_jit.hip; hiprtc

@@ -261,6 +261,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   constexpr bool FOLD = wave_fold(sizeof(T), NP, KFIX, RFIX, DFIX, PIPED, COEFF, GRAM);
   constexpr int HALF = NP / 2;    // (FOLD) lanes per neighbourhood; lane l owns rows l and HALF + l
   constexpr int NGS = HALF / WD.E;  // (FOLD) 16-byte groups of a short row
+  constexpr int LOGH = NP == 64 ? 5 : (NP == 32 ? 4 : 3);
   constexpr bool MFROW = MF && MGP_MFMA == 2 && !FOLD;
   constexpr bool MFX = MF && !MFROW;
   constexpr int BA = WD.BA;       // own rows per lane        } register blocking of the pair scheme,
@@ -1092,7 +1093,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     if constexpr (FOLD) {
       // the half-wave of this task of the pair picks its rows up, sixteen lanes per neighbourhood
       if ((lane >> 5) == fold_sub) {
-        const T* Kq = tile + (NH == 1 ? 0 : (lane / HALF) & 1) * KMAT;
+        const T* Kq = tile + (NH == 1 ? 0 : (lane >> LOGH) & 1) * KMAT;
         const int lh = lane & (HALF - 1);
 #pragma unroll
         for (int c4 = 0; c4 < NGS; ++c4) FS[c4] = *reinterpret_cast<const V*>(Kq + rowoff(lh) + c4 * E);
@@ -1135,7 +1136,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 #endif
       if (MGP_PHASE(g, 8)) {
         const int lh = lane & (HALF - 1);
-        T* colq = colbuf + (lane / HALF) * NP;  // the neighbourhood's column buffer (together: the row-address array's space)
+        T* colq = colbuf + (lane >> LOGH) * NP;  // the neighbourhood's column buffer (together: the row-address array's space)
         if constexpr (sizeof(T) == 4) {
           colq[HALF + lh] = FL[0][0];
           colq[lh] = FS[0][0];
@@ -1214,7 +1215,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         constexpr int QF = KFIX, YF = KFIX + 1;
         const int l16 = lane & (HALF - 1);
         const bool second = (lane >> 5) != 0;
-        const int64_t nbq = (second ? task : fold_task_a) * NH + (NH == 1 ? 0 : (lane / HALF) & 1);
+        const int64_t nbq = (second ? task : fold_task_a) * NH + (NH == 1 ? 0 : (lane >> LOGH) & 1);
         const bool liveq = nbq < a.b && (!second || have_b);
         T* mean = static_cast<T*>(a.mean);
         T* var = static_cast<T*>(a.var);
