@@ -50,7 +50,10 @@ struct RhsGeom {
 // steps, and mean_r = w . y_r are R plain dot products.  Per elimination step that is 1 instead of 1 + R
 // v_readlane_b32 and 1 instead of (1 + R) / 2 packed FMAs on the right-hand sides: at R = 16, 24 of ~90
 // instructions per step.
-template <typename T, int RC, bool BACK = false>  // RC: compiled number of response columns (run-time R <= RC)
+// GRAM (fp32, one feature stage, not Matern-1/2): rows centred on the query in place, pair
+// distances as |a'|^2 + |b'|^2 - 2 a'.b' -- one packed FMA per two features of a pair instead of a packed
+// subtract and a packed FMA -- and the crosswise distance of a lane is its row's norm, exactly.
+template <typename T, int RC, bool BACK = false, bool GRAM = false>  // RC: compiled number of response columns (run-time R <= RC)
 __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel(FusedArgs a, RhsGeom g) {
   constexpr int NP = 64;
   constexpr int NS = NP / 2;
@@ -158,6 +161,58 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
         for (int s = 0; s < NS; ++s) acc[s] = ACC(0);
       }
       const T* xq = tile + NP * xs;
+      if constexpr (GRAM) {
+        // centre row i on the query (times the inverse length scales), in place; |a'|^2 behind the row (column dst)
+        {
+          T* xrow = tile + i * xs;
+          ACC n2[2] = {ACC(0), ACC(0)};
+          for (int c0 = 0; c0 < wp; c0 += CH) {
+            V x0 = *reinterpret_cast<const V*>(xrow + c0), x1 = *reinterpret_cast<const V*>(xrow + c0 + E);
+            x0 = vsub(x0, *reinterpret_cast<const V*>(xq + c0));
+            x1 = vsub(x1, *reinterpret_cast<const V*>(xq + c0 + E));
+            if (aniso) {
+              x0 = x0 * *reinterpret_cast<const V*>(ilbuf + c0);
+              x1 = x1 * *reinterpret_cast<const V*>(ilbuf + c0 + E);
+            }
+            norm_accum(n2[0], x0);
+            norm_accum(n2[1], x1);
+            *reinterpret_cast<V*>(xrow + c0) = x0;
+            *reinterpret_cast<V*>(xrow + c0 + E) = x1;
+          }
+          const T nrm = acc_total(n2[0] + n2[1]);
+          xrow[dst] = nrm;
+          accq = ACC(0);
+          accq.x = nrm;  // the crosswise squared distance
+        }
+        __syncthreads();
+        for (int c0 = 0; c0 < wp; c0 += CH) {
+          V own0[BA], own1[BA];
+#pragma unroll
+          for (int j = 0; j < BA; ++j) {
+            const T* xj = tile + ((i + own_offset(j)) & (NP - 1)) * xs + c0;
+            own0[j] = *reinterpret_cast<const V*>(xj);
+            own1[j] = *reinterpret_cast<const V*>(xj + E);
+          }
+          static_for<BP>([&](auto sc) {
+            constexpr int s = decltype(sc)::value + 1;
+            const T* xo = tile + ((i + s) & (NP - 1)) * xs + c0;
+            const V o0 = *reinterpret_cast<const V*>(xo), o1 = *reinterpret_cast<const V*>(xo + E);
+            gram_block<BA, BP>(&acc[s - 1], own0, o0);
+            gram_block<BA, BP>(&acc[s - 1], own1, o1);
+          });
+        }
+        T nown[BA];
+#pragma unroll
+        for (int j = 0; j < BA; ++j) nown[j] = tile[((i + own_offset(j)) & (NP - 1)) * xs + dst];
+        static_for<BP>([&](auto sc) {
+          constexpr int s = decltype(sc)::value;
+          const T npar = tile[((i + s + 1) & (NP - 1)) * xs + dst];
+          static_for<BA>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            gram_finish(acc[j * BP + s], nown[j] + npar);
+          });
+        });
+      } else
       for (int c0 = 0; c0 < wp; c0 += CH) {
         V own0[BA], own1[BA];
 #pragma unroll
@@ -233,22 +288,27 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
     {
       T kv[NS];
       T kq = T(0);
+      auto sqd = [](const ACC& v) {
+        if constexpr (GRAM) return gram_sq(v);
+        else return acc_total(v);
+      };
+      const T cscale = post_scale;  // (1 under Anisotropy: the rows are scaled)
       kernel_dispatch(a.kernel_id, a.metric_id, [&](auto kid, auto mid) {
         constexpr int KID = decltype(kid)::value, MID = decltype(mid)::value;
         if constexpr (sizeof(T) == 4) {
           static_for<NS / 2>([&](auto sc) {  // two covariances per packed instruction
             constexpr int s = 2 * decltype(sc)::value;
-            const f2 kk = cov_from_sqdist2(f2{acc_total(acc[s]), acc_total(acc[s + 1])}, KID, MID, post_scale);
+            const f2 kk = cov_from_sqdist2(f2{sqd(acc[s]), sqd(acc[s + 1])}, KID, MID, cscale);
             kv[s] = kk.x;
             kv[s + 1] = kk.y;
           });
         } else {
           static_for<NS>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            kv[s] = cov_from_sqdist<T>(acc_total(acc[s]), KID, MID, post_scale);
+            kv[s] = cov_from_sqdist<T>(sqd(acc[s]), KID, MID, cscale);
           });
         }
-        kq = cov_from_sqdist<T>(acc_total(accq), KID, MID, post_scale);
+        kq = cov_from_sqdist<T>(sqd(accq), KID, MID, cscale);
       });
       static_for<NS>([&](auto sc) {
         constexpr int s = decltype(sc)::value + 1;
@@ -402,8 +462,8 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
   }
 }
 
-template <typename T, int RC, bool BACK = false>
-static int launch_rhs(const FusedArgs& a, hipStream_t stream) {
+template <typename T, int RC, bool BACK = false, bool GRAM = false>
+static int launch_rhs_impl(const FusedArgs& a, hipStream_t stream) {
   constexpr int NP = 64;
   constexpr int E = v16<T>::N;
   constexpr int CH = 2 * E;
@@ -421,13 +481,30 @@ static int launch_rhs(const FusedArgs& a, hipStream_t stream) {
   lds = (lds + 15) & ~(size_t)15;
   static Residency res;
   int per_cu = 0, cus = 0;
-  const int rc = res.lookup(reinterpret_cast<const void*>(&fused_rhs_kernel<T, RC, BACK>), 64, lds, &per_cu, &cus);
+  const int rc = res.lookup(reinterpret_cast<const void*>(&fused_rhs_kernel<T, RC, BACK, GRAM>), 64, lds, &per_cu, &cus);
   if (rc != MGP_OK) return rc;
   int64_t grid = (int64_t)cus * per_cu;
   if (grid > g.ntasks) grid = g.ntasks;
-  hipLaunchKernelGGL((fused_rhs_kernel<T, RC, BACK>), dim3((unsigned)grid), dim3(64), lds, stream, a, g);
+  hipLaunchKernelGGL((fused_rhs_kernel<T, RC, BACK, GRAM>), dim3((unsigned)grid), dim3(64), lds, stream, a, g);
   MGP_HIP_CHECK_LAUNCH();
   return MGP_OK;
+}
+
+#ifndef MGP_RHS_GRAM
+#define MGP_RHS_GRAM 1
+#endif
+template <typename T, int RC, bool BACK = false>
+static int launch_rhs(const FusedArgs& a, hipStream_t stream) {
+  if constexpr (sizeof(T) == 4 && MGP_RHS_GRAM) {
+    constexpr int CH = 2 * v16<T>::N;
+    // one feature stage (the norms live behind the staged row), and not the Matern-1/2 kernel: its slope at
+    // zero distance turns the cancellation error of the Gram form into covariance error
+    // (and rows of whole 16-byte groups, at least two: the tiny-d fixtures gain nothing and the 1-d one is
+    // ill-conditioned enough for the cancellation error to show)
+    if ((a.d + CH - 1) / CH * CH <= 64 && a.d % v16<T>::N == 0 && a.d >= CH && a.kernel_id != MGP_KERNEL_MATERN_05)
+      return launch_rhs_impl<T, RC, BACK, true>(a, stream);
+  }
+  return launch_rhs_impl<T, RC, BACK, false>(a, stream);
 }
 
 template <typename T>
