@@ -217,8 +217,10 @@ constexpr int wave_min_waves(int es, int NP, int KFIX) {
 #define MGP_FOLD64 1
 #endif
 constexpr bool wave_fold(int es, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF, bool GRAM) {
-  return MGP_FOLD && PIPED && KFIX > 0 && RFIX == 1 && DFIX > 0 && !COEFF && KFIX >= NP / 2 &&
-         es == 4 && ((NP == 32 && GRAM) || (NP == 64 && MGP_FOLD64));  // (fp64, 64 slots: 168 parked VGPRs -- spills)
+  // (fp64, 64 slots: 168 parked VGPRs -- spills; the difference-form distance phase needs more registers than
+  // the Gram form and spills too)
+  return MGP_FOLD && PIPED && KFIX > 0 && RFIX >= 1 && DFIX > 0 && !COEFF && KFIX >= NP / 2 && es == 4 && GRAM &&
+         (NP == 32 || (NP == 64 && MGP_FOLD64));
 }
 constexpr int wave_colbuf_bytes(int es, int NP, bool fold) {
   const int need = fold ? (64 / (NP / 2)) * NP * es : 64 * es;
@@ -1210,8 +1212,33 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 #if MGP_CHOL_PRIO
       __builtin_amdgcn_s_setprio(0);
 #endif
-      // Schur block: the query row KFIX and the response row KFIX + 1 are rows 16 + l of lanes KFIX - 16, KFIX - 15
-      {
+      // Schur block: the query row KFIX and the response rows behind it are long rows (lanes KFIX - HALF ...)
+      if constexpr (RFIX > 1) {
+        constexpr int QF = KFIX;
+        const int l16 = lane & (HALF - 1);
+        const bool second = (lane >> 5) != 0;
+        const int64_t nbq = (second ? task : fold_task_a) * NH + (NH == 1 ? 0 : (lane >> LOGH) & 1);
+        const bool liveq = nbq < a.b && (!second || have_b);
+        T* mean = static_cast<T*>(a.mean);
+        T* var = static_cast<T*>(a.var);
+        T* yk = static_cast<T*>(a.ykinvy);
+        const T sq = FL[QF / E][QF % E];  // column q of the lane's long row
+        T sd = T(0);                       // its diagonal: column HALF + l, picked out by a compare-select sweep
+        if (yk) {
+#pragma unroll
+          for (int c = QF + 1; c < NG * E; ++c) sd = c == HALF + l16 ? FL[c / E][c % E] : sd;
+        }
+        if (liveq) {
+          if (l16 == QF - HALF) {
+            var[nbq] = bad ? num<T>::nan() : sq;
+            if (bad && a.info) atomicAdd(a.info, 1);
+          } else if (l16 > QF - HALF && l16 <= QF - HALF + RFIX) {
+            const int r = l16 - (QF - HALF) - 1;
+            mean[nbq * RFIX + r] = bad ? num<T>::nan() : -sq;
+            if (yk) yk[nbq * RFIX + r] = bad ? num<T>::nan() : -sd;
+          }
+        }
+      } else {
         constexpr int QF = KFIX, YF = KFIX + 1;
         const int l16 = lane & (HALF - 1);
         const bool second = (lane >> 5) != 0;

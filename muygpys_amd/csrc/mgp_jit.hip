@@ -166,10 +166,41 @@ void store_cached(const Key& key, const std::string& name, const std::string& co
   if (!ok || rename(tmp.c_str(), path.c_str()) != 0) remove(tmp.c_str());
 }
 
-// compile (or fetch from disk) the code object of one instantiation; no GPU needed
+// VGPRs the register allocator spilled, from the code object's msgpack metadata (".vgpr_spill_count" is a
+// fixstr key followed by a small unsigned integer); -1 when the entry is not found
+int spilled_vgprs(const std::string& code) {
+  static const char key[] = "\xb1.vgpr_spill_count";
+  const size_t i = code.find(key, 0, sizeof key - 1);
+  if (i == std::string::npos || i + sizeof key - 1 + 3 > code.size()) return -1;
+  const unsigned char* p = reinterpret_cast<const unsigned char*>(code.data()) + i + sizeof key - 1;
+  if (p[0] < 0x80) return p[0];
+  if (p[0] == 0xcc) return p[1];
+  if (p[0] == 0xcd) return (p[1] << 8) | p[2];
+  return -1;
+}
+
+int compile_once(const Key& key, const char* extra_option, std::string* name, std::string* code);
+
+// compile (or fetch from disk) the code object of one instantiation; no GPU needed.  The folded elimination
+// (mgp_fused_wave_kernel.h, phase 4F) parks 48-96 registers across a task: where that makes the allocator
+// spill, the unfolded kernel is the faster one and is what gets cached.
 int ensure_code(const Key& key, std::string* name, std::string* code) {
-  Env& e = env();
   if (load_cached(key, name, code)) return MGP_OK;
+  int rc = compile_once(key, nullptr, name, code);
+  if (rc == MGP_OK && spilled_vgprs(*code) > 0) {
+    std::string name2, code2;
+    if (compile_once(key, "-DMGP_FOLD=0", &name2, &code2) == MGP_OK && spilled_vgprs(code2) == 0) {
+      if (env().trace) fprintf(stderr, "mgp: %s spills with the folded elimination: built without\n", instantiation(key).c_str());
+      *name = name2;
+      *code = code2;
+    }
+  }
+  if (rc == MGP_OK) store_cached(key, *name, *code);
+  return rc;
+}
+
+int compile_once(const Key& key, const char* extra_option, std::string* name, std::string* code) {
+  Env& e = env();
   if (!e.rtc.ok || !e.sources_ok) return MGP_EUNSUPPORTED;
   const std::string inst = instantiation(key);
   const std::string src = "#include \"mgp_fused_wave_kernel.h\"\ntemplate __global__ void " + inst +
@@ -179,6 +210,7 @@ int ensure_code(const Key& key, std::string* name, std::string* code) {
   std::vector<const char*> opts(kOptions, kOptions + sizeof kOptions / sizeof *kOptions);
   const std::string inc = "-I" + e.src_dir;
   opts.push_back(inc.c_str());
+  if (extra_option) opts.push_back(extra_option);
   int rc = MGP_EUNSUPPORTED;
   if (e.rtc.add_name(prog, inst.c_str()) == HIPRTC_SUCCESS &&
       e.rtc.compile(prog, (int)opts.size(), opts.data()) == HIPRTC_SUCCESS) {
@@ -189,7 +221,6 @@ int ensure_code(const Key& key, std::string* name, std::string* code) {
       code->resize(n);
       if (e.rtc.code(prog, &(*code)[0]) == HIPRTC_SUCCESS) {
         *name = lowered;
-        store_cached(key, *name, *code);
         rc = MGP_OK;
       }
     }

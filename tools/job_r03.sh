@@ -1,5 +1,5 @@
-python3 -m pytest tests -m gpu -q -x 2>&1 | tail -3
-python3 bench.py --cpu-sample 0 --no-secondary --config 5 --steps 5 | python3 -c "
-import json,sys; d=json.load(sys.stdin); print('c5', round(d['value']/1e6,1),'M/s', d['ms_per_step'], d['roofline']['frac'], d['roofline']['kernel'])"
-python3 tools/abtime.py --variants default --rounds 2 --aniso 1
-python3 tools/abtime.py --variants default --rounds 2 --dtype f64
+python3 -m pytest tests/test_gpu_jit.py tests/test_gpu_fused.py tests/test_gpu_backend.py -m gpu -q -x 2>&1 | tail -3
+for f in 1 0; do
+MGP_TRACE=0 python3 tools/kbench.py --k 28 --d 32 --R 3 --b 500000 --paths auto --packed 1 --rounds 3 2>&1 | tail -1
+done
+python3 tools/abtime.py --variants default --rounds 2
