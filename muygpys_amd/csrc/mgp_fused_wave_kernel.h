@@ -216,11 +216,15 @@ constexpr int wave_min_waves(int es, int NP, int KFIX) {
 #ifndef MGP_FOLD64
 #define MGP_FOLD64 1
 #endif
+// (fp64, 32 slots, folded: 96 parked VGPRs, 4-6 spilled at the headline shape -- measured 3.894 vs 3.899 ms: nothing)
+#ifndef MGP_FOLD_F64
+#define MGP_FOLD_F64 0
+#endif
 constexpr bool wave_fold(int es, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF, bool GRAM) {
   // (fp64, 64 slots: 168 parked VGPRs -- spills; the difference-form distance phase needs more registers than
   // the Gram form and spills too)
-  return MGP_FOLD && PIPED && KFIX > 0 && RFIX >= 1 && DFIX > 0 && !COEFF && KFIX >= NP / 2 && es == 4 && GRAM &&
-         (NP == 32 || (NP == 64 && MGP_FOLD64));
+  return MGP_FOLD && PIPED && KFIX > 0 && RFIX >= 1 && DFIX > 0 && !COEFF && KFIX >= NP / 2 &&
+         ((es == 4 && GRAM && (NP == 32 || (NP == 64 && MGP_FOLD64))) || (es == 8 && NP == 32 && MGP_FOLD_F64));
 }
 constexpr int wave_colbuf_bytes(int es, int NP, bool fold) {
   const int need = fold ? (64 / (NP / 2)) * NP * es : 64 * es;
@@ -463,7 +467,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 #ifndef MGP_FOLD_DPRE
 #define MGP_FOLD_DPRE 0
 #endif
-  constexpr bool XPK = XPRE && (NS > 16 || (FOLD && MGP_FOLD_XPK));  // (FOLD: the parked rows need the registers)
+  constexpr bool XPK = XPRE && (NS > 16 || (FOLD && (MGP_FOLD_XPK || sizeof(T) == 8)));  // (FOLD, fp64: the parked rows need the registers)
   static_assert(!XPK || NH * KMAT < 65536, "packed exchange offsets are 16-bit");
   int xoff[XPRE ? (XPK ? (NS + 1) / 2 : NS) : 1];
   unsigned xkeep = 0;

@@ -1,5 +1,3 @@
-python3 -m pytest tests/test_gpu_jit.py tests/test_gpu_fused.py tests/test_gpu_backend.py -m gpu -q -x 2>&1 | tail -3
-for f in 1 0; do
-MGP_TRACE=0 python3 tools/kbench.py --k 28 --d 32 --R 3 --b 500000 --paths auto --packed 1 --rounds 3 2>&1 | tail -1
-done
-python3 tools/abtime.py --variants default --rounds 2
+export MUYGPYS_HIP_JIT=0
+python3 tools/abtime.py --variants default,f64fold --rounds 3 --dtype f64
+MUYGPYS_HIP_LIB=$PWD/variants/lib_f64fold.so python3 -m pytest tests/test_gpu_fused.py -m gpu -q 2>&1 | tail -2
