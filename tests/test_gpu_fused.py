@@ -195,6 +195,46 @@ def test_static_headline_shape_variants(mode):
     assert_close(var.cpu().numpy(), v_ref, RTOL["float32"], f"var ({mode})")
 
 
+def test_folded_elimination_pairs_every_batch_size():
+    """The folded elimination (csrc/mgp_fused_wave_kernel.h, phase 4F) works on PAIRS of a workgroup's tasks:
+    every small batch size -- a workgroup with one task, an unpaired last task, a half-empty last wave, fewer
+    tasks than workgroups -- against the oracle, and a singular neighbourhood flagged on its own whichever half of
+    whichever task of a pair it sits in (the four neighbourhoods of one elimination share every instruction)."""
+    from muygpys_amd.fused import KernelSpec, posterior_mean_var
+
+    rng = np.random.default_rng(4)
+    N, d, k = 2000, 40, 30
+    X = rng.normal(size=(N, d))
+    y = np.sin(X[:, :3].sum(1))
+    Xd, yd = to_dev(X, torch.float32), to_dev(y, torch.float32)
+    spec, ospec = KernelSpec("matern15", "l2", 5.0, 1e-3), orc.Spec("matern15", "l2", 5.0, 1e-3)
+    for b in (1, 2, 3, 4, 5, 7, 8, 9, 6143, 6144, 6145, 12289, 12291):
+        bi = rng.choice(N, size=b, replace=True)
+        ni = np.stack([rng.choice(np.delete(np.arange(N), i), size=k, replace=False) for i in bi])
+        info = torch.zeros(1, dtype=torch.int32, device="cuda")
+        mean, var, yk = posterior_mean_var(spec, Xd, Xd, to_dev(bi), to_dev(ni), yd, want_ykinvy=True, info=info)
+        torch.cuda.synchronize()
+        assert int(info.item()) == 0
+        pick = np.unique(np.concatenate([np.arange(min(b, 40)), np.arange(max(b - 40, 0), b)]))
+        m_ref, v_ref = orc.posterior_mean_var(ospec, X, X, bi[pick], ni[pick], y)
+        assert_close(mean.cpu().numpy()[pick], m_ref, RTOL["float32"], f"mean (b={b})")
+        assert_close(var.cpu().numpy()[pick], v_ref, RTOL["float32"], f"var (b={b})")
+        assert torch.isfinite(yk).all()
+    # singular neighbourhoods (a duplicated neighbour, zero nugget): each position flagged alone
+    b = 24581
+    bi = rng.choice(N, size=b, replace=True)
+    ni = np.stack([rng.choice(np.delete(np.arange(N), i), size=k, replace=False) for i in bi])
+    broken = np.array([0, 1, 2, 3, 12290, 12291, 12293, b - 1])
+    ni[broken, 1] = ni[broken, 0]
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    mean, var = posterior_mean_var(KernelSpec("matern15", "l2", 5.0, 0.0), Xd, Xd, to_dev(bi), to_dev(ni), yd, info=info)
+    torch.cuda.synchronize()
+    nan_rows = torch.isnan(var).cpu().numpy()
+    assert int(info.item()) == len(broken)
+    assert sorted(np.flatnonzero(nan_rows)) == sorted(broken)
+    assert torch.isnan(mean.reshape(b, -1)[torch.from_numpy(broken).cuda()]).all()
+
+
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_rhs_columns_kernel_matches_golden(golden, dtype):
     """The right-hand-sides-as-columns kernel (mgp_fused_rhs.hip: k <= 64, R <= 16) on every
