@@ -1,5 +1,9 @@
 // Backward pass (vector-Jacobian product) on the phases of the wave kernel: k + 2 <= 64 slots,
-// Isotropy, d <= 64.  mgp_backward.hip states the maths (and remains the path for everything else):
+// d <= 64; Isotropy or (round 3) Anisotropy: the rows are scaled by the inverse length scales in place, after
+// which everything is the isotropic computation at l = 1, the feature cotangents pick the factor up again and
+// the per-feature length-scale partials are  dL/dl_f = -1/l_f sum_ij q_ij (z_if - z_jf)^2  (z = x / l, every
+// ordered pair once: the sweep of phase 7 visits each unordered pair from both ends and the factor 2 of
+// d(z^2)/dl cancels the 1/2).  mgp_backward.hip states the maths (and remains the path for everything else):
 //
 //   a = K^-1 c,  w = K^-1 (Y gm),   gK_ij = 2 gv a_i a_j - (a_i w_j + a_j w_i),  gc_j = w_j - 2 gv a_j
 //   q_ij = gK_ij dkappa/dacc_ij ;  gx_i = 2 / l^2 sum_j q_ij (x_i - x_j)        (reference: torch autograd
@@ -36,7 +40,8 @@ __global__ __launch_bounds__(64, 2) void backward_wave_kernel(BackwardArgs g, in
   T* colbuf = M + NH * NP * KS;                  // 64
   T* avec = colbuf + 64;                         // 64
   T* wvec = avec + 64;                           // 64
-  int64_t* idxbuf = reinterpret_cast<int64_t*>(wvec + 64);  // 64 row offsets (elements)
+  T* ilb = wvec + 64;                            // 64: inverse length scales (Anisotropy; zero past d)
+  int64_t* idxbuf = reinterpret_cast<int64_t*>(ilb + 64);  // 64 row offsets (elements)
 
   const T* feat_q = static_cast<const T*>(a.feat_q);
   const T* feat_nn = static_cast<const T*>(a.feat_nn);
@@ -50,8 +55,13 @@ __global__ __launch_bounds__(64, 2) void backward_wave_kernel(BackwardArgs g, in
   T* gls = static_cast<T*>(g.grad_ls);
   T* gnz = static_cast<T*>(g.grad_noise);
   const bool l2 = a.metric_id == MGP_METRIC_L2;
-  const T inv_l = T(1) / static_cast<const T*>(a.length_scale)[0];
+  const bool aniso = a.ls_count > 1;
+  const T inv_l = aniso ? T(1) : T(1) / static_cast<const T*>(a.length_scale)[0];
   const T post_scale = l2 ? inv_l : inv_l * inv_l;
+  if (aniso) {
+    const int f = threadIdx.x;
+    ilb[f] = f < a.d ? T(1) / static_cast<const T*>(a.length_scale)[f] : T(0);
+  }
   constexpr int wp = DG * E;                     // padded feature count (a multiple of the distance loop's chunk)
   static_assert(wp % CH == 0, "DG must be even");
   const int dv = (d + E - 1) / E;
@@ -109,6 +119,16 @@ __global__ __launch_bounds__(64, 2) void backward_wave_kernel(BackwardArgs g, in
       }
     }
     __syncthreads();
+    if (aniso) {  // z = x / l, in place (slot rows only: the right-hand-side slot is a zero row)
+      T* xrow = Xh + i * xs;
+#pragma unroll
+      for (int c4 = 0; c4 < DG; ++c4) {
+        V x = *reinterpret_cast<const V*>(xrow + c4 * E);
+        x = x * *reinterpret_cast<const V*>(ilb + c4 * E);
+        *reinterpret_cast<V*>(xrow + c4 * E) = x;
+      }
+      __syncthreads();
+    }
 
     // ---- phase 2: squared distances of the lane's NS pairs (kept: the derivative needs them) --------
     ACC acc[NS];
@@ -275,7 +295,7 @@ __global__ __launch_bounds__(64, 2) void backward_wave_kernel(BackwardArgs g, in
       if (gtg && gmean && i < k)
         for (int r = 0; r < R; ++r) unsafeAtomicAdd(gtg + myidx * (int64_t)R + r, gmean[nb * R + r] * xa);
     }
-    if (gls) {
+    if (gls && !aniso) {
       // sum over the lanes of the half
       T s = liso;
       for (int off = NP / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
@@ -284,11 +304,13 @@ __global__ __launch_bounds__(64, 2) void backward_wave_kernel(BackwardArgs g, in
     __syncthreads();
 
     // ---- phase 7: feature cotangents: gx_i = 2 sum_j q_ij (x_i - x_j) (the metric's 1/l^2 is in q) ------
-    if (gq || gnn) {
-      V xi[DG], sv[DG], qrow[NP / E];
+    const bool want_gl = gls && aniso;
+    if (gq || gnn || want_gl) {
+      V xi[DG], sv[DG], s2[DG], qrow[NP / E];
 #pragma unroll
       for (int c4 = 0; c4 < DG; ++c4) {
         sv[c4] = V(0);
+        s2[c4] = V(0);
         xi[c4] = *reinterpret_cast<const V*>(Xh + i * xs + c4 * E);
       }
 #pragma unroll
@@ -301,8 +323,17 @@ __global__ __launch_bounds__(64, 2) void backward_wave_kernel(BackwardArgs g, in
           V xr[DG];
 #pragma unroll
           for (int c4 = 0; c4 < DG; ++c4) xr[c4] = *reinterpret_cast<const V*>(xj + c4 * E);
+          if (want_gl) {  // (uniform)
 #pragma unroll
-          for (int c4 = 0; c4 < DG; ++c4) sv[c4] = (xi[c4] - xr[c4]) * qv + sv[c4];
+            for (int c4 = 0; c4 < DG; ++c4) {
+              const V t = (xi[c4] - xr[c4]) * qv;
+              sv[c4] = sv[c4] + t;
+              s2[c4] = t * (xi[c4] - xr[c4]) + s2[c4];
+            }
+          } else {
+#pragma unroll
+            for (int c4 = 0; c4 < DG; ++c4) sv[c4] = (xi[c4] - xr[c4]) * qv + sv[c4];
+          }
         }
       }
       // out through the tile (every lane is done reading it): consecutive lanes then add consecutive
@@ -310,7 +341,11 @@ __global__ __launch_bounds__(64, 2) void backward_wave_kernel(BackwardArgs g, in
       // lines per instruction (measured: 57 ms of a 65 ms launch)
       __syncthreads();
 #pragma unroll
-      for (int c4 = 0; c4 < DG; ++c4) *reinterpret_cast<V*>(Xh + i * xs + c4 * E) = (skip || i > k) ? V(0) : V(T(2)) * sv[c4];
+      for (int c4 = 0; c4 < DG; ++c4) {
+        V o = (skip || i > k) ? V(0) : V(T(2)) * sv[c4];
+        if (aniso) o = o * *reinterpret_cast<const V*>(ilb + c4 * E);  // dz/dx = 1 / l
+        *reinterpret_cast<V*>(Xh + i * xs + c4 * E) = o;
+      }
       __syncthreads();
       // consecutive lanes add consecutive features (row-major over the rows of the task): an atomic
       // instruction then touches 2-3 cache lines; (row, feature) advance incrementally, no division
@@ -330,6 +365,18 @@ __global__ __launch_bounds__(64, 2) void backward_wave_kernel(BackwardArgs g, in
           }
         }
       }
+      if (want_gl) {
+        // per-feature length-scale partials: the rows' sums go through the tile once more, lane f adds column f
+        __syncthreads();
+#pragma unroll
+        for (int c4 = 0; c4 < DG; ++c4) *reinterpret_cast<V*>(Xh + i * xs + c4 * E) = i > k ? V(0) : s2[c4];
+        __syncthreads();
+        for (int f = i; f < d; f += NP) {
+          T acc = T(0);
+          for (int j = 0; j <= k; ++j) acc += Xh[j * xs + f];
+          if (!skip) gls[nb * (int64_t)d + f] = -ilb[f] * acc;
+        }
+      }
     }
     if (bad && live && i == 0 && a.info) atomicAdd(a.info, 1);
   }
@@ -341,7 +388,7 @@ static int launch_bwd_np(const BackwardArgs& g, hipStream_t stream) {
   constexpr int E = v16<T>::N, KS = NP + E, xs = DG * E + E;
   const uintptr_t align = (uintptr_t)g.f.feat_q | (uintptr_t)g.f.feat_nn;
   const int vec_ok = (g.f.d % E == 0) && (align % 16 == 0);
-  const size_t lds = ((size_t)NH * NP * xs + (size_t)NH * NP * KS + 3 * 64) * sizeof(T) + 64 * sizeof(int64_t);
+  const size_t lds = ((size_t)NH * NP * xs + (size_t)NH * NP * KS + 4 * 64) * sizeof(T) + 64 * sizeof(int64_t);
   static Residency res;
   int per_cu = 0, cus = 0;
   const int rc = res.lookup(reinterpret_cast<const void*>(&backward_wave_kernel<T, NP, DG>), 64, lds, &per_cu, &cus);
@@ -369,11 +416,11 @@ static int launch_bwd_dg(const BackwardArgs& g, hipStream_t stream) {
   }
 }
 
-// Isotropy, d <= 64 (fp32) / 16 (fp64), k + 2 <= 64 (fp32) / 32 (fp64); everything else: MGP_EUNSUPPORTED (the LDS workgroup kernel)
+// d <= 64 (fp32) / 16 (fp64), k + 2 <= 64 (fp32) / 32 (fp64); everything else: MGP_EUNSUPPORTED (the LDS workgroup kernel)
 template <typename T>
 int launch_backward_wave(const BackwardArgs& g, hipStream_t stream) {
   const int rows = g.f.k + 2;
-  if (g.f.ls_count != 1 || g.f.d > 16 * (16 / (int)sizeof(T)) || rows > 64) return MGP_EUNSUPPORTED;
+  if ((g.f.ls_count != 1 && g.f.ls_count != g.f.d) || g.f.d > 16 * (16 / (int)sizeof(T)) || rows > 64) return MGP_EUNSUPPORTED;
   if (rows <= 32) return launch_bwd_dg<T, 32>(g, stream);
   if constexpr (sizeof(T) == 8) return MGP_EUNSUPPORTED;  // 64 fp64 row registers + the sweep's: spills
   else return launch_bwd_dg<T, 64>(g, stream);

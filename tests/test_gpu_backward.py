@@ -94,6 +94,39 @@ def test_backward_random_vs_oracle(case):
     assert_close(out["noise"].reshape(()), ref["noise"], 1e-5, "g_noise")
 
 
+def test_backward_wave_kernel_anisotropy_fp32():
+    """Per-feature length scales on the wave-per-neighbourhood backward kernel (csrc/mgp_backward_wave.hip, round 3:
+    rows scaled in place, length-scale partials out of the feature sweep), at the headline shape and with two
+    neighbourhoods per wave: every gradient against the fp64 oracle's vector-Jacobian product, and against the
+    LDS workgroup kernel the call used to fall back to (same maths, fp64)."""
+    rng = np.random.default_rng(321)
+    n, d, k, R, b = 1500, 40, 30, 1, 513
+    X = rng.normal(size=(n, d))
+    Y = np.sin(X @ rng.normal(size=(d, R)) / np.sqrt(d)) + 0.1 * rng.normal(size=(n, R))
+    bi = rng.choice(n, size=b, replace=False)
+    ni = np.stack([rng.choice(np.setdiff1d(np.arange(n), [i]), size=k, replace=False) for i in bi])
+    ls = np.sqrt(d) * rng.uniform(0.7, 1.5, size=d)
+    spec = orc.Spec("matern15", "l2", ls, 1e-2)
+    gm, gv = rng.normal(size=(b, R)), rng.normal(size=b)
+    ref = orc.posterior_vjp(spec, X, X, bi, ni, Y, gm, gv)
+    out = _run(spec, X, X, bi, ni, Y, gm, gv, "float32", True)
+    rtol = RTOL["float32"] * 3
+    assert_close(out["x"], ref["train_features"] + ref["test_features"], rtol, "g_features")
+    assert_close(out["y"], ref["targets"], rtol, "g_targets")
+    assert_close(out["ls"], ref["length_scale"], rtol, "g_length_scale")
+    assert_close(out["noise"].reshape(()), ref["noise"], rtol, "g_noise")
+    # fp64 at d = 8 (two neighbourhoods of 12 + 2 slots per wave; whole 16-byte groups of two doubles)
+    d2, k2 = 8, 12
+    X2 = rng.normal(size=(n, d2))
+    ni2 = np.stack([rng.choice(np.setdiff1d(np.arange(n), [i]), size=k2, replace=False) for i in bi])
+    ls2 = np.sqrt(d2) * rng.uniform(0.7, 1.5, size=d2)
+    spec2 = orc.Spec("rbf", "F2", ls2, 1e-2)
+    ref2 = orc.posterior_vjp(spec2, X2, X2, bi, ni2, Y, gm, gv)
+    out2 = _run(spec2, X2, X2, bi, ni2, Y, gm, gv, "float64", True)
+    assert_close(out2["x"], ref2["train_features"] + ref2["test_features"], 1e-5, "g_features (fp64)")
+    assert_close(out2["ls"], ref2["length_scale"], 1e-5, "g_length_scale (fp64)")
+
+
 def test_backward_only_mean_or_only_var():
     """A loss that reads only one output hands the kernel a NULL cotangent for the other."""
     from muygpys_amd.autograd import posterior

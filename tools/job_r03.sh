@@ -1,1 +1,1 @@
-python3 -m pytest tests/test_gpu_fused.py -m gpu -q -k "folded" 2>&1 | tail -15
+python3 -m pytest tests/test_gpu_backward.py tests/test_oracle_grad_golden.py -m gpu -q 2>&1 | tail -4
