@@ -1,2 +1,6 @@
-python3 bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err; python3 -c "
-import json; d=json.load(open('gpurun_out/bench_final.json')); print(d['value'], d['steps'], d['warmup'], d['ms_per_step'], d['roofline']['frac']); print({k:(round(v.get('value')/1e6,1),round(v.get('roofline',{}).get('frac'),4), v['steps']) for k,v in d['secondary'].items()}); print(d['cpu_baseline'])"
+for r in 1 2; do
+for v in variants/lib_head.so muygpys_amd/lib/libmuygpys_hip.so; do
+MUYGPYS_HIP_LIB=$PWD/$v python3 bench.py --cpu-sample 0 --no-secondary --config 5 --steps 30 --warmup 10 | python3 -c "
+import json,sys; d=json.load(sys.stdin); print('$v', round(d['value']/1e6,1),'M/s', round(d['ms_per_step'],3), round(d['roofline']['frac'],4))"
+done; done
+python3 -m pytest tests/test_gpu_fused.py tests/test_gpu_backend.py -m gpu -q 2>&1 | tail -2
