@@ -1,6 +1,4 @@
-for r in 1 2; do
-for v in variants/lib_head.so muygpys_amd/lib/libmuygpys_hip.so; do
-MUYGPYS_HIP_LIB=$PWD/$v python3 bench.py --cpu-sample 0 --no-secondary --config 5 --steps 30 --warmup 10 | python3 -c "
-import json,sys; d=json.load(sys.stdin); print('$v', round(d['value']/1e6,1),'M/s', round(d['ms_per_step'],3), round(d['roofline']['frac'],4))"
-done; done
-python3 -m pytest tests/test_gpu_fused.py tests/test_gpu_backend.py -m gpu -q 2>&1 | tail -2
+python3 -m pytest tests/test_gpu_fused.py tests/test_gpu_jit.py -m gpu -q 2>&1 | tail -2
+python3 bench.py --cpu-sample 0 --no-secondary --config 4 --steps 8 --warmup 3 | python3 -c "
+import json,sys; d=json.load(sys.stdin); print('c4', round(d['value']/1e6,1),'M/s', round(d['ms_per_step'],3), round(d['roofline']['frac'],4))"
+MUYGPYS_HIP_JIT=0 python3 tools/abtime.py --variants default --rounds 2 --dtype f64 --iters 30
