@@ -1288,14 +1288,17 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     // step is its own basic block -- two taken branches per step, and the wait-count pass, which starts
     // each block pessimistic, puts `s_waitcnt lgkmcnt(0)` in front of the trailing update, i.e. waits for
     // the look-ahead pivot it has just requested.  In one block the waits are counted.
+    // (static shapes only: with a run-time k every step stays a block of its own anyway, and the hoisted test costs
+    // the 64-slot fp64 run-time kernel 120 more spilled registers)
+    constexpr bool ONEB = MGP_CHOL_ONE_BLOCK && STAT;
 #if MGP_FAKE_HALFCHOL
     if (((task - task0) / t_step) & 1)  // timing experiment: every second elimination skipped (results invalid)
-#elif MGP_CHOL_ONE_BLOCK
-    if (MGP_PHASE(g, 8))
+#else
+    if (!ONEB || MGP_PHASE(g, 8))
 #endif
 #pragma unroll
     for (int j = 0; j < (STAT ? KFIX : NP - 2); ++j) {
-      if (j < k && (MGP_CHOL_ONE_BLOCK || MGP_PHASE(g, 8))) {
+      if (j < k && (ONEB || MGP_PHASE(g, 8))) {
         const T ajj = A[j / E][j % E];
         if constexpr (!LOOK) colh[i] = ajj;
         if constexpr (sizeof(T) == 8) {
