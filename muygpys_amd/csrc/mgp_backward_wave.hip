@@ -22,7 +22,9 @@ namespace mgp {
 
 // DG: 16-byte groups of a (zero-padded) feature row: the tile rows hold DG groups + one pad slot, so the
 // loops over features are compile-time and read zeros past d
-template <typename T, int NP, int DG>
+// KFIX > 0: nn_count known at compile time (the elimination, the back-substitution and the sweep lose their
+// per-step run-time tests: one basic block each, counted LDS waits)
+template <typename T, int NP, int DG, int KFIX = 0>
 __global__ __launch_bounds__(64, 2) void backward_wave_kernel(BackwardArgs g, int vec_ok) {
   constexpr int NH = 64 / NP;
   constexpr int NS = NP / 2, BA = 4, BP = NS / BA;
@@ -32,7 +34,7 @@ __global__ __launch_bounds__(64, 2) void backward_wave_kernel(BackwardArgs g, in
   using V = typename v16<T>::type;
   using ACC = typename v16<T>::acc;
   const FusedArgs& a = g.f;
-  const int k = a.k, d = a.d, R = a.R;
+  const int k = KFIX > 0 ? KFIX : a.k, d = a.d, R = a.R;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* X = reinterpret_cast<T*>(smem);             // NH * NP rows x xs
@@ -148,10 +150,18 @@ __global__ __launch_bounds__(64, 2) void backward_wave_kernel(BackwardArgs g, in
         const T* xo = Xh + ((i + s) & (NP - 1)) * xs + c0;
         const V o0 = *reinterpret_cast<const V*>(xo);
         const V o1 = *reinterpret_cast<const V*>(xo + E);
+        if constexpr (sizeof(T) == 4 && BA == 4) {
+          // hand-ordered packed blocks: no instruction reads its predecessor's result (mgp_wave_common.h)
+          dist_block4(acc[s - 1], acc[BP + s - 1], acc[2 * BP + s - 1], acc[3 * BP + s - 1], own0[0], own0[1], own0[2],
+                      own0[3], o0);
+          dist_block4(acc[s - 1], acc[BP + s - 1], acc[2 * BP + s - 1], acc[3 * BP + s - 1], own1[0], own1[1], own1[2],
+                      own1[3], o1);
+        } else {
 #pragma unroll
-        for (int j = 0; j < BA; ++j) {
-          accum(acc[j * BP + s - 1], vsub(own0[j], o0));
-          accum(acc[j * BP + s - 1], vsub(own1[j], o1));
+          for (int j = 0; j < BA; ++j) {
+            accum(acc[j * BP + s - 1], vsub(own0[j], o0));
+            accum(acc[j * BP + s - 1], vsub(own1[j], o1));
+          }
         }
       }
     }
@@ -198,8 +208,8 @@ __global__ __launch_bounds__(64, 2) void backward_wave_kernel(BackwardArgs g, in
     __builtin_amdgcn_s_setprio(2);  // chains of short dependent steps go first
     bool bad = false;
 #pragma unroll
-    for (int j = 0; j < NP - 2; ++j) {
-      if (j < k) {
+    for (int j = 0; j < (KFIX > 0 ? KFIX : NP - 2); ++j) {
+      if (KFIX > 0 || j < k) {
         const T ajj = A[j / E][j % E];
         colh[i] = ajj;
         __syncthreads();
@@ -228,18 +238,24 @@ __global__ __launch_bounds__(64, 2) void backward_wave_kernel(BackwardArgs g, in
     // ---- phase 5: back-substitution L^T [a w] = D^-1 L^-1 [c yt] ----------------------------------------
     T xa = i < k ? Mh[k * KS + i] : T(0);
     T xw = i < k ? Mh[(k + 1) * KS + i] : T(0);
-    for (int m = k - 1; m >= 1; --m) {
+    auto back_step = [&](int m) {
       T am = lane_value(xa, m), wm = lane_value(xw, m);
       if constexpr (NH == 2) {
         const T am1 = lane_value(xa, m + NP), wm1 = lane_value(xw, m + NP);
         am = h == 0 ? am : am1;
         wm = h == 0 ? wm : wm1;
       }
+      const T l = Mh[m * KS + (KFIX > 0 ? i : (i < m ? i : 0))];
       if (i < m) {
-        const T l = Mh[m * KS + i];
         xa = fma_t(-l, am, xa);
         xw = fma_t(-l, wm, xw);
       }
+    };
+    if constexpr (KFIX > 0) {
+#pragma unroll
+      for (int m = KFIX - 1; m >= 1; --m) back_step(m);
+    } else {
+      for (int m = k - 1; m >= 1; --m) back_step(m);
     }
     __builtin_amdgcn_s_setprio(0);
     __syncthreads();  // every lane is done with the multipliers: M becomes the q matrix
@@ -315,9 +331,11 @@ __global__ __launch_bounds__(64, 2) void backward_wave_kernel(BackwardArgs g, in
       }
 #pragma unroll
       for (int c4 = 0; c4 < NP / E; ++c4) qrow[c4] = *reinterpret_cast<const V*>(Mh + i * KS + c4 * E);
+      const int k_rt = a.k;  // (the run-time value on purpose: with every test folded the compiler hoists the 310
+                             //  row reads of the unrolled sweep to its top and spills -- measured 88 instead of 13 ms)
 #pragma unroll
-      for (int j = 0; j < NP - 1; ++j) {
-        if (j <= k) {  // uniform; the DG reads of a row are issued together
+      for (int j = 0; j < (KFIX > 0 ? KFIX + 1 : NP - 1); ++j) {
+        if (j <= k_rt) {  // uniform; the DG reads of a row are issued together
           const V qv = V(qrow[j / E][j % E]);
           const T* xj = Xh + j * xs;
           V xr[DG];
@@ -382,7 +400,7 @@ __global__ __launch_bounds__(64, 2) void backward_wave_kernel(BackwardArgs g, in
   }
 }
 
-template <typename T, int NP, int DG>
+template <typename T, int NP, int DG, int KFIX = 0>
 static int launch_bwd_np(const BackwardArgs& g, hipStream_t stream) {
   constexpr int NH = 64 / NP;
   constexpr int E = v16<T>::N, KS = NP + E, xs = DG * E + E;
@@ -391,12 +409,12 @@ static int launch_bwd_np(const BackwardArgs& g, hipStream_t stream) {
   const size_t lds = ((size_t)NH * NP * xs + (size_t)NH * NP * KS + 4 * 64) * sizeof(T) + 64 * sizeof(int64_t);
   static Residency res;
   int per_cu = 0, cus = 0;
-  const int rc = res.lookup(reinterpret_cast<const void*>(&backward_wave_kernel<T, NP, DG>), 64, lds, &per_cu, &cus);
+  const int rc = res.lookup(reinterpret_cast<const void*>(&backward_wave_kernel<T, NP, DG, KFIX>), 64, lds, &per_cu, &cus);
   if (rc != MGP_OK) return rc;
   const int64_t ntasks = (g.f.b + NH - 1) / NH;
   int64_t grid = (int64_t)cus * per_cu;
   if (grid > ntasks) grid = ntasks;
-  hipLaunchKernelGGL((backward_wave_kernel<T, NP, DG>), dim3((unsigned)grid), dim3(64), lds, stream, g, vec_ok);
+  hipLaunchKernelGGL((backward_wave_kernel<T, NP, DG, KFIX>), dim3((unsigned)grid), dim3(64), lds, stream, g, vec_ok);
   MGP_HIP_CHECK_LAUNCH();
   return MGP_OK;
 }
@@ -410,7 +428,12 @@ static int launch_bwd_dg(const BackwardArgs& g, hipStream_t stream) {
   if constexpr (sizeof(T) == 8) {
     return MGP_EUNSUPPORTED;  // fp64 rows of more than 16 features: the sweep's registers spill
   } else {
-    if (dv <= 10) return launch_bwd_np<T, NP, 10>(g, stream);  // d = 40: 2 KB of LDS less than DG = 12, one more wave per CU
+    if (dv <= 10) {  // d = 40: 2 KB of LDS less than DG = 12, one more wave per CU
+      if constexpr (NP == 32) {
+        if (g.f.k == 30 && dv == 10) return launch_bwd_np<T, NP, 10, 30>(g, stream);  // the headline shape, static
+      }
+      return launch_bwd_np<T, NP, 10>(g, stream);
+    }
     if (dv <= 12) return launch_bwd_np<T, NP, 12>(g, stream);
     return launch_bwd_np<T, NP, 16>(g, stream);
   }
