@@ -216,6 +216,10 @@ constexpr int wave_min_waves(int es, int NP, int KFIX) {
 #ifndef MGP_FOLD64
 #define MGP_FOLD64 1
 #endif
+// (16 slots, eight lanes per neighbourhood: k = 10, d = 8 / 40 / 64: 0.140 / 0.289 / 0.460 vs 0.138 / 0.292 / 0.463 ms -- nothing)
+#ifndef MGP_FOLD16
+#define MGP_FOLD16 0
+#endif
 // (fp64, 32 slots, folded: 96 parked VGPRs, 4-6 spilled at the headline shape -- measured 3.894 vs 3.899 ms: nothing)
 #ifndef MGP_FOLD_F64
 #define MGP_FOLD_F64 0
@@ -224,7 +228,7 @@ constexpr bool wave_fold(int es, int NP, int KFIX, int RFIX, int DFIX, bool PIPE
   // (fp64, 64 slots: 168 parked VGPRs -- spills; the difference-form distance phase needs more registers than
   // the Gram form and spills too)
   return MGP_FOLD && PIPED && KFIX > 0 && RFIX >= 1 && DFIX > 0 && !COEFF && KFIX >= NP / 2 &&
-         ((es == 4 && GRAM && (NP == 32 || (NP == 64 && MGP_FOLD64))) || (es == 8 && NP == 32 && MGP_FOLD_F64));
+         ((es == 4 && GRAM && (NP == 32 || (NP == 64 && MGP_FOLD64) || (NP == 16 && MGP_FOLD16))) || (es == 8 && NP == 32 && MGP_FOLD_F64));
 }
 constexpr int wave_colbuf_bytes(int es, int NP, bool fold) {
   const int need = fold ? (64 / (NP / 2)) * NP * es : 64 * es;
@@ -1099,7 +1103,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     if constexpr (FOLD) {
       // the half-wave of this task of the pair picks its rows up, sixteen lanes per neighbourhood
       if ((lane >> 5) == fold_sub) {
-        const T* Kq = tile + (NH == 1 ? 0 : (lane >> LOGH) & 1) * KMAT;
+        const T* Kq = tile + (NH == 1 ? 0 : (lane >> LOGH) & (NH - 1)) * KMAT;
         const int lh = lane & (HALF - 1);
 #pragma unroll
         for (int c4 = 0; c4 < NGS; ++c4) FS[c4] = *reinterpret_cast<const V*>(Kq + rowoff(lh) + c4 * E);
@@ -1221,7 +1225,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         constexpr int QF = KFIX;
         const int l16 = lane & (HALF - 1);
         const bool second = (lane >> 5) != 0;
-        const int64_t nbq = (second ? task : fold_task_a) * NH + (NH == 1 ? 0 : (lane >> LOGH) & 1);
+        const int64_t nbq = (second ? task : fold_task_a) * NH + (NH == 1 ? 0 : (lane >> LOGH) & (NH - 1));
         const bool liveq = nbq < a.b && (!second || have_b);
         T* mean = static_cast<T*>(a.mean);
         T* var = static_cast<T*>(a.var);
@@ -1246,7 +1250,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         constexpr int QF = KFIX, YF = KFIX + 1;
         const int l16 = lane & (HALF - 1);
         const bool second = (lane >> 5) != 0;
-        const int64_t nbq = (second ? task : fold_task_a) * NH + (NH == 1 ? 0 : (lane >> LOGH) & 1);
+        const int64_t nbq = (second ? task : fold_task_a) * NH + (NH == 1 ? 0 : (lane >> LOGH) & (NH - 1));
         const bool liveq = nbq < a.b && (!second || have_b);
         T* mean = static_cast<T*>(a.mean);
         T* var = static_cast<T*>(a.var);
