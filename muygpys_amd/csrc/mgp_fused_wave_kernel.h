@@ -122,9 +122,6 @@
 #ifndef MGP_FOLD
 #define MGP_FOLD 1
 #endif
-#ifndef MGP_FAKE_HALFCHOL
-#define MGP_FAKE_HALFCHOL 0
-#endif
 
 namespace mgp {
 
@@ -1295,11 +1292,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     // (static shapes only: with a run-time k every step stays a block of its own anyway, and the hoisted test costs
     // the 64-slot fp64 run-time kernel 120 more spilled registers)
     constexpr bool ONEB = MGP_CHOL_ONE_BLOCK && STAT;
-#if MGP_FAKE_HALFCHOL
-    if (((task - task0) / t_step) & 1)  // timing experiment: every second elimination skipped (results invalid)
-#else
     if (!ONEB || MGP_PHASE(g, 8))
-#endif
 #pragma unroll
     for (int j = 0; j < (STAT ? KFIX : NP - 2); ++j) {
       if (j < k && (ONEB || MGP_PHASE(g, 8))) {

@@ -122,21 +122,6 @@ __device__ __forceinline__ void dist_block4(f2& a0, f2& a1, f2& a2, f2& a3, cons
                                             const v16<float>::type& w1, const v16<float>::type& w2,
                                             const v16<float>::type& w3, const v16<float>::type& o) {
   f2 t0, t1, t2, t3;
-#ifdef MGP_FAKE_GRAM
-  asm volatile(
-      "v_pk_fma_f32 %0, %8, %16, %0\n\t"
-      "v_pk_fma_f32 %1, %10, %16, %1\n\t"
-      "v_pk_fma_f32 %2, %12, %16, %2\n\t"
-      "v_pk_fma_f32 %3, %14, %16, %3\n\t"
-      "v_pk_fma_f32 %0, %9, %17, %0\n\t"
-      "v_pk_fma_f32 %1, %11, %17, %1\n\t"
-      "v_pk_fma_f32 %2, %13, %17, %2\n\t"
-      "v_pk_fma_f32 %3, %15, %17, %3"
-      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-      : "v"(w0.xy), "v"(w0.zw), "v"(w1.xy), "v"(w1.zw), "v"(w2.xy), "v"(w2.zw), "v"(w3.xy), "v"(w3.zw), "v"(o.xy),
-        "v"(o.zw));
-  return;
-#endif
   asm volatile(
       "v_pk_add_f32 %4, %8, %16 neg_lo:[0,1] neg_hi:[0,1]\n\t"
       "v_pk_add_f32 %5, %10, %16 neg_lo:[0,1] neg_hi:[0,1]\n\t"
@@ -248,11 +233,7 @@ __device__ __forceinline__ float half_pair_sum(float x) {
 __device__ __forceinline__ float gram_sq(const f2& a) { return a.x; }
 __device__ __forceinline__ double gram_sq(const double& a) { return a; }
 
-#ifdef MGP_FAKE_GRAM
-__device__ __forceinline__ float acc_total(const v16<float>::acc& a) { return __builtin_fabsf(a.x + a.y) * 4.0f + 20.0f; }
-#else
 __device__ __forceinline__ float acc_total(const v16<float>::acc& a) { return a.x + a.y; }
-#endif
 __device__ __forceinline__ double acc_total(const double& a) { return a; }
 
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
