@@ -111,11 +111,6 @@
 #ifndef MGP_F64_GC
 #define MGP_F64_GC 6
 #endif
-// fp32, 32 slots, static shapes, Gram form: the Gram matrix of the centred rows on the matrix cores
-// (v_mfma_f32_32x32x2_f32: exact fp32, a k-ordered fmaf chain), see the MF phases of the kernel
-#ifndef MGP_MFMA
-#define MGP_MFMA 0
-#endif
 // fp32, 32 slots, static shapes with k >= 16 and one response: the elimination FOLDED -- sixteen lanes per
 // neighbourhood, lane l holding the lower-triangle parts of rows l and 16 + l, four neighbourhoods (two
 // consecutive tasks of the workgroup) per elimination.  See phase 4F.
@@ -255,22 +250,12 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   constexpr bool MODM = WD.MODM;  // pair scheme modulo M feature rows (wave_dims)
   constexpr int M = WD.M;
   constexpr int NS = WD.NS;       // pairs per lane
-  // MF: the squared distances of a neighbourhood as ONE 32 x 32 product on the matrix cores instead of the
-  // lanes' pair scheme (phases 1b-3 below marked MF).  fp32, 32 slots, static shapes, Gram form.
-  constexpr bool MF = GRAM && sizeof(T) == 4 && NP == 32 && STAT && MGP_MFMA;
-  // how the products reach the elimination.  Default: through the exchange matrix -- the MFMA result (every
-  // pair twice) is written there, each lane picks its NS pairs of the cyclic scheme up, evaluates the
-  // covariance ONCE per pair and the rows are assembled as in the VALU kernels.  -DMGP_MFMA=2: no exchange,
-  // v_permlane32_swap leaves every lane its whole row and it evaluates all 32 entries itself (twice the
-  // transcendental work: measured slower, 1.90 vs 1.81 ms on the headline shape).
   // (32 slots, fp32, Gram form; or -- MGP_FOLD64 -- 64 slots: one neighbourhood per half-wave.  The query and
   // response rows must be among the long rows: k >= NP / 2)
   constexpr bool FOLD = wave_fold(sizeof(T), NP, KFIX, RFIX, DFIX, PIPED, COEFF, GRAM);
   constexpr int HALF = NP / 2;    // (FOLD) lanes per neighbourhood; lane l owns rows l and HALF + l
   constexpr int NGS = HALF / WD.E;  // (FOLD) 16-byte groups of a short row
   constexpr int LOGH = NP == 64 ? 5 : (NP == 32 ? 4 : 3);
-  constexpr bool MFROW = MF && MGP_MFMA == 2 && !FOLD;
-  constexpr bool MFX = MF && !MFROW;
   constexpr int BA = WD.BA;       // own rows per lane        } register blocking of the pair scheme,
   constexpr int BP = WD.BP;       // partner rows per lane    } see phase 2
   auto own_offset = [](int j) { return j == 0 ? 0 : (j + 1) * BP + 1; };
@@ -335,8 +320,6 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     const T l = ls[0];
     post_scale = a.metric_id == MGP_METRIC_L2 ? T(1) / l : T(1) / (l * l);
   }
-  // (MFX: the pair registers hold d^2 / 2)
-  const T cov_scale = MFX ? post_scale * (a.metric_id == MGP_METRIC_L2 ? T(1.41421356237309515) : T(2)) : post_scale;
   const bool nopad = k == q;  // every slot below q is a real neighbour
 
   // XCD-aware task order: workgroups b and b+8 share an XCD (round-robin dispatch), so give
@@ -472,7 +455,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   static_assert(!XPK || NH * KMAT < 65536, "packed exchange offsets are 16-bit");
   int xoff[XPRE ? (XPK ? (NS + 1) / 2 : NS) : 1];
   unsigned xkeep = 0;
-  if constexpr (XPRE && !MFROW) {
+  if constexpr (XPRE) {
     const int i0 = threadIdx.x & (NP - 1);
     const int hbase = (NH == 1 ? 0 : (int)threadIdx.x / NP) * KMAT;
     const int dump0 = TRI ? KMAT - E : (NP - 1) * KS + NP;
@@ -497,7 +480,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   // feature-tile rows of the lane's own and partner rows (phase 2), static shapes: lane-only as well
   constexpr bool DPRE = XPRE && DFIX > 0 && NP <= 32 && (!FOLD || MGP_FOLD_DPRE);  // (the 64-slot static kernels have no registers left for it)
   int down[DPRE ? BA : 1], dpar[DPRE ? BP : 1];
-  if constexpr (DPRE && !MF) {
+  if constexpr (DPRE) {
     const int i0 = threadIdx.x & (NP - 1);
     const int hb = (NH == 1 ? 0 : (int)threadIdx.x / NP) * NP * xs;
 #pragma unroll
@@ -552,9 +535,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       }
     }
 
-    ACC acc[MFROW ? 1 : NS];
-    typedef float mf_acc_t __attribute__((ext_vector_type(16)));
-    mf_acc_t mfa, mfb;  // (MF) the two neighbourhoods' products, then the lane's row
+    ACC acc[NS];
 #if MGP_CHOL_PRIO && MGP_PRIO_LATE_DROP
     __builtin_amdgcn_s_setprio(0);  // the distance phase: long independent streams, lowest priority
 #endif
@@ -636,97 +617,11 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         for (int c = lane; c < wp; c += 64) ilbuf[c] = c < w ? T(1) / ls[d0 + c] : T(0);
       __syncthreads();
 
-      if (d0 == 0 && !MFROW) {
+      if (d0 == 0) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) acc[s] = ACC(0);
       }
-      if constexpr (MF) {
-        // ---- phases 1b + 2 (MF): centred half rows in registers, -d^2/2 of all pairs by MFMA -------------
-        // Lane l takes features [hf HF, (hf + 1) HF) (hf = l / 32) of rows l % 32 of BOTH neighbourhoods,
-        // centres them on the query row (times the inverse length scales under Anisotropy) and feeds
-        // them, one feature per instruction, as the A and the B operand of v_mfma_f32_32x32x2_f32 (lane l
-        // supplies A[i = l % 32][k = l / 32] and B[k][j = l % 32]: the same value): D = X' X'^T.  One more
-        // instruction with A = (-n_i / 2, 1), B = (1, -n_j / 2) (n = squared norms of the centred rows) makes
-        // D_ij = a'.b' - (|a'|^2 + |b'|^2) / 2 = -d^2_ij / 2: the norms never travel through LDS.  The product
-        // is an fmaf chain over the features in fp32 (no wider accumulator), symmetric bit for bit.
-        if (MGP_PHASE(g, 2)) {
-          constexpr int HF = DSTFIX / 2, HG = HF / E;
-          static_assert(HF % E == 0, "half rows are whole 16-byte groups");
-          const int r = lane & 31, hf = lane >> 5;
-          const T* rowa = tile + r * xs + hf * HF;
-          const T* qa = tile + q * xs + hf * HF;
-          V xa[HG], xb[HG];
-          {
-            V qva[HG], qvb[HG];
-#pragma unroll
-            for (int c = 0; c < HG; ++c) {
-              xa[c] = *reinterpret_cast<const V*>(rowa + c * E);
-              xb[c] = *reinterpret_cast<const V*>(rowa + NP * xs + c * E);
-              qva[c] = *reinterpret_cast<const V*>(qa + c * E);
-              qvb[c] = *reinterpret_cast<const V*>(qa + NP * xs + c * E);
-            }
-#pragma unroll
-            for (int c = 0; c < HG; ++c) {
-              xa[c] = vsub(xa[c], qva[c]);
-              xb[c] = vsub(xb[c], qvb[c]);
-            }
-            if (aniso) {
-#pragma unroll
-              for (int c = 0; c < HG; ++c) {
-                const V il = *reinterpret_cast<const V*>(ilbuf + hf * HF + c * E);
-                xa[c] = xa[c] * il;
-                xb[c] = xb[c] * il;
-              }
-            }
-          }
-          ACC na2[2] = {ACC(0), ACC(0)}, nb2[2] = {ACC(0), ACC(0)};
-#pragma unroll
-          for (int c = 0; c < HG; ++c) {
-            norm_accum(na2[c & 1], xa[c]);
-            norm_accum(nb2[c & 1], xb[c]);
-          }
-          // squared norm of the whole row: this half + the half of lane l ^ 32 (same order in both lanes)
-          const float na = half_pair_sum(acc_total(na2[0] + na2[1])), nb = half_pair_sum(acc_total(nb2[0] + nb2[1]));
-#pragma unroll
-          for (int v = 0; v < 16; ++v) mfa[v] = mfb[v] = 0.0f;
-#pragma unroll
-          for (int c = 0; c < HG; ++c)
-#pragma unroll
-            for (int e = 0; e < E; ++e) {  // two independent accumulation chains, interleaved
-              mfa = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[c][e], xa[c][e], mfa, 0, 0, 0);
-              mfb = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[c][e], xb[c][e], mfb, 0, 0, 0);
-            }
-          mfa = __builtin_amdgcn_mfma_f32_32x32x2f32(hf == 0 ? -0.5f * na : 1.0f, hf == 0 ? 1.0f : -0.5f * na, mfa, 0, 0, 0);
-          mfb = __builtin_amdgcn_mfma_f32_32x32x2f32(hf == 0 ? -0.5f * nb : 1.0f, hf == 0 ? 1.0f : -0.5f * nb, mfb, 0, 0, 0);
-          // D has its column on the lane (l % 32) and rows 8 (v / 4) + 4 (l / 32) + v % 4 in register v --
-          // by symmetry: ROW l % 32, those columns.  Swapping the upper half of mfa with the lower half of mfb
-          // (v_permlane32_swap) leaves lane (h, i) with all 32 columns of row i of neighbourhood h: column
-          // 8 (v / 4) + v % 4 in mfa[v], + 4 in mfb[v].  No exchange matrix.
-          if constexpr (MFROW) {
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-              float lo = mfa[v], hi = mfb[v];
-              swap_halves(lo, hi);
-              mfa[v] = lo;
-              mfb[v] = hi;
-            }
-          } else {
-            // into the exchange matrices (the tile is free: every operand sits in registers, and LDS runs in
-            // order): entry [row j = l % 32][column 8 b + 4 hf + e] <- register 4 b + e; then the lane's pairs
-            T* drow = tile + r * KS + hf * E;
-#pragma unroll
-            for (int b4 = 0; b4 < 4; ++b4) {
-              *reinterpret_cast<V*>(drow + 8 * b4) = V{mfa[4 * b4], mfa[4 * b4 + 1], mfa[4 * b4 + 2], mfa[4 * b4 + 3]};
-              *reinterpret_cast<V*>(drow + KMAT + 8 * b4) = V{mfb[4 * b4], mfb[4 * b4 + 1], mfb[4 * b4 + 2], mfb[4 * b4 + 3]};
-            }
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {  // d^2 / 2 (the factor rides in cov_scale)
-              acc[s].x = __builtin_fmaxf(-tile[xoff[s]], 0.0f);
-              acc[s].y = 0.0f;
-            }
-          }
-        }
-      } else if constexpr (GRAM) {
+      if constexpr (GRAM) {
         // ---- phase 1b: centre the rows on the query, in place; squared norms --------------------
         // Row i becomes a' = (a - q) [x inverse length scales]; |a'|^2 goes to the first element of the
         // row's padding slot (column dst), where the lanes that pair with the row pick it up.  The query
@@ -912,99 +807,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 #endif
     __syncthreads();  // every lane is done reading the feature tile (Kh aliases it)
     V A[NG];
-    if constexpr (MFROW) {
-      // ---- phase 3 (MF): covariances of the lane's row in place, nugget, response rows ------------------
-      int i3 = i;
-      asm volatile("" : "+v"(i3));
-      constexpr int NC = NG * E;  // columns of the live 16-byte groups
-      float rowv[NC];
-      // the responses of the neighbours, one column per response row, where the response lanes pick up
-      // their rows (the tile is free: every operand sits in registers)
-      T* ybuf = tile + (NH == 1 ? 0 : (lane / NP)) * (R * NP);
-      ybuf[i3] = myy0;
-      if (PACKED && !a.targets_batch) {
-#pragma unroll
-        for (int r = 1; r < E; ++r)
-          if (r < R) ybuf[r * NP + i3] = i3 < k ? myyv[r] : T(0);
-      } else {
-        for (int r = 1; r < R; ++r) ybuf[r * NP + i3] = i3 < k ? targets[mytg * (int64_t)R + r] : T(0);
-      }
-      if (MGP_PHASE(g, 4)) {
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {  // d^2 / 2 = max(-D, 0)
-          const int v = 4 * (c / 8) + c % 4;
-          rowv[c] = __builtin_fmaxf(-((c & 4) ? mfb[v] : mfa[v]), 0.0f);
-        }
-        // the metric's argument first (the registers hold d^2 / 2: the factor goes into the scale), then one
-        // dispatch over the kernel function alone: 5 + 1 copies of the 32-entry evaluation instead of 11
-        {
-          const bool l2m = a.metric_id == MGP_METRIC_L2;
-          const float post2 = post_scale * (l2m ? 1.41421356237309515f : 2.0f);
-          if (l2m) {
-#pragma unroll
-            for (int c = 0; c < NC; ++c) rowv[c] = sqrt_fast(rowv[c]);
-          }
-#pragma unroll
-          for (int c = 0; c < NC; c += 2) {
-            const f2 x = f2{rowv[c], rowv[c + 1]} * f2{post2, post2};
-            rowv[c] = x.x;
-            rowv[c + 1] = x.y;
-          }
-        }
-        kernel_dispatch_gen(a.kernel_id, MGP_METRIC_F2, [&](auto kid, auto mid) {
-          constexpr int KID = decltype(kid)::value;
-          if constexpr (KID == MGP_KERNEL_MATERN_GEN) {
-            // entries that are a covariance: columns <= q other than the diagonal, of rows <= q
-            const unsigned livec = i3 <= q ? (((2u << q) - 1u) & ~(1u << i3)) : 0u;
-            // (at most 16 at a time: the node loop keeps three registers per entry)
-            constexpr int C1 = NC < 16 ? NC : 16, C2 = NC - C1;
-            {
-              float part[C1];
-#pragma unroll
-              for (int u = 0; u < C1; ++u) part[u] = rowv[u];
-              matern_gen_eval<C1>(part, livec, gtab, (float)a.smoothness, g.gen_h, g.gen_lc);
-#pragma unroll
-              for (int u = 0; u < C1; ++u) rowv[u] = part[u];
-            }
-            if constexpr (C2 > 0) {
-              float part[C2 > 0 ? C2 : 1];
-#pragma unroll
-              for (int u = 0; u < C2; ++u) part[u] = rowv[C1 + u];
-              matern_gen_eval<(C2 > 0 ? C2 : 1)>(part, livec >> 16, gtab, (float)a.smoothness, g.gen_h, g.gen_lc);
-#pragma unroll
-              for (int u = 0; u < C2; ++u) rowv[C1 + u] = part[u];
-            }
-          } else {
-#pragma unroll
-            for (int c = 0; c < NC; c += 2) {
-              const f2 kk = cov_from_sqdist2(f2{rowv[c], rowv[c + 1]}, KID, MGP_METRIC_F2, 1.0f);
-              rowv[c] = kk.x;
-              rowv[c + 1] = kk.y;
-            }
-          }
-        });
-      }
-      // the diagonal: 1 + nugget (neighbours), 1 (query).  Column c is the diagonal in lanes c and c + 32: a
-      // constant lane mask, shifted along (one v_cndmask_b32 per column, no compare).
-      {
-        const float dv = i3 < k ? 1.0f + myeps : 1.0f;
-        unsigned long long dmask = 0x0000000100000001ull;
-        asm volatile("" : "+s"(dmask));
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          if (c <= KFIX) asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(rowv[c]) : "v"(dv), "s"(dmask));
-          dmask <<= 1;
-        }
-      }
-#pragma unroll
-      for (int c4 = 0; c4 < NG; ++c4) A[c4] = V{rowv[c4 * E], rowv[c4 * E + 1], rowv[c4 * E + 2], rowv[c4 * E + 3]};
-      // response lanes: their rows are the response columns (zero from column k on)
-      if (i3 > q && i3 < NPL) {
-        const T* yrow = ybuf + (i3 - q - 1) * NP;
-#pragma unroll
-        for (int c4 = 0; c4 < NG; ++c4) A[c4] = *reinterpret_cast<const V*>(yrow + c4 * E);
-      }
-    } else {
+    {
       // re-materialise the slot index here so that the per-offset masks/addresses of this phase
       // are computed now and not kept alive (or spilled) across the distance loop
       int i3 = i;
@@ -1043,7 +846,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
                 float sqd;
                 if constexpr (GRAM) sqd = gram_sq(acc[s]);
                 else sqd = acc_total(acc[s]);
-                kv[s] = (MID == MGP_METRIC_L2 ? sqrt_fast(sqd) : sqd) * cov_scale;
+                kv[s] = (MID == MGP_METRIC_L2 ? sqrt_fast(sqd) : sqd) * post_scale;
               }
               matern_gen_eval<NS>(kv, xkeep, gtab, (float)a.smoothness, g.gen_h, g.gen_lc);
 #pragma unroll
@@ -1058,11 +861,11 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
             };
 #pragma unroll
             for (int s = 0; s + 1 < NS; s += 2) {
-              const f2 kk = cov_from_sqdist2(f2{sq(s), sq(s + 1)}, KID, MID, cov_scale);
+              const f2 kk = cov_from_sqdist2(f2{sq(s), sq(s + 1)}, KID, MID, post_scale);
               kv[s] = kk.x;
               kv[s + 1] = kk.y;
             }
-            if constexpr (NS % 2 == 1) kv[NS - 1] = cov_from_sqdist<T>(sq(NS - 1), KID, MID, cov_scale);
+            if constexpr (NS % 2 == 1) kv[NS - 1] = cov_from_sqdist<T>(sq(NS - 1), KID, MID, post_scale);
 #pragma unroll
             for (int s = 1; s <= NS; ++s) put(s, kv[s - 1]);
           } else {
@@ -1107,7 +910,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 #pragma unroll
         for (int c4 = 0; c4 < NG; ++c4) FL[c4] = *reinterpret_cast<const V*>(Kq + rowoff(HALF + lh) + c4 * E);
       }
-    } else if constexpr (!MFROW) {
+    } else {
       const T* myrow = Kh + rowoff(NPL == NP ? i : min(i, NPL - 1));  // (idle lanes re-read the last live row)
 #pragma unroll
       for (int c4 = 0; c4 < NG; ++c4) A[c4] = *reinterpret_cast<const V*>(myrow + c4 * E);

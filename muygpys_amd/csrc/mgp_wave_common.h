@@ -217,19 +217,6 @@ __device__ __forceinline__ void gram_finish(f2& a, float nsum) {  // |a'|^2 + |b
   a.y = 0.0f;
 }
 __device__ __forceinline__ void gram_finish(double& a, double nsum) { a = __builtin_fmax(__builtin_fma(-2.0, a, nsum), 0.0); }
-// v_permlane32_swap_b32: lanes 32..63 of `lo` trade places with lanes 0..31 of `hi`.  Inline assembly: with
-// hipcc 7.2 both elements of __builtin_amdgcn_permlane32_swap's result read back as the FIRST (the IR
-// carries `extractvalue 0` twice).  The two wait states a VALU write of either operand needs before the
-// swap reads it ride inside the string (the hazard recogniser does not look into it).
-__device__ __forceinline__ void swap_halves(float& lo, float& hi) {
-  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
-}
-// x(l) + x(l ^ 32), added in the same order in both lanes
-__device__ __forceinline__ float half_pair_sum(float x) {
-  float lo = x, hi = x;
-  swap_halves(lo, hi);  // lo = x(l % 32), hi = x(l % 32 + 32) in every lane
-  return lo + hi;
-}
 __device__ __forceinline__ float gram_sq(const f2& a) { return a.x; }
 __device__ __forceinline__ double gram_sq(const double& a) { return a; }
 
