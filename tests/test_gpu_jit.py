@@ -27,6 +27,13 @@ SHAPES = [
     (40, 40, 1, "float32", "matern15", "l2", False, True),     # the reference's default nn_count
     (45, 24, 4, "float32", "rbf", "F2", False, False),
     (62, 16, 1, "float32", "matern15", "l2", False, True),     # 64 slots exactly
+    # the folded elimination's corners (fp32 Gram-form shapes with k >= slots / 2; phase 4F)
+    (16, 8, 1, "float32", "matern15", "l2", False, True),      # k = slots / 2: the query row is the first long row
+    (16, 16, 4, "float32", "rbf", "F2", False, True),          # ... with four responses from the prepared table
+    (29, 24, 2, "float32", "matern25", "l2", True, True),      # two responses, anisotropic, 32 of 32 slots
+    (22, 56, 1, "float32", "matern15", "l2", False, False),    # long rows: centred four groups at a time; plain tables
+    (32, 8, 1, "float32", "matern15", "l2", False, True),      # 64 slots, k = slots / 2
+    (33, 12, 3, "float32", "maternInf", "l2", False, True),    # 64 slots, three responses
     (10, 8, 1, "float64", "matern15", "l2", False, True),
     (25, 16, 1, "float64", "matern25", "l2", True, True),
     (40, 8, 2, "float64", "matern15", "l2", False, False),
