@@ -8,7 +8,7 @@ from typing import Callable, Dict, List, Tuple
 
 import numpy as np
 
-from .scalar import NamedParameter, Parameter
+from .scalar import NamedParameter, Parameter, _KeywordRouting
 
 
 class VectorParameter:
@@ -33,7 +33,7 @@ class VectorParameter:
         return all(p.fixed() for p in self._params)
 
 
-class NamedVectorParameter(VectorParameter):
+class NamedVectorParameter(_KeywordRouting, VectorParameter):
     def __init__(self, name: str, param: VectorParameter):
         self._params = [NamedParameter(name + str(i), p) for i, p in enumerate(param._params)]
         self._name = name
@@ -56,20 +56,6 @@ class NamedVectorParameter(VectorParameter):
         mine, _ = self.filter_kwargs(**kwargs)
         # element order = index order, whatever order the optimiser passed the keywords in
         return np.array([float(mine[p.name()]) for p in self._params], dtype=np.float64)
-
-    def apply_fn(self, fn: Callable) -> Callable:
-        def applied_fn(*args, **kwargs):
-            mine, rest = self.filter_kwargs(**kwargs)
-            return fn(*args, **mine, **rest)
-
-        return applied_fn
-
-    def apply_embedding_fn(self, fn: Callable, deformation_fn: Callable) -> Callable:
-        def embedded_fn(dists, *args, **kwargs):
-            mine, rest = self.filter_kwargs(**kwargs)
-            return fn(deformation_fn(dists, **mine), *args, **rest)
-
-        return embedded_fn
 
     def append_lists(self, names: List[str], params: List[float], bounds: List[Tuple[float, float]]):
         for p in self._params:
