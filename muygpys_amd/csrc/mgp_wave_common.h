@@ -244,7 +244,42 @@ __device__ __forceinline__ float exp_neg(float t) {
   const float e = __builtin_amdgcn_exp2f(hi);
   return __builtin_fmaf(e * lo, 0.693147180559945f, e);
 }
-__device__ __forceinline__ double exp_neg(double t) { return ::exp(-t); }
+// exp(-t) in fp64, t >= 0 (every caller passes a scaled distance).  The library exp is the same algorithm -- n =
+// rint(-t log2 e), r = -t - n ln 2 in two pieces, a degree-11 polynomial, ldexp -- but the compiler emits its
+// Horner steps as v_fmac_f64 into a register that has to be re-loaded with the coefficient first: 18 v_mov_b32
+// per evaluation next to 14 FMAs.  Here the coefficients are SGPR operands of v_fma_f64 (inline assembly: the
+// "s" constraint), written by the scalar unit.  Coefficients: the library's (degree 12, minimax on [-ln2/2, ln2/2]); the
+// overflow side needs no test (the argument is <= 0), underflow is ldexp's.
+#ifndef MGP_EXP64_LIB
+#define MGP_EXP64_LIB 0
+#endif
+__device__ __forceinline__ double fma_sc(double a, double b, double c_uniform) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c_uniform));
+  return d;
+}
+__device__ __forceinline__ double exp_neg(double t) {
+#if MGP_EXP64_LIB
+  return ::exp(-t);
+#else
+  const double n = __builtin_rint(t * -1.4426950408889634074);
+  double r = __builtin_fma(n, -6.93147180369123816490e-01, -t);
+  r = __builtin_fma(n, -1.90821492927058770002e-10, r);
+  constexpr auto C = [](unsigned long long bits) { return __builtin_bit_cast(double, bits); };
+  double p = fma_sc(r, C(0x3e5ae64567f544e4ull), C(0x3e928af3fca7ab0cull));  // ~ 1/12!, 1/11!
+  p = fma_sc(p, r, C(0x3ec71dee623fde64ull));
+  p = fma_sc(p, r, C(0x3efa01997c89e6b0ull));
+  p = fma_sc(p, r, C(0x3f2a01a014761f6eull));
+  p = fma_sc(p, r, C(0x3f56c16c1852b7b0ull));
+  p = fma_sc(p, r, C(0x3f81111111122322ull));
+  p = fma_sc(p, r, C(0x3fa55555555502a1ull));
+  p = fma_sc(p, r, C(0x3fc5555555555511ull));
+  p = fma_sc(p, r, C(0x3fe000000000000bull));
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return __builtin_amdgcn_ldexp(p, (int)__builtin_fmax(n, -1100.0));
+#endif
+}
 __device__ __forceinline__ float sqrt_fast(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ double sqrt_fast(double x) { return ::sqrt(x); }
 
