@@ -210,7 +210,9 @@ int mgp_posterior_gen_f64(const double* feat_q, const double* feat_nn, const voi
  * loops are compiled for exactly that shape: built into the library for the BASELINE shapes, compiled
  * on first use (hiprtc, ~1 s, cached on disk next to the library) for any other shape with
  * k + 1 + R <= 64, 16-byte rows and d <= 64 (fp32) / 32 (fp64) -- when the call has at least
- * MUYGPYS_HIP_JIT_MIN_BATCH neighbourhoods (default 65536).  MUYGPYS_HIP_JIT=0 turns it off (the
+ * MUYGPYS_HIP_JIT_MIN_BATCH neighbourhoods (default 65536); a shape whose kernel is loaded or in the disk
+ * cache already (the build compiles 78 common ones) is served by it from MUYGPYS_HIP_JIT_CACHED_MIN_BATCH
+ * neighbourhoods on (default 4096), without ever compiling.  MUYGPYS_HIP_JIT=0 turns it off (the
  * run-time-shape kernels serve every call), =force applies it to every call.  Results do not depend
  * on which kernel served a call beyond the rounding of a different summation order.
  *   mgp_jit_prepare: compile one shape into the disk cache ahead of time (no GPU needed);

@@ -102,11 +102,12 @@ template <typename T> int launch_solve_wave(const SolveArgs&, hipStream_t);  // 
 // register-resident wave-per-neighbourhood kernels; MGP_EUNSUPPORTED when the shape is not covered
 template <typename T> int launch_fused_wave(const FusedArgs&, hipStream_t);
 // run-time specialisation of the wave kernel (mgp_jit.hip)
-int jit_wave_function(int es, int np, int k, int R, int d, bool packed, bool gram, hipFunction_t* fn);
+int jit_wave_function(int es, int np, int k, int R, int d, bool packed, bool gram, hipFunction_t* fn, bool allow_compile = true);
 int jit_wave_prepare(int es, int np, int k, int R, int d, bool packed, bool gram);
 int jit_mode();
 int jit_loaded_count();
 int64_t jit_min_batch();
+int64_t jit_cached_min_batch();
 int prepare_fused_wave(int elem_size, int d, int k, int R, int packed, int kernel_id);  // compile into the disk cache
 // k <= 64 with up to 16 responses carried as right-hand-side columns (mgp_fused_rhs.hip)
 template <typename T> int launch_fused_rhs(const FusedArgs&, hipStream_t);

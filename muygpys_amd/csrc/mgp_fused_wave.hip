@@ -134,7 +134,7 @@ static int launch_jit(const FusedArgs& a, hipStream_t stream) {
   if (a.kernel_id == MGP_KERNEL_MATERN_GEN && sizeof(T) != 4) return MGP_EUNSUPPORTED;
   const bool gram = MGP_GRAM && gram_allowed<T>(a);
   hipFunction_t fn = nullptr;
-  const int jrc = jit_wave_function(sizeof(T), NP, a.k, a.R, a.d, packed, gram, &fn);
+  const int jrc = jit_wave_function(sizeof(T), NP, a.k, a.R, a.d, packed, gram, &fn, jit_mode() == 2 || a.b >= jit_min_batch());
   if (jrc != MGP_OK) return jrc;
   const WaveDims WD = wave_dims(sizeof(T), NP, a.k, a.R, a.d, false, gram);
   WaveGeom g;
@@ -185,7 +185,9 @@ int launch_fused_wave(const FusedArgs& a, hipStream_t stream) {
   }
   // other static shapes: the instantiation compiled at run time, when allowed and worth it (mgp_jit.hip)
   const bool builtin = a.R == 1 && ((a.k == 30 && a.d == 40) || (a.k == 50 && a.d == 8));
-  const bool try_jit = !builtin && jit_mode() != 0 && (jit_mode() == 2 || a.b >= jit_min_batch());
+  // (calls from MUYGPYS_HIP_JIT_MIN_BATCH neighbourhoods on may compile; shorter ones, from
+  // MUYGPYS_HIP_JIT_CACHED_MIN_BATCH on, take a kernel that is loaded or in the disk cache already)
+  const bool try_jit = !builtin && jit_mode() != 0 && (jit_mode() == 2 || a.b >= jit_cached_min_batch());
   if (a.packed_nn != nullptr) {  // prepared tables: the pipelined kernels only
     if (a.k == 30 && a.R == 1 && a.d == 40) return launch_np<T, 32, 30, 1, 40, true, false, true>(a, stream);
     if (a.k == 50 && a.R == 1 && a.d == 8) return launch_np<T, 64, 50, 1, 8, true, false, true>(a, stream);

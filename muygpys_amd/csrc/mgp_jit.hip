@@ -246,14 +246,23 @@ std::map<std::pair<int, Key>, Loaded> g_loaded;
 
 }  // namespace
 
-// MGP_OK and the kernel of one static instantiation on the current device, or MGP_EUNSUPPORTED
-int jit_wave_function(int es, int np, int k, int R, int d, bool packed, bool gram, hipFunction_t* fn) {
+// MGP_OK and the kernel of one static instantiation on the current device, or MGP_EUNSUPPORTED.
+// allow_compile = false: only what is loaded already or lies in the disk cache (the shapes compiled at build time,
+// or by an earlier run) -- a call too short to pay for a compile still gets its specialised kernel then.
+int jit_wave_function(int es, int np, int k, int R, int d, bool packed, bool gram, hipFunction_t* fn, bool allow_compile) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return MGP_EHIP;
   const Key key{es, np, k, R, d, packed ? 1 : 0, gram ? 1 : 0};
   std::lock_guard<std::mutex> lock(g_mu);
   Loaded& l = g_loaded[{dev, key}];
-  if (l.fn == nullptr && l.module == nullptr && l.status == MGP_EUNSUPPORTED) {
+  if (l.fn == nullptr && l.module == nullptr && (l.status == MGP_EUNSUPPORTED || (l.status == -4 && allow_compile))) {
+    if (!allow_compile) {
+      struct stat st;
+      if (stat(cache_path(key).c_str(), &st) != 0) {
+        l.status = -4;  // not cached (asked without the right to compile): a later large call may still build it
+        return MGP_EUNSUPPORTED;
+      }
+    }
     l.status = -3;  // tried
     std::string name, code;
     if (ensure_code(key, &name, &code) == MGP_OK && hipModuleLoadData(&l.module, code.data()) == hipSuccess &&
@@ -292,6 +301,15 @@ int jit_mode() {
     return 1;
   }();
   return mode;
+}
+// ... and from MUYGPYS_HIP_JIT_CACHED_MIN_BATCH neighbourhoods on (default 4096) when the shape's kernel is
+// already loaded or on disk
+int64_t jit_cached_min_batch() {
+  static const int64_t n = [] {
+    const char* s = getenv("MUYGPYS_HIP_JIT_CACHED_MIN_BATCH");
+    return s && *s ? (int64_t)atoll(s) : (int64_t)4096;
+  }();
+  return n;
 }
 int64_t jit_min_batch() {
   static const int64_t n = [] {

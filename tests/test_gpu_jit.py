@@ -102,3 +102,34 @@ def test_small_batches_keep_the_runtime_shape_kernels():
     posterior_mean_var(KernelSpec("matern15", "l2", 5.0, 1e-3), X, X, bi, ni, y)
     torch.cuda.synchronize()
     assert lib.mgp_jit_loaded_count() == before
+
+
+def test_medium_batches_take_cached_kernels_but_never_compile():
+    """From MUYGPYS_HIP_JIT_CACHED_MIN_BATCH (4096) neighbourhoods on a call takes the specialised kernel of its
+    shape when that lies in the disk cache already (the shapes compiled at build time) -- and still never waits
+    for a compile below MUYGPYS_HIP_JIT_MIN_BATCH."""
+    from muygpys_amd import _lib
+    from muygpys_amd.fused import KernelSpec, posterior_mean_var
+
+    lib = _lib.load()
+    if lib.mgp_jit_mode() != 1:
+        pytest.skip("automatic mode only")
+    gen = torch.Generator(device="cuda").manual_seed(8)
+    b = 8192 + 3
+
+    def run(k, d):
+        X = torch.randn(6000, d, device="cuda", generator=gen)
+        y = torch.randn(6000, device="cuda", generator=gen)
+        bi = torch.randint(0, 6000, (b,), device="cuda", generator=gen)
+        ni = torch.randint(0, 6000, (b, k), device="cuda", generator=gen)
+        spec = KernelSpec("matern15", "l2", float(np.sqrt(2 * d)), 1e-3)
+        before = lib.mgp_jit_loaded_count()
+        got = posterior_mean_var(spec, X, X, bi, ni, y, packed=True)
+        ref = posterior_mean_var(spec, X, X, bi, ni, y, path="generic", packed=False)
+        torch.cuda.synchronize()
+        for g, r in zip(got, ref):
+            assert_close(g.cpu().numpy(), r.cpu().numpy(), RTOL["float32"], f"k={k} d={d}")
+        return lib.mgp_jit_loaded_count() - before
+
+    assert run(25, 16) == 1, "a shape of the build-time cache must be served by its specialised kernel"
+    assert run(23, 28) == 0, "a shape that would have to be compiled must not be, at this batch size"
