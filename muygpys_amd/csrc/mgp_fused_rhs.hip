@@ -430,13 +430,25 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
     }
     if constexpr (BACK) {
       // w = K^-1 c: L^T w = D^-1 u, from the last row up; lane j takes l_mj w_m off for every m > j
+      // Eight steps per block: their multipliers are requested together (they do not depend on w), so the chain of
+      // dependent steps waits for LDS once per block instead of once per step (a test and an LDS round trip per step
+      // were 63 exposed latencies per neighbourhood).  The k test is per block, as in the elimination: the unused
+      // slots up to the end of k's block are identity rows whose multipliers were written as zeros.
       T w = u * inv_d;
 #pragma unroll
-      for (int m = NP - 1; m >= 1; --m) {
-        if (m < k) {  // (uniform)
-          const T lmj = Lm[i * LS + m];  // multiplier of row m at step i (junk for i >= m: masked below)
-          const T wm = lane_value(w, m);
-          if (i < m) w = fma_t(-lmj, wm, w);
+      for (int mb = NP - JB; mb >= 0; mb -= JB) {
+        if (mb < k) {  // (uniform)
+          T lm[JB];
+#pragma unroll
+          for (int e = 0; e < JB; ++e) lm[e] = Lm[i * LS + mb + e];  // multiplier of row mb + e at step i (junk for i >= mb + e: masked below)
+#pragma unroll
+          for (int e = JB - 1; e >= 0; --e) {
+            const int m = mb + e;
+            if (m >= 1) {
+              const T wm = lane_value(w, m);
+              if (i < m) w = fma_t(-lm[e], wm, w);
+            }
+          }
         }
       }
 #pragma unroll
