@@ -35,6 +35,9 @@
 #ifndef MGP_RHS_BACK
 #define MGP_RHS_BACK 1
 #endif
+#ifndef MGP_RHS_BACK_BLOCK
+#define MGP_RHS_BACK_BLOCK 32
+#endif
 
 namespace mgp {
 
@@ -430,19 +433,21 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
     }
     if constexpr (BACK) {
       // w = K^-1 c: L^T w = D^-1 u, from the last row up; lane j takes l_mj w_m off for every m > j
-      // Eight steps per block: their multipliers are requested together (they do not depend on w), so the chain of
+      // MGP_RHS_BACK_BLOCK (32; measured 4 / 8 / 16 / 32 / 64: 93.0 / 93.2 / 94.2 / 94.9 / 93.4 M/s on config 5) steps per
+      // block: their multipliers are requested together (they do not depend on w), so the chain of
       // dependent steps waits for LDS once per block instead of once per step (a test and an LDS round trip per step
       // were 63 exposed latencies per neighbourhood).  The k test is per block, as in the elimination: the unused
       // slots up to the end of k's block are identity rows whose multipliers were written as zeros.
       T w = u * inv_d;
+      constexpr int BB = MGP_RHS_BACK_BLOCK;
 #pragma unroll
-      for (int mb = NP - JB; mb >= 0; mb -= JB) {
+      for (int mb = NP - BB; mb >= 0; mb -= BB) {
         if (mb < k) {  // (uniform)
-          T lm[JB];
+          T lm[BB];
 #pragma unroll
-          for (int e = 0; e < JB; ++e) lm[e] = Lm[i * LS + mb + e];  // multiplier of row mb + e at step i (junk for i >= mb + e: masked below)
+          for (int e = 0; e < BB; ++e) lm[e] = Lm[i * LS + mb + e];  // multiplier of row mb + e at step i (junk for i >= mb + e: masked below)
 #pragma unroll
-          for (int e = JB - 1; e >= 0; --e) {
+          for (int e = BB - 1; e >= 0; --e) {
             const int m = mb + e;
             if (m >= 1) {
               const T wm = lane_value(w, m);
