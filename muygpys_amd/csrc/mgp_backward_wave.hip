@@ -238,24 +238,35 @@ __global__ __launch_bounds__(64, 2) void backward_wave_kernel(BackwardArgs g, in
     // ---- phase 5: back-substitution L^T [a w] = D^-1 L^-1 [c yt] ----------------------------------------
     T xa = i < k ? Mh[k * KS + i] : T(0);
     T xw = i < k ? Mh[(k + 1) * KS + i] : T(0);
-    auto back_step = [&](int m) {
-      T am = lane_value(xa, m), wm = lane_value(xw, m);
-      if constexpr (NH == 2) {
-        const T am1 = lane_value(xa, m + NP), wm1 = lane_value(xw, m + NP);
-        am = h == 0 ? am : am1;
-        wm = h == 0 ? wm : wm1;
-      }
-      const T l = Mh[m * KS + (KFIX > 0 ? i : (i < m ? i : 0))];
-      if (i < m) {
-        xa = fma_t(-l, am, xa);
-        xw = fma_t(-l, wm, xw);
-      }
-    };
-    if constexpr (KFIX > 0) {
+    // Eight steps per block: the multipliers do not depend on the solution and are requested together, the updates
+    // are selects, not branches -- a step that reads its multiplier inside a divergent `if` is a basic block of its
+    // own with an LDS round trip in the open (29 of them per neighbourhood; the same cure as in mgp_fused_rhs.hip).
+    {
+      constexpr int BB = 8;
+      constexpr int KTOP = KFIX > 0 ? KFIX : NP - 2;  // steps m = KTOP - 1 .. 1
 #pragma unroll
-      for (int m = KFIX - 1; m >= 1; --m) back_step(m);
-    } else {
-      for (int m = k - 1; m >= 1; --m) back_step(m);
+      for (int mb = (KTOP - 1) / BB * BB; mb >= 0; mb -= BB) {
+        if (KFIX > 0 || mb < k) {  // (uniform)
+          T lm[BB];
+#pragma unroll
+          for (int e = 0; e < BB; ++e) lm[e] = Mh[(mb + e) * KS + i];
+#pragma unroll
+          for (int e = BB - 1; e >= 0; --e) {
+            const int m = mb + e;
+            if (m >= 1 && m < KTOP) {
+              T am = lane_value(xa, m), wm = lane_value(xw, m);
+              if constexpr (NH == 2) {
+                const T am1 = lane_value(xa, m + NP), wm1 = lane_value(xw, m + NP);
+                am = h == 0 ? am : am1;
+                wm = h == 0 ? wm : wm1;
+              }
+              const bool on = i < m && (KFIX > 0 || m < k);
+              xa = on ? fma_t(-lm[e], am, xa) : xa;
+              xw = on ? fma_t(-lm[e], wm, xw) : xw;
+            }
+          }
+        }
+      }
     }
     __builtin_amdgcn_s_setprio(0);
     __syncthreads();  // every lane is done with the multipliers: M becomes the q matrix
