@@ -15,7 +15,13 @@ RBF prediction.
 itself with RANK / LOCAL_RANK / WORLD_SIZE set and relays rank 0's line.  Every rank holds a
 replica of the tables and its own b neighbourhoods (weak scaling, no data-path collective:
 the path shards embarrassingly); the timed region is bracketed by barrier + synchronize on
-both sides and the MAX over ranks is reported.
+both sides and the MAX over ranks is reported.  ``--scaling strong`` shards ONE global batch of the
+config's size over the ranks instead (reference chunk rule, _src/mpi_utils.py:36-41: BASELINE config 3's
+"same 1M batch sharded across 8 GPUs"); the line says which of the two was run.
+
+After every timed loop (headline and each secondary) 256 of the outputs the loop left in HBM are compared with
+the fp64 LDS workgroup kernel (an independent kernel family, plain tables) and the largest error goes into the
+line as ``check``: a number from a kernel whose results are wrong is not a number.
 
 Prints ONE JSON line on rank 0.
 """
@@ -219,9 +225,13 @@ def launch_ranks(n: int, argv) -> int:
     return rc
 
 
-def build_workload(cfg, dev, rank: int, knn: bool):
-    """Synthetic tables + neighbourhood indices of one config, resident in HBM."""
+def build_workload(cfg, dev, rank: int, knn: bool, world: int = 1, strong: bool = False):
+    """Synthetic tables + neighbourhood indices of one config, resident in HBM.  Weak scaling: every rank draws
+    its own b neighbourhoods; strong scaling: every rank draws the SAME global batch of b neighbourhoods and keeps
+    its contiguous block (the reference's chunk rule, _src/mpi_utils.py:36-41)."""
     import torch
+
+    from muygpys_amd.distributed import shard_bounds
 
     td = torch.float32 if cfg["dtype"] == "f32" else torch.float64
     n, k, d, R = cfg["points"], cfg["k"], cfg["d"], cfg["R"]
@@ -230,13 +240,16 @@ def build_workload(cfg, dev, rank: int, knn: bool):
     Xd = torch.from_numpy(X).to(dev, td)
     yd = torch.from_numpy(y).to(dev, td)
     del X, y
+    lo, hi = shard_bounds(b, rank, world) if strong else (0, b)
+    seed = 1 if strong else 1 + rank
     if knn:
-        bi_np = np.random.default_rng(1 + rank).permutation(n)[:b].astype(np.int64)
+        bi_np = np.random.default_rng(seed).permutation(n)[:b].astype(np.int64)[lo:hi]
         bi = torch.from_numpy(bi_np).to(dev)
         ni = knn_neighbors(Xd.float(), bi, k)
     else:
-        bi_np, ni_np = random_neighbors(n, b, k, 1 + rank)
-        bi, ni = torch.from_numpy(bi_np).to(dev), torch.from_numpy(ni_np).to(dev)
+        bi_np, ni_np = random_neighbors(n, b, k, seed)
+        bi, ni = torch.from_numpy(bi_np[lo:hi].copy()).to(dev), torch.from_numpy(ni_np[lo:hi].copy()).to(dev)
+    b = hi - lo
     ell = float(np.sqrt(d / 40.0) * 5.0)
     if cfg["metric"] == "F2":
         ell = 5.0
@@ -340,6 +353,50 @@ def time_steps(step, warmup: int, steps: int, dist, backend: str, dev):
     return elapsed, kern_ms, ranks_seen, last
 
 
+def spot_check(cfg, w, mean, var, rows: int = 256):
+    """Largest error of `rows` evenly spaced neighbourhoods of the outputs a timed loop left behind, against the
+    fp64 LDS workgroup kernel on plain tables (mgp_posterior_generic_f64: another kernel family, the one every
+    register kernel is tested against, itself pinned to the oracle and the reference fixtures in tests/).  Error
+    measure and tolerance are the test-suite's (tests/util.py: |a - b| <= rtol (|b| + rms(b)), north_star rtol)."""
+    import torch
+
+    from muygpys_amd.fused import KernelSpec, posterior_mean_var
+
+    b, k, R = w["b"], w["k"], w["R"]
+    if b == 0:
+        return None
+    pick = torch.unique(torch.linspace(0, b - 1, min(rows, b), device=w["bi"].device).round().long())
+    bi, ni = w["bi"][pick], w["ni"][pick]
+    # a compact fp64 copy of just the rows these neighbourhoods touch (the full tables can be gigabytes)
+    used = torch.unique(torch.cat([bi, ni.reshape(-1)]))
+    X64 = w["X"][used].double()
+    y64 = w["y"][used].double()
+    bi_c, ni_c = torch.searchsorted(used, bi), torch.searchsorted(used, ni.reshape(-1)).reshape(ni.shape)
+    ls = w["ls"]
+    spec = KernelSpec(cfg["kernel"], cfg["metric"], ls, cfg["noise"])
+    m_ref, v_ref = posterior_mean_var(spec, X64, X64, bi_c, ni_c, y64, path="generic", packed=False)
+    m_got = mean.reshape(b, -1)[pick].double().reshape(m_ref.shape)
+    v_got = var.reshape(b)[pick].double()
+
+    def rel(got, ref):
+        rms = torch.sqrt(torch.mean(ref * ref))
+        return float(((got - ref).abs() / (ref.abs() + rms)).max())
+
+    err = max(rel(m_got, m_ref), rel(v_got, v_ref))
+    tol = 1e-3 if cfg["dtype"] == "f32" else 1e-5
+    return {"rows": int(pick.numel()), "max_rel_err": err, "tol": tol, "ok": bool(err <= tol),
+            "against": "mgp_posterior_generic_f64 (fp64 LDS workgroup kernel, plain tables) on the same rows"}
+
+
+def _outputs_of(cfg, w, route: str, last):
+    """(mean, var) device tensors of the last timed step."""
+    if route == "fused" and cfg["objective"]:
+        return last["mean"], last["var"]
+    if route == "fused":
+        return w["mean"], w["var"]
+    return last[0], last[1]
+
+
 def roofline_of(cfg, w, avg_ms: float, kernel_name: str, objective: bool):
     s = 4 if cfg["dtype"] == "f32" else 8
     k, d, R, b = w["k"], w["d"], w["R"], w["b"]
@@ -360,7 +417,7 @@ def roofline_of(cfg, w, avg_ms: float, kernel_name: str, objective: bool):
     }
 
 
-def secondary_line(name: str, cfg_id: int, route: str, args, dev, steps: int = 5):
+def secondary_line(name: str, cfg_id: int, route: str, args, dev, steps: int = 5, knn: bool = False, **override):
     """A short run of another BASELINE config (or of the drop-in route on the headline config) for
     the driver's one line: value, ms_per_step, roofline / VALU fraction, kernel."""
     import gc
@@ -370,8 +427,8 @@ def secondary_line(name: str, cfg_id: int, route: str, args, dev, steps: int = 5
     from muygpys_amd import _lib
     from muygpys_amd.fused import PackedTable, clear_caches, pack_table
 
-    cfg = dict(CONFIGS[cfg_id])
-    w = build_workload(cfg, dev, 0, False)
+    cfg = dict(CONFIGS[cfg_id], **override)
+    w = build_workload(cfg, dev, 0, knn)
     gathered_route = route == "dropin_plain"
     use_packed = PackedTable.supported(w["d"], w["R"], w["k"], w["td"])
     if use_packed and route == "fused":
@@ -389,8 +446,8 @@ def secondary_line(name: str, cfg_id: int, route: str, args, dev, steps: int = 5
     if route == "fused" and cfg["objective"]:
         assert np.isfinite(last["lool"]) and np.isfinite(last["sigma_sq"]), f"{name}: non-finite objective"
     avg_ms = float(np.mean(kern_ms))
-    roof = roofline_of(cfg, w, avg_ms, _lib.served_by(w["d"], w["k"], w["R"], w["td"], bool(use_packed), "auto"),
-                       cfg["objective"])
+    roof = roofline_of(cfg, w, avg_ms, _lib.last_kernel(), cfg["objective"])  # the instantiation actually launched
+    check = spot_check(cfg, w, *_outputs_of(cfg, w, route, last))
     out = {
         "baseline_config": cfg_id, "route": route, "what": cfg["what"], "dtype": cfg["dtype"],
         "value": w["b"] * steps / elapsed, "unit": "neighborhoods/s", "steps": steps, "ms_per_step": elapsed / steps * 1e3,
@@ -398,8 +455,10 @@ def secondary_line(name: str, cfg_id: int, route: str, args, dev, steps: int = 5
         "roofline": {"frac": roof["frac"], "achieved": roof["achieved"], "traffic": roof["traffic"],
                      "traffic_source": roof["traffic_source"], "kernel_ms": avg_ms},
         "valu": {"frac": roof["valu"]["frac"], "achieved": roof["valu"]["achieved"], "unit": "TFLOP/s"},
-        "kernel": roof["kernel"],
+        "kernel": roof["kernel"], "check": check,
     }
+    if override or knn:
+        out["override"] = dict(override, **({"neighbours": "exact kNN (GPU brute force)"} if knn else {}))
     if gathered_route:
         out["note"] = ("responses in a plain torch tensor: the reference's own train_targets[nn_indices] materialises "
                        "(b, k) per step (a torch gather inside the timed step); features from the prepared table")
@@ -435,6 +494,9 @@ def main():
     ap.add_argument("--no-prepared-tables", action="store_true", help="read the plain feature / target tables")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the short runs of configs 3 / 4 / 5 and of the drop-in route attached as `secondary`")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank its own batch of the config's size; strong: ONE global batch of that size "
+                         "sharded over the ranks with the reference's chunk rule (BASELINE config 3)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for self-tests)")
     ap.add_argument("--one-device", action="store_true",
                     help="self-test only: every rank uses cuda:0 (exercises the N>1 logic on a 1-GPU box)")
@@ -481,8 +543,10 @@ def main():
         cfg["objective"] = True
     if args.route != "fused" and cfg["objective"]:
         raise SystemExit("bench.py: --route dropin times the prediction call sequence (configs 2 / 5)")
-    w = build_workload(cfg, dev, rank, args.knn)
+    strong = args.scaling == "strong"
+    w = build_workload(cfg, dev, rank, args.knn, world, strong)
     td, n, k, d, R, b = w["td"], w["n"], w["k"], w["d"], w["R"], w["b"]
+    total_b = min(cfg["batch"], n) if strong else world * b  # neighbourhoods all ranks process per step
     # the prepared tables are built once, outside the timed loop (they are constant across all
     # objective evaluations / prediction batches of a model; DESIGN.md sec. 5 gives the pack time)
     use_packed = (not args.no_prepared_tables) and args.path == "auto" and PackedTable.supported(d, R, k, td)
@@ -500,6 +564,7 @@ def main():
     step = make_step(cfg, w, args.route, args.path, use_packed if args.route == "fused" else "auto")
     elapsed, kern_ms, ranks_seen, last = time_steps(step, args.warmup, args.steps, dist, args.backend, dev)
     non_spd = int(w["info"].item())
+    kernel_name = _lib.last_kernel()  # the instantiation the timed steps actually launched (this thread's last call)
     if cfg["objective"]:
         assert np.isfinite(last["lool"]) and np.isfinite(last["sigma_sq"]), "non-finite objective"
     elif args.route == "fused":
@@ -509,15 +574,16 @@ def main():
 
     if rank == 0:
         avg_ms = float(np.mean(kern_ms))
-        kernel_name = _lib.served_by(d, k, R, td, bool(use_packed), args.path)
         roof = roofline_of(cfg, w, avg_ms, kernel_name, cfg["objective"])
+        check = spot_check(cfg, w, *_outputs_of(cfg, w, args.route, last))
+        assert check is None or check["ok"], f"timed outputs differ from the fp64 workgroup kernel: {check}"
         if pack_ms is not None:
             roof["prepared_table_pack_kernel_ms"] = pack_ms
             roof["frac_with_pack_per_step"] = roof["frac"] * avg_ms / (avg_ms + pack_ms)
         out = {
             "metric": "neighborhoods/sec (posterior mean+var)" if not cfg["objective"]
                       else "neighborhoods/sec (LOOCV objective evaluation)",
-            "value": world * b * args.steps / elapsed,
+            "value": total_b * args.steps / elapsed,
             "unit": "neighborhoods/s",
             "n_gpus": world,
             "ranks_seen": ranks_seen,
@@ -526,22 +592,25 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": cfg["dtype"],
             "data": "synthetic",
             "config": {
                 "workload": f"BASELINE config {args.config}: {cfg['what']}; {cfg['kernel']} nu-fixed, {n} synthetic "
-                            f"points, d={d}, nn_count={k}, responses={R}, {b} neighbourhoods per GPU per step, "
+                            f"points, d={d}, nn_count={k}, responses={R}, "
+                            + (f"ONE batch of {total_b} neighbourhoods per step sharded over {world} GPU(s) ({b} on rank 0), "
+                               if strong else f"{b} neighbourhoods per GPU per step, ") +
                             f"{'exact kNN' if args.knn else 'random'} neighbour rows, "
                             f"{'Anisotropy' if cfg['aniso'] else 'Isotropy'}/{cfg['metric']}, noise={cfg['noise']}",
                 "baseline_config": args.config, "route": args.route,
-                "points": n, "batch_per_gpu": b, "nn_count": k, "feature_count": d, "response_count": R,
+                "points": n, "batch_per_gpu": b, "batch_all_gpus": total_b, "nn_count": k, "feature_count": d, "response_count": R,
                 "kernel_path": args.path, "prepared_tables": bool(use_packed),
                 "prepared_table_pack_ms": pack_ms,
                 "non_spd_neighbourhoods": non_spd,
             },
             "roofline": roof,
+            "check": check,
         }
         if cfg["objective"]:
             out["config"]["lool"] = last["lool"]
@@ -560,15 +629,23 @@ def main():
             clear_caches()
             torch.cuda.empty_cache()
             sec = {}
-            plan = [("dropin", 2, "dropin"), ("dropin_plain", 2, "dropin_plain"), ("c3", 3, "fused"), ("c4", 4, "fused"),
-                    ("c5", 5, "fused")]
-            for name, cid, route in plan:
-                if cid == args.config and route == args.route:
+            # knn: config 2 on exact k-NN neighbourhoods (real gather locality instead of uniform-random rows);
+            # points8M: config 2 on an 8 M-row table (1.5 GB prepared: far beyond the 256 MB Infinity Cache);
+            # c3_shard8: one LOOCV evaluation of 125 k neighbourhoods = what each of 8 ranks runs under --scaling strong
+            plan = [("dropin", 2, "dropin", {}), ("dropin_plain", 2, "dropin_plain", {}), ("c3", 3, "fused", {}),
+                    ("c4", 4, "fused", {}), ("c5", 5, "fused", {}), ("knn", 2, "fused", {"knn": True}),
+                    ("points8M", 2, "fused", {"points": 8_000_000}), ("c3_shard8", 3, "fused", {"batch": 125_000})]
+            for name, cid, route, over in plan:
+                if cid == args.config and route == args.route and not over:
                     continue
                 try:
-                    sec[name] = secondary_line(name, cid, route, args, dev)
+                    sec[name] = secondary_line(name, cid, route, args, dev, **over)
                 except Exception as exc:  # a secondary line must never take the headline down
                     sec[name] = {"error": f"{type(exc).__name__}: {exc}"}
+            if "value" in sec.get("c3_shard8", {}) and "value" in sec.get("c3", {}):
+                # what strong scaling over 8 GPUs can reach at best: the 125 k-neighbourhood launch's rate relative to
+                # the 1 M-neighbourhood launch's (grid fill, clock ramp and the fixed cost of an evaluation)
+                sec["c3_shard8"]["rate_vs_full_batch"] = sec["c3_shard8"]["value"] / sec["c3"]["value"]
             out["secondary"] = sec
         if args.cpu_sample > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(k, d, args.cpu_sample, 20241008)

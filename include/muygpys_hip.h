@@ -156,6 +156,12 @@ int mgp_posterior_gathered_f64(const double* feat_q, const double* feat_nn, int 
  * duration they report).  Writes a NUL-terminated string into buf. */
 int mgp_posterior_kernel_name(int elem_size, int d, int k, int R, int packed, int path, char* buf, int len);
 
+/* Name of the kernel instantiation the calling thread's most recent mgp_posterior_* / mgp_loocv_* call actually
+ * launched ("" before the first).  Unlike mgp_posterior_kernel_name this reflects everything the dispatch looked at:
+ * batch thresholds and disk cache of the run-time compiler, table alignment, Gram-form eligibility of the
+ * covariance function.  Tests use it to prove that the kernel a benchmark line times is one the oracle has checked. */
+int mgp_last_kernel_name(char* buf, int len);
+
 /* ---------------------------------------------------------------------------
  * Prepared tables.  The gathers of T1/T2/T4 (_src/gp/tensors/numpy.py:47-69,
  * gp/muygps.py:474,543,545) read, per neighbour, a feature row and a 4/8-byte
@@ -219,10 +225,13 @@ int mgp_posterior_gen_f64(const double* feat_q, const double* feat_nn, const voi
  *                    MGP_OK, or MGP_EUNSUPPORTED (shape outside the static kernels, or no hiprtc).
  *   mgp_jit_mode:    0 off, 1 automatic, 2 forced.
  *   mgp_jit_loaded_count: run-time compiled kernels loaded in this process so far.
+ *   mgp_jit_source_hash:  the 16 hex digits every cache file name of THIS build ends in (kernel sources, compile
+ *                         options, hiprtc version); files with another suffix belong to other builds.
  * ------------------------------------------------------------------------- */
 int mgp_jit_prepare(int elem_size, int k, int R, int d, int packed, int kernel_id);
 int mgp_jit_mode(void);
 int mgp_jit_loaded_count(void);
+int mgp_jit_source_hash(char* buf, int len);
 int mgp_table_pack_f32(const float* features, const float* targets, int64_t n, int d, int R, void* packed,
                        int64_t stride_bytes, void* stream);
 int mgp_table_pack_f64(const double* features, const double* targets, int64_t n, int d, int R, void* packed,

@@ -108,6 +108,8 @@ def load():
     lib.mgp_knn_scan_bf16x3.restype = _i
     lib.mgp_posterior_kernel_name.argtypes = [_i, _i, _i, _i, _i, _i, C.c_char_p, _i]
     lib.mgp_posterior_kernel_name.restype = _i
+    lib.mgp_last_kernel_name.argtypes = [C.c_char_p, _i]
+    lib.mgp_last_kernel_name.restype = _i
     lib.mgp_reduce_scratch_doubles.restype = _i
     lib.mgp_matern_gen_constants.argtypes = [_d, C.POINTER(C.c_double)]
     lib.mgp_matern_gen_constants.restype = _i
@@ -157,6 +159,13 @@ def served_by(d: int, k: int, R: int, dtype, packed: bool = False, path: str = "
     if rc == -2 and packed:
         return served_by(d, k, R, dtype, False, path)
     check(rc, "mgp_posterior_kernel_name")
+    return buf.value.decode()
+
+
+def last_kernel() -> str:
+    """The instantiation this thread's most recent fused call actually launched (``mgp_last_kernel_name``)."""
+    buf = C.create_string_buffer(256)
+    check(load().mgp_last_kernel_name(buf, 256), "mgp_last_kernel_name")
     return buf.value.decode()
 
 

@@ -55,6 +55,13 @@ def _obj_fn_adapter(obj_fn, x0_names):
 
 def _get_opt_lists(muygps, verbose: bool = False):
     x0_names, x0, bounds = muygps.get_opt_params()
+    # Under sharded reductions every rank must walk the SAME trajectory (equal numbers of all-reduces, every
+    # shard evaluated at the same hyper-parameters): the start point is rank 0's, whenever and however this
+    # rank's model was built ("sample" / "log_sample" values drawn before the block was entered differ per rank).
+    from muygpys_amd import distributed as _D
+
+    if _D.reductions_active() and len(x0):
+        x0 = _D.broadcast_vector(np.asarray(x0, dtype=np.float64), _D.active_group())
     if verbose:
         print(f"parameters to be optimized: {x0_names}")
         print(f"bounds: {bounds}")

@@ -141,15 +141,19 @@ def prewarm(verbose: bool = False) -> int:
     ok = sum(1 for _, rc in done if rc == 0)
     if verbose:
         print(f"run-time specialisation cache: {ok} of {len(jobs)} shapes ready", file=sys.stderr)
-    # drop objects of older builds: the file name ends in the hash of the kernel sources, and the newest
-    # object carries the current one
+    # drop objects of other builds: a file name ends in the hash of kernel sources + options + compiler, and the
+    # library says which one is its own (the newest file need not be: an A -> B -> A source sequence keeps A's
+    # older objects, and a first-use compile of another source tree may be newer still)
     jit = os.path.join(LIBDIR, "jit")
     if ok and os.path.isdir(jit):
-        files = [f for f in os.listdir(jit) if f.endswith(".hsaco")]
-        if files:
-            current = max(files, key=lambda f: os.path.getmtime(os.path.join(jit, f))).rsplit("_", 1)[-1]
-            for f in files:
-                if f.rsplit("_", 1)[-1] != current:
+        import ctypes
+
+        lib = ctypes.CDLL(LIB)
+        buf = ctypes.create_string_buffer(32)
+        if lib.mgp_jit_source_hash(buf, 32) == 0:
+            current = buf.value.decode() + ".hsaco"
+            for f in os.listdir(jit):
+                if f.endswith(".hsaco") and f.rsplit("_", 1)[-1] != current:
                     os.remove(os.path.join(jit, f))
     return ok
 

@@ -106,6 +106,7 @@ int jit_wave_function(int es, int np, int k, int R, int d, bool packed, bool gra
 int jit_wave_prepare(int es, int np, int k, int R, int d, bool packed, bool gram);
 int jit_mode();
 int jit_loaded_count();
+uint64_t jit_source_hash();
 int64_t jit_min_batch();
 int64_t jit_cached_min_batch();
 int prepare_fused_wave(int elem_size, int d, int k, int R, int packed, int kernel_id);  // compile into the disk cache
@@ -116,6 +117,10 @@ template <typename T> int launch_fused_wide(const FusedArgs&, hipStream_t);
 int launch_fused_wide64(const FusedArgs&, hipStream_t);  // fp64, two lanes per row
 int max_nn_count(int elem_size, int R);
 int describe_fused_wave(int elem_size, int d, int k, int R, int packed, char* buf, int len);
+// the instantiation a posterior launcher actually put on the stream, per calling thread (mgp_last_kernel_name):
+// what served a call depends on more than the shape (batch thresholds of the run-time compiler, its disk cache,
+// alignment, the kernel's Gram-form eligibility), so tests and bench.py report THIS, not a description of the shape
+void note_launch(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 
 template <typename T>
 int launch_crosswise_diffs(const T*, const T*, int, const int64_t*, const int64_t*, int64_t, int, T*, hipStream_t);

@@ -5,7 +5,17 @@
 
 #include "mgp_args.h"
 
+#include <cstdarg>
+
 namespace mgp {
+
+static thread_local char g_last_kernel[256] = "";
+void note_launch(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_last_kernel, sizeof(g_last_kernel), fmt, ap);
+  va_end(ap);
+}
 
 static bool valid_kernel(int id) { return id >= MGP_KERNEL_RBF && id <= MGP_KERNEL_MATERN_INF; }
 static bool valid_metric(int id) { return id == MGP_METRIC_L2 || id == MGP_METRIC_F2; }
@@ -188,12 +198,22 @@ int mgp_posterior_kernel_name(int elem_size, int d, int k, int R, int packed, in
     snprintf(buf, len, "mgp::fused_generic_kernel<%s>", t);
   return MGP_OK;
 }
+int mgp_last_kernel_name(char* buf, int len) {
+  if (!buf || len < 1) return MGP_EINVAL;
+  snprintf(buf, len, "%s", mgp::g_last_kernel);
+  return MGP_OK;
+}
 int mgp_jit_prepare(int elem_size, int k, int R, int d, int packed, int kernel_id) {
   if ((elem_size != 4 && elem_size != 8) || k < 1 || R < 1 || d < 1 || !valid_kernel(kernel_id)) return MGP_EINVAL;
   return prepare_fused_wave(elem_size, d, k, R, packed, kernel_id);
 }
 int mgp_jit_mode(void) { return jit_mode(); }
 int mgp_jit_loaded_count(void) { return jit_loaded_count(); }
+int mgp_jit_source_hash(char* buf, int len) {
+  if (!buf || len < 17) return MGP_EINVAL;
+  snprintf(buf, len, "%016llx", (unsigned long long)jit_source_hash());
+  return MGP_OK;
+}
 int64_t mgp_packed_row_bytes(int d, int R, int elem_size) {
   if (d < 1 || R < 0 || (elem_size != 4 && elem_size != 8)) return MGP_EINVAL;
   // the gather always reads the 16-byte slot behind the features (the responses), also from a table

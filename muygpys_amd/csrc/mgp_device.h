@@ -33,12 +33,14 @@ template <> struct num<float> {
   static __device__ __forceinline__ float sqrt(float x) { return sqrtf(x); }
   static __device__ __forceinline__ float rsqrt(float x) { return 1.0f / sqrtf(x); }
   static __device__ __forceinline__ float nan() { return __builtin_nanf(""); }
+  static __device__ __forceinline__ float inf() { return __builtin_inff(); }
 };
 template <> struct num<double> {
   static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
   static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
   static __device__ __forceinline__ double rsqrt(double x) { return 1.0 / ::sqrt(x); }
   static __device__ __forceinline__ double nan() { return __builtin_nan(""); }
+  static __device__ __forceinline__ double inf() { return __builtin_inf(); }
 };
 
 // acc = sum_d (diff)^2 [anisotropic: sum_d (diff / l_d)^2].  Returns the kernel's

@@ -63,6 +63,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
   // register blocking of the pair scheme (mgp_fused_wave.hip, phase 2): BA own rows x BP partners
   constexpr int BA = 4;
   constexpr int BP = NS / BA;
+  static_assert(BA == 4, "the guarded Gram finish below is written for four own rows");
   auto own_offset = [](int j) { return j == 0 ? 0 : (j + 1) * BP + 1; };
   constexpr int E = v16<T>::N;
   constexpr int CH = 2 * E;
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
             *reinterpret_cast<V*>(xrow + c0 + E) = x1;
           }
           const T nrm = acc_total(n2[0] + n2[1]);
-          xrow[dst] = nrm;
+          xrow[dst] = i < k ? nrm : num<T>::inf();  // (unused slots: an infinite norm keeps their pairs away from the cancellation guard)
           accq = ACC(0);
           accq.x = nrm;  // the crosswise squared distance
         }
@@ -207,14 +208,28 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
         T nown[BA];
 #pragma unroll
         for (int j = 0; j < BA; ++j) nown[j] = tile[((i + own_offset(j)) & (NP - 1)) * xs + dst];
+        T guard = T(1);
         static_for<BP>([&](auto sc) {
           constexpr int s = decltype(sc)::value;
           const T npar = tile[((i + s + 1) & (NP - 1)) * xs + dst];
-          static_for<BA>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            gram_finish(acc[j * BP + s], nown[j] + npar);
-          });
+          gram_finish2(acc[s], acc[BP + s], nown[0] + npar, nown[1] + npar, guard);
+          gram_finish2(acc[2 * BP + s], acc[3 * BP + s], nown[2] + npar, nown[3] + npar, guard);
         });
+        // the cancellation guard tripped (mgp_wave_common.h): this neighbourhood's pair distances
+        // again in the difference form, on the same centred rows, pair by pair (rare: registers before speed)
+        if (gram_guard_tripped(guard)) {
+          static_for<NS>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            const T* xa = tile + ((i + own_offset(s / BP)) & (NP - 1)) * xs;
+            const T* xb = tile + ((i + s % BP + 1) & (NP - 1)) * xs;
+            ACC sum = ACC(0);
+#pragma nounroll
+            for (int c0 = 0; c0 < wp; c0 += E)
+              accum(sum, vsub(*reinterpret_cast<const V*>(xa + c0), *reinterpret_cast<const V*>(xb + c0)));
+            gram_from_diff(sum);
+            acc[s] = sum;
+          });
+        }
       } else
       for (int c0 = 0; c0 < wp; c0 += CH) {
         V own0[BA], own1[BA];
@@ -437,7 +452,10 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
       // block: their multipliers are requested together (they do not depend on w), so the chain of
       // dependent steps waits for LDS once per block instead of once per step (a test and an LDS round trip per step
       // were 63 exposed latencies per neighbourhood).  The k test is per block, as in the elimination: the unused
-      // slots up to the end of k's block are identity rows whose multipliers were written as zeros.
+      // slots behind k are identity rows (zero multipliers).  The elimination writes multiplier rows in blocks
+      // of JB = 8 steps and skips whole blocks behind k, so ROW i of Lm is written (by all 64 lanes) only for
+      // i < roundup8(k): a lane i >= k must not touch its row -- it would read never-written LDS (stale bits
+      // of an earlier launch; NaN x 0 = NaN), and its w is 0 anyway.  Hence the `i < min(m, k)` guard below.
       T w = u * inv_d;
       constexpr int BB = MGP_RHS_BACK_BLOCK;
 #pragma unroll
@@ -445,13 +463,13 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
         if (mb < k) {  // (uniform)
           T lm[BB];
 #pragma unroll
-          for (int e = 0; e < BB; ++e) lm[e] = Lm[i * LS + mb + e];  // multiplier of row mb + e at step i (junk for i >= mb + e: masked below)
+          for (int e = 0; e < BB; ++e) lm[e] = Lm[i * LS + mb + e];  // multiplier of row mb + e at step i (junk for i >= mb + e or i >= k: masked below)
 #pragma unroll
           for (int e = BB - 1; e >= 0; --e) {
             const int m = mb + e;
             if (m >= 1) {
               const T wm = lane_value(w, m);
-              if (i < m) w = fma_t(-lm[e], wm, w);
+              if (i < min(m, k)) w = fma_t(-lm[e], wm, w);
             }
           }
         }
@@ -504,6 +522,8 @@ static int launch_rhs_impl(const FusedArgs& a, hipStream_t stream) {
   if (grid > g.ntasks) grid = g.ntasks;
   hipLaunchKernelGGL((fused_rhs_kernel<T, RC, BACK, GRAM>), dim3((unsigned)grid), dim3(64), lds, stream, a, g);
   MGP_HIP_CHECK_LAUNCH();
+  note_launch("mgp::fused_rhs_kernel<%s,%d,%s,%s>", sizeof(T) == 4 ? "float" : "double", RC, BACK ? "true" : "false",
+              GRAM ? "true" : "false");
   return MGP_OK;
 }
 

@@ -89,6 +89,8 @@ static int launch_np_impl(const FusedArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL((fused_wave_kernel<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF, PACKED, GRAM>), dim3((unsigned)grid), dim3(64),
                      lds, stream, a, g);
   MGP_HIP_CHECK_LAUNCH();
+  note_launch("mgp::fused_wave_kernel<%s,%d,%d,%d,%d,%s,%s,%s,%s>", sizeof(T) == 4 ? "float" : "double", NP, KFIX, RFIX, DFIX,
+              PIPED ? "true" : "false", COEFF ? "true" : "false", PACKED ? "true" : "false", GRAM ? "true" : "false");
   return MGP_OK;
 }
 
@@ -171,6 +173,8 @@ static int launch_jit(const FusedArgs& a, hipStream_t stream) {
   void* params[] = {&args, &g};
   const hipError_t err = hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 64, 1, 1, (unsigned)lds, stream, params, nullptr);
   if (err != hipSuccess) return -(1000 + (int)err);
+  note_launch("mgp::fused_wave_kernel<%s,%d,%d,%d,%d,true,false,%s,%s> [run-time compiled]", sizeof(T) == 4 ? "float" : "double", NP,
+              a.k, a.R, a.d, packed ? "true" : "false", gram ? "true" : "false");
   return MGP_OK;
 }
 

@@ -192,7 +192,10 @@ constexpr int wave_tile_rows(const WaveDims& w, int NP, int KFIX, int xs) {
   if (!(w.STAT && w.NH == 1)) return w.NH * NP;
   const int spr = xs / w.E, pieces = ((KFIX + 1) * spr + 63) / 64;
   const int covered = (pieces * 64 + spr - 1) / spr;
-  return covered > w.NPL ? covered : w.NPL;
+  // (without the modulo-M pair scheme the pairs cycle over all NP slots: the rows behind the live ones must exist --
+  // the Gram path parks an infinite norm in them so that their pairs cannot trip the cancellation guard)
+  const int rows = w.MODM ? w.NPL : NP;
+  return covered > rows ? covered : rows;
 }
 constexpr int wave_gather_pieces(const WaveDims& w, int KFIX, int xs) {
   const int spr = xs / w.E;
@@ -669,6 +672,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
             }
             const ACC n2 = (n4[0] + n4[1]) + (n4[2] + n4[3]);
             if (has) xrow[dst] = acc_total(n2);
+            else if (!MODM) xrow[dst] = num<T>::inf();  // (no features: its pairs must not trip the cancellation guard)
           } else if constexpr (DFIX > 0) {
             V qv[NCF];
 #pragma unroll
@@ -691,6 +695,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
             for (int c = 0; c < NCF; ++c) norm_accum(n4[c & 3], x[c]);
             const ACC n2 = (n4[0] + n4[1]) + (n4[2] + n4[3]);
             if (has) xrow[dst] = acc_total(n2);
+            else if (!MODM) xrow[dst] = num<T>::inf();
           } else {
             ACC n2 = ACC(0);
             for (int c0 = 0; c0 < wp; c0 += CH) {
@@ -712,6 +717,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
               }
             }
             if (has) xrow[dst] = acc_total(n2);
+            else if (!MODM) xrow[dst] = num<T>::inf();
           }
         }
         __syncthreads();
@@ -747,10 +753,33 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
           for (int j = 0; j < BA; ++j) nown[j] = (DPRE ? tile + down[DPRE ? j : 0] : Xh + wrap(i + own_offset(j)) * xs)[dst];
 #pragma unroll
           for (int s = 1; s <= BP; ++s) npar[s - 1] = (DPRE ? tile + dpar[DPRE ? s - 1 : 0] : Xh + wrap(i + s) * xs)[dst];
+          T guard = T(1);
 #pragma unroll
-          for (int j = 0; j < BA; ++j)
+          for (int s = 0; s + 1 < NS; s += 2)
+            gram_finish2(acc[s], acc[s + 1], nown[s / BP] + npar[s % BP], nown[(s + 1) / BP] + npar[(s + 1) % BP], guard);
+          if constexpr (NS % 2 == 1) gram_finish1(acc[NS - 1], nown[(NS - 1) / BP] + npar[(NS - 1) % BP], guard);
+          // ---- phase 2G: the cancellation guard tripped (mgp_wave_common.h) -- some pair of this task lies much
+          // closer together than its rows lie to the query.  Rare (a query far outside a tight cluster), and
+          // wave-uniform: the task's distances again, in the difference form, on the same centred rows
+          // (a' - b' = a - b; under Anisotropy the rows are scaled already).  One 16-byte group per iteration,
+          // rolled: this path must cost the common one no registers.
+          if (gram_guard_tripped(guard)) {
+            // (pair by pair, one 16-byte group per iteration: two row addresses and three groups of registers
+            // live -- blocked like the common path it costs the headline kernel five spilled registers)
+            const int ngrp = (DFIX > 0 ? DSTFIX : wp) / E;
 #pragma unroll
-            for (int s = 0; s < BP; ++s) gram_finish(acc[j * BP + s], nown[j] + npar[s]);
+            for (int s = 0; s < NS; ++s) {
+              const T* xa = DPRE ? tile + down[DPRE ? s / BP : 0] : Xh + wrap(i + own_offset(s / BP)) * xs;
+              const T* xb = DPRE ? tile + dpar[DPRE ? s % BP : 0] : Xh + wrap(i + s % BP + 1) * xs;
+              ACC sum = ACC(0);
+#pragma nounroll
+              for (int c = 0; c < ngrp; ++c)
+                accum(sum, vsub(*reinterpret_cast<const V*>(xa + c * E), *reinterpret_cast<const V*>(xb + c * E)));
+              acc[s] = sum;
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) gram_from_diff(acc[s]);
+          }
         }
       } else
       if (MGP_PHASE(g, 2)) {

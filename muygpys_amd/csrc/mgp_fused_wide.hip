@@ -364,6 +364,7 @@ int launch_fused_wide(const FusedArgs& a, hipStream_t stream) {
               a.R, (long long)grid, lds, per_cu);
     hipLaunchKernelGGL(fused_wide_kernel, dim3((unsigned)grid), dim3(NP), lds, stream, a, g);
     MGP_HIP_CHECK_LAUNCH();
+    note_launch("mgp::fused_wide_kernel");
     return MGP_OK;
   }
 }

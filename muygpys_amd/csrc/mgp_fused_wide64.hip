@@ -359,6 +359,7 @@ int launch_fused_wide64(const FusedArgs& a, hipStream_t stream) {
             a.R, (long long)grid, lds, per_cu);
   hipLaunchKernelGGL(fused_wide64_kernel, dim3((unsigned)grid), dim3(256), lds, stream, a, g);
   MGP_HIP_CHECK_LAUNCH();
+  note_launch("mgp::fused_wide64_kernel");
   return MGP_OK;
 }
 

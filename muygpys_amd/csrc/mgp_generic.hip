@@ -220,6 +220,7 @@ int launch_fused_generic(const FusedArgs& in, hipStream_t stream) {
   hipLaunchKernelGGL(fused_generic_kernel<T>, dim3(grid_for(a.b, lds)), dim3(block_threads(a.k + 1 + a.R)), lds,
                      stream, a);
   MGP_HIP_CHECK_LAUNCH();
+  note_launch("mgp::fused_generic_kernel<%s>", sizeof(T) == 4 ? "float" : "double");
   return MGP_OK;
 }
 

@@ -41,6 +41,7 @@ struct Rtc {
   decltype(&hiprtcGetCodeSize) code_size = nullptr;
   decltype(&hiprtcGetCode) code = nullptr;
   decltype(&hiprtcDestroyProgram) destroy = nullptr;
+  decltype(&hiprtcVersion) version = nullptr;
   bool ok = false;
   Rtc() {
     for (const char* name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) {
@@ -58,6 +59,7 @@ struct Rtc {
     MGP_RTC_SYM(code_size, hiprtcGetCodeSize);
     MGP_RTC_SYM(code, hiprtcGetCode);
     MGP_RTC_SYM(destroy, hiprtcDestroyProgram);
+    MGP_RTC_SYM(version, hiprtcVersion);
 #undef MGP_RTC_SYM
     ok = create && add_name && compile && log_size && log && lowered && code_size && code && destroy;
   }
@@ -116,6 +118,10 @@ struct Env {
       h = fnv1a(text, h);
     }
     for (const char* o : kOptions) h = fnv1a(o, h);
+    // ... and the compiler: an object built by another hiprtc is not reused after an upgrade
+    int major = 0, minor = 0;
+    if (rtc.ok && rtc.version && rtc.version(&major, &minor) == HIPRTC_SUCCESS)
+      h = fnv1a("hiprtc " + std::to_string(major) + "." + std::to_string(minor), h);
     src_hash = h;
   }
 };
@@ -156,7 +162,7 @@ bool load_cached(const Key& key, std::string* name, std::string* code) {
 }
 
 void store_cached(const Key& key, const std::string& name, const std::string& code) {
-  mkdir(env().cache_dir.c_str(), 0777);
+  mkdir(env().cache_dir.c_str(), 0755);  // code objects: writable by their owner only
   const std::string path = cache_path(key), tmp = path + ".tmp" + std::to_string((long)getpid());
   FILE* f = fopen(tmp.c_str(), "wb");
   if (!f) return;  // a read-only tree: the object lives in this process only
@@ -275,6 +281,9 @@ int jit_wave_function(int es, int np, int k, int R, int d, bool packed, bool gra
   *fn = l.fn;
   return MGP_OK;
 }
+
+// the hash every cache file name of this build ends in (sources + options + compiler): build.py drops the others
+uint64_t jit_source_hash() { return env().src_hash; }
 
 // run-time compiled kernels loaded in this process so far (all devices)
 int jit_loaded_count() {

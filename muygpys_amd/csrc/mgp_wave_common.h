@@ -217,6 +217,45 @@ __device__ __forceinline__ void gram_finish(f2& a, float nsum) {  // |a'|^2 + |b
   a.y = 0.0f;
 }
 __device__ __forceinline__ void gram_finish(double& a, double nsum) { a = __builtin_fmax(__builtin_fma(-2.0, a, nsum), 0.0); }
+// The same with the CANCELLATION GUARD (fp32).  |a'|^2 + |b'|^2 - 2 a'.b' loses log2((|a'|^2 + |b'|^2) / d^2) bits: harmless
+// when the neighbours are about as far from each other as from the query (k-NN neighbourhoods, random rows), fatal when
+// they form a tight cluster far from the query -- d^2 = 2e-4 l^2 under norms of 9 l^2 leaves the covariances with ~1e-5
+// absolute error and the posterior mean of a nugget-1e-3 model with 6e-3 (tests/test_gpu_gram_stress.py; the difference
+// form on the same data: 4e-5).  `guard` goes negative when a pair's squared distance comes out below 1 / MGP_GRAM_GUARD
+// of the norm sum it was subtracted from (more than 5 bits cancelled: relative error of d^2 above ~1e-5); the wave then
+// recomputes the task's distances in the difference form (wave kernels: phase 2G).  A pair with a slot that has no
+// features carries an infinite norm (phase 1b writes it): its test value is NaN, which v_min_f32 ignores.
+#ifndef MGP_GRAM_GUARD
+#define MGP_GRAM_GUARD 32.0f
+#endif
+__device__ __forceinline__ void gram_finish2(f2& a, f2& b, float nsa, float nsb, float& guard) {
+  const float da = __builtin_fmaf(-2.0f, a.x + a.y, nsa), db = __builtin_fmaf(-2.0f, b.x + b.y, nsb);
+  const float ta = __builtin_fmaf(da, MGP_GRAM_GUARD, -nsa), tb = __builtin_fmaf(db, MGP_GRAM_GUARD, -nsb);
+  guard = __builtin_fminf(__builtin_fminf(guard, ta), tb);  // v_min3_f32
+  a.x = __builtin_fmaxf(da, 0.0f);
+  a.y = 0.0f;
+  b.x = __builtin_fmaxf(db, 0.0f);
+  b.y = 0.0f;
+}
+__device__ __forceinline__ void gram_finish1(f2& a, float nsa, float& guard) {
+  const float da = __builtin_fmaf(-2.0f, a.x + a.y, nsa);
+  guard = __builtin_fminf(guard, __builtin_fmaf(da, MGP_GRAM_GUARD, -nsa));
+  a.x = __builtin_fmaxf(da, 0.0f);
+  a.y = 0.0f;
+}
+__device__ __forceinline__ void gram_finish2(double& a, double& b, double nsa, double nsb, double&) {  // fp64: no guard needed
+  gram_finish(a, nsa);
+  gram_finish(b, nsb);
+}
+__device__ __forceinline__ void gram_finish1(double& a, double nsa, double&) { gram_finish(a, nsa); }
+__device__ __forceinline__ bool gram_guard_tripped(float guard) { return __builtin_amdgcn_ballot_w64(guard < 0.0f) != 0; }
+__device__ __forceinline__ bool gram_guard_tripped(double) { return false; }
+// difference-form result (two partial sums) -> the layout the Gram path leaves behind (squared distance in .x)
+__device__ __forceinline__ void gram_from_diff(f2& a) {
+  a.x = a.x + a.y;
+  a.y = 0.0f;
+}
+__device__ __forceinline__ void gram_from_diff(double&) {}
 __device__ __forceinline__ float gram_sq(const f2& a) { return a.x; }
 __device__ __forceinline__ double gram_sq(const double& a) { return a; }
 

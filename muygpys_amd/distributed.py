@@ -100,6 +100,20 @@ class sharded_reductions:
         return False
 
 
+def enable_sharded_mode(group=None) -> None:
+    """Process-wide switch, the equivalent of running the reference with ``MUYGPYS_BACKEND=mpi`` (its
+    ``_is_mpi_mode()`` is process-global): from here on the loss / scale functions all-reduce their sums and a
+    ``Parameter("sample" | "log_sample")`` is rank 0's draw on every rank AT CONSTRUCTION
+    (gp/hyperparameter/scalar.py:145-146) -- call it on every rank right after ``init_process_group``, before any
+    model is built.  (Models built outside a sharded block keep per-rank draws; the optimisation drivers then start
+    from rank 0's values anyway, see ``_get_opt_lists`` in ``_src/optimize/chassis/hip.py``.)"""
+    _ACTIVE.update(on=True, group=group)
+
+
+def disable_sharded_mode() -> None:
+    _ACTIVE.update(on=False, group=None)
+
+
 def reductions_active() -> bool:
     return bool(_ACTIVE["on"]) and _world(_ACTIVE["group"])[1] > 1
 
@@ -128,6 +142,20 @@ def broadcast_scalar(value: float, group=None, root: int = 0) -> float:
     t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
     dist.broadcast(t, src=root, group=group)
     return float(t.item())
+
+
+def broadcast_vector(values, group=None, root: int = 0):
+    """Rank ``root``'s float64 vector on every rank (the start point of a sharded optimisation)."""
+    import numpy as np
+    import torch.distributed as dist
+
+    values = np.asarray(values, dtype=np.float64)
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return values
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    t = torch.as_tensor(values, dtype=torch.float64).to(dev)
+    dist.broadcast(t, src=root, group=group)
+    return t.cpu().numpy()
 
 
 def synchronized_seed(group=None) -> int:

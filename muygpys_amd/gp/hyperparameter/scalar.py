@@ -86,9 +86,12 @@ class Parameter:
     def _set_val(self, val) -> None:
         if isinstance(val, str):
             val = self._limits().draw(val)
-            # under sharded reductions (the mpi-backend layout) every rank starts from rank 0's draw
-            # (scalar.py:145-146: bcast(root=0) when _is_mpi_mode()); a plain torch.distributed job that
-            # samples on some ranks only is left alone
+            # under sharded reductions (the mpi-backend layout: distributed.enable_sharded_mode() process-wide, like
+            # the reference's MUYGPYS_BACKEND=mpi, or inside a sharded_reductions block) every rank starts from
+            # rank 0's draw (scalar.py:145-146: bcast(root=0) when _is_mpi_mode()).  A plain torch.distributed job
+            # that samples on some ranks only is left alone (a broadcast there would hang); a model built that way
+            # is still safe to optimise sharded: the drivers start every rank from rank 0's values
+            # (_src/optimize/chassis/hip.py: _get_opt_lists)
             from muygpys_amd import distributed as _D
 
             if _D.reductions_active():

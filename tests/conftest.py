@@ -23,7 +23,7 @@ def _npz_names():
 
 def golden_names():
     """Forward-path fixtures (tests/golden/make_golden.py)."""
-    return [n for n in _npz_names() if not n.startswith(("grad_", "fast_", "gen_", "fp32_"))]
+    return [n for n in _npz_names() if not n.startswith(("grad_", "fast_", "gen_", "fp32_", "scale_"))]
 
 
 def fast_golden_names():

@@ -120,8 +120,12 @@ def test_chunk_rule_matches_reference_fixture():
         assert all(bounds[i][1] == bounds[i + 1][0] for i in range(p - 1))
 
 
-def _opt_worker(rank, world, port, q):
-    """L-BFGS-B over a length scale, the objective evaluated shard-wise with one all-reduce."""
+def _opt_worker(rank, world, port, q, mode="block"):
+    """L-BFGS-B over a length scale, the objective evaluated shard-wise with one all-reduce.
+    mode "block": the sampled parameter is built inside a sharded_reductions block; "global": after
+    enable_sharded_mode() (the reference's process-global mpi mode); "outside": built with no mode on at all --
+    every rank its own draw -- and only the optimisation runs under sharded reductions (round-3 advisor finding:
+    the ranks must still start from rank 0's value, or they walk different trajectories and the job hangs)."""
     sys.path.insert(0, ROOT)
     if world > 1:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -143,28 +147,59 @@ def _opt_worker(rank, world, port, q):
         # "sample": drawn on rank 0 and broadcast (scalar.py:145-146); ranks seed differently on purpose
         # (opt-in like the reference's _is_mpi_mode(): only inside a sharded_reductions block)
         np.random.seed(100 + rank)
-        with D.sharded_reductions():
+        if mode == "block":
+            with D.sharded_reductions():
+                ls = Parameter("sample", (0.5, 8.0))
+        elif mode == "global":
+            D.enable_sharded_mode()
+            ls = Parameter("sample", (0.5, 8.0))
+            D.disable_sharded_mode()
+        else:
             ls = Parameter("sample", (0.5, 8.0))
         model = MuyGPS(Matern(smoothness=Parameter(1.5), deformation=Isotropy(l2, length_scale=ls)),
                        noise=HomoscedasticNoise(g["meta"]["noise"]))
         start = model.kernel.deformation.length_scale()
-        model.kernel.deformation.length_scale._set_val(2.0)
         obj = D.spec_objective(lambda length_scale: KernelSpec("matern15", "l2", length_scale, g["meta"]["noise"]),
                                X, y, bi, ni, loss="lool", local_fn=oracle_local_partials)
-        opt = _scipy_optimize(model, obj)
+        if mode == "outside":
+            with D.sharded_reductions():  # the drivers take rank 0's start point
+                opt = _scipy_optimize(model, obj)
+        else:
+            model.kernel.deformation.length_scale._set_val(2.0)
+            opt = _scipy_optimize(model, obj)
         q.put((rank, float(start), float(opt.kernel.deformation.length_scale()), float(obj(length_scale=3.0))))
     finally:
         if world > 1:
             dist.destroy_process_group()
 
 
-def test_two_rank_lbfgsb_equals_serial():
+def test_two_ranks_with_different_draws_still_walk_one_trajectory():
+    """A model built BEFORE any sharded mode is on carries a per-rank "sample" draw; optimised under sharded
+    reductions both ranks must start from rank 0's value, finish (no hang on mismatched all-reduce counts) and
+    agree bit for bit."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_opt_worker, args=(r, 2, port, q, "outside")) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][1] != got[1][1], "the test needs different draws to mean anything"
+    assert got[0][2] == got[1][2], "both ranks must walk the same trajectory"
+    assert got[0][3] == got[1][3]
+
+
+@pytest.mark.parametrize("mode", ["block", "global"])
+def test_two_rank_lbfgsb_equals_serial(mode):
     """Reference: _make_mpi_obj_fn (loss/mpi.py:28-34) -- every rank runs the same optimiser on the
     same global objective; the optimum equals the single-process one."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_opt_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_opt_worker, args=(r, 2, port, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
     got = sorted(q.get(timeout=300) for _ in procs)

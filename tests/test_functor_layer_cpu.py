@@ -232,3 +232,46 @@ def test_lbfgsb_and_bayes_drivers_recover_length_scale():
         assert 0.5 <= ls <= 20.0
         assert float(obj(length_scale=ls)) >= start
         assert m.kernel.deformation.length_scale() == 1.5, "the input model must not be modified"
+
+
+@pytest.mark.parametrize("name", ["m15_iso_l2_k10_d8", "m25_iso_l2_k30_d40", "rbf_iso_F2_k10_d1"])
+def test_analytic_scale_iteration_matches_reference(name):
+    """AnalyticScale(iteration_count = 1..4) against values the reference itself produced
+    (tests/golden/make_golden_scale_iter.py; src/MuyGPyS/gp/hyperparameter/scale.py:205-217) -- with ONE backend
+    evaluation, whatever the iteration count (f(s K) = f(K) / s)."""
+    import os
+
+    from muygpys_amd.gp.hyperparameter import AnalyticScale
+    from tests.conftest import GOLDEN_DIR
+
+    want = np.load(os.path.join(GOLDEN_DIR, "scale_iter.npz"))[name]
+    g = load_golden(name)
+    for it, ref in zip((1, 2, 3, 4), want):
+        calls = []
+
+        def backend(K, y, **kw):
+            calls.append(1)
+            return orc.analytic_scale_optim(K, y)
+
+        m = numpy_model(g["meta"], g)
+        m.scale = AnalyticScale(iteration_count=it, _backend_fn=backend)
+        m._make()
+        _, pair, _, y_nn = m.make_train_tensors(g["batch_idx"], g["nn_idx"], g["features"], g["targets"], materialize=True)
+        m.optimize_scale(pair, y_nn)
+        close(m.scale(), ref, rtol=1e-10)
+        assert len(calls) == 1
+
+
+def test_analytic_scale_iteration_is_skipped_for_non_scalar_values():
+    """The reference's guard (scale.py:207-209): a non-scalar value comes back after the first evaluation."""
+    from muygpys_amd.gp.hyperparameter import AnalyticScale
+
+    class _M:
+        class noise:
+            @staticmethod
+            def perturb(K):
+                return K
+
+    s = AnalyticScale(iteration_count=3, _backend_fn=lambda K, y, **kw: np.array([2.0, 3.0]))
+    out = s.get_opt_fn(_M)(np.eye(2)[None], np.ones((1, 2, 2)))
+    close(out, [2.0, 3.0])

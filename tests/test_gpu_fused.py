@@ -264,6 +264,101 @@ def test_rhs_columns_kernel_matches_golden(golden, dtype):
     assert_close(sig, g["sigma_sq"], rtol, "sigma_sq")
 
 
+BACK_CASES = [
+    # dtype, kernel, k, d, R, path, b -- the prediction variant of the rhs-column kernel (fused_rhs_kernel<T,16,BACK=true>:
+    # 5 <= R <= 16 and no y^T K^-1 y requested): what BASELINE config 5's bench line times.  Gram form (fp32, d a
+    # multiple of 8, not Matern-1/2) and difference form; k on and off the 8- and 32-step block boundaries of the
+    # elimination / back-substitution; one launch long enough for every workgroup to loop over many tasks.
+    ("float32", "rbf", 64, 40, 16, "auto", 66_000),
+    ("float32", "rbf", 64, 40, 16, "auto", 1200),
+    ("float32", "matern15", 50, 40, 8, "auto", 1200),       # k + 1 + R = 59 fits the row form: auto must still be right
+    ("float32", "matern15", 50, 40, 16, "auto", 1200),      # 67 rows -> rhs columns, BACK, Gram
+    ("float32", "matern25", 33, 40, 5, "rhs", 1200),
+    ("float32", "matern05", 64, 6, 16, "auto", 1200),       # difference form (Matern-1/2, d = 6)
+    ("float32", "matern05", 50, 6, 8, "rhs", 1200),
+    ("float32", "rbf", 33, 6, 16, "rhs", 1200),
+    ("float32", "matern15", 20, 8, 5, "rhs", 1200),         # k < 24: the rows 24..31 of the multiplier matrix are never written
+    ("float32", "matern15", 40, 16, 8, "rhs", 1200),
+    ("float32", "matern15", 48, 24, 16, "auto", 1200),      # k = 48: the advisor's reachable-on-auto case (k + 1 + R > 64)
+    ("float64", "rbf", 64, 40, 16, "auto", 1200),
+    ("float64", "matern15", 50, 8, 16, "auto", 1200),
+    ("float64", "matern05", 33, 6, 5, "rhs", 1200),
+    ("float64", "matern25", 64, 12, 8, "auto", 66_000),
+]
+
+
+@pytest.mark.parametrize("case", BACK_CASES, ids=[f"{c[0]}-{c[1]}-k{c[2]}-d{c[3]}-R{c[4]}-{c[5]}-b{c[6]}" for c in BACK_CASES])
+def test_rhs_prediction_variant_matches_oracle(case):
+    """``want_ykinvy=False`` with 5..16 responses selects the back-substitution instantiation of the rhs-column
+    kernel -- a different instantiation from the one every ``want_ykinvy=True`` test reaches.  Against the oracle,
+    after a launch that leaves NaN bits in every resident workgroup's LDS (the multiplier rows behind k are
+    never written: round-3 advisor finding)."""
+    from muygpys_amd import _lib
+    from muygpys_amd.fused import KernelSpec, posterior_mean_var
+
+    dtype, kernel, k, d, R, path, b = case
+    td = getattr(torch, dtype)
+    rng = np.random.default_rng(1000 + BACK_CASES.index(case))
+    N = 20_000
+    X = rng.normal(size=(N, d))
+    Y = np.sin(X @ rng.normal(size=(d, R)) / np.sqrt(d)) + 0.1 * rng.normal(size=(N, R))
+    bi = rng.integers(0, N, size=b)
+    ni = rng.integers(0, N - 1, size=(b, k))
+    ni = ni + (ni >= bi[:, None])
+    metric = "F2" if kernel == "rbf" else "l2"
+    ls = float(np.sqrt(2 * d)) if metric == "l2" else float(np.sqrt(np.sqrt(2 * d)) * 1.5)
+    spec_o = orc.Spec(kernel, metric, ls, 1e-2)
+    Xd, Yd, bid, nid = to_dev(X, td), to_dev(Y, td), to_dev(bi), to_dev(ni)
+    other = torch.float64 if td == torch.float32 else torch.float32
+    poison = torch.full((N, 64), float("nan"), device="cuda", dtype=other)
+    posterior_mean_var(KernelSpec(kernel, metric, ls, 1e-2), poison, poison, bid, nid, Yd.to(other), packed=False)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    mean, var = posterior_mean_var(KernelSpec(kernel, metric, ls, 1e-2), Xd, Xd, bid, nid, Yd, info=info, path=path,
+                                   packed=False)
+    torch.cuda.synchronize()
+    served = _lib.last_kernel()
+    if path == "rhs" or k + 1 + R > 64:
+        assert served.startswith(f"mgp::fused_rhs_kernel<{'float' if dtype == 'float32' else 'double'},16,true"), served
+    assert int(info.item()) == 0
+    assert bool(torch.isfinite(mean).all()) and bool(torch.isfinite(var).all()), f"non-finite outputs from {served}"
+    pick = np.arange(b) if b <= 1500 else rng.choice(b, size=1500, replace=False)
+    if b > 1500:
+        pick[:4] = [0, 1, b - 2, b - 1]
+    m_ref, v_ref = orc.posterior_mean_var(spec_o, X, X, bi[pick], ni[pick], Y)
+    rtol = RTOL[dtype]
+    assert_close(mean.cpu().numpy()[pick], m_ref.reshape(len(pick), R), rtol, f"mean [{served}]")
+    assert_close(var.cpu().numpy()[pick], v_ref, rtol, f"var [{served}]")
+    # the same call with y^T K^-1 y requested goes through the forward-only instantiation: same answers
+    m2, v2, _ = posterior_mean_var(KernelSpec(kernel, metric, ls, 1e-2), Xd, Xd, bid, nid, Yd, want_ykinvy=True,
+                                   path=path, packed=False)
+    torch.cuda.synchronize()
+    assert_close(mean.cpu().numpy(), m2.cpu().numpy(), 10 * rtol if dtype == "float32" else rtol, "BACK vs forward-only")
+    assert_close(var.cpu().numpy(), v2.cpu().numpy(), 10 * rtol if dtype == "float32" else rtol, "BACK vs forward-only (var)")
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_config5_fixture_through_the_prediction_variant(dtype):
+    """The reference-generated config-5 fixture (RBF, k = 64, R = 16, d = 40) through the exact call bench.py's
+    config-5 line makes: no y^T K^-1 y, dispatcher's choice."""
+    from muygpys_amd import _lib
+    from muygpys_amd.fused import posterior_mean_var
+    from tests.conftest import load_golden
+
+    g = load_golden("rbf_iso_R16_k64_d40_c5")
+    meta = g["meta"]
+    td = getattr(torch, dtype)
+    X, y = to_dev(g["features"], td), to_dev(g["targets"], td)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    mean, var = posterior_mean_var(_kspec(meta, g, td), X, X, to_dev(g["batch_idx"]), to_dev(g["nn_idx"]), y, info=info)
+    torch.cuda.synchronize()
+    assert "fused_rhs_kernel" in _lib.last_kernel() and ",16,true" in _lib.last_kernel(), _lib.last_kernel()
+    assert int(info.item()) == 0
+    assert_close(mean.cpu().numpy(), g["mean"], RTOL[dtype], "mean")
+    assert_close(var.cpu().numpy(), g["var_unscaled"], RTOL[dtype], "var")
+    assert_rel_close(var.cpu().numpy(), g["var_unscaled"], RTOL[dtype], "var (relative)",
+                     calibration=fp32_reference(meta["name"])[1] if dtype == "float32" else None)
+
+
 PERSISTENT_CASES = [
     # dtype, kernel, k, d, R, aniso  -- run-time shapes; b is large enough that every workgroup
     # loops over many tasks (the software-pipelined gather crosses task boundaries)
@@ -373,6 +468,7 @@ STALE_LDS_CASES = [
     (50, 1, "float32"), (50, 1, "float64"), (61, 1, "float32"), (30, 1, "float32"), (29, 2, "float64"),
     (64, 16, "float32"), (63, 4, "float64"),
     (126, 1, "float64"), (125, 1, "float64"), (99, 2, "float64"), (65, 1, "float64"),   # two lanes per row
+    (48, 16, "float32"), (50, 16, "float32"), (56, 12, "float32"), (50, 16, "float64"),  # rhs columns, back-substitution variant
 ]
 
 
