@@ -52,7 +52,7 @@ static int launch_np_impl(const FusedArgs& a, hipStream_t stream) {
   if ((DFIX > 0 || PIPED) && !g.vec_ok) return MGP_EUNSUPPORTED;
   if (PIPED && a.d > g.dst) return MGP_EUNSUPPORTED;  // more than one feature stage
   g.ntasks = (a.b + NH - 1) / NH;
-  const size_t tile_feat = (size_t)wave_tile_rows(WD, NP, KFIX, g.xs) * g.xs, tile_mat = (size_t)NH * KMAT;
+  const size_t tile_feat = (size_t)wave_tile_rows(WD, NP, KFIX, g.xs) * g.xs + wave_stage_elems(WD), tile_mat = (size_t)NH * KMAT;
   const size_t tile_elems = tile_feat > tile_mat ? tile_feat : tile_mat;
   constexpr bool PIPE = PIPED;
   size_t lds = PIPE ? tile_elems * sizeof(T) +
@@ -147,7 +147,7 @@ static int launch_jit(const FusedArgs& a, hipStream_t stream) {
   g.xs = g.dst + WD.E;
   g.vec_ok = 1;
   g.ntasks = (a.b + WD.NH - 1) / WD.NH;
-  const size_t tile_feat = (size_t)wave_tile_rows(WD, NP, a.k, g.xs) * g.xs, tile_mat = (size_t)WD.NH * WD.KMAT;
+  const size_t tile_feat = (size_t)wave_tile_rows(WD, NP, a.k, g.xs) * g.xs + wave_stage_elems(WD), tile_mat = (size_t)WD.NH * WD.KMAT;
   const size_t tile_elems = tile_feat > tile_mat ? tile_feat : tile_mat;
   size_t lds = tile_elems * sizeof(T) + wave_colbuf_bytes(sizeof(T), NP, wave_fold(sizeof(T), NP, a.k, a.R, a.d, true, false, gram));
   lds = (lds + 15) & ~(size_t)15;

@@ -117,6 +117,12 @@
 #ifndef MGP_FOLD
 #define MGP_FOLD 1
 #endif
+// fp64, 64 slots, static shapes with one response: the lower triangle of the augmented system DEALT over the lanes
+// in vertical pairs (rows 2r, 2r+1 of one column per 16-byte register group, column-major, 64 consecutive pairs per
+// slot) instead of a row per lane.  See phase 4D.
+#ifndef MGP_DLT
+#define MGP_DLT 1
+#endif
 
 namespace mgp {
 
@@ -140,7 +146,14 @@ struct WaveGeom {
 struct WaveDims {
   int E, CH, NH, NPL, NG, KS, KMAT, BA, BP, NS, M;
   bool STAT, TRI, MODM;
+  bool DLT;             // dealt lower triangle (phase 4D)
+  int NR2, NPAIR, NSL;  // (DLT) row pairs per column 0, pairs in all, 64-pair slots = register groups per lane
 };
+// (DLT) first pair of column c: columns 2m and 2m + 1 start at row pair m and hold NR2 - m pairs each
+constexpr int dlt_col_start(int c, int NR2) {
+  const int m = c >> 1, b = c & 1;
+  return 2 * m * NR2 - m * (m - 1) + b * (NR2 - m);
+}
 constexpr WaveDims wave_dims(int es, int NP, int KFIX, int RFIX, int DFIX, bool COEFF, bool GRAM) {
   WaveDims w{};
   w.E = 16 / es;
@@ -151,10 +164,15 @@ constexpr WaveDims wave_dims(int es, int NP, int KFIX, int RFIX, int DFIX, bool 
   w.NG = (w.NPL + w.E - 1) / w.E;                        // 16-byte groups of a lane's row
   w.KS = NP + w.E;
   w.TRI = NP == 64 && !COEFF;
+  w.DLT = MGP_DLT && es == 8 && NP == 64 && w.STAT && RFIX == 1;
+  w.NR2 = (w.NPL + 1) / 2;
+  w.NPAIR = dlt_col_start(w.NPL, w.NR2);
+  w.NSL = (w.NPAIR + 63) / 64;
   // elements per exchange matrix (packed: up to the last live row, the NG groups a lane reads from
   // there, a dump slot)
   w.KMAT = w.TRI ? w.E * ((w.NPL - 1) / w.E + 1) * (w.E * ((w.NPL - 1) / w.E) / 2 + (w.NPL - 1) % w.E) + w.NG * w.E + w.E
                  : NP * w.KS;
+  if (w.DLT) w.KMAT = 2 * 64 * w.NSL + 2;  // NSL slots of 64 pairs, and a dump pair
   // Pair scheme.  Generic: the NP slots form the cycle, NP/2 pairs per lane in 4 x NP/8 blocks (the
   // half-way distance twice; pairs with a response or padding slot computed and discarded).  Static
   // shapes run the cycle modulo the feature-row count M = k + 1 instead when that is shorter: cyclic
@@ -201,6 +219,9 @@ constexpr int wave_gather_pieces(const WaveDims& w, int KFIX, int xs) {
   const int spr = xs / w.E;
   return (w.STAT && w.NH == 1) ? ((KFIX + 1) * spr + 63) / 64 : spr;
 }
+// (DLT) elements of the posted-column staging area behind the feature tile: two slots of 64 pairs and a bias of 32
+// pairs in front (a consumer addresses it relative to row pair j / 2 of the pivot column)
+constexpr int wave_stage_elems(const WaveDims& w) { return w.DLT ? 2 * (32 + 128) : 0; }
 // waves per SIMD the register allocation is held to
 constexpr int wave_min_waves(int es, int NP, int KFIX) {
   return es == 4 ? (NP <= 32 ? (KFIX == 30 && MGP_W4 ? 4 : 3) : 2) : (NP <= 32 ? 2 : (KFIX > 0 && MGP_C4_W3 ? 3 : 2));
@@ -282,6 +303,16 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   };
   constexpr int NG = WD.NG;      // 16-byte groups of a lane's row
   constexpr int KMAT = WD.KMAT;  // elements per exchange matrix
+  // Dealt lower triangle (phase 4D): entry (i, c), i >= c, lives in pair cs2(c) + i/2 - c/2, element i & 1; lane l holds
+  // pairs 64 s + l, s = 0 .. NSL-1.  The exchange matrix is stored in exactly that order, so the read-back is NSL
+  // lane-linear ds_read_b128.
+  constexpr bool DLT = WD.DLT;
+  constexpr int NR2 = WD.NR2, NPAIR = WD.NPAIR, NSL = WD.NSL;
+  auto cs2 = [](int c) { return dlt_col_start(c, NR2); };
+  auto eoff = [&](int hi, int lo) {  // element offset of entry (hi, lo) of a neighbourhood's exchange matrix, hi >= lo
+    if constexpr (DLT) return 2 * (cs2(lo) + (hi >> 1) - (lo >> 1)) + (hi & 1);
+    else return rowoff(hi) + lo;
+  };
   constexpr int DPADFIX = (DFIX + CH - 1) / CH * CH;
   constexpr int DSTFIX = DFIX > 0 ? (DPADFIX < 64 ? DPADFIX : 64) : CH;
   using V = typename v16<T>::type;
@@ -295,7 +326,8 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   const int dst = DFIX > 0 ? DSTFIX : g.dst;
   const int xs = DFIX > 0 ? DSTFIX + E : g.xs;
   const int tile_rows = wave_tile_rows(WD, NP, KFIX, xs);
-  const int tile_elems = tile_rows * xs > NH * KMAT ? tile_rows * xs : NH * KMAT;
+  const int tile_feat = tile_rows * xs + wave_stage_elems(WD);  // (DLT: the staging area lies behind the rows the gather fills)
+  const int tile_elems = tile_feat > NH * KMAT ? tile_feat : NH * KMAT;
   T* tile = reinterpret_cast<T*>(smem);               // feature tile, later the exchange matrix
   // Plain kernels: [tile][colbuf 64][ilbuf dst][idxbuf 64 x int64].  Pipelined kernels keep LDS
   // at tile + 256 bytes (9 allocation granules of 1280 B -> 14 workgroups per CU): the 32-bit row
@@ -461,7 +493,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   if constexpr (XPRE) {
     const int i0 = threadIdx.x & (NP - 1);
     const int hbase = (NH == 1 ? 0 : (int)threadIdx.x / NP) * KMAT;
-    const int dump0 = TRI ? KMAT - E : (NP - 1) * KS + NP;
+    const int dump0 = DLT ? KMAT - 2 : (TRI ? KMAT - E : (NP - 1) * KS + NP);
 #pragma unroll
     for (int s = 1; s <= NS; ++s) {
       const int r1 = wrap(i0 + own_offset((s - 1) / BP));
@@ -469,7 +501,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       const int hi = max(r1, c), lo = min(r1, c);
       // (dropped: a response / padding slot, a lane that repeats another, and -- tiny M -- a surplus
       // distance that wraps onto the row itself)
-      const int xo = hbase + (hi <= q && hi != lo && i0 < M ? rowoff(hi) + lo : dump0);
+      const int xo = hbase + (hi <= q && hi != lo && i0 < M ? eoff(hi, lo) : dump0);
       if constexpr (XPK) {
         if ((s - 1) % 2 == 0) xoff[(s - 1) / 2] = xo;
         else xoff[(s - 1) / 2] |= xo << 16;
@@ -492,6 +524,24 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     for (int s2 = 1; s2 <= BP; ++s2) dpar[s2 - 1] = hb + wrap(i0 + s2) * xs;
   }
   static_assert(!MODM || XPRE, "the modulo-M pair scheme relies on the per-lane exchange offsets");
+  static_assert(!DLT || XPRE, "the dealt layout is written through the per-lane exchange offsets");
+
+  // (DLT) what the lane's pair of slot s needs in an elimination step: the scaled column's row pair (element
+  // offset 2 r into the column buffer) and its own column's entry (element offset c).  Lane-only: once per kernel.
+  int wrow[DLT ? NSL : 1], wcol[DLT ? NSL : 1];
+  if constexpr (DLT) {
+#pragma unroll
+    for (int s = 0; s < NSL; ++s) {
+      const int e = 64 * s + (int)threadIdx.x;
+      int c = 0;
+#pragma unroll
+      for (int cc = 1; cc < NPL; ++cc)
+        if (cs2(cc) < 64 * (s + 1)) c += cs2(cc) <= 64 * s ? 1 : (e >= cs2(cc) ? 1 : 0);  // (columns that start inside this slot: one compare each)
+      wcol[s] = c;
+      wrow[s] = 2 * (e - cs2(c) + (c >> 1));
+      if (e >= NPAIR) wrow[s] = 0;  // (behind the last pair: any valid address; the values are never used)
+    }
+  }
 
   // (FOLD) the folded rows: FS = row l (columns 0 .. 15), FL = row 16 + l, of the neighbourhood of the lane's
   // quarter; quarters 0 / 1 belong to the first task of a pair, 2 / 3 to the second
@@ -835,7 +885,8 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     __builtin_amdgcn_s_setprio(sizeof(T) == 4 || MGP_F64_SAME_PRIO ? MGP_XCHG_PRIO : MGP_DIST_PRIO);
 #endif
     __syncthreads();  // every lane is done reading the feature tile (Kh aliases it)
-    V A[NG];
+    V A[DLT ? 1 : NG];
+    V Dp[DLT ? NSL : 1];
     {
       // re-materialise the slot index here so that the per-offset masks/addresses of this phase
       // are computed now and not kept alive (or spilled) across the distance loop
@@ -913,9 +964,9 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
           }
         });
       }
-      if (NPL == NP || i3 < NPL) Kh3[rowoff(i3) + i3] = i3 < k ? T(1) + myeps : (i3 <= q ? T(1) : T(0));
+      if (NPL == NP || i3 < NPL) Kh3[eoff(i3, i3)] = i3 < k ? T(1) + myeps : (i3 <= q ? T(1) : T(0));
       // response rows: lower-triangle columns only (a packed row ends at its diagonal)
-      if (!TRI || i3 <= q + 1) Kh3[rowoff(q + 1) + i3] = myy0;
+      if (!TRI || i3 <= q + 1) Kh3[eoff(q + 1, i3)] = myy0;
       if (PACKED && !a.targets_batch) {
 #pragma unroll
         for (int r = 1; r < E; ++r)
@@ -939,6 +990,10 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 #pragma unroll
         for (int c4 = 0; c4 < NG; ++c4) FL[c4] = *reinterpret_cast<const V*>(Kq + rowoff(HALF + lh) + c4 * E);
       }
+    } else if constexpr (DLT) {
+      // the lane's pairs: slot s holds pair 64 s + lane of the dealt order (lane-linear, conflict-free)
+#pragma unroll
+      for (int s = 0; s < NSL; ++s) Dp[s] = *reinterpret_cast<const V*>(Kh + 2 * (64 * s) + 2 * lane);
     } else {
       const T* myrow = Kh + rowoff(NPL == NP ? i : min(i, NPL - 1));  // (idle lanes re-read the last live row)
 #pragma unroll
@@ -1093,6 +1148,94 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
             mean[nbq] = bad ? num<T>::nan() : -sq;
             if (yk) yk[nbq] = bad ? num<T>::nan() : -sy;
           }
+        }
+      }
+      continue;
+    }
+    if constexpr (DLT) {
+      // ---- phase 4D: elimination on the DEALT lower triangle (fp64, one neighbourhood per wave) --------------
+      // Row-per-lane elimination issues an FMA for every column right of the pivot in every lane: 3.8 x the
+      // arithmetic of the factorisation (finished rows idle, the upper triangle is updated too), and a 104-register
+      // row.  Here the lower triangle of the augmented system is dealt over the lanes in column-major order, two
+      // rows of one column per 16-byte group: NSL (11 at k = 50) groups per lane, and because a slot holds 64
+      // CONSECUTIVE pairs, all of its columns are finished together -- step j touches slots cs2(j + 1) / 64 .. only:
+      // 217 slot updates (434 FMAs) per neighbourhood at k = 50 instead of 688 group updates (1 376 FMAs).
+      // What a pair (rows 2r, 2r + 1; column c) needs in step j -- l_2r,j, l_2r+1,j and a_c,j = l_c,j p_j -- it
+      // reads from the posted column: one ds_read_b128 and one ds_read_b64 at per-lane addresses (wrow / wcol),
+      // i.e. 6 LDS-array cycles per two FMAs against 4 per two for the broadcast reads of the row form -- on
+      // a third of the FMAs.  Per step: pivot from its (compile-time) lane by v_readlane, one reciprocal, the
+      // column's lanes post l_.,j = a_.,j / p_j (one ds_write_b128), every live slot reads, multiplies once and
+      // updates twice.  Entries of finished columns and the odd upper-triangle elements that ride along in
+      // pairs receive junk updates; nobody reads them again.  The Schur block lands in three compile-time lanes.
+      bool bad = false;
+#if MGP_CHOL_PRIO
+      __builtin_amdgcn_s_setprio(MGP_CHOL_PRIO);
+#endif
+      if (MGP_PHASE(g, 8)) {
+        // staging area of the posted column: behind the tile rows the next task's gather is filling meanwhile.  The
+        // slot(s) that hold column j write ALL their pairs, scaled, in lane order (no predicate, no per-lane store
+        // address: pairs of other columns land where nobody reads); pair (r, j) then lies cs2(j) - 64 s0 + r - j/2
+        // pairs in, so a consumer's addresses are its own 2 r / c plus a per-step constant.
+        T* stg = tile + tile_rows * xs + 64;
+        // pivot of column j from its compile-time lane, reciprocal, post the scaled column
+        T p = T(1);
+        auto post = [&](int j) {
+          const int ep = cs2(j);  // pair of (j, j): the first of column j
+          p = lane_value(Dp[ep >> 6][j & 1], ep & 63);
+          bad = bad || !(p > T(0));
+          const V rp2 = V(pivot_rcp(p));
+          const int s0 = cs2(j) >> 6, s1 = (cs2(j + 1) - 1) >> 6;  // the slot(s) that hold column j
+#pragma unroll
+          for (int s = s0; s <= s1; ++s) *reinterpret_cast<V*>(stg + 2 * (64 * (s - s0)) + 2 * lane) = Dp[s] * rp2;
+        };
+        post(0);
+#pragma unroll
+        for (int j = 0; j < KFIX; ++j) {
+          const T np = -p;
+          const int cj = 2 * (cs2(j) - 64 * (cs2(j) >> 6) - (j >> 1));  // (>= -64: the bias in front of stg)
+          const int sl = cs2(j + 1) >> 6;                                 // first slot with a pair of a column right of j
+          // all operands of the step are requested together (a read -> wait -> FMA chain per slot would expose an LDS
+          // round trip per slot) ...
+          V wp[NSL];
+          T wc[NSL];
+#pragma unroll
+          for (int s = sl; s < NSL; ++s) {
+            wp[s] = *reinterpret_cast<const V*>(stg + cj + wrow[s]);
+            wc[s] = (stg + cj)[wcol[s]];
+          }
+          // ... LOOK-AHEAD: the slot(s) of column j + 1 are updated first, its pivot fetched and the column posted
+          // (the reads above were issued before that write; LDS executes in order), the other slots follow while
+          // the reciprocal chain and the write-to-read turnaround of the next step are under way
+          const int n1 = j + 1 < KFIX ? (cs2(j + 2) - 1) >> 6 : sl - 1;  // last slot of column j + 1
+          auto update = [&](int s) {
+            const T ngq = wc[s] * np;  // -a_c,j
+            Dp[s][0] = fma_t(wp[s][0], ngq, Dp[s][0]);
+            Dp[s][1] = fma_t(wp[s][1], ngq, Dp[s][1]);
+          };
+#pragma unroll
+          for (int s = sl; s <= n1; ++s) update(s);
+          if (j + 1 < KFIX) post(j + 1);
+#pragma unroll
+          for (int s = n1 + 1; s < NSL; ++s) update(s);
+        }
+      }
+#if MGP_CHOL_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
+      {
+        constexpr int QF = KFIX, YF = KFIX + 1;
+        const int eq = cs2(QF), em = cs2(QF) + (YF >> 1) - (QF >> 1), ey = cs2(YF);  // pairs of (q, q), (q+1, q), (q+1, q+1)
+        T* mean = static_cast<T*>(a.mean);
+        T* var = static_cast<T*>(a.var);
+        T* yk = static_cast<T*>(a.ykinvy);
+        const int64_t nb = nb0;
+        if (live) {
+          if (lane == (eq & 63)) {
+            var[nb] = bad ? num<T>::nan() : Dp[eq >> 6][QF & 1];
+            if (bad && a.info) atomicAdd(a.info, 1);
+          }
+          if (lane == (em & 63)) mean[nb] = bad ? num<T>::nan() : -Dp[em >> 6][YF & 1];
+          if (yk && lane == (ey & 63)) yk[nb] = bad ? num<T>::nan() : -Dp[ey >> 6][YF & 1];
         }
       }
       continue;

@@ -38,6 +38,16 @@ SHAPES = [
     (25, 16, 1, "float64", "matern25", "l2", True, True),
     (40, 8, 2, "float64", "matern15", "l2", False, False),
     (30, 32, 1, "float64", "rbf", "F2", False, True),
+    # the dealt-lower-triangle elimination (fp64, 64 slots, one response; phase 4D): odd and even nn_count (row pairs
+    # start on an upper-triangle element for odd columns; an odd row count pads a phantom row), a column whose pairs
+    # straddle two slots at every step parity, the full 64 slots, plain and prepared tables, both deformations
+    (31, 8, 1, "float64", "matern15", "l2", False, True),
+    (33, 12, 1, "float64", "matern25", "l2", True, True),
+    (40, 40, 1, "float64", "matern15", "l2", False, True),
+    (47, 16, 1, "float64", "rbf", "F2", False, False),
+    (50, 16, 1, "float64", "matern05", "l2", False, True),
+    (61, 8, 1, "float64", "maternInf", "l2", True, True),
+    (62, 24, 1, "float64", "matern15", "l2", False, False),
 ]
 
 
