@@ -953,9 +953,21 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 #pragma unroll
             for (int s0 = 0; s0 < NS; s0 += CB) {
               T kv[CB];
+#ifndef MGP_COV_BATCH64
+#define MGP_COV_BATCH64 1
+#endif
+              if constexpr (sizeof(T) == 8 && MGP_COV_BATCH64) {
+#pragma unroll
+                for (int u = 0; u < CB; ++u) {
+                  const int su = s0 + u < NS ? s0 + u : NS - 1;  // (a short last batch repeats its last pair)
+                  kv[u] = GRAM ? gram_sq(acc[su]) : acc_total(acc[su]);
+                }
+                cov_batch64<CB, KID, MID>(kv, post_scale);
+              } else {
 #pragma unroll
               for (int u = 0; u < CB; ++u)
                 if (s0 + u < NS) kv[u] = cov_from_sqdist<T>(GRAM ? gram_sq(acc[s0 + u]) : acc_total(acc[s0 + u]), KID, MID, post_scale);
+              }
 #pragma unroll
               for (int u = 0; u < CB; ++u)
                 if (s0 + u < NS) put(s0 + u + 1, kv[u]);
@@ -1177,21 +1189,28 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         // address: pairs of other columns land where nobody reads); pair (r, j) then lies cs2(j) - 64 s0 + r - j/2
         // pairs in, so a consumer's addresses are its own 2 r / c plus a per-step constant.
         T* stg = tile + tile_rows * xs + 64;
-        // pivot of column j from its compile-time lane, reciprocal, post the scaled column
-        T p = T(1);
+        // Column j is posted RAW (a copy of the registers: nothing on the path from the last update of the column to
+        // the LDS write), its pivot is fetched from its compile-time lane and the reciprocal chain runs while the
+        // write-to-read turnaround is under way; a consumer forms l_2r,j a_c,j = a_2r,j (a_c,j / p_j).
+        // Pivot test on the scalar unit: p > 0 and finite <=> 0 < high dword < 0x7FF00000 as an integer (a positive
+        // denormal pivot counts as singular too), accumulated as an unsigned maximum of (high dword - 1).
+        T nrp = T(0);
+        unsigned badm = 0;
         auto post = [&](int j) {
           const int ep = cs2(j);  // pair of (j, j): the first of column j
-          p = lane_value(Dp[ep >> 6][j & 1], ep & 63);
-          bad = bad || !(p > T(0));
-          const V rp2 = V(pivot_rcp(p));
-          const int s0 = cs2(j) >> 6, s1 = (cs2(j + 1) - 1) >> 6;  // the slot(s) that hold column j
+          const int s0 = ep >> 6, s1 = (cs2(j + 1) - 1) >> 6;  // the slot(s) that hold column j
 #pragma unroll
-          for (int s = s0; s <= s1; ++s) *reinterpret_cast<V*>(stg + 2 * (64 * (s - s0)) + 2 * lane) = Dp[s] * rp2;
+          for (int s = s0; s <= s1; ++s) *reinterpret_cast<V*>(stg + 2 * (64 * (s - s0)) + 2 * lane) = Dp[s];
+          const long long pb = __double_as_longlong(Dp[s0][j & 1]);
+          const unsigned plo = __builtin_amdgcn_readlane((int)(pb & 0xFFFFFFFFll), ep & 63);
+          const unsigned phi = __builtin_amdgcn_readlane((int)(pb >> 32), ep & 63);
+          badm = max(badm, phi - 1u);
+          nrp = -pivot_rcp(__longlong_as_double(((long long)phi << 32) | plo));
         };
         post(0);
 #pragma unroll
         for (int j = 0; j < KFIX; ++j) {
-          const T np = -p;
+          const T nrpj = nrp;
           const int cj = 2 * (cs2(j) - 64 * (cs2(j) >> 6) - (j >> 1));  // (>= -64: the bias in front of stg)
           const int sl = cs2(j + 1) >> 6;                                 // first slot with a pair of a column right of j
           // all operands of the step are requested together (a read -> wait -> FMA chain per slot would expose an LDS
@@ -1203,12 +1222,12 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
             wp[s] = *reinterpret_cast<const V*>(stg + cj + wrow[s]);
             wc[s] = (stg + cj)[wcol[s]];
           }
-          // ... LOOK-AHEAD: the slot(s) of column j + 1 are updated first, its pivot fetched and the column posted
-          // (the reads above were issued before that write; LDS executes in order), the other slots follow while
-          // the reciprocal chain and the write-to-read turnaround of the next step are under way
+          // ... LOOK-AHEAD: the slot(s) of column j + 1 are updated first and the column posted (the reads above
+          // were issued before that write; LDS executes in order), the other slots follow while the reciprocal
+          // chain and the write-to-read turnaround of the next step are under way
           const int n1 = j + 1 < KFIX ? (cs2(j + 2) - 1) >> 6 : sl - 1;  // last slot of column j + 1
           auto update = [&](int s) {
-            const T ngq = wc[s] * np;  // -a_c,j
+            const T ngq = wc[s] * nrpj;  // -a_c,j / p_j
             Dp[s][0] = fma_t(wp[s][0], ngq, Dp[s][0]);
             Dp[s][1] = fma_t(wp[s][1], ngq, Dp[s][1]);
           };
@@ -1218,6 +1237,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 #pragma unroll
           for (int s = n1 + 1; s < NSL; ++s) update(s);
         }
+        bad = badm >= 0x7FEFFFFFu;
       }
 #if MGP_CHOL_PRIO
       __builtin_amdgcn_s_setprio(0);

@@ -345,6 +345,88 @@ __device__ __forceinline__ T cov_from_sqdist(T acc, int kernel_id, int metric_id
   }
 }
 
+// CB fp64 covariances evaluated STAGE BY STAGE (every stage a loop over the batch), so that the CB dependent chains --
+// a software square root and a software exp of ~30 instructions between them -- are interleaved in the instruction
+// stream: one evaluation after the other (what the compiler makes of CB separate calls) leaves every v_fma_f64 waiting
+// for its predecessor's result at two waves per SIMD.  The square root is the hardware's reciprocal-square-root
+// estimate with one Goldschmidt step and one Newton correction (the library's version adds denormal scaling, a second
+// correction and a class test: 18 instructions; here 9): its argument is a squared distance -- zero (identical rows)
+// is lifted by adding 1e-280 (a no-op for every x >= 1e-264), whose root, 1e-140, is zero for every covariance function; relative error < 2^-50.  The exp is
+// exp_neg() above without the clamp on the exponent (v_cvt_i32_f64 saturates, v_ldexp_f64 underflows to zero).
+template <int CB, int KID, int MID>
+__device__ __forceinline__ void cov_batch64(double (&v)[CB], double post_scale) {
+  constexpr auto C = [](unsigned long long bits) { return __builtin_bit_cast(double, bits); };
+  double t[CB], w[CB];
+  if constexpr (MID == MGP_METRIC_L2) {
+    double y[CB], h[CB];
+#pragma unroll
+    for (int u = 0; u < CB; ++u) v[u] = v[u] + 1e-280;  // (one v_add_f64; fmax() costs a canonicalising second instruction)
+#pragma unroll
+    for (int u = 0; u < CB; ++u) y[u] = __builtin_amdgcn_rsq(v[u]);
+#pragma unroll
+    for (int u = 0; u < CB; ++u) t[u] = v[u] * y[u];  // g ~ sqrt(x)
+#pragma unroll
+    for (int u = 0; u < CB; ++u) h[u] = y[u] * 0.5;
+#pragma unroll
+    for (int u = 0; u < CB; ++u) y[u] = __builtin_fma(-h[u], t[u], 0.5);
+#pragma unroll
+    for (int u = 0; u < CB; ++u) t[u] = __builtin_fma(t[u], y[u], t[u]);
+#pragma unroll
+    for (int u = 0; u < CB; ++u) h[u] = __builtin_fma(h[u], y[u], h[u]);
+#pragma unroll
+    for (int u = 0; u < CB; ++u) y[u] = __builtin_fma(-t[u], t[u], v[u]);
+#pragma unroll
+    for (int u = 0; u < CB; ++u) v[u] = __builtin_fma(y[u], h[u], t[u]);
+  }
+  // kernel argument x = metric * post_scale; t = what goes into exp(-t); w = the polynomial factor
+#pragma unroll
+  for (int u = 0; u < CB; ++u) {
+    const double x = v[u] * post_scale;
+    if constexpr (KID == MGP_KERNEL_RBF) {
+      t[u] = x * 0.5;
+      w[u] = 1.0;
+    } else if constexpr (KID == MGP_KERNEL_MATERN_05) {
+      t[u] = x;
+      w[u] = 1.0;
+    } else if constexpr (KID == MGP_KERNEL_MATERN_15) {
+      t[u] = x * 1.7320508075688772935;
+      w[u] = 1.0 + t[u];
+    } else if constexpr (KID == MGP_KERNEL_MATERN_25) {
+      t[u] = x * 2.2360679774997896964;
+      w[u] = 1.0 + t[u] + t[u] * t[u] * (1.0 / 3.0);
+    } else {
+      t[u] = x * x * 0.5;
+      w[u] = 1.0;
+    }
+  }
+  double n[CB], r[CB], q[CB];
+#pragma unroll
+  for (int u = 0; u < CB; ++u) n[u] = __builtin_rint(t[u] * -1.4426950408889634074);
+#pragma unroll
+  for (int u = 0; u < CB; ++u) r[u] = __builtin_fma(n[u], -6.93147180369123816490e-01, -t[u]);
+#pragma unroll
+  for (int u = 0; u < CB; ++u) r[u] = __builtin_fma(n[u], -1.90821492927058770002e-10, r[u]);
+#pragma unroll
+  for (int u = 0; u < CB; ++u) q[u] = fma_sc(r[u], C(0x3e5ae64567f544e4ull), C(0x3e928af3fca7ab0cull));
+  constexpr unsigned long long coef[8] = {0x3ec71dee623fde64ull, 0x3efa01997c89e6b0ull, 0x3f2a01a014761f6eull, 0x3f56c16c1852b7b0ull,
+                                          0x3f81111111122322ull, 0x3fa55555555502a1ull, 0x3fc5555555555511ull, 0x3fe000000000000bull};
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int u = 0; u < CB; ++u) q[u] = fma_sc(q[u], r[u], C(coef[c]));
+#pragma unroll
+  for (int u = 0; u < CB; ++u) q[u] = __builtin_fma(q[u], r[u], 1.0);
+#pragma unroll
+  for (int u = 0; u < CB; ++u) q[u] = __builtin_fma(q[u], r[u], 1.0);
+#pragma unroll
+  for (int u = 0; u < CB; ++u) q[u] = __builtin_amdgcn_ldexp(q[u], (int)n[u]);
+#pragma unroll
+  for (int u = 0; u < CB; ++u) {
+    if constexpr (KID == MGP_KERNEL_MATERN_15 || KID == MGP_KERNEL_MATERN_25) v[u] = w[u] * q[u];
+    else v[u] = q[u];
+  }
+}
+
 // Two covariances at once (fp32): the polynomial / scaling arithmetic runs as packed ops
 // (v_pk_mul_f32 / v_pk_fma_f32), only v_sqrt_f32 and v_exp_f32 stay scalar.  Same formulas and
 // the same two-term log2(e) as the scalar form above.
