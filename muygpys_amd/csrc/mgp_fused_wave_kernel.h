@@ -88,7 +88,7 @@
 #define MGP_OWN_REG 0
 #endif
 #ifndef MGP_C4_W3
-#define MGP_C4_W3 0
+#define MGP_C4_W3 1
 #endif
 #ifndef MGP_MODM
 #define MGP_MODM 1
@@ -122,6 +122,9 @@
 // slot) instead of a row per lane.  See phase 4D.
 #ifndef MGP_DLT
 #define MGP_DLT 1
+#endif
+#ifndef MGP_F64_DIST_HALF
+#define MGP_F64_DIST_HALF 0
 #endif
 
 namespace mgp {
@@ -223,8 +226,11 @@ constexpr int wave_gather_pieces(const WaveDims& w, int KFIX, int xs) {
 // pairs in front (a consumer addresses it relative to row pair j / 2 of the pivot column)
 constexpr int wave_stage_elems(const WaveDims& w) { return w.DLT ? 2 * (32 + 128) : 0; }
 // waves per SIMD the register allocation is held to
-constexpr int wave_min_waves(int es, int NP, int KFIX) {
-  return es == 4 ? (NP <= 32 ? (KFIX == 30 && MGP_W4 ? 4 : 3) : 2) : (NP <= 32 ? 2 : (KFIX > 0 && MGP_C4_W3 ? 3 : 2));
+// (fp64, 64 slots: the dealt-lower-triangle kernels -- 44 instead of 104 registers of matrix -- fit three waves:
+// config 4 158.0 vs 153.1 M/s; the row-per-lane ones spill there, measured 10 % slower)
+constexpr int wave_min_waves(int es, int NP, int KFIX, int RFIX = 0, int DFIX = 0) {
+  return es == 4 ? (NP <= 32 ? (KFIX == 30 && MGP_W4 ? 4 : 3) : 2)
+                 : (NP <= 32 ? 2 : (MGP_C4_W3 && wave_dims(es, NP, KFIX, RFIX, DFIX, false, false).DLT ? 3 : 2));
 }
 
 // Folded elimination (phase 4F): which instantiations use it, and the bytes of column buffers behind the tile
@@ -251,6 +257,28 @@ constexpr int wave_colbuf_bytes(int es, int NP, bool fold) {
   return need > 512 ? need : 512;
 }
 
+// (DLT) per (slot, lane): element offsets into the posted column of the pair's two rows (2 r) and of its column's
+// entry (c).  A compile-time table in the code object's constant data, fetched per task right before the elimination
+// (11 coalesced 8-byte loads at k = 50; L2-resident) -- as 22 registers computed once per kernel they were live across
+// the distance phase, the kernel's register peak.
+template <int NPL_>
+struct DltMeta {
+  static constexpr int NR2 = (NPL_ + 1) / 2;
+  static constexpr int NPAIR = dlt_col_start(NPL_, NR2);
+  static constexpr int NSL = (NPAIR + 63) / 64;
+  int rc[NSL * 64][2];
+  constexpr DltMeta() : rc{} {
+    int c = 0;
+    for (int e = 0; e < NSL * 64; ++e) {
+      while (c + 1 < NPL_ && dlt_col_start(c + 1, NR2) <= e) ++c;
+      rc[e][0] = e < NPAIR ? 2 * (e - dlt_col_start(c, NR2) + (c >> 1)) : 0;  // (behind the last pair: any valid offset)
+      rc[e][1] = c;
+    }
+  }
+};
+template <int NPL_>
+__device__ const DltMeta<NPL_> g_dlt_meta{};
+
 // KFIX / RFIX / DFIX > 0: nn_count / response_count / feature_count known at compile time.
 // PIPED: software-pipelined direct-to-LDS gather (one feature stage, 16-byte aligned rows).
 // COEFF: also emit K^-1 y (the fast-posterior-mean coefficients): multipliers kept, back-substitution.
@@ -262,7 +290,7 @@ constexpr int wave_colbuf_bytes(int es, int NP, bool fold) {
 //        two features of a pair instead of a packed subtract + a packed FMA.  See phase 1b / 2.
 template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF = false, bool PACKED = false,
           bool GRAM = false>
-__global__ __launch_bounds__(64, wave_min_waves(sizeof(T), NP, KFIX))
+__global__ __launch_bounds__(64, wave_min_waves(sizeof(T), NP, KFIX, RFIX, DFIX))
 void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   static_assert(!PACKED || PIPED, "prepared tables are gathered by the direct-to-LDS pipeline");
   static_assert(!GRAM || (PIPED && !COEFF), "Gram form: one feature stage");
@@ -525,23 +553,6 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   }
   static_assert(!MODM || XPRE, "the modulo-M pair scheme relies on the per-lane exchange offsets");
   static_assert(!DLT || XPRE, "the dealt layout is written through the per-lane exchange offsets");
-
-  // (DLT) what the lane's pair of slot s needs in an elimination step: the scaled column's row pair (element
-  // offset 2 r into the column buffer) and its own column's entry (element offset c).  Lane-only: once per kernel.
-  int wrow[DLT ? NSL : 1], wcol[DLT ? NSL : 1];
-  if constexpr (DLT) {
-#pragma unroll
-    for (int s = 0; s < NSL; ++s) {
-      const int e = 64 * s + (int)threadIdx.x;
-      int c = 0;
-#pragma unroll
-      for (int cc = 1; cc < NPL; ++cc)
-        if (cs2(cc) < 64 * (s + 1)) c += cs2(cc) <= 64 * s ? 1 : (e >= cs2(cc) ? 1 : 0);  // (columns that start inside this slot: one compare each)
-      wcol[s] = c;
-      wrow[s] = 2 * (e - cs2(c) + (c >> 1));
-      if (e >= NPAIR) wrow[s] = 0;  // (behind the last pair: any valid address; the values are never used)
-    }
-  }
 
   // (FOLD) the folded rows: FS = row l (columns 0 .. 15), FL = row 16 + l, of the neighbourhood of the lane's
   // quarter; quarters 0 / 1 belong to the first task of a pair, 2 / 3 to the second
@@ -847,7 +858,24 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
           }
           __syncthreads();
         }
-        {
+        if constexpr (sizeof(T) == 8 && MGP_F64_DIST_HALF) {
+          // fp64: one 16-byte group of the own rows at a time (the same reads and arithmetic as the two-group form
+          // below with half the own-row registers: 20 instead of 40 at five own rows)
+#pragma unroll
+          for (int c0 = 0; c0 < (DFIX > 0 ? DSTFIX : wp); c0 += E) {
+            V own[BA];
+#pragma unroll
+            for (int j = 0; j < BA; ++j)
+              own[j] = *reinterpret_cast<const V*>((DPRE ? tile + down[DPRE ? j : 0] : Xh + wrap(i + own_offset(j)) * xs) + c0);
+#pragma unroll
+            for (int s = 1; s <= BP; ++s) {
+              const V o = *reinterpret_cast<const V*>((DPRE ? tile + dpar[DPRE ? s - 1 : 0] : Xh + wrap(i + s) * xs) + c0);
+#pragma unroll
+              for (int j = 0; j < BA; ++j) accum(acc[j * BP + s - 1], vsub(own[j], o));
+            }
+            if (MGP_F64_DIST_HALF == 2) __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
 #pragma unroll
           for (int c0 = 0; c0 < (DFIX > 0 ? DSTFIX : wp); c0 += CH) {
             V own0[BA], own1[BA];
@@ -887,6 +915,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     __syncthreads();  // every lane is done reading the feature tile (Kh aliases it)
     V A[DLT ? 1 : NG];
     V Dp[DLT ? NSL : 1];
+    int wrow[DLT ? NSL : 1], wcol[DLT ? NSL : 1];
     {
       // re-materialise the slot index here so that the per-offset masks/addresses of this phase
       // are computed now and not kept alive (or spilled) across the distance loop
@@ -1003,7 +1032,15 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         for (int c4 = 0; c4 < NG; ++c4) FL[c4] = *reinterpret_cast<const V*>(Kq + rowoff(HALF + lh) + c4 * E);
       }
     } else if constexpr (DLT) {
-      // the lane's pairs: slot s holds pair 64 s + lane of the dealt order (lane-linear, conflict-free)
+      // the lane's pairs: slot s holds pair 64 s + lane of the dealt order (lane-linear, conflict-free); and what each
+      // needs in an elimination step (g_dlt_meta above)
+#pragma unroll
+      for (int s = 0; s < NSL; ++s) {
+        typedef int i2 __attribute__((ext_vector_type(2)));
+        const i2 m = *reinterpret_cast<const i2*>(&g_dlt_meta<DLT ? NPL : 2>.rc[64 * s + lane][0]);
+        wrow[s] = m.x;
+        wcol[s] = m.y;
+      }
 #pragma unroll
       for (int s = 0; s < NSL; ++s) Dp[s] = *reinterpret_cast<const V*>(Kh + 2 * (64 * s) + 2 * lane);
     } else {
@@ -1215,27 +1252,40 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
           const int sl = cs2(j + 1) >> 6;                                 // first slot with a pair of a column right of j
           // all operands of the step are requested together (a read -> wait -> FMA chain per slot would expose an LDS
           // round trip per slot) ...
-          V wp[NSL];
-          T wc[NSL];
-#pragma unroll
-          for (int s = sl; s < NSL; ++s) {
-            wp[s] = *reinterpret_cast<const V*>(stg + cj + wrow[s]);
-            wc[s] = (stg + cj)[wcol[s]];
-          }
-          // ... LOOK-AHEAD: the slot(s) of column j + 1 are updated first and the column posted (the reads above
-          // were issued before that write; LDS executes in order), the other slots follow while the reciprocal
-          // chain and the write-to-read turnaround of the next step are under way
+          // (MGP_DLT_CHUNK slots at a time: the whole step in flight needs 6 registers per slot)
+#ifndef MGP_DLT_CHUNK
+#define MGP_DLT_CHUNK 4  // (config 4 at three waves per SIMD: 4 / 6 slots per chunk 158.0 / 155.8 M/s; two waves, whole step: 153.1)
+#endif
+          constexpr int CHK = MGP_DLT_CHUNK;
           const int n1 = j + 1 < KFIX ? (cs2(j + 2) - 1) >> 6 : sl - 1;  // last slot of column j + 1
-          auto update = [&](int s) {
-            const T ngq = wc[s] * nrpj;  // -a_c,j / p_j
-            Dp[s][0] = fma_t(wp[s][0], ngq, Dp[s][0]);
-            Dp[s][1] = fma_t(wp[s][1], ngq, Dp[s][1]);
-          };
 #pragma unroll
-          for (int s = sl; s <= n1; ++s) update(s);
-          if (j + 1 < KFIX) post(j + 1);
+          for (int sc = sl; sc < NSL; sc += CHK) {
+            V wp[CHK];
+            T wc[CHK];
 #pragma unroll
-          for (int s = n1 + 1; s < NSL; ++s) update(s);
+            for (int u = 0; u < CHK; ++u)
+              if (sc + u < NSL) {
+                wp[u] = *reinterpret_cast<const V*>(stg + cj + wrow[sc + u]);
+                wc[u] = (stg + cj)[wcol[sc + u]];
+              }
+            // ... LOOK-AHEAD: the slot(s) of column j + 1 are updated first and the column posted (the reads of the
+            // first chunk were issued before that write, and a later chunk's reads of the CURRENT column would come
+            // after it: the post therefore waits until the last chunk has been requested), the other slots follow
+            // while the reciprocal chain and the write-to-read turnaround of the next step are under way
+            auto update = [&](int u) {
+              const T ngq = wc[u] * nrpj;  // -a_c,j / p_j
+              Dp[sc + u][0] = fma_t(wp[u][0], ngq, Dp[sc + u][0]);
+              Dp[sc + u][1] = fma_t(wp[u][1], ngq, Dp[sc + u][1]);
+            };
+            const bool last_chunk = sc + CHK >= NSL;
+#pragma unroll
+            for (int u = 0; u < CHK; ++u)
+              if (sc + u < NSL && sc + u <= n1) update(u);
+            if (last_chunk && j + 1 < KFIX) post(j + 1);
+#pragma unroll
+            for (int u = 0; u < CHK; ++u)
+              if (sc + u < NSL && sc + u > n1) update(u);
+          }
         }
         bad = badm >= 0x7FEFFFFFu;
       }

@@ -194,11 +194,16 @@ int ensure_code(const Key& key, std::string* name, std::string* code) {
   if (load_cached(key, name, code)) return MGP_OK;
   int rc = compile_once(key, nullptr, name, code);
   if (rc == MGP_OK && spilled_vgprs(*code) > 0) {
-    std::string name2, code2;
-    if (compile_once(key, "-DMGP_FOLD=0", &name2, &code2) == MGP_OK && spilled_vgprs(code2) == 0) {
-      if (env().trace) fprintf(stderr, "mgp: %s spills with the folded elimination: built without\n", instantiation(key).c_str());
-      *name = name2;
-      *code = code2;
+    // register-hungry options an instantiation may not afford: the folded elimination (fp32), three waves per SIMD
+    // for the dealt-lower-triangle kernels (fp64) -- the first build without spills is what gets cached
+    for (const char* opt : {"-DMGP_FOLD=0", "-DMGP_C4_W3=0"}) {
+      std::string name2, code2;
+      if (compile_once(key, opt, &name2, &code2) == MGP_OK && spilled_vgprs(code2) == 0) {
+        if (env().trace) fprintf(stderr, "mgp: %s spills: built with %s\n", instantiation(key).c_str(), opt);
+        *name = name2;
+        *code = code2;
+        break;
+      }
     }
   }
   if (rc == MGP_OK) store_cached(key, *name, *code);
