@@ -507,6 +507,14 @@ int mgp_loss_sums_f32(const float* pred, const float* target, const float* var, 
 int mgp_loss_sums_f64(const double* pred, const double* target, const double* var, int64_t n,
                       const double* scale_dev, double huber_delta, double looph_delta, double* out,
                       double* scratch, void* stream);
+/* The one collective of the path: in-place SUM all-reduce of `count` device doubles (the partial sums mgp_loocv_* /
+ * mgp_loss_sums_* / mgp_column_sums_* leave behind) over the caller's RCCL communicator (an ncclComm_t passed as
+ * void*), enqueued on `stream`.  Replaces comm_world.allreduce(..., op=MPI.SUM) of _src/optimize/loss/mpi.py:23-24,57
+ * and _src/optimize/scale/mpi.py:35-36.  RCCL is opened with dlopen on first use (MUYGPYS_HIP_RCCL overrides the
+ * library name); MGP_EUNSUPPORTED when none is found, MGP_EINVAL for a NULL pointer / communicator or count < 1,
+ * -(2000 + ncclResult_t) when RCCL reports an error. */
+int mgp_allreduce_partials(double* partials, int count, void* nccl_comm, void* stream);
+
 /* Column sums in fp64: out[r] = sum_i x[i, r]  (x is (n, R)); used for
  * sum_b y^T K^-1 y (scale/numpy.py:9-15).  out is a device double[R]; scratch as above. */
 int mgp_column_sums_f32(const float* x, int64_t n, int R, double* out, double* scratch, void* stream);

@@ -70,8 +70,33 @@ def _muygps_fast_posterior_mean_precompute(Kin, train_nn_targets_fast, **kwargs)
     return torch.squeeze(co)
 
 
+def _fast_mean_fused(Kcross, coeffs_tensor):
+    """A lazy crosswise covariance handle and the gathered coefficients ``coeffs[closest_index]`` (b, k[, R]) --
+    what the reference's workflow hands over (examples/from_indices.py:113-118) -- through the fused prediction kernel
+    (``mgp_fast_posterior_mean_*``: gather, distances, kernel, dot product in one launch; nothing of size (b, k) is
+    formed).  None when the handle is not a plain crosswise covariance the kernel evaluates."""
+    from muygpys_amd.fused import KernelSpec, fast_posterior_mean
+
+    c = Kcross.diffs
+    if not (c.kind == "crosswise" and c.reduced and c.metric in ("l2", "F2") and Kcross.kernel != "matern_gen"):
+        return None
+    if not (isinstance(coeffs_tensor, torch.Tensor) and coeffs_tensor.is_cuda and coeffs_tensor.ndim in (2, 3)):
+        return None
+    b, k = c.nn_indices.shape
+    if tuple(coeffs_tensor.shape[:2]) != (b, k) or coeffs_tensor.dtype != c.dtype:
+        return None
+    spec = KernelSpec(Kcross.kernel, c.metric, 1.0 if c.length_scale is None else c.length_scale, 0.0)
+    rows = torch.arange(b, device=coeffs_tensor.device)
+    out = fast_posterior_mean(spec, c.data, c.nn_data, c.data_indices, c.nn_indices, coeffs_tensor, rows)
+    return torch.squeeze(out)
+
+
 def _muygps_fast_posterior_mean(Kcross, coeffs_tensor, **kwargs):
     """numpy.py:70-77: einsum('ij,ijk->ik')."""
+    if isinstance(Kcross, lazy.LazyCov):
+        out = _fast_mean_fused(Kcross, lazy.force(coeffs_tensor))
+        if out is not None:
+            return out
     Kcross, coeffs_tensor = lazy.force(Kcross), lazy.force(coeffs_tensor)
     _lib.require_cuda(Kcross, coeffs_tensor)
     C = torch.atleast_3d(coeffs_tensor)  # (k,) -> (1,k,1), (b,k) -> (b,k,1), like np.atleast_3d

@@ -139,6 +139,7 @@ template <typename T>
 int launch_loocv_partials(const T*, const T*, const T*, const void*, int64_t, const int64_t*, int64_t, double, double*,
                           double*, hipStream_t);
 int reduce_scratch_doubles();
+int allreduce_partials(double* partials_dev, int count, void* nccl_comm, hipStream_t stream);  // mgp_collective.hip
 template <typename T> int launch_matern_gen(const T*, int64_t, double, double, T*, hipStream_t);
 void matern_gen_constants_host(double nu, double* out7);
 template <typename T> int launch_table_pack(const T*, const T*, int64_t, int, int, void*, int64_t, hipStream_t);

@@ -203,6 +203,9 @@ int mgp_last_kernel_name(char* buf, int len) {
   snprintf(buf, len, "%s", mgp::g_last_kernel);
   return MGP_OK;
 }
+int mgp_allreduce_partials(double* partials, int count, void* nccl_comm, void* st) {
+  return allreduce_partials(partials, count, nccl_comm, S_(st));
+}
 int mgp_jit_prepare(int elem_size, int k, int R, int d, int packed, int kernel_id) {
   if ((elem_size != 4 && elem_size != 8) || k < 1 || R < 1 || d < 1 || !valid_kernel(kernel_id)) return MGP_EINVAL;
   return prepare_fused_wave(elem_size, d, k, R, packed, kernel_id);

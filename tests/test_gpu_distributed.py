@@ -2,6 +2,8 @@
 the combine step reproduce the reference's sigma_sq / lool / mse; shards concatenate to the
 serial result (single process; the N>1 collective path is covered over gloo on CPU)."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -175,3 +177,47 @@ def test_two_processes_hip_partials_and_collective_match_serial():
     cw, pw, bt, bnt = model.make_train_tensors(bi, ni, X, y)
     serial = L_BFGS_B_optimize(model, bt, bnt, cw, pw)
     np.testing.assert_allclose(got[0][4], float(serial.kernel.deformation.length_scale()), rtol=1e-6)
+
+
+def test_mgp_allreduce_partials_over_a_real_rccl_communicator():
+    """The C-ABI collective (mgp_allreduce_partials: RCCL opened with dlopen, communicator handed over as void*):
+    a one-rank communicator made through RCCL's own API sums a partial vector in place (a single-GPU box cannot
+    hold two ranks -- RCCL refuses two ranks on one device -- so what this pins is the binding: library lookup,
+    argument order, data type and reduction codes, stream)."""
+    import ctypes as C
+
+    from muygpys_amd import _lib
+
+    lib = _lib.load()
+    rccl = None
+    for name in (os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "librccl.so", "/opt/rocm/lib/librccl.so"):
+        try:
+            rccl = C.CDLL(name, mode=C.RTLD_GLOBAL)
+            break
+        except OSError:
+            continue
+    if rccl is None:
+        pytest.skip("no RCCL library on this machine")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        x = torch.tensor([1.5, -2.0, 3.25, 7.0, 0.0, 1e300], device="cuda", dtype=torch.float64)
+        want = x.clone()
+        rc = lib.mgp_allreduce_partials(_lib.ptr(x), x.numel(), comm, _lib.stream_ptr())
+        torch.cuda.synchronize()
+        assert rc == 0, rc
+        assert torch.equal(x, want)
+        assert lib.mgp_allreduce_partials(None, 6, comm, _lib.stream_ptr()) == -1
+        assert lib.mgp_allreduce_partials(_lib.ptr(x), 0, comm, _lib.stream_ptr()) == -1
+        assert lib.mgp_allreduce_partials(_lib.ptr(x), 6, None, _lib.stream_ptr()) == -1
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)

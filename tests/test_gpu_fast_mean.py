@@ -120,3 +120,49 @@ def test_fused_coefficients_wide_neighbourhoods(dtype):
     spec64 = KernelSpec("matern25", "l2", [1.5, 2.0, 1.0, 3.0, 2.5, 1.2, 1.8, 2.2], noise.double())
     ref, _ = fast_coefficients(spec64, X.double().cuda(), y.double().cuda(), nn.cuda(), fused=False)
     assert_close(got.cpu().numpy(), ref.cpu().numpy(), RTOL[dtype] * (3 if dtype == "float32" else 1), "coefficients")
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("name", __import__("tests.conftest", fromlist=["fast_golden_names"]).fast_golden_names())
+def test_family_level_fast_mean_on_lazy_handles_is_one_fused_launch(name, dtype, monkeypatch):
+    """The reference's own call sequence (examples/from_indices.py:93-118: crosswise_tensor -> kernel ->
+    muygps.fast_posterior_mean(Kcross, coeffs[closest_index])) on lazy handles: the family function
+    ``_muygps_fast_posterior_mean`` ends in the fused prediction kernel (no (b, k) covariance tensor, no einsum) and
+    reproduces the reference's fast-mean output."""
+    from muygpys_amd import fused as F
+    from muygpys_amd.gp import MuyGPS
+    from muygpys_amd.gp.deformation import Anisotropy, Isotropy, F2, l2
+    from muygpys_amd.gp.hyperparameter import Parameter, VectorParameter
+    from muygpys_amd.gp.kernels import RBF, Matern
+    from muygpys_amd.gp.noise import HomoscedasticNoise
+    from tests.conftest import load_golden
+
+    g = load_golden(name)
+    meta = g["meta"]
+    td = getattr(torch, dtype)
+    Xd, Qd = to_dev(g["features"], td), to_dev(g["test_features"], td)
+    metric = l2 if meta["metric"] == "l2" else F2
+    ls = meta["length_scale"]
+    deformation = (Anisotropy(metric, VectorParameter(*[Parameter(v) for v in ls])) if isinstance(ls, list)
+                   else Isotropy(metric, Parameter(ls)))
+    if meta["kernel"] == "rbf":
+        kernel = RBF(deformation=deformation)
+    else:
+        kernel = Matern(smoothness=Parameter({"matern05": 0.5, "matern15": 1.5, "matern25": 2.5}[meta["kernel"]]),
+                        deformation=deformation)
+    m = MuyGPS(kernel=kernel, noise=HomoscedasticNoise(meta["noise"]))
+    calls = []
+    real = F.fast_posterior_mean
+    monkeypatch.setattr(F, "fast_posterior_mean", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    closest = to_dev(g["closest_neighbor"])
+    cset = to_dev(g["closest_set"])
+    coeffs = to_dev(g["coeffs"], td)
+    crosswise = m.kernel.deformation.crosswise_tensor(Qd, Xd, torch.arange(Qd.shape[0], device="cuda"), cset, lazy=True)
+    Kcross = m.kernel(crosswise)
+    mean = m.fast_posterior_mean(Kcross, coeffs[closest])
+    torch.cuda.synchronize()
+    assert calls == [1], "the lazy crosswise handle must end in the fused prediction kernel"
+    assert_close(mean.cpu().numpy(), g["fast_mean"], 3 * RTOL[dtype], "fast posterior mean (functor layer)")
+    # the materialised route (the reference's tensors) agrees
+    dense = m.fast_posterior_mean(Kcross.materialize(), coeffs[closest])
+    assert_close(dense.cpu().numpy(), g["fast_mean"], 3 * RTOL[dtype], "fast posterior mean (materialised)")

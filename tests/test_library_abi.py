@@ -51,3 +51,10 @@ def test_headline_kernels_hold_their_register_budget():
         r = res[name]
         assert r["VGPRs Spill"] == 0 and r["ScratchSize [bytes/lane]"] == 0, (name, r)
         assert r["Occupancy [waves/SIMD]"] >= 3, (name, r)
+    # BASELINE config 4 (fp64, k = 50, d = 8): the dealt-lower-triangle kernels at three waves per SIMD, no spills
+    c4 = [k for k in res if "fused_wave_kernelIdLi64ELi50ELi1ELi8ELb1ELb0E" in k]
+    assert len(c4) == 2, sorted(res)
+    for name in c4:
+        r = res[name]
+        assert r["VGPRs Spill"] == 0 and r["ScratchSize [bytes/lane]"] == 0, (name, r)
+        assert r["Occupancy [waves/SIMD]"] >= 3, (name, r)
