@@ -133,5 +133,12 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=1_000_000)
     ap.add_argument("--optimizer", default="bayes", choices=["bayes", "lbfgs"])
     ap.add_argument("--n-iter", type=int, default=20)
+    ap.add_argument("--out", default="", help="write the result (per-stage seconds included) as JSON to this file")
     a = ap.parse_args()
-    run(points=a.points, test_points=a.test_points, batch=a.batch, optimizer=a.optimizer, n_iter=a.n_iter)
+    res = run(points=a.points, test_points=a.test_points, batch=a.batch, optimizer=a.optimizer, n_iter=a.n_iter)
+    if a.out:
+        import json
+
+        with open(a.out, "w") as f:
+            json.dump(res, f, indent=1)
+            f.write("\n")

@@ -687,8 +687,8 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       }
       if constexpr (GRAM) {
         // ---- phase 1b: centre the rows on the query, in place; squared norms --------------------
-        // Row i becomes a' = (a - q) [x inverse length scales]; |a'|^2 goes to the first element of the
-        // row's padding slot (column dst), where the lanes that pair with the row pick it up.  The query
+        // Row i becomes a' = (a - q) [x inverse length scales]; |a'|^2 goes to the norm array (below), where the
+        // lanes that pair with the row pick it up.  The query
         // row becomes exactly zero (norm 0), so a pair with the query is |a'|^2: the cross-covariances
         // keep the difference form.  All reads of the query row are issued before any lane's writes (one
         // wave, LDS executes in order).  Slots without features (responses, padding) are left alone:
@@ -696,6 +696,23 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         // (-DMGP_OWN_REG=1: the centred row of the lane's own slot stays in registers -- it is own row 0 of
         // the pair scheme, so the Gram loop below need not read it back: 10 of 330 LDS instructions at
         // d = 40 for 38 more VGPRs.  Measured 1.826 vs 1.819 ms: nothing; off.)
+        // The squared norms go to a compact array (one entry per slot, in the column-buffer space, which is free
+        // between two eliminations): behind the rows -- stride 44 floats at d = 40 -- eight of their 32 banks served
+        // a half-wave's ds_read_b32, a four-way conflict on each of the eight norm reads of a lane (~50 of the 136
+        // conflict cycles per task of round 3).
+        // fp32: every norm is stored TWICE, a cycle length apart, so that the norm of row (i + o) mod cycle is entry
+        // i + o: one lane-linear address and immediate offsets instead of eight wrapped per-lane addresses (which
+        // cost the headline kernel five spilled registers).
+        constexpr bool NDUP = sizeof(T) == 4;
+        constexpr int NCYC = MODM ? M : NP;
+        T* nrmh = colbuf + h * (NDUP ? 2 * NP : NP);
+        const int iw = MODM ? wrap(i) : i;
+        auto put_norm = [&](bool has, T n2) {
+          if (MODM && !has) return;  // (modulo scheme: idle lanes repeat a live one; they store nothing)
+          const T v = has ? n2 : num<T>::inf();
+          nrmh[iw] = v;
+          if constexpr (NDUP) nrmh[iw + NCYC] = v;
+        };
         constexpr int NCF = DFIX > 0 ? DSTFIX / E : 1;  // 16-byte groups per row (static shapes)
         constexpr bool OWNREG = MGP_OWN_REG && DFIX > 0;
         V x[DFIX > 0 ? NCF : 1];
@@ -732,8 +749,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
               __builtin_amdgcn_sched_barrier(0);  // keep the chunks apart (hoisted loads are what spills)
             }
             const ACC n2 = (n4[0] + n4[1]) + (n4[2] + n4[3]);
-            if (has) xrow[dst] = acc_total(n2);
-            else if (!MODM) xrow[dst] = num<T>::inf();  // (no features: its pairs must not trip the cancellation guard)
+            put_norm(has, acc_total(n2));  // (no features: infinite -- its pairs must not trip the cancellation guard)
           } else if constexpr (DFIX > 0) {
             V qv[NCF];
 #pragma unroll
@@ -755,8 +771,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 #pragma unroll
             for (int c = 0; c < NCF; ++c) norm_accum(n4[c & 3], x[c]);
             const ACC n2 = (n4[0] + n4[1]) + (n4[2] + n4[3]);
-            if (has) xrow[dst] = acc_total(n2);
-            else if (!MODM) xrow[dst] = num<T>::inf();
+            put_norm(has, acc_total(n2));
           } else {
             ACC n2 = ACC(0);
             for (int c0 = 0; c0 < wp; c0 += CH) {
@@ -777,8 +792,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
                 *reinterpret_cast<V*>(xrow + c0 + E) = x1;
               }
             }
-            if (has) xrow[dst] = acc_total(n2);
-            else if (!MODM) xrow[dst] = num<T>::inf();
+            put_norm(has, acc_total(n2));
           }
         }
         __syncthreads();
@@ -811,9 +825,9 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
           // (acc[].y = 0) so that the covariance stage below reads it like a difference-form sum
           T nown[BA], npar[BP];
 #pragma unroll
-          for (int j = 0; j < BA; ++j) nown[j] = (DPRE ? tile + down[DPRE ? j : 0] : Xh + wrap(i + own_offset(j)) * xs)[dst];
+          for (int j = 0; j < BA; ++j) nown[j] = NDUP ? nrmh[iw + own_offset(j)] : nrmh[wrap(i + own_offset(j))];
 #pragma unroll
-          for (int s = 1; s <= BP; ++s) npar[s - 1] = (DPRE ? tile + dpar[DPRE ? s - 1 : 0] : Xh + wrap(i + s) * xs)[dst];
+          for (int s = 1; s <= BP; ++s) npar[s - 1] = NDUP ? nrmh[iw + s] : nrmh[wrap(i + s)];
           T guard = T(1);
 #pragma unroll
           for (int s = 0; s + 1 < NS; s += 2)
