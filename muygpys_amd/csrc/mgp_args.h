@@ -102,8 +102,9 @@ template <typename T> int launch_solve_wave(const SolveArgs&, hipStream_t);  // 
 // register-resident wave-per-neighbourhood kernels; MGP_EUNSUPPORTED when the shape is not covered
 template <typename T> int launch_fused_wave(const FusedArgs&, hipStream_t);
 // run-time specialisation of the wave kernel (mgp_jit.hip)
-int jit_wave_function(int es, int np, int k, int R, int d, bool packed, bool gram, hipFunction_t* fn, bool allow_compile = true);
-int jit_wave_prepare(int es, int np, int k, int R, int d, bool packed, bool gram);
+int jit_wave_function(int es, int np, int k, int R, int d, bool packed, bool gram, hipFunction_t* fn, bool allow_compile = true,
+                      bool gen64 = false);
+int jit_wave_prepare(int es, int np, int k, int R, int d, bool packed, bool gram, bool gen64 = false);
 int jit_mode();
 int jit_loaded_count();
 uint64_t jit_source_hash();

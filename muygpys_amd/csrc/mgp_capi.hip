@@ -163,7 +163,7 @@ static int posterior_gen(const T* fq, const T* fn, const void* packed_q, int64_t
   if (noise_mode < MGP_NOISE_SCALAR || noise_mode > MGP_NOISE_BATCH) return MGP_EINVAL;
   if (noise_mode != MGP_NOISE_SCALAR && !nd) return MGP_EINVAL;
   if (ls_count != 1 && ls_count != d) return MGP_EINVAL;
-  if (sizeof(T) != 4 || smoothness > 30.0) return MGP_EUNSUPPORTED;  // fp32 tables; beyond nu = 30 the RBF limit is the better model anyway
+  if (smoothness > 30.0) return MGP_EUNSUPPORTED;  // beyond nu = 30 the RBF limit is the better model anyway
   FusedArgs a{fq, fn, bi, ni, tg, nd, ls, mean, var, yk, info, b, eps, d, k, R, noise_mode, MGP_KERNEL_MATERN_GEN, metric_id,
               ls_count, 0};
   a.targets_batch = targets_batch;
@@ -207,7 +207,8 @@ int mgp_allreduce_partials(double* partials, int count, void* nccl_comm, void* s
   return allreduce_partials(partials, count, nccl_comm, S_(st));
 }
 int mgp_jit_prepare(int elem_size, int k, int R, int d, int packed, int kernel_id) {
-  if ((elem_size != 4 && elem_size != 8) || k < 1 || R < 1 || d < 1 || !valid_kernel(kernel_id)) return MGP_EINVAL;
+  if ((elem_size != 4 && elem_size != 8) || k < 1 || R < 1 || d < 1 || !(valid_kernel(kernel_id) || kernel_id == MGP_KERNEL_MATERN_GEN))
+    return MGP_EINVAL;
   return prepare_fused_wave(elem_size, d, k, R, packed, kernel_id);
 }
 int mgp_jit_mode(void) { return jit_mode(); }

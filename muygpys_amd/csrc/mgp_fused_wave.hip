@@ -15,20 +15,31 @@ int g_lds_pad = 0;      // extra dynamic LDS bytes per workgroup
 
 // general-smoothness Matern: the node table (2 x MGP_GEN_NODES floats) goes behind everything else in
 // LDS; spacing and the log2 of h 2^(1-nu)/Gamma(nu) are launch constants
-static void gen_geometry(const FusedArgs& a, WaveGeom* g, size_t* lds) {
+static void gen_geometry(const FusedArgs& a, WaveGeom* g, size_t* lds, int elem_size) {
   g->gen_tab = 0;
   g->gen_h = 0.5f;
   g->gen_lc = 0.0f;
+  g->gen_h64 = 0.3;
+  g->gen_lc64 = 0.0;
+  g->gen_xmin64 = 1e-12;
   if (a.kernel_id != MGP_KERNEL_MATERN_GEN) return;
   const double nu = a.smoothness, h = gen_step(nu);
   g->gen_tab = (int)*lds;
   g->gen_h = (float)h;
   g->gen_lc = (float)((log(h) + (1.0 - nu) * log(2.0) - lgamma(nu)) / log(2.0));
-  *lds += 2 * MGP_GEN_NODES * sizeof(float);
+  if (elem_size == 8) {  // fp64: finer step, natural logarithms, a larger table
+    const double h64 = gen_step64(nu);
+    g->gen_h64 = h64;
+    g->gen_lc64 = log(h64) + (1.0 - nu) * log(2.0) - lgamma(nu);
+    g->gen_xmin64 = gen_xmin64(nu);
+    *lds += 2 * MGP_GEN_NODES64 * sizeof(double);
+  } else {
+    *lds += 2 * MGP_GEN_NODES * sizeof(float);
+  }
 }
 
 template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF = false, bool PACKED = false,
-          bool GRAM = false>
+          bool GRAM = false, bool GEN64 = false>
 static int launch_np_impl(const FusedArgs& a, hipStream_t stream) {
   constexpr WaveDims WD = wave_dims(sizeof(T), NP, KFIX, RFIX, DFIX, COEFF, GRAM);
   constexpr int NH = WD.NH;
@@ -59,8 +70,11 @@ static int launch_np_impl(const FusedArgs& a, hipStream_t stream) {
                           wave_colbuf_bytes(sizeof(T), NP, wave_fold(sizeof(T), NP, KFIX, RFIX, DFIX, PIPED, COEFF, GRAM))
                     : (tile_elems + 64 + g.dst + (g.dst & 1)) * sizeof(T) + 64 * sizeof(int64_t);
   lds = (lds + 15) & ~(size_t)15;
-  if (a.kernel_id == MGP_KERNEL_MATERN_GEN && !(sizeof(T) == 4 && (NP <= 32 || KFIX > 0) && !COEFF)) return MGP_EUNSUPPORTED;
-  gen_geometry(a, &g, &lds);
+  // (the general Matern needs the per-lane pair tables: 32-slot or static shapes; fp64 -- round 4 -- in the GEN64
+  // instantiations only)
+  if (a.kernel_id == MGP_KERNEL_MATERN_GEN && !((NP <= 32 || KFIX > 0) && !COEFF && (sizeof(T) == 4 || GEN64))) return MGP_EUNSUPPORTED;
+  if (GEN64 && a.kernel_id != MGP_KERNEL_MATERN_GEN) return MGP_EUNSUPPORTED;
+  gen_geometry(a, &g, &lds, (int)sizeof(T));
 #ifdef MGP_DEBUG_HOOKS
   lds += (size_t)g_lds_pad;
 #endif
@@ -71,7 +85,7 @@ static int launch_np_impl(const FusedArgs& a, hipStream_t stream) {
   static Residency res;
   int per_cu = 0, cus = 0;
   const int rrc = res.lookup(
-      reinterpret_cast<const void*>(&fused_wave_kernel<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF, PACKED, GRAM>), 64, lds, &per_cu,
+      reinterpret_cast<const void*>(&fused_wave_kernel<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF, PACKED, GRAM, GEN64>), 64, lds, &per_cu,
       &cus);
   if (rrc != MGP_OK) return rrc;
 #ifdef MGP_DEBUG_HOOKS
@@ -86,11 +100,12 @@ static int launch_np_impl(const FusedArgs& a, hipStream_t stream) {
             sizeof(T) == 4 ? "float" : "double", NP, KFIX, RFIX, DFIX, PIPED ? "pipe" : "stage", PACKED ? ",packed" : "",
             GRAM ? ",gram" : "",
             (long long)a.b, a.k, a.d, a.R, (long long)grid, lds);
-  hipLaunchKernelGGL((fused_wave_kernel<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF, PACKED, GRAM>), dim3((unsigned)grid), dim3(64),
+  hipLaunchKernelGGL((fused_wave_kernel<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF, PACKED, GRAM, GEN64>), dim3((unsigned)grid), dim3(64),
                      lds, stream, a, g);
   MGP_HIP_CHECK_LAUNCH();
-  note_launch("mgp::fused_wave_kernel<%s,%d,%d,%d,%d,%s,%s,%s,%s>", sizeof(T) == 4 ? "float" : "double", NP, KFIX, RFIX, DFIX,
-              PIPED ? "true" : "false", COEFF ? "true" : "false", PACKED ? "true" : "false", GRAM ? "true" : "false");
+  note_launch("mgp::fused_wave_kernel<%s,%d,%d,%d,%d,%s,%s,%s,%s%s>", sizeof(T) == 4 ? "float" : "double", NP, KFIX, RFIX, DFIX,
+              PIPED ? "true" : "false", COEFF ? "true" : "false", PACKED ? "true" : "false", GRAM ? "true" : "false",
+              GEN64 ? ",gen64" : "");
   return MGP_OK;
 }
 
@@ -108,6 +123,14 @@ static bool gram_allowed(const FusedArgs& a) {
 
 template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF = false, bool PACKED = false>
 static int launch_np(const FusedArgs& a, hipStream_t stream) {
+  // fp64 general-smoothness Matern: its own instantiations, for the run-time-shape 32-slot kernels (static shapes:
+  // compiled at run time, launch_jit); the difference form throughout
+  if constexpr (sizeof(T) == 8) {
+    if (a.kernel_id == MGP_KERNEL_MATERN_GEN) {
+      if constexpr (NP == 32 && KFIX == 0 && !COEFF) return launch_np_impl<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF, PACKED, false, true>(a, stream);
+      else return MGP_EUNSUPPORTED;
+    }
+  }
   if constexpr (PIPED && !COEFF && MGP_GRAM && (sizeof(T) == 4 || MGP_GRAM64)) {
     if (gram_allowed<T>(a)) return launch_np_impl<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF, PACKED, true>(a, stream);
   }
@@ -133,10 +156,10 @@ static int launch_jit(const FusedArgs& a, hipStream_t stream) {
   const uintptr_t align = packed ? ((uintptr_t)a.packed_q | (uintptr_t)a.packed_nn | (uintptr_t)a.q_stride | (uintptr_t)a.nn_stride)
                                  : ((uintptr_t)a.feat_q | (uintptr_t)a.feat_nn);
   if (align % 16 != 0) return MGP_EUNSUPPORTED;
-  if (a.kernel_id == MGP_KERNEL_MATERN_GEN && sizeof(T) != 4) return MGP_EUNSUPPORTED;
-  const bool gram = MGP_GRAM && gram_allowed<T>(a);
+  const bool gen64 = sizeof(T) == 8 && a.kernel_id == MGP_KERNEL_MATERN_GEN;
+  const bool gram = MGP_GRAM && gram_allowed<T>(a) && !gen64;
   hipFunction_t fn = nullptr;
-  const int jrc = jit_wave_function(sizeof(T), NP, a.k, a.R, a.d, packed, gram, &fn, jit_mode() == 2 || a.b >= jit_min_batch());
+  const int jrc = jit_wave_function(sizeof(T), NP, a.k, a.R, a.d, packed, gram, &fn, jit_mode() == 2 || a.b >= jit_min_batch(), gen64);
   if (jrc != MGP_OK) return jrc;
   const WaveDims WD = wave_dims(sizeof(T), NP, a.k, a.R, a.d, false, gram);
   WaveGeom g;
@@ -151,7 +174,7 @@ static int launch_jit(const FusedArgs& a, hipStream_t stream) {
   const size_t tile_elems = tile_feat > tile_mat ? tile_feat : tile_mat;
   size_t lds = tile_elems * sizeof(T) + wave_colbuf_bytes(sizeof(T), NP, wave_fold(sizeof(T), NP, a.k, a.R, a.d, true, false, gram));
   lds = (lds + 15) & ~(size_t)15;
-  gen_geometry(a, &g, &lds);
+  gen_geometry(a, &g, &lds, (int)sizeof(T));
   static Residency res;
   int per_cu = 0, cus = 0;
   const int rrc = res.lookup(fn, 64, lds, &per_cu, &cus);
@@ -173,8 +196,8 @@ static int launch_jit(const FusedArgs& a, hipStream_t stream) {
   void* params[] = {&args, &g};
   const hipError_t err = hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 64, 1, 1, (unsigned)lds, stream, params, nullptr);
   if (err != hipSuccess) return -(1000 + (int)err);
-  note_launch("mgp::fused_wave_kernel<%s,%d,%d,%d,%d,true,false,%s,%s> [run-time compiled]", sizeof(T) == 4 ? "float" : "double", NP,
-              a.k, a.R, a.d, packed ? "true" : "false", gram ? "true" : "false");
+  note_launch("mgp::fused_wave_kernel<%s,%d,%d,%d,%d,true,false,%s,%s%s> [run-time compiled]", sizeof(T) == 4 ? "float" : "double", NP,
+              a.k, a.R, a.d, packed ? "true" : "false", gram ? "true" : "false", gen64 ? ",gen64" : "");
   return MGP_OK;
 }
 
@@ -188,13 +211,14 @@ int launch_fused_wave(const FusedArgs& a, hipStream_t stream) {
     return MGP_EUNSUPPORTED;
   }
   // other static shapes: the instantiation compiled at run time, when allowed and worth it (mgp_jit.hip)
-  const bool builtin = a.R == 1 && ((a.k == 30 && a.d == 40) || (a.k == 50 && a.d == 8));
+  const bool gen64 = sizeof(T) == 8 && a.kernel_id == MGP_KERNEL_MATERN_GEN;  // (no built-in static instantiation)
+  const bool builtin = !gen64 && a.R == 1 && ((a.k == 30 && a.d == 40) || (a.k == 50 && a.d == 8));
   // (calls from MUYGPYS_HIP_JIT_MIN_BATCH neighbourhoods on may compile; shorter ones, from
   // MUYGPYS_HIP_JIT_CACHED_MIN_BATCH on, take a kernel that is loaded or in the disk cache already)
   const bool try_jit = !builtin && jit_mode() != 0 && (jit_mode() == 2 || a.b >= jit_cached_min_batch());
   if (a.packed_nn != nullptr) {  // prepared tables: the pipelined kernels only
-    if (a.k == 30 && a.R == 1 && a.d == 40) return launch_np<T, 32, 30, 1, 40, true, false, true>(a, stream);
-    if (a.k == 50 && a.R == 1 && a.d == 8) return launch_np<T, 64, 50, 1, 8, true, false, true>(a, stream);
+    if (builtin && a.k == 30) return launch_np<T, 32, 30, 1, 40, true, false, true>(a, stream);
+    if (builtin && a.k == 50) return launch_np<T, 64, 50, 1, 8, true, false, true>(a, stream);
     if (try_jit) {
       const int rc = launch_jit<T>(a, stream);
       if (rc != MGP_EUNSUPPORTED) return rc;
@@ -203,11 +227,11 @@ int launch_fused_wave(const FusedArgs& a, hipStream_t stream) {
     if (rows <= 64) return launch_np<T, 64, 0, 0, 0, true, false, true>(a, stream);
     return MGP_EUNSUPPORTED;
   }
-  if (a.k == 30 && a.R == 1 && a.d == 40) {  // BASELINE configs 2/3 (and their fp64 form), all shapes static
+  if (builtin && a.k == 30) {  // BASELINE configs 2/3 (and their fp64 form), all shapes static
     const int rc = launch_np<T, 32, 30, 1, 40, true>(a, stream);
     if (rc != MGP_EUNSUPPORTED) return rc;
   }
-  if (a.k == 50 && a.R == 1 && a.d == 8) {  // BASELINE config 4 shape, all shapes static
+  if (builtin && a.k == 50) {  // BASELINE config 4 shape, all shapes static
     const int rc = launch_np<T, 64, 50, 1, 8, true>(a, stream);
     if (rc != MGP_EUNSUPPORTED) return rc;
   }
@@ -249,11 +273,12 @@ int describe_fused_wave(int elem_size, int d, int k, int R, int packed, char* bu
 
 // compile the static instantiation of a shape into the disk cache (no GPU needed)
 int prepare_fused_wave(int elem_size, int d, int k, int R, int packed, int kernel_id) {
-  if (R == 1 && ((k == 30 && d == 40) || (k == 50 && d == 8))) return MGP_OK;  // built into the library
+  const bool gen64 = elem_size == 8 && kernel_id == MGP_KERNEL_MATERN_GEN;  // (fp64 general Matern: an instantiation of its own)
+  if (!gen64 && R == 1 && ((k == 30 && d == 40) || (k == 50 && d == 8))) return MGP_OK;  // built into the library
   const int np = static_slots(elem_size, d, k, R, packed != 0, false);
   if (np == 0) return MGP_EUNSUPPORTED;
-  const bool gram = MGP_GRAM && (elem_size == 8 ? MGP_GRAM64 != 0 : kernel_id != MGP_KERNEL_MATERN_05);
-  return jit_wave_prepare(elem_size, np, k, R, d, packed != 0, gram);
+  const bool gram = !gen64 && MGP_GRAM && (elem_size == 8 ? MGP_GRAM64 != 0 : kernel_id != MGP_KERNEL_MATERN_05);
+  return jit_wave_prepare(elem_size, np, k, R, d, packed != 0, gram, gen64);
 }
 
 template int launch_fused_wave<float>(const FusedArgs&, hipStream_t);

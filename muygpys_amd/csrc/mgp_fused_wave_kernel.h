@@ -140,6 +140,8 @@ struct WaveGeom {
   // in LDS (2 x MGP_GEN_NODES floats), node spacing, log2(h 2^(1-nu) / Gamma(nu))
   int gen_tab;
   float gen_h, gen_lc;
+  // ... and in fp64 (2 x MGP_GEN_NODES64 doubles; natural logarithms; smallest scaled distance the table covers)
+  double gen_h64, gen_lc64, gen_xmin64;
 };
 
 // Sizes shared by the kernel and its launchers.  Plain constexpr functions of the shape (element size es,
@@ -288,10 +290,15 @@ __device__ const DltMeta<NPL_> g_dlt_meta{};
 // GRAM: (pipelined kernels) squared distances as |a'|^2 + |b'|^2 - 2 a'.b' on rows centred on the query
 //        in place (a' = a - q, times the inverse length scales under Anisotropy): one packed FMA per
 //        two features of a pair instead of a packed subtract + a packed FMA.  See phase 1b / 2.
+// GEN64: (fp64) the general-smoothness Matern is the covariance function of this instantiation (the trapezoidal
+//        K_nu of mgp_wave_common.h in software exp: a body of its own, kept out of the fixed-smoothness kernels, where
+//        it cost the config-4 kernel spilled registers).  fp32 kernels carry their (hardware-exp) form in every
+//        instantiation.
 template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF = false, bool PACKED = false,
-          bool GRAM = false>
+          bool GRAM = false, bool GEN64 = false>
 __global__ __launch_bounds__(64, wave_min_waves(sizeof(T), NP, KFIX, RFIX, DFIX))
 void fused_wave_kernel(FusedArgs a, WaveGeom g) {
+  static_assert(!GEN64 || sizeof(T) == 8, "GEN64 is the fp64 general-smoothness instantiation");
   static_assert(!PACKED || PIPED, "prepared tables are gathered by the direct-to-LDS pipeline");
   static_assert(!GRAM || (PIPED && !COEFF), "Gram form: one feature stage");
   constexpr WaveDims WD = wave_dims(sizeof(T), NP, KFIX, RFIX, DFIX, COEFF, GRAM);
@@ -369,8 +376,10 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   const T** rowaddr = reinterpret_cast<const T**>(colbuf);  // 64 row pointers (pipelined; overlays colbuf + 256 B)
 
   const float* gtab = reinterpret_cast<const float*>(smem + g.gen_tab);
-  if (a.kernel_id == MGP_KERNEL_MATERN_GEN)  // node table of the launch's smoothness, once per workgroup
-    gen_build_table(reinterpret_cast<float*>(smem + g.gen_tab), (float)a.smoothness, g.gen_h, (int)threadIdx.x);
+  if (a.kernel_id == MGP_KERNEL_MATERN_GEN) {  // node table of the launch's smoothness, once per workgroup
+    if constexpr (sizeof(T) == 4) gen_build_table(reinterpret_cast<float*>(smem + g.gen_tab), (float)a.smoothness, g.gen_h, (int)threadIdx.x);
+    else if constexpr (GEN64) gen_build_table64(reinterpret_cast<double*>(smem + g.gen_tab), a.smoothness, g.gen_h64, (int)threadIdx.x);
+  }
 
   const T* feat_q = static_cast<const T*>(a.feat_q);
   const T* feat_nn = static_cast<const T*>(a.feat_nn);
@@ -957,7 +966,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
             Kh3[hi <= q && hi != lo ? rowoff(hi) + lo : dump] = v;
           }
         };
-        kernel_dispatch_gen(a.kernel_id, a.metric_id, [&](auto kid, auto mid) {
+        auto covariances = [&](auto kid, auto mid) {
           constexpr int KID = decltype(kid)::value, MID = decltype(mid)::value;
           if constexpr (KID == MGP_KERNEL_MATERN_GEN) {
             // general smoothness (fp32 kernels with per-lane pair tables; the launcher admits nothing else):
@@ -974,6 +983,38 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
               matern_gen_eval<NS>(kv, xkeep, gtab, (float)a.smoothness, g.gen_h, g.gen_lc);
 #pragma unroll
               for (int s = 1; s <= NS; ++s) put(s, kv[s - 1]);
+            } else if constexpr (sizeof(T) == 8 && XPRE) {
+              // fp64 (round 4): the same rule with a finer step and the software exp, CB pairs at a time
+#ifndef MGP_F64_GEN_BATCH
+#define MGP_F64_GEN_BATCH 3  // (seven doubles per chain in the node loop: five chains cost the config-4 kernel two spilled registers)
+#endif
+              constexpr int CB = MGP_F64_GEN_BATCH;
+              const double* gtab64 = reinterpret_cast<const double*>(smem + g.gen_tab);
+              // which of the lane's pairs are real (both rows neighbours, or neighbour x query): recomputed here -- as a
+              // register kept across the task loop it would cost the fixed-smoothness kernels two spilled registers
+              unsigned keep = 0;
+#pragma unroll
+              for (int s = 1; s <= NS; ++s) {
+                const int r1 = wrap(i3 + own_offset((s - 1) / BP)), c = wrap(i3 + (s - 1) % BP + 1);
+                const int hi = max(r1, c), lo = min(r1, c);
+                if (lo < k && (hi < k || hi == q) && hi != lo) keep |= 1u << (s - 1);
+              }
+#pragma unroll
+              for (int s0 = 0; s0 < NS; s0 += CB) {
+                double kv[CB];
+#pragma unroll
+                for (int u = 0; u < CB; ++u) {
+                  const int su = s0 + u < NS ? s0 + u : NS - 1;
+                  kv[u] = GRAM ? gram_sq(acc[su]) : acc_total(acc[su]);
+                }
+                metric_batch64<CB, MID>(kv, post_scale);
+                matern_gen_batch64<CB>(kv, (keep >> s0) & ((1u << CB) - 1u), gtab64, a.smoothness, g.gen_h64, g.gen_lc64,
+                                       g.gen_xmin64);
+#pragma unroll
+                for (int u = 0; u < CB; ++u)
+                  if (s0 + u < NS) put(s0 + u + 1, kv[u]);
+                __builtin_amdgcn_sched_barrier(0);
+              }
             }
           } else if constexpr (sizeof(T) == 4) {
             T kv[NS];
@@ -1017,7 +1058,15 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
               __builtin_amdgcn_sched_barrier(0);  // keep the batches apart
             }
           }
-        });
+        };
+        if constexpr (GEN64) {  // this instantiation serves kernel_id == MGP_KERNEL_MATERN_GEN only
+          if (a.metric_id == MGP_METRIC_L2) covariances(ic<MGP_KERNEL_MATERN_GEN>{}, ic<MGP_METRIC_L2>{});
+          else covariances(ic<MGP_KERNEL_MATERN_GEN>{}, ic<MGP_METRIC_F2>{});
+        } else if constexpr (sizeof(T) == 4) {
+          kernel_dispatch_gen(a.kernel_id, a.metric_id, covariances);
+        } else {
+          kernel_dispatch(a.kernel_id, a.metric_id, covariances);
+        }
       }
       if (NPL == NP || i3 < NPL) Kh3[eoff(i3, i3)] = i3 < k ? T(1) + myeps : (i3 <= q ? T(1) : T(0));
       // response rows: lower-triangle columns only (a packed row ends at its diagonal)

@@ -131,20 +131,20 @@ Env& env() {
   return e;
 }
 
-using Key = std::tuple<int, int, int, int, int, int, int>;  // es, np, k, R, d, packed, gram
+using Key = std::tuple<int, int, int, int, int, int, int, int>;  // es, np, k, R, d, packed, gram, gen64
 
 std::string instantiation(const Key& key) {
   char buf[160];
-  snprintf(buf, sizeof buf, "mgp::fused_wave_kernel<%s, %d, %d, %d, %d, true, false, %s, %s>",
+  snprintf(buf, sizeof buf, "mgp::fused_wave_kernel<%s, %d, %d, %d, %d, true, false, %s, %s, %s>",
            std::get<0>(key) == 4 ? "float" : "double", std::get<1>(key), std::get<2>(key), std::get<3>(key), std::get<4>(key),
-           std::get<5>(key) ? "true" : "false", std::get<6>(key) ? "true" : "false");
+           std::get<5>(key) ? "true" : "false", std::get<6>(key) ? "true" : "false", std::get<7>(key) ? "true" : "false");
   return buf;
 }
 
 std::string cache_path(const Key& key) {
   char buf[128];
-  snprintf(buf, sizeof buf, "/wave_f%d_np%d_k%d_r%d_d%d_p%d_g%d_%016llx.hsaco", std::get<0>(key) * 8, std::get<1>(key),
-           std::get<2>(key), std::get<3>(key), std::get<4>(key), std::get<5>(key), std::get<6>(key),
+  snprintf(buf, sizeof buf, "/wave_f%d_np%d_k%d_r%d_d%d_p%d_g%d%s_%016llx.hsaco", std::get<0>(key) * 8, std::get<1>(key),
+           std::get<2>(key), std::get<3>(key), std::get<4>(key), std::get<5>(key), std::get<6>(key), std::get<7>(key) ? "_n1" : "",
            (unsigned long long)env().src_hash);
   return env().cache_dir + buf;
 }
@@ -260,10 +260,10 @@ std::map<std::pair<int, Key>, Loaded> g_loaded;
 // MGP_OK and the kernel of one static instantiation on the current device, or MGP_EUNSUPPORTED.
 // allow_compile = false: only what is loaded already or lies in the disk cache (the shapes compiled at build time,
 // or by an earlier run) -- a call too short to pay for a compile still gets its specialised kernel then.
-int jit_wave_function(int es, int np, int k, int R, int d, bool packed, bool gram, hipFunction_t* fn, bool allow_compile) {
+int jit_wave_function(int es, int np, int k, int R, int d, bool packed, bool gram, hipFunction_t* fn, bool allow_compile, bool gen64) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return MGP_EHIP;
-  const Key key{es, np, k, R, d, packed ? 1 : 0, gram ? 1 : 0};
+  const Key key{es, np, k, R, d, packed ? 1 : 0, gram ? 1 : 0, gen64 ? 1 : 0};
   std::lock_guard<std::mutex> lock(g_mu);
   Loaded& l = g_loaded[{dev, key}];
   if (l.fn == nullptr && l.module == nullptr && (l.status == MGP_EUNSUPPORTED || (l.status == -4 && allow_compile))) {
@@ -299,9 +299,9 @@ int jit_loaded_count() {
 }
 
 // compile into the disk cache only (build time; no GPU): MGP_OK / MGP_EUNSUPPORTED
-int jit_wave_prepare(int es, int np, int k, int R, int d, bool packed, bool gram) {
+int jit_wave_prepare(int es, int np, int k, int R, int d, bool packed, bool gram, bool gen64) {
   std::string name, code;
-  return ensure_code(Key{es, np, k, R, d, packed ? 1 : 0, gram ? 1 : 0}, &name, &code);
+  return ensure_code(Key{es, np, k, R, d, packed ? 1 : 0, gram ? 1 : 0, gen64 ? 1 : 0}, &name, &code);
 }
 
 // MUYGPYS_HIP_JIT: "0" never; "force" every eligible shape; otherwise (default) eligible shapes from

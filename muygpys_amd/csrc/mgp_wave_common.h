@@ -518,8 +518,8 @@ __device__ __forceinline__ void matern_gen_eval(float (&r)[NS], unsigned live, c
   for (int s = 0; s < NP2 * 2; ++s) {
     float x = 1.0f;
     if (s < NS && ((live >> s) & 1u)) {
-      if (!(r[s] > 0.0f)) zero |= 1u << s;  // identical rows: k(0) = 1 (the reference nudges zeros to eps)
-      x = __builtin_fminf(__builtin_fmaxf(r[s] * s2nu, 1e-6f), 3.0e4f);
+      if (r[s] == 0.0f) zero |= 1u << s;  // identical rows: k(0) = 1 (the reference nudges zeros to eps); a NaN distance stays NaN
+      x = r[s] != r[s] ? r[s] : __builtin_fminf(__builtin_fmaxf(r[s] * s2nu, 1e-6f), 3.0e4f);
     }
     const float lx = __builtin_amdgcn_logf(x);  // log2
     // nodes until x cosh t - nu t > ~22: T = ln(2 (22 + nu max(1, ln(44 / x))) / x)
@@ -554,6 +554,113 @@ __device__ __forceinline__ void matern_gen_eval(float (&r)[NS], unsigned live, c
   }
 #pragma unroll
   for (int s = 0; s < NS; ++s) r[s] = (zero >> s) & 1u ? 1.0f : (s & 1 ? acc2[s / 2].y : acc2[s / 2].x);
+}
+
+// ---- the same in fp64 (round 4) ----------------------------------------------------------------------------------
+// Natural logarithms, the software exp of exp_neg(), the trapezoidal rule with a finer step (error ~ exp(-pi^2 / h):
+// h = 0.30 / 0.25 / 0.18 / 0.13 for nu <= 2 / 4 / 10 / 30 -> <= 6e-13 absolute against scipy over r in [1e-7, 20],
+// tests/test_matern_gen_cpu.py) and nodes until x cosh t - nu t > 37.  CB covariances per call, stage by stage like
+// cov_batch64(); the node count is the wave's maximum.  A zero distance is the reference's eps
+// (_src/gp/kernels/numpy.py:38); x is clamped from below to what the node table covers (`xmin`, a launch constant:
+// ~1e-11 at nu = 30, far smaller below -- |k(x) - k(xmin)| is of that order at most).
+#define MGP_GEN_NODES64 256
+__host__ __device__ inline double gen_step64(double nu) { return nu <= 2.0 ? 0.30 : (nu <= 4.0 ? 0.25 : (nu <= 10.0 ? 0.18 : 0.13)); }
+// nodes needed at scaled distance x: T(x) / h + 3 with T = ln(2 (37 + nu max(1, ln(74 / x))) / x)
+__host__ __device__ inline double gen_span64(double x, double nu) {
+  const double lx = log(x);
+  const double inner = 37.0 + nu * fmax(1.0, 4.30406509320417 - lx);
+  return log(2.0 * inner) - lx;
+}
+#ifndef __HIPCC_RTC__
+inline double gen_xmin64(double nu) {  // smallest x the MGP_GEN_NODES64-node table integrates to the end (bisection, host)
+  const double reach = (MGP_GEN_NODES64 - 4) * gen_step64(nu);
+  double lo = -300.0, hi = 0.0;  // log10 x
+  for (int it = 0; it < 80; ++it) {
+    const double mid = 0.5 * (lo + hi);
+    (gen_span64(pow(10.0, mid), nu) > reach ? lo : hi) = mid;
+  }
+  return pow(10.0, hi);
+}
+#endif
+__device__ __forceinline__ void gen_build_table64(double* tab, double nu, double h, int lane) {
+  for (int n = lane; n < MGP_GEN_NODES64; n += 64) {
+    const double t = n * h, a = nu * t;
+    tab[2 * n] = -cosh(t);
+    tab[2 * n + 1] = a + log1p(exp(-2.0 * a)) - 0.693147180559945309417 - (n == 0 ? 0.693147180559945309417 : 0.0);
+  }
+}
+// in: v[u] = metric argument (scaled distance) of CB pairs, `live` bit u set for pairs whose value is used; out: covariances
+template <int CB>
+__device__ __forceinline__ void matern_gen_batch64(double (&v)[CB], unsigned live, const double* tab, double nu, double h, double lc,
+                                                   double xmin) {
+  constexpr auto C = [](unsigned long long bits) { return __builtin_bit_cast(double, bits); };
+  double x[CB], L[CB], acc[CB];
+  const double s2nu = ::sqrt(2.0 * nu);
+  double tmax = 1.0;
+#pragma unroll
+  for (int u = 0; u < CB; ++u) {
+    double xx = 1.0;
+    if ((live >> u) & 1u) {
+      const double r = v[u] == 0.0 ? 2.220446049250313e-16 : v[u];
+      xx = r != r ? r : __builtin_fmin(__builtin_fmax(r * s2nu, xmin), 1.0e5);
+    }
+    const double lx = ::log(xx);
+    tmax = __builtin_fmax(tmax, ::log(2.0 * (37.0 + nu * __builtin_fmax(1.0, 4.30406509320417 - lx))) - lx);
+    x[u] = xx;
+    L[u] = __builtin_fma(nu, lx, lc);
+    acc[u] = 0.0;
+  }
+  int N = (int)(tmax / h) + 3;
+  N = N < MGP_GEN_NODES64 ? N : MGP_GEN_NODES64;
+  for (int n = 0; n < MGP_GEN_NODES64; ++n) {
+    if (__builtin_amdgcn_ballot_w64(n < N) == 0) break;  // (uniform: the longest tail of the wave)
+    const double negc = tab[2 * n], l = tab[2 * n + 1];  // uniform LDS reads: (-cosh t_n, ln cosh(nu t_n) [- ln 2 at n = 0])
+    // exp(L + l - x cosh t), CB chains interleaved (exp_neg() of mgp_wave_common.h, stage by stage)
+    double t[CB], m[CB], r[CB], q[CB];
+#pragma unroll
+    for (int u = 0; u < CB; ++u) t[u] = -__builtin_fma(x[u], negc, L[u] + l);
+#pragma unroll
+    for (int u = 0; u < CB; ++u) m[u] = __builtin_rint(t[u] * -1.4426950408889634074);
+#pragma unroll
+    for (int u = 0; u < CB; ++u) r[u] = __builtin_fma(m[u], -6.93147180369123816490e-01, -t[u]);
+#pragma unroll
+    for (int u = 0; u < CB; ++u) r[u] = __builtin_fma(m[u], -1.90821492927058770002e-10, r[u]);
+#pragma unroll
+    for (int u = 0; u < CB; ++u) q[u] = fma_sc(r[u], C(0x3e5ae64567f544e4ull), C(0x3e928af3fca7ab0cull));
+    constexpr unsigned long long coef[8] = {0x3ec71dee623fde64ull, 0x3efa01997c89e6b0ull, 0x3f2a01a014761f6eull, 0x3f56c16c1852b7b0ull,
+                                            0x3f81111111122322ull, 0x3fa55555555502a1ull, 0x3fc5555555555511ull, 0x3fe000000000000bull};
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int u = 0; u < CB; ++u) q[u] = fma_sc(q[u], r[u], C(coef[c]));
+#pragma unroll
+    for (int u = 0; u < CB; ++u) q[u] = __builtin_fma(q[u], r[u], 1.0);
+#pragma unroll
+    for (int u = 0; u < CB; ++u) q[u] = __builtin_fma(q[u], r[u], 1.0);
+#pragma unroll
+    for (int u = 0; u < CB; ++u) acc[u] += __builtin_amdgcn_ldexp(q[u], (int)m[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < CB; ++u) v[u] = acc[u];
+}
+// metric argument of CB squared distances in fp64: the lean square root of cov_batch64() under the l2 metric
+template <int CB, int MID>
+__device__ __forceinline__ void metric_batch64(double (&v)[CB], double post_scale) {
+  if constexpr (MID == MGP_METRIC_L2) {
+#pragma unroll
+    for (int u = 0; u < CB; ++u) {
+      if (v[u] > 0.0) {  // (an exact zero stays zero: the general Matern treats it as the reference does)
+        const double y = __builtin_amdgcn_rsq(v[u]);
+        double g = v[u] * y, hh = y * 0.5;
+        const double e = __builtin_fma(-hh, g, 0.5);
+        g = __builtin_fma(g, e, g);
+        hh = __builtin_fma(hh, e, hh);
+        v[u] = __builtin_fma(__builtin_fma(-g, g, v[u]), hh, g);
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < CB; ++u) v[u] = v[u] * post_scale;
 }
 
 // value of x in a given (wave-uniform) lane

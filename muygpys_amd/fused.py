@@ -27,8 +27,8 @@ class KernelSpec:
 
     kernel: "rbf" | "matern05" | "matern15" | "matern25" | "maternInf"
         (_src/gp/kernels/numpy.py:12-31; Matern with fixed nu, gp/kernels/matern.py:61-81), or
-        "matern_gen" with ``smoothness`` = nu (numpy.py:34-43: any nu > 0; fp32 tables only on the fused
-        path -- :class:`FusedUnsupported` otherwise, and the caller materialises)
+        "matern_gen" with ``smoothness`` = nu (numpy.py:34-43: any 0 < nu <= 30 on the fused path, fp32 and -- since
+        round 4 -- fp64 tables; :class:`FusedUnsupported` otherwise, and the caller materialises)
     metric: "l2" | "F2"  (gp/deformation/metric.py:237-265)
     length_scale: scalar -> Isotropy (isotropy.py:60-89); sequence of d -> Anisotropy
         (anisotropy.py:43-70)
@@ -57,8 +57,8 @@ class KernelSpec:
 
 
 class FusedUnsupported(RuntimeError):
-    """The fused kernels do not serve this model / shape (general-smoothness Matern on fp64 tables, more than
-    32 slots in a small batch ...): evaluate through the per-function kernels instead."""
+    """The fused kernels do not serve this model / shape (general-smoothness Matern beyond nu = 30, or with more
+    than 32 slots in a batch too small to compile a kernel for ...): evaluate through the per-function kernels instead."""
 
 
 # device-resident length scales of host-valued hyper-parameters, keyed by (values, device, dtype): an

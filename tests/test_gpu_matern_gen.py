@@ -22,9 +22,14 @@ SHAPES = [
 ]
 
 
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
 @pytest.mark.parametrize("nu", [0.42, 1.0, 2.2, 3.7, 8.0])
 @pytest.mark.parametrize("shape", SHAPES, ids=lambda s: f"k{s[0]}_d{s[1]}_R{s[2]}_b{s[3]}{'_aniso' if s[4] else ''}{'_packed' if s[5] else ''}")
-def test_fused_general_smoothness_matches_oracle(shape, nu):
+def test_fused_general_smoothness_matches_oracle(shape, nu, dtype):
+    """fp32: the hardware-exp trapezoid in every wave kernel; fp64 (round 4): the software-exp form in the GEN64
+    instantiations (run-time-shape 32-slot kernels built in, static shapes compiled at run time), held to the
+    north_star's 1e-5."""
+    from muygpys_amd import _lib
     from muygpys_amd.fused import KernelSpec, posterior_mean_var
 
     k, d, R, b, aniso, packed = shape
@@ -41,26 +46,46 @@ def test_fused_general_smoothness_matches_oracle(shape, nu):
     base = float(np.sqrt(d)) * 1.3
     ls = list(base * np.exp(rng.uniform(-0.3, 0.3, size=d))) if aniso else base
     spec = KernelSpec("matern_gen", "l2", ls, 2e-3, smoothness=nu)
-    td = torch.float32
+    td = getattr(torch, dtype)
+    rtol = 1e-3 if dtype == "float32" else 1e-5
     mean, var, yk = posterior_mean_var(spec, to_dev(X, td), to_dev(X, td), to_dev(bi), to_dev(ni), to_dev(y, td),
                                        want_ykinvy=True, packed=packed)  # raises FusedUnsupported if not fused
     torch.cuda.synchronize()
+    if dtype == "float64":
+        assert "gen64" in _lib.last_kernel(), _lib.last_kernel()
     rows = np.unique(np.concatenate([np.arange(0, 200, 1), np.arange(b - 64, b), np.arange(0, b, 97)[:60]]))
     ospec = orc.Spec(lambda r: orc.matern_gen_fn(r, nu), "l2", np.asarray(ls) if aniso else ls, 2e-3)
     m_ref, v_ref = orc.posterior_mean_var(ospec, X, X, bi[rows], ni[rows], y)
-    assert_close(mean.cpu().numpy()[rows].reshape(m_ref.shape), m_ref, 1e-3, "mean")
-    assert_close(var.cpu().numpy()[rows], v_ref, 1e-3, "var")
+    assert_close(mean.cpu().numpy()[rows].reshape(m_ref.shape), m_ref, rtol, "mean")
+    assert_close(var.cpu().numpy()[rows], v_ref, rtol, "var")
     assert torch.isfinite(mean).all() and torch.isfinite(var).all() and torch.isfinite(yk).all()
 
 
-def test_fp64_tables_are_left_to_the_materialising_route():
+def test_fp64_free_smoothness_is_fused_and_matches_the_reference_fixture():
+    """fp64 tables (the reference's default precision) with a free smoothness are served by the fused kernels since
+    round 4 (GEN64 instantiations) -- against the reference-generated model with nu = 0.42
+    (tests/golden/make_golden_gen.py); a 64-slot shape in a batch too small to compile for still raises
+    FusedUnsupported (the caller materialises, as before)."""
+    from muygpys_amd import _lib
     from muygpys_amd.fused import FusedUnsupported, KernelSpec, posterior_mean_var
+    from tests.conftest import load_golden
 
+    g = load_golden("gen_m042_iso_k10_d6")
+    meta = g["meta"]
+    X, y = to_dev(g["features"], torch.float64), to_dev(g["targets"], torch.float64)
+    spec = KernelSpec("matern_gen", meta["metric"], meta["length_scale"], meta["noise"], smoothness=meta["smoothness"])
+    mean, var, yk = posterior_mean_var(spec, X, X, to_dev(g["batch_idx"]), to_dev(g["nn_idx"]), y, want_ykinvy=True)
+    torch.cuda.synchronize()
+    assert "gen64" in _lib.last_kernel(), _lib.last_kernel()
+    assert_close(mean.cpu().numpy(), g["mean"], 1e-5, "mean")
+    assert_close(var.cpu().numpy(), g["var_unscaled"], 1e-5, "var")
+    b, k = g["nn_idx"].shape
+    assert_close(yk.double().sum().cpu().numpy().reshape(-1) / (b * k), np.asarray(g["sigma_sq"]).reshape(-1), 1e-5, "sigma_sq")
     gen = torch.Generator(device="cuda").manual_seed(1)
     X = torch.randn(500, 8, device="cuda", dtype=torch.float64, generator=gen)
     y = torch.randn(500, device="cuda", dtype=torch.float64, generator=gen)
     bi = torch.arange(50, device="cuda")
-    ni = torch.randint(50, 500, (50, 10), device="cuda", generator=gen)
+    ni = torch.randint(50, 500, (50, 40), device="cuda", generator=gen)
     with pytest.raises(FusedUnsupported):
         posterior_mean_var(KernelSpec("matern_gen", "l2", 2.0, 1e-3, smoothness=0.7), X, X, bi, ni, y)
 
