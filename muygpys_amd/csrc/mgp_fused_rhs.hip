@@ -43,6 +43,7 @@ namespace mgp {
 
 struct RhsGeom {
   int dst, xs, vec_ok;
+  int resp_vec;  // all RC responses of a row in 16-byte loads (R == RC, rows 16-byte aligned)
   int64_t ntasks;
 };
 
@@ -95,14 +96,26 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
     post_scale = a.metric_id == MGP_METRIC_L2 ? T(1) / l : T(1) / (l * l);
   }
 
+  // Index prefetch (as in the wave kernels): the neighbour index of task t + 1 is requested at the top of task t, so
+  // that the row gather of a task does not start with a dependent global round trip (two waves per SIMD: ~1.5 us of a
+  // ~22 us task that nothing hid).  One branch-free load per lane (lanes behind k read a valid dummy entry).
+  int64_t next_idx = 0, next_q = 0;
+  if ((int64_t)blockIdx.x < g.ntasks) {
+    next_idx = a.nn_idx[(int64_t)blockIdx.x * k + ((int)threadIdx.x < k ? (int)threadIdx.x : 0)];
+    next_q = a.batch_idx ? a.batch_idx[blockIdx.x] : (int64_t)blockIdx.x;
+  }
   for (int64_t nb = blockIdx.x; nb < g.ntasks; nb += gridDim.x) {
     int i = threadIdx.x;
     asm volatile("" : "+v"(i));  // keep per-lane addresses out of LICM (register pressure)
 
     // ---- indices, nugget, responses ------------------------------------------------------
-    int64_t myidx = 0;
-    if (i < k) myidx = a.nn_idx[nb * k + i];
-    const int64_t qidx = a.batch_idx ? a.batch_idx[nb] : nb;
+    const int64_t myidx = i < k ? next_idx : 0;
+    const int64_t qidx = next_q;
+    if (nb + gridDim.x < g.ntasks) {
+      const int64_t nn = nb + gridDim.x;
+      next_idx = a.nn_idx[nn * k + (i < k ? i : 0)];
+      next_q = a.batch_idx ? a.batch_idx[nn] : nn;
+    }
     __syncthreads();
     idxbuf[i] = myidx * (int64_t)d;
     if (i == 0) idxbuf[NP] = qidx * (int64_t)d;
@@ -291,9 +304,18 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
     for (int r = 0; r < NR; ++r) rhs[r] = T(0);
     if (i < k) {
       const T* ty = targets + (a.targets_batch ? nb * k + i : myidx) * (int64_t)R;
+      if (g.resp_vec) {  // (uniform) RC / E loads of 16 bytes instead of RC single ones under RC tests
 #pragma unroll
-      for (int r = 0; r < RC; ++r)
-        if (r < R) rhs[1 + r] = ty[r];
+        for (int r4 = 0; r4 < RC / E; ++r4) {
+          const V v = *reinterpret_cast<const V*>(ty + r4 * E);
+#pragma unroll
+          for (int e = 0; e < E; ++e) rhs[1 + r4 * E + e] = v[e];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < RC; ++r)
+          if (r < R) rhs[1 + r] = ty[r];
+      }
     }
 
     // ---- covariances -> exchange matrix -> row per lane; cross-covariance stays in the lane ----
@@ -510,6 +532,7 @@ static int launch_rhs_impl(const FusedArgs& a, hipStream_t stream) {
   g.xs = g.dst + E;
   const uintptr_t align = (uintptr_t)a.feat_q | (uintptr_t)a.feat_nn;
   g.vec_ok = (a.d % E == 0) && (align % 16 == 0);
+  g.resp_vec = a.R == RC && RC % E == 0 && (uintptr_t)a.targets % 16 == 0;
   g.ntasks = a.b;
   const size_t tile_elems = (size_t)((NP + 1) * g.xs > NP * KS ? (NP + 1) * g.xs : NP * KS);
   size_t lds = (tile_elems + 64 + NRV * E + g.dst + (g.dst & 1)) * sizeof(T) + 66 * sizeof(int64_t);
