@@ -304,17 +304,20 @@ __device__ __forceinline__ void neg_thr_split(float qn, float tau, unsigned& hi,
   lo = bf16_rne(v - __uint_as_float(hi << 16));
 }
 
-template <int KP>
+// TN: training rows per staged tile.  64 for the wider rows; 128 at KP = 16 (d <= 14: BASELINE config 4's d = 8), where a
+// 64-row tile is only 12 MFMAs per wave between two workgroup barriers (round 4: the 10 M-point search of config 4 ran at
+// 18 % matrix-pipe occupancy, barrier-bound).
+template <int KP, int TN>
 __global__ __launch_bounds__(256, (KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void knn_scan_bf16x3_kernel(KnnPackedArgs a) {
   constexpr int RB = 4 * KP;            // bytes of a packed row: KP bf16 hi + KP bf16 lo
   constexpr int SPR = RB / 16 + 1;      // 16-byte slots of a staged row (odd)
   constexpr int XSB = SPR * 16;         // LDS row stride in bytes
   constexpr int NQ = KP / 16;           // 16-byte operand pieces per half row = MFMAs per chain
-  constexpr int NPASS = KNN_TN * SPR / 64;
-  static_assert(KNN_TN * SPR % 64 == 0, "tile must be whole wave passes");
+  constexpr int NPASS = TN * SPR / 64;
+  static_assert(TN * SPR % 64 == 0, "tile must be whole wave passes");
   extern __shared__ __attribute__((aligned(16))) char smem[];  // carved by hand, see knn_scan_kernel
-  char* tile0 = smem;                                                     // [2][KNN_TN * XSB]
-  int* q_i = reinterpret_cast<int*>(smem + 2 * KNN_TN * XSB);             // [KB_QB * KB_CAP]
+  char* tile0 = smem;                                                     // [2][TN * XSB]
+  int* q_i = reinterpret_cast<int*>(smem + 2 * TN * XSB);             // [KB_QB * KB_CAP]
   int* q_cnt = q_i + KB_QB * KB_CAP;                                      // [KB_QB]
   float* tau_s = reinterpret_cast<float*>(q_cnt + KB_QB);                 // [KB_QB]
 
@@ -366,12 +369,12 @@ __global__ __launch_bounds__(256, (KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void knn_sc
       const int c = min(sigma - row * SPR, SPR - 2);
       const int64_t grow = min(t0 + row, a.n - 1);
       lds_dma16(reinterpret_cast<const char*>(a.packed_train) + grow * (int64_t)RB + c * 16,
-                lds_offset(tile0 + buf * KNN_TN * XSB) + p * 1024);
+                lds_offset(tile0 + buf * TN * XSB) + p * 1024);
     }
   };
-  const int64_t ntiles = (a.n - a.start + KNN_TN - 1) / KNN_TN;  // staggered walk, see knn_scan_kernel
+  const int64_t ntiles = (a.n - a.start + TN - 1) / TN;  // staggered walk, see knn_scan_kernel
   const int64_t tile_off = ((int64_t)blockIdx.x * 7919) % ntiles;
-  auto tile_row = [&](int64_t j) { return a.start + ((j + tile_off) % ntiles) * KNN_TN; };
+  auto tile_row = [&](int64_t j) { return a.start + ((j + tile_off) % ntiles) * TN; };
   issue_tile(0, tile_row(0));
   int buf = 0;
   int64_t next_drain = 0;
@@ -380,10 +383,10 @@ __global__ __launch_bounds__(256, (KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void knn_sc
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     if (tj + 1 < ntiles) issue_tile(buf ^ 1, tile_row(tj + 1));
-    const char* tl = tile0 + buf * KNN_TN * XSB;
+    const char* tl = tile0 + buf * TN * XSB;
 
 #pragma unroll
-    for (int ct = 0; ct < KNN_TN / 32; ++ct) {
+    for (int ct = 0; ct < TN / 32; ++ct) {
       const int col = ct * 32 + r32;
       const char* xrow = tl + col * XSB;
       u4x bhi[NQ], blo[NQ];
@@ -437,7 +440,11 @@ __global__ __launch_bounds__(256, (KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void knn_sc
     // batching makes the waves drain together.  A query collects ~ 64 k / rows_seen candidates per
     // tile, so the interval grows with the rows already seen (queues hold KB_CAP entries).
     if (tj < next_drain && tj + 1 < ntiles) continue;
-    next_drain = tj + (tj < 64 ? 1 : tj < 256 ? 4 : tj < 1024 ? 8 : 16);
+    {  // (cadence in ROWS seen by this workgroup: every 64 up to 4 096, then 256 / 512 / 1 024 -- whatever the tile size)
+      const int64_t rows = tj * TN;
+      const int every = rows < 4096 ? 64 : rows < 16384 ? 256 : rows < 65536 ? 512 : 1024;
+      next_drain = tj + (every / TN > 1 ? every / TN : 1);
+    }
     // Lane-per-query: lane r merges the queue of the wave's query r into that query's k-best list,
     // so all 64 queries drain at once and a drain costs a few memory latencies however many
     // queries are pending.  Round e handles every lane's e-th queue entry: exact squared distance
@@ -505,16 +512,20 @@ __global__ __launch_bounds__(256, (KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void knn_sc
   }
 }
 
+#ifndef MGP_KNN_TN16
+#define MGP_KNN_TN16 128
+#endif
 template <int KP>
 static int launch_knn_packed_kp(const KnnPackedArgs& a, hipStream_t stream) {
+  constexpr int TN = KP <= 16 ? MGP_KNN_TN16 : KNN_TN;
   const int64_t grid = (a.m + KB_QB - 1) / KB_QB;
-  const size_t lds = 2 * KNN_TN * (4 * KP + 16) + (KB_QB * KB_CAP + 2 * KB_QB) * sizeof(float);
+  const size_t lds = 2 * TN * (4 * KP + 16) + (KB_QB * KB_CAP + 2 * KB_QB) * sizeof(float);
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_scan_bf16x3_kernel<KP>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_scan_bf16x3_kernel<KP, TN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return -(1000 + (int)e);
   }
-  hipLaunchKernelGGL(knn_scan_bf16x3_kernel<KP>, dim3((unsigned)grid), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((knn_scan_bf16x3_kernel<KP, TN>), dim3((unsigned)grid), dim3(256), lds, stream, a);
   MGP_HIP_CHECK_LAUNCH();
   return MGP_OK;
 }
