@@ -83,6 +83,15 @@ class TableTensor(torch.Tensor):
     other use of the handle materialises it.  A plain tensor is wrapped, without a copy, by
     ``muygpys_amd.integration.table(t)``."""
 
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        """Only the table itself carries the lazy gather: what a torch function computes FROM it is a plain
+        ``torch.Tensor`` (the default would hand the subclass on to every result -- ``features * 2``,
+        ``targets.mean()`` ... -- which would then turn their own 2-D integer gathers into handles and pay this
+        dispatch on every later op; round-3 advisor finding)."""
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **(kwargs or {}))
+
     def __getitem__(self, item):
         if (
             config.state.lazy_tensors and isinstance(item, torch.Tensor) and item.ndim == 2
@@ -91,7 +100,7 @@ class TableTensor(torch.Tensor):
             from muygpys_amd import lazy
 
             return lazy.LazyTargets(self.as_subclass(torch.Tensor), item)
-        return super().__getitem__(item)
+        return torch.Tensor.__getitem__(self.as_subclass(torch.Tensor), item)
 
 
 def farray(x, **kwargs):

@@ -56,7 +56,7 @@ def main():
             ms = float(np.median(ts))
             F = algorithmic_flops(k, d, 1)
             rows.append(dict(k=k, d=d, ms=ms, mnbhd=args.b / ms / 1e3, tflops=F * args.b / ms / 1e9,
-                             kernel=_lib.served_by(d, k, 1, td, True, "auto").replace("mgp::", "")))
+                             kernel=_lib.last_kernel().replace("mgp::", "")))
             print(rows[-1], flush=True)
         del Xd, yd
         clear_caches()
