@@ -847,22 +847,27 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
           // wave-uniform: the task's distances again, in the difference form, on the same centred rows
           // (a' - b' = a - b; under Anisotropy the rows are scaled already).  One 16-byte group per iteration,
           // rolled: this path must cost the common one no registers.
-          if (gram_guard_tripped(guard)) {
+          const unsigned long long tripped = gram_guard_lanes(guard);
+          if (tripped != 0) {
             // (pair by pair, one 16-byte group per iteration: two row addresses and three groups of registers
-            // live -- blocked like the common path it costs the headline kernel five spilled registers)
+            // live -- blocked like the common path it costs the headline kernel five spilled registers.  Only the
+            // neighbourhood(s) of the wave whose own guard tripped take the new values: what a neighbourhood
+            // returns must not depend on its wave-mates)
+            const bool mine = NH == 1 || ((tripped >> (h * NP)) & ((NP == 32 ? 0xFFFFFFFFull : 0xFFFFull))) != 0;
             const int ngrp = (DFIX > 0 ? DSTFIX : wp) / E;
+            if (mine) {  // (the other neighbourhoods' lanes sit this out)
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-              const T* xa = DPRE ? tile + down[DPRE ? s / BP : 0] : Xh + wrap(i + own_offset(s / BP)) * xs;
-              const T* xb = DPRE ? tile + dpar[DPRE ? s % BP : 0] : Xh + wrap(i + s % BP + 1) * xs;
-              ACC sum = ACC(0);
+              for (int s = 0; s < NS; ++s) {
+                const T* xa = DPRE ? tile + down[DPRE ? s / BP : 0] : Xh + wrap(i + own_offset(s / BP)) * xs;
+                const T* xb = DPRE ? tile + dpar[DPRE ? s % BP : 0] : Xh + wrap(i + s % BP + 1) * xs;
+                ACC sum = ACC(0);
 #pragma nounroll
-              for (int c = 0; c < ngrp; ++c)
-                accum(sum, vsub(*reinterpret_cast<const V*>(xa + c * E), *reinterpret_cast<const V*>(xb + c * E)));
-              acc[s] = sum;
+                for (int c = 0; c < ngrp; ++c)
+                  accum(sum, vsub(*reinterpret_cast<const V*>(xa + c * E), *reinterpret_cast<const V*>(xb + c * E)));
+                gram_from_diff(sum);
+                acc[s] = sum;
+              }
             }
-#pragma unroll
-            for (int s = 0; s < NS; ++s) gram_from_diff(acc[s]);
           }
         }
       } else

@@ -250,6 +250,11 @@ __device__ __forceinline__ void gram_finish2(double& a, double& b, double nsa, d
 __device__ __forceinline__ void gram_finish1(double& a, double nsa, double&) { gram_finish(a, nsa); }
 __device__ __forceinline__ bool gram_guard_tripped(float guard) { return __builtin_amdgcn_ballot_w64(guard < 0.0f) != 0; }
 __device__ __forceinline__ bool gram_guard_tripped(double) { return false; }
+// the lanes whose guard tripped (a wave kernel with several neighbourhoods per wave redoes only the tripped ones: a
+// neighbourhood's bits must not depend on which other neighbourhood shares its wave -- shards of a batch concatenate
+// bit for bit, tests/test_gpu_properties.py)
+__device__ __forceinline__ unsigned long long gram_guard_lanes(float guard) { return __builtin_amdgcn_ballot_w64(guard < 0.0f); }
+__device__ __forceinline__ unsigned long long gram_guard_lanes(double) { return 0ull; }
 // difference-form result (two partial sums) -> the layout the Gram path leaves behind (squared distance in .x)
 __device__ __forceinline__ void gram_from_diff(f2& a) {
   a.x = a.x + a.y;

@@ -105,7 +105,7 @@ def test_gram_guard_in_a_long_launch_and_in_run_time_compiled_kernels(case):
     from muygpys_amd import _lib
     from muygpys_amd.fused import KernelSpec, posterior_mean_var
 
-    for k, d in ((30, 40), (25, 16)):
+    for k, d in ((30, 40), (20, 8)):  # (a shape test_gpu_jit.py does not count loads of)
         rng = np.random.default_rng(7 + k)
         b = 70_000 if case == "mixed" else 12_000
         X, Q, bi, ni, ell = _case(case, rng, k, d, 1, b)
