@@ -117,7 +117,7 @@
 #ifndef MGP_FOLD
 #define MGP_FOLD 1
 #endif
-// fp64, 64 slots, static shapes with one response: the lower triangle of the augmented system DEALT over the lanes
+// fp64, 64 slots, static shapes: the lower triangle of the augmented system DEALT over the lanes
 // in vertical pairs (rows 2r, 2r+1 of one column per 16-byte register group, column-major, 64 consecutive pairs per
 // slot) instead of a row per lane.  See phase 4D.
 #ifndef MGP_DLT
@@ -169,7 +169,7 @@ constexpr WaveDims wave_dims(int es, int NP, int KFIX, int RFIX, int DFIX, bool 
   w.NG = (w.NPL + w.E - 1) / w.E;                        // 16-byte groups of a lane's row
   w.KS = NP + w.E;
   w.TRI = NP == 64 && !COEFF;
-  w.DLT = MGP_DLT && es == 8 && NP == 64 && w.STAT && RFIX == 1;
+  w.DLT = MGP_DLT && es == 8 && NP == 64 && w.STAT && RFIX >= 1;
   w.NR2 = (w.NPL + 1) / 2;
   w.NPAIR = dlt_col_start(w.NPL, w.NR2);
   w.NSL = (w.NPAIR + 63) / 64;
@@ -1079,10 +1079,10 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       if (PACKED && !a.targets_batch) {
 #pragma unroll
         for (int r = 1; r < E; ++r)
-          if (r < R && (!TRI || i3 <= q + 1 + r)) Kh3[rowoff(q + 1 + r) + i3] = i3 < k ? myyv[r] : T(0);
+          if (r < R && (!TRI || i3 <= q + 1 + r)) Kh3[eoff(q + 1 + r, i3)] = i3 < k ? myyv[r] : T(0);
       } else {
         for (int r = 1; r < R; ++r)
-          if (!TRI || i3 <= q + 1 + r) Kh3[rowoff(q + 1 + r) + i3] = i3 < k ? targets[mytg * (int64_t)R + r] : T(0);
+          if (!TRI || i3 <= q + 1 + r) Kh3[eoff(q + 1 + r, i3)] = i3 < k ? targets[mytg * (int64_t)R + r] : T(0);
       }
     }
     __syncthreads();
@@ -1361,8 +1361,9 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       __builtin_amdgcn_s_setprio(0);
 #endif
       {
-        constexpr int QF = KFIX, YF = KFIX + 1;
-        const int eq = cs2(QF), em = cs2(QF) + (YF >> 1) - (QF >> 1), ey = cs2(YF);  // pairs of (q, q), (q+1, q), (q+1, q+1)
+        // the Schur block sits in compile-time lanes: (q, q) = variance, (q + 1 + r, q) = -mean_r, (q + 1 + r, q + 1 + r) = -y_r^T K^-1 y_r
+        constexpr int QF = KFIX;
+        const int eq = cs2(QF);
         T* mean = static_cast<T*>(a.mean);
         T* var = static_cast<T*>(a.var);
         T* yk = static_cast<T*>(a.ykinvy);
@@ -1372,8 +1373,13 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
             var[nb] = bad ? num<T>::nan() : Dp[eq >> 6][QF & 1];
             if (bad && a.info) atomicAdd(a.info, 1);
           }
-          if (lane == (em & 63)) mean[nb] = bad ? num<T>::nan() : -Dp[em >> 6][YF & 1];
-          if (yk && lane == (ey & 63)) yk[nb] = bad ? num<T>::nan() : -Dp[ey >> 6][YF & 1];
+#pragma unroll
+          for (int r = 0; r < RFIX; ++r) {
+            const int YF = QF + 1 + r;
+            const int em = cs2(QF) + (YF >> 1) - (QF >> 1), ey = cs2(YF);
+            if (lane == (em & 63)) mean[nb * RFIX + r] = bad ? num<T>::nan() : -Dp[em >> 6][YF & 1];
+            if (yk && lane == (ey & 63)) yk[nb * RFIX + r] = bad ? num<T>::nan() : -Dp[ey >> 6][YF & 1];
+          }
         }
       }
       continue;

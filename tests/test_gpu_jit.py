@@ -48,6 +48,10 @@ SHAPES = [
     (50, 16, 1, "float64", "matern05", "l2", False, True),
     (61, 8, 1, "float64", "maternInf", "l2", True, True),
     (62, 24, 1, "float64", "matern15", "l2", False, False),
+    # ... with several responses (response rows q + 1 + r of the dealt triangle; two ride in a prepared fp64 row)
+    (33, 8, 2, "float64", "matern15", "l2", True, True),
+    (45, 12, 3, "float64", "rbf", "F2", False, False),
+    (58, 16, 4, "float64", "matern25", "l2", False, False),
 ]
 
 
