@@ -832,16 +832,20 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
           }
           // squared distance of a pair: |a'|^2 + |b'|^2 - 2 a'.b', clamped at zero; left in acc[].x
           // (acc[].y = 0) so that the covariance stage below reads it like a difference-form sum
-          T nown[BA], npar[BP];
+          // (partner-major: one partner norm live at a time -- loading all BA + BP norms first cost the d = 64
+          // instantiation a spilled register)
+          T nown[BA];
 #pragma unroll
           for (int j = 0; j < BA; ++j) nown[j] = NDUP ? nrmh[iw + own_offset(j)] : nrmh[wrap(i + own_offset(j))];
-#pragma unroll
-          for (int s = 1; s <= BP; ++s) npar[s - 1] = NDUP ? nrmh[iw + s] : nrmh[wrap(i + s)];
           T guard = T(1);
 #pragma unroll
-          for (int s = 0; s + 1 < NS; s += 2)
-            gram_finish2(acc[s], acc[s + 1], nown[s / BP] + npar[s % BP], nown[(s + 1) / BP] + npar[(s + 1) % BP], guard);
-          if constexpr (NS % 2 == 1) gram_finish1(acc[NS - 1], nown[(NS - 1) / BP] + npar[(NS - 1) % BP], guard);
+          for (int s = 0; s < BP; ++s) {
+            const T np1 = NDUP ? nrmh[iw + s + 1] : nrmh[wrap(i + s + 1)];
+#pragma unroll
+            for (int j = 0; j + 1 < BA; j += 2)
+              gram_finish2(acc[j * BP + s], acc[(j + 1) * BP + s], nown[j] + np1, nown[j + 1] + np1, guard);
+            if constexpr (BA % 2 == 1) gram_finish1(acc[(BA - 1) * BP + s], nown[BA - 1] + np1, guard);
+          }
           // ---- phase 2G: the cancellation guard tripped (mgp_wave_common.h) -- some pair of this task lies much
           // closer together than its rows lie to the query.  Rare (a query far outside a tight cluster), and
           // wave-uniform: the task's distances again, in the difference form, on the same centred rows
