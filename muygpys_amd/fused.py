@@ -93,7 +93,12 @@ class PackedTable:
     """A prepared table (``mgp_table_pack_*``): rows ``[features | responses | pad]`` at a 64-byte
     multiple stride, so that the gather of a neighbour row brings its responses along (two cache
     lines per neighbour instead of three at d = 40, fp32).  Built once per (features, targets) pair
-    -- the tables do not change across the objective evaluations of a hyper-parameter search."""
+    -- the tables do not change across the objective evaluations of a hyper-parameter search.
+
+    Feature rows that are not whole 16-byte groups (d = 1, 2, 3, 5, 6 ... in fp32; odd d in fp64) are padded with
+    zero features up to the next group (``d_kernel``): a zero feature adds nothing to any distance, so the kernels run
+    on ``d_kernel`` features (Anisotropy: the padded features get length scale 1) and every shape takes the pipelined
+    prepared-table kernels -- the reference's univariate tutorial (d = 1) included."""
 
     def __init__(self, features: torch.Tensor, targets: Optional[torch.Tensor] = None):
         _lib.require_cuda(features, targets)
@@ -107,13 +112,17 @@ class PackedTable:
         # their addresses, which must not be handed to another tensor meanwhile
         self._sources = (features, targets)
         self.n, self.d = f.shape
+        group = 16 // f.element_size()
+        self.d_kernel = (self.d + group - 1) // group * group
+        if self.d_kernel != self.d:
+            f = torch.nn.functional.pad(f, (0, self.d_kernel - self.d))
         self.R = 0 if t is None else t.shape[1]
         self.dtype = f.dtype
-        self.stride = int(_lib.load().mgp_packed_row_bytes(self.d, self.R, f.element_size()))
+        self.stride = int(_lib.load().mgp_packed_row_bytes(self.d_kernel, self.R, f.element_size()))
         self.data = torch.empty(self.n * self.stride, dtype=torch.uint8, device=f.device)
         _lib.check(
             _lib.fn("table_pack", f.dtype)(
-                _lib.ptr(f), _lib.ptr(t), self.n, self.d, self.R, _lib.ptr(self.data), self.stride, _lib.stream_ptr()
+                _lib.ptr(f), _lib.ptr(t), self.n, self.d_kernel, self.R, _lib.ptr(self.data), self.stride, _lib.stream_ptr()
             ),
             "mgp_table_pack",
         )
@@ -121,7 +130,14 @@ class PackedTable:
     @staticmethod
     def supported(d: int, R: int, k: int, dtype) -> bool:
         es = 4 if dtype == torch.float32 else 8
-        return (d * es) % 16 == 0 and R * es <= 16 and k + 1 + R <= 64
+        dk = (d * es + 15) // 16 * 16 // es  # (rows are padded to whole 16-byte groups)
+        return dk <= 64 and R * es <= 16 and k + 1 + R <= 64
+
+    def kernel_length_scale(self, ls: torch.Tensor) -> torch.Tensor:
+        """Per-feature length scales padded to ``d_kernel`` entries (ones: the padded features are all zero)."""
+        if ls.numel() == 1 or self.d_kernel == self.d:
+            return ls
+        return torch.cat([ls, torch.ones(self.d_kernel - self.d, device=ls.device, dtype=ls.dtype)])
 
 
 # Prepared tables are kept per (features, targets) identity: at most _PACK_CACHE_SIZE entries and
@@ -282,12 +298,13 @@ def posterior_mean_var(
         if use_packed:
             pn = pack_table(train_features, None if gathered else train_targets, query=False)
             pq = pn if test_features is train_features else pack_table(test_features, None)
+        lsk = pn.kernel_length_scale(ls) if use_packed else ls
         rc = _lib.fn("posterior_gen", dtype)(
             None if use_packed else _lib.ptr(fq), None if use_packed else _lib.ptr(fn),
             _lib.ptr(pq.data) if use_packed else None, pq.stride if use_packed else 0,
             _lib.ptr(pn.data) if use_packed else None, pn.stride if use_packed else 0,
-            d, _lib.ptr(bi), _lib.ptr(ni), b, k, _lib.ptr(tg), R, 1 if gathered else 0, mode, eps, _lib.ptr(nz),
-            float(spec.smoothness), spec.metric_id(), _lib.ptr(ls), ls.numel(),
+            pn.d_kernel if use_packed else d, _lib.ptr(bi), _lib.ptr(ni), b, k, _lib.ptr(tg), R, 1 if gathered else 0, mode, eps,
+            _lib.ptr(nz), float(spec.smoothness), spec.metric_id(), _lib.ptr(lsk), lsk.numel(),
             _lib.ptr(mean), _lib.ptr(var), _lib.ptr(yk), _lib.ptr(info), _lib.stream_ptr(),
         )
         if rc == -2:
@@ -310,17 +327,19 @@ def posterior_mean_var(
     if use_packed and gathered:
         pn = pack_table(train_features, None, query=False)
         pq = pn if test_features is train_features else pack_table(test_features, None)
+        lsk = pn.kernel_length_scale(ls)
         rc = _lib.fn("posterior_packed_gathered", dtype)(
-            _lib.ptr(pq.data), pq.stride, _lib.ptr(pn.data), pn.stride, d, _lib.ptr(bi), _lib.ptr(ni), b, k,
-            _lib.ptr(tg), R, mode, eps, _lib.ptr(nz), spec.kernel_id(), spec.metric_id(), _lib.ptr(ls), ls.numel(),
+            _lib.ptr(pq.data), pq.stride, _lib.ptr(pn.data), pn.stride, pn.d_kernel, _lib.ptr(bi), _lib.ptr(ni), b, k,
+            _lib.ptr(tg), R, mode, eps, _lib.ptr(nz), spec.kernel_id(), spec.metric_id(), _lib.ptr(lsk), lsk.numel(),
             _lib.ptr(mean), _lib.ptr(var), _lib.ptr(yk), _lib.ptr(info), _lib.stream_ptr(),
         )
     elif use_packed:
         pn = pack_table(train_features, train_targets)
         pq = pn if test_features is train_features else pack_table(test_features, None)
+        lsk = pn.kernel_length_scale(ls)
         rc = _lib.fn("posterior_packed", dtype)(
-            _lib.ptr(pq.data), pq.stride, _lib.ptr(pn.data), pn.stride, d, _lib.ptr(bi), _lib.ptr(ni), b, k, R,
-            mode, eps, _lib.ptr(nz), spec.kernel_id(), spec.metric_id(), _lib.ptr(ls), ls.numel(),
+            _lib.ptr(pq.data), pq.stride, _lib.ptr(pn.data), pn.stride, pn.d_kernel, _lib.ptr(bi), _lib.ptr(ni), b, k, R,
+            mode, eps, _lib.ptr(nz), spec.kernel_id(), spec.metric_id(), _lib.ptr(lsk), lsk.numel(),
             _lib.ptr(mean), _lib.ptr(var), _lib.ptr(yk), _lib.ptr(info), _lib.stream_ptr(),
         )
     if rc == -2:  # MGP_EUNSUPPORTED on the prepared tables (or not tried): the plain tables
@@ -393,7 +412,9 @@ def loocv_partials(
         use_packed = key in _PACK_CACHE or b * (k + 1) >= fn.shape[0] // 4
     if use_packed:
         pn = pack_table(train_features, train_targets)
-        rc = _lib.fn("loocv_packed", dtype)(_lib.ptr(pn.data), pn.stride, d, _lib.ptr(bi), _lib.ptr(ni), b, k, *tail)
+        lsk = pn.kernel_length_scale(ls)
+        tail = tail[:5] + (_lib.ptr(lsk), lsk.numel()) + tail[7:]
+        rc = _lib.fn("loocv_packed", dtype)(_lib.ptr(pn.data), pn.stride, pn.d_kernel, _lib.ptr(bi), _lib.ptr(ni), b, k, *tail)
     if rc == -2:
         rc = _lib.fn("loocv", dtype)(_lib.ptr(fn), d, _lib.ptr(bi), _lib.ptr(ni), b, k, _lib.ptr(tg), *tail)
     _lib.check(rc, "mgp_loocv")
