@@ -18,6 +18,8 @@
 // One wave (= one workgroup) per neighbourhood; phases 0-3 as in mgp_fused_wave.hip (register
 // staged row-walking gather; cyclic difference-form distances among the k rows plus one
 // crosswise distance per lane; covariances exchanged through LDS into row-per-lane registers).
+#include <cstdio>
+#include <cstdlib>
 #include "mgp_wave_common.h"
 
 // issue priorities per phase: covariances / exchange / elimination before the other wave's distances
@@ -57,8 +59,28 @@ struct RhsGeom {
 // GRAM (fp32, one feature stage, not Matern-1/2): rows centred on the query in place, pair
 // distances as |a'|^2 + |b'|^2 - 2 a'.b' -- one packed FMA per two features of a pair instead of a packed
 // subtract and a packed FMA -- and the crosswise distance of a lane is its row's norm, exactly.
-template <typename T, int RC, bool BACK = false, bool GRAM = false>  // RC: compiled number of response columns (run-time R <= RC)
-__global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel(FusedArgs a, RhsGeom g) {
+// W3 (round 4; fp32 prediction variant with the Gram form -- BASELINE config 5): held to three waves per SIMD.  The
+// kernel is bound by its two waves (occupancy sweep), and BOTH limits sat at eight workgroups
+// per CU: 254 registers and 18.5 KB of LDS.  Here (i) the exchange matrix is packed lower-triangular (8.7 instead of
+// 17.4 KB: a lane's row of the system only ever needs its lower triangle), (ii) the multipliers are not stored to LDS
+// step by step but kept IN PLACE -- entry (i, j) of a lane's row is dead once column j is eliminated -- and the rows
+// are dumped once, in the same packed layout, where the back-substitution reads L column-wise with consecutive lanes
+// on consecutive addresses, (iii) the column of a step is consumed in two halves instead of copied whole.
+#ifndef MGP_RHS_W3_WAVES
+#define MGP_RHS_W3_WAVES 3
+#endif
+#ifndef MGP_RHS_W3_SCHED
+#define MGP_RHS_W3_SCHED 0
+#endif
+#ifndef MGP_RHS_W3_HG
+#define MGP_RHS_W3_HG 8
+#endif
+#ifndef MGP_RHS_ATTR
+#define MGP_RHS_ATTR
+#endif
+template <typename T, int RC, bool BACK = false, bool GRAM = false, bool W3 = false>  // RC: compiled number of response columns (run-time R <= RC)
+__global__ __launch_bounds__(64, (sizeof(T) == 4 ? (W3 ? MGP_RHS_W3_WAVES : 2) : 1)) MGP_RHS_ATTR void fused_rhs_kernel(FusedArgs a, RhsGeom g) {
+  static_assert(!W3 || (sizeof(T) == 4 && BACK), "W3: the fp32 prediction variant");
   constexpr int NP = 64;
   constexpr int NS = NP / 2;
   // register blocking of the pair scheme (mgp_fused_wave.hip, phase 2): BA own rows x BP partners
@@ -69,6 +91,17 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
   constexpr int E = v16<T>::N;
   constexpr int CH = 2 * E;
   constexpr int KS = NP + E;
+  // (W3) packed lower-triangular exchange matrix: row r holds its r + 1 entries padded to whole 16-byte groups, at
+  // rowoff(r) = E (a + 1) (E a / 2 + r % E), a = r / E (as the 64-slot wave kernels, mgp_fused_wave_kernel.h)
+  auto rowoff = [](int r) {
+    if constexpr (W3) {
+      const int a_ = r / E;
+      return E * (a_ + 1) * (E * a_ / 2 + r % E);
+    } else {
+      return r * KS;
+    }
+  };
+  constexpr int KMAT = W3 ? E * ((NP - 1) / E + 1) * (E * ((NP - 1) / E) / 2 + (NP - 1) % E) + NP + E : NP * KS;
   constexpr int NR = 1 + RC;                       // rhs columns: cross-covariance + responses
   constexpr int NRV = (NR + E - 1) / E;            // ... in 16-byte groups
   using V = typename v16<T>::type;
@@ -77,10 +110,10 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int k = a.k, d = a.d, R = a.R, xs = g.xs, dst = g.dst;
   const int rows_x = NP + 1;                       // tile rows: 64 slots + the query
-  const int tile_elems = rows_x * xs > NP * KS ? rows_x * xs : NP * KS;
+  const int tile_elems = rows_x * xs > KMAT ? rows_x * xs : KMAT;
   T* tile = reinterpret_cast<T*>(smem);            // feature tile, later the exchange matrix
-  T* colbuf = tile + tile_elems;                   // 64
-  T* rhsbuf = colbuf + 64;                         // NRV * E
+  T* colbuf = tile + tile_elems;                   // 64 (W3: two column buffers)
+  T* rhsbuf = colbuf + (W3 ? 2 * NP : NP);         // NRV * E
   T* ilbuf = rhsbuf + NRV * E;                     // dst
   int64_t* idxbuf = reinterpret_cast<int64_t*>(ilbuf + dst + (dst & 1));  // 65
 
@@ -132,6 +165,10 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
     // ---- gather + distances (pairwise: cyclic scheme; crosswise: lane i vs the query) ------
     ACC acc[NS];
     ACC accq = ACC(0);
+    // (zeroed HERE, not under `d0 == 0` inside the loop: a conditional first store makes the 64 accumulator registers
+    // a value carried around the persistent loop -- live, untouched, through the whole elimination)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = ACC(0);
     for (int d0 = 0; d0 < d; d0 += dst) {
       const int w = min(dst, d - d0);
       const int wp = (w + CH - 1) / CH * CH;
@@ -173,10 +210,6 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
       if (aniso)
         for (int c = i; c < wp; c += 64) ilbuf[c] = c < w ? T(1) / ls[d0 + c] : T(0);
       __syncthreads();
-      if (d0 == 0) {
-#pragma unroll
-        for (int s = 0; s < NS; ++s) acc[s] = ACC(0);
-      }
       const T* xq = tile + NP * xs;
       if constexpr (GRAM) {
         // centre row i on the query (times the inverse length scales), in place; |a'|^2 behind the row (column dst)
@@ -355,15 +388,15 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
         const int r1 = (i + own_offset((s - 1) / BP)) & (NP - 1);  // pair j * BP + p - 1: (own row j, partner p)
         const int c = (i + (s - 1) % BP + 1) & (NP - 1);
         const int hi = max(r1, c), lo = min(r1, c);
-        tile[hi * KS + lo] = hi < k ? kv[s - 1] : T(0);  // unused slots: identity rows
+        tile[rowoff(hi) + lo] = hi < k ? kv[s - 1] : T(0);  // unused slots: identity rows
       });
-      tile[i * KS + i] = i < k ? T(1) + myeps : T(1);
+      tile[rowoff(i) + i] = i < k ? T(1) + myeps : T(1);
       rhs[0] = i < k ? kq : T(0);
     }
     __syncthreads();
     V A[NP / E];
 #pragma unroll
-    for (int c4 = 0; c4 < NP / E; ++c4) A[c4] = *reinterpret_cast<const V*>(tile + i * KS + c4 * E);
+    for (int c4 = 0; c4 < NP / E; ++c4) A[c4] = *reinterpret_cast<const V*>(tile + rowoff(i) + c4 * E);  // (W3: beyond the diagonal belongs to later rows -- never used)
 
 #if MGP_RHS_PRIO
     __builtin_amdgcn_s_setprio(MGP_RHS_PRIO);
@@ -391,6 +424,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
     // the LDS round trip in front of the next step's reciprocal runs under the packed FMAs of this one.
     // (Requesting the whole next column that early would need a second 64-register copy: spills.)
     V piv = V(0);
+    V mreg = V(0);  // (W3) the multipliers of the current 16-byte group of columns
     if constexpr (sizeof(T) == 4) {
       colbuf[i] = A[0][0];
       piv = *reinterpret_cast<const V*>(colbuf);
@@ -406,7 +440,56 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
         for (int r4 = 0; r4 < NRE; ++r4)
 #pragma unroll
           for (int e = 0; e < E; ++e) bj[r4][e] = r4 * E + e < (BACK ? 1 : NR) ? lane_value(rv[r4][e], j) : T(0);
-        if constexpr (sizeof(T) == 4) {
+        if constexpr (W3) {
+          // The column in two chunks of HG groups instead of a whole-column copy (64 registers).  The column buffer is
+          // double: column j lives in buffer j & 1, the look-ahead posts column j + 1 into the other one, so the second
+          // chunk of column j can still be read after that post.  The multiplier of this step goes to `mreg` and, once
+          // its 16-byte group of columns is finished (no later step updates that group), into the row's own dead
+          // group: the row ends up holding its row of L.
+          T* cb = colbuf + (j & 1) * NP;
+          T* cbn = colbuf + ((j + 1) & 1) * NP;
+          const T p = piv[j % E];
+          bad = bad || !(p > T(0));
+          if (i == j) mypiv = p;
+          const T t = i > j ? ajj * pivot_rcp(p) : T(0);  // rows <= j are finished: leave them alone
+          const V nt = V(-t);
+          constexpr int JN = NP - 1, NGR = NP / E, HG = MGP_RHS_W3_HG;
+          const int g0 = j / E, g1 = (j < JN ? j + 1 : j) / E;
+          {
+            V col[HG];
+            col[0] = piv;
+#pragma unroll
+            for (int u = 1; u < HG; ++u)
+              if (g0 + u < NGR) col[u] = *reinterpret_cast<const V*>(cb + (g0 + u) * E);
+            A[g1] = col[g1 - g0] * nt + A[g1];
+            if (j < JN) {
+              cbn[i] = A[g1][(j + 1) % E];
+              piv = *reinterpret_cast<const V*>(cbn + g1 * E);
+            }
+#pragma unroll
+            for (int u = 0; u < HG; ++u)
+              if (g0 + u < NGR && g0 + u != g1) A[g0 + u] = col[u] * nt + A[g0 + u];
+          }
+#pragma unroll
+          for (int h = g0 + HG; h < NGR; h += HG) {
+#if MGP_RHS_W3_SCHED & 1
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            V col[HG];
+#pragma unroll
+            for (int u = 0; u < HG; ++u)
+              if (h + u < NGR) col[u] = *reinterpret_cast<const V*>(cb + (h + u) * E);
+#pragma unroll
+            for (int u = 0; u < HG; ++u)
+              if (h + u < NGR) A[h + u] = col[u] * nt + A[h + u];
+          }
+          rv[0] = bj[0] * nt + rv[0];
+          mreg[j % E] = t;
+          if (j % E == E - 1) A[g0] = mreg;  // group g0 is finished: nobody updates it again
+#if MGP_RHS_W3_SCHED & 2
+          __builtin_amdgcn_sched_barrier(0);
+#endif
+        } else if constexpr (sizeof(T) == 4) {
           V col[NP / E];
           col[j / E] = piv;
 #pragma unroll
@@ -416,7 +499,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
           if (i == j) mypiv = p;
           const T t = i > j ? ajj * pivot_rcp(p) : T(0);  // rows <= j are finished: leave them alone
           const V nt = V(-t);
-          if constexpr (BACK) Lm[j * LS + i] = t;
+          if constexpr (BACK && !W3) Lm[j * LS + i] = t;
           constexpr int JN = NP - 1;
           const int g1 = (j < JN ? j + 1 : j) / E;  // group of the next column (compile-time after unrolling)
           A[g1] = col[g1] * nt + A[g1];
@@ -480,12 +563,24 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
       // of an earlier launch; NaN x 0 = NaN), and its w is 0 anyway.  Hence the `i < min(m, k)` guard below.
       T w = u * inv_d;
       constexpr int BB = MGP_RHS_BACK_BLOCK;
+      if constexpr (W3) {
+        // the rows of L, kept in place during the elimination, go to LDS once, in the packed layout of the exchange
+        // matrix (which is dead by now): row i, the groups that hold columns < i.  Every row is written -- also the
+        // identity rows behind k (zero multipliers) -- so nothing stale is ever read; what lies beyond a row's
+        // diagonal inside its last group is junk that the `i < min(m, k)` mask below keeps out.
+        __syncthreads();
+#pragma unroll
+        for (int c4 = 0; c4 < NP / E; ++c4)
+          if (c4 * E < i) *reinterpret_cast<V*>(tile + rowoff(i) + c4 * E) = A[c4];
+        __syncthreads();
+      }
 #pragma unroll
       for (int mb = NP - BB; mb >= 0; mb -= BB) {
         if (mb < k) {  // (uniform)
           T lm[BB];
 #pragma unroll
-          for (int e = 0; e < BB; ++e) lm[e] = Lm[i * LS + mb + e];  // multiplier of row mb + e at step i (junk for i >= mb + e or i >= k: masked below)
+          for (int e = 0; e < BB; ++e)  // multiplier of row mb + e at step i (junk for i >= mb + e or i >= k: masked below)
+            lm[e] = W3 ? tile[rowoff(mb + e) + i] : Lm[i * LS + mb + e];  // (W3: lanes read L column-wise, consecutive addresses)
 #pragma unroll
           for (int e = BB - 1; e >= 0; --e) {
             const int m = mb + e;
@@ -519,12 +614,13 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void fused_rhs_kernel
   }
 }
 
-template <typename T, int RC, bool BACK = false, bool GRAM = false>
+template <typename T, int RC, bool BACK = false, bool GRAM = false, bool W3 = false>
 static int launch_rhs_impl(const FusedArgs& a, hipStream_t stream) {
   constexpr int NP = 64;
   constexpr int E = v16<T>::N;
   constexpr int CH = 2 * E;
   constexpr int KS = NP + E;
+  constexpr int KMAT = W3 ? E * ((NP - 1) / E + 1) * (E * ((NP - 1) / E) / 2 + (NP - 1) % E) + NP + E : NP * KS;
   constexpr int NRV = (1 + RC + E - 1) / E;
   RhsGeom g;
   const int dpad = (a.d + CH - 1) / CH * CH;
@@ -534,19 +630,23 @@ static int launch_rhs_impl(const FusedArgs& a, hipStream_t stream) {
   g.vec_ok = (a.d % E == 0) && (align % 16 == 0);
   g.resp_vec = a.R == RC && RC % E == 0 && (uintptr_t)a.targets % 16 == 0;
   g.ntasks = a.b;
-  const size_t tile_elems = (size_t)((NP + 1) * g.xs > NP * KS ? (NP + 1) * g.xs : NP * KS);
-  size_t lds = (tile_elems + 64 + NRV * E + g.dst + (g.dst & 1)) * sizeof(T) + 66 * sizeof(int64_t);
+  const size_t tile_elems = (size_t)((NP + 1) * g.xs > KMAT ? (NP + 1) * g.xs : KMAT);
+  size_t lds = (tile_elems + (W3 ? 2 * NP : NP) + NRV * E + g.dst + (g.dst & 1)) * sizeof(T) + 66 * sizeof(int64_t);
   lds = (lds + 15) & ~(size_t)15;
   static Residency res;
   int per_cu = 0, cus = 0;
-  const int rc = res.lookup(reinterpret_cast<const void*>(&fused_rhs_kernel<T, RC, BACK, GRAM>), 64, lds, &per_cu, &cus);
+  const int rc = res.lookup(reinterpret_cast<const void*>(&fused_rhs_kernel<T, RC, BACK, GRAM, W3>), 64, lds, &per_cu, &cus);
   if (rc != MGP_OK) return rc;
+  static const int env_per_cu = getenv("MGP_RHS_PER_CU") ? atoi(getenv("MGP_RHS_PER_CU")) : 0;  // occupancy experiments
+  if (env_per_cu > 0 && env_per_cu < per_cu) per_cu = env_per_cu;
+  static const bool trace = getenv("MGP_TRACE") != nullptr;
+  if (trace) fprintf(stderr, "[mgp] fused_rhs_kernel<%d,%d,%d,%d>: lds %zu B, %d workgroups per CU\n", RC, (int)BACK, (int)GRAM, (int)W3, lds, per_cu);
   int64_t grid = (int64_t)cus * per_cu;
   if (grid > g.ntasks) grid = g.ntasks;
-  hipLaunchKernelGGL((fused_rhs_kernel<T, RC, BACK, GRAM>), dim3((unsigned)grid), dim3(64), lds, stream, a, g);
+  hipLaunchKernelGGL((fused_rhs_kernel<T, RC, BACK, GRAM, W3>), dim3((unsigned)grid), dim3(64), lds, stream, a, g);
   MGP_HIP_CHECK_LAUNCH();
-  note_launch("mgp::fused_rhs_kernel<%s,%d,%s,%s>", sizeof(T) == 4 ? "float" : "double", RC, BACK ? "true" : "false",
-              GRAM ? "true" : "false");
+  note_launch("mgp::fused_rhs_kernel<%s,%d,%s,%s%s>", sizeof(T) == 4 ? "float" : "double", RC, BACK ? "true" : "false",
+              GRAM ? "true" : "false", W3 ? ",w3" : "");
   return MGP_OK;
 }
 
@@ -561,8 +661,13 @@ static int launch_rhs(const FusedArgs& a, hipStream_t stream) {
     // zero distance turns the cancellation error of the Gram form into covariance error
     // (and rows of whole 16-byte groups, at least two: the tiny-d fixtures gain nothing and the 1-d one is
     // ill-conditioned enough for the cancellation error to show)
-    if ((a.d + CH - 1) / CH * CH <= 64 && a.d % v16<T>::N == 0 && a.d >= CH && a.kernel_id != MGP_KERNEL_MATERN_05)
+    if ((a.d + CH - 1) / CH * CH <= 64 && a.d % v16<T>::N == 0 && a.d >= CH && a.kernel_id != MGP_KERNEL_MATERN_05) {
+#ifndef MGP_RHS_W3
+#define MGP_RHS_W3 1
+#endif
+      if constexpr (BACK && MGP_RHS_W3) return launch_rhs_impl<T, RC, BACK, true, true>(a, stream);
       return launch_rhs_impl<T, RC, BACK, true>(a, stream);
+    }
   }
   return launch_rhs_impl<T, RC, BACK, false>(a, stream);
 }

@@ -609,6 +609,11 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     }
 
     ACC acc[NS];
+    // (zeroed here, not under `d0 == 0` inside the feature loop: with a run-time feature count a conditional first
+    // store makes the accumulators a value carried around the persistent loop -- NS registers (pairs) live, untouched,
+    // through the whole elimination; found in the rhs-column kernel, round 4)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = ACC(0);
 #if MGP_CHOL_PRIO && MGP_PRIO_LATE_DROP
     __builtin_amdgcn_s_setprio(0);  // the distance phase: long independent streams, lowest priority
 #endif
@@ -690,10 +695,6 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         for (int c = lane; c < wp; c += 64) ilbuf[c] = c < w ? T(1) / ls[d0 + c] : T(0);
       __syncthreads();
 
-      if (d0 == 0) {
-#pragma unroll
-        for (int s = 0; s < NS; ++s) acc[s] = ACC(0);
-      }
       if constexpr (GRAM) {
         // ---- phase 1b: centre the rows on the query, in place; squared norms --------------------
         // Row i becomes a' = (a - q) [x inverse length scales]; |a'|^2 goes to the norm array (below), where the

@@ -65,6 +65,8 @@ def main():
             if out.returncode != 0:
                 print(v, "FAILED", out.stderr[-400:])
                 continue
+            for ln in sorted({ln for ln in out.stderr.splitlines() if ln.startswith("[mgp]")}):  # (MGP_TRACE=1)
+                print("   ", ln)
             d = json.loads(out.stdout.strip().splitlines()[-1])
             res[v].append(d["median"])
             sums[v] = (d["csum"], d["vsum"])
