@@ -41,6 +41,30 @@
 #define MGP_RHS_BACK_BLOCK 32
 #endif
 
+#ifndef MGP_RHS_TIMING
+#define MGP_RHS_TIMING 0
+#endif
+#if MGP_RHS_TIMING
+// phase timing (experiments only; tools/rhs_timing.py): s_memtime differences summed per wave and phase
+__device__ unsigned long long g_rhs_timing[8];
+#define MGP_RHS_T(slot)                                      \
+  {                                                          \
+    const unsigned long long tnow_ = __builtin_readcyclecounter(); \
+    tacc_[slot] += tnow_ - tlast_;                           \
+    tlast_ = tnow_;                                          \
+  }
+extern "C" int mgp_debug_rhs_timing(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rhs_timing), sizeof(g_rhs_timing)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_rhs_timing), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#else
+#define MGP_RHS_T(slot)
+#endif
+
 namespace mgp {
 
 struct RhsGeom {
@@ -78,9 +102,34 @@ struct RhsGeom {
 #ifndef MGP_RHS_ATTR
 #define MGP_RHS_ATTR
 #endif
-template <typename T, int RC, bool BACK = false, bool GRAM = false, bool W3 = false>  // RC: compiled number of response columns (run-time R <= RC)
+#ifndef MGP_RHS_FOLD_SCHED
+#define MGP_RHS_FOLD_SCHED 0
+#endif
+#ifndef MGP_RHS_FOLD_UNROLL
+#define MGP_RHS_FOLD_UNROLL 1
+#endif
+#ifndef MGP_RHS_FOLD_HG
+#define MGP_RHS_FOLD_HG 8
+#endif
+#ifndef MGP_RHS_FOLD_BLOCK
+#define MGP_RHS_FOLD_BLOCK 16
+#endif
+// FOLD (round 4; same variant): TWO neighbourhoods per wave share one elimination.  Row-per-lane elimination keeps
+// all 64 lanes busy on every column right of the pivot although a row only needs its lower triangle and rows above
+// the pivot are finished: 544 16-byte group updates per neighbourhood where the factorisation needs a third of that.
+// Folded (as the 32-slot wave kernels, mgp_fused_wave_kernel.h phase 4F): lane l of a half-wave owns row l -- columns
+// 0 .. 31 matter, 8 groups -- and row 32 + l (16 groups) of ONE neighbourhood; the two half-waves hold two
+// neighbourhoods.  A step serves both with the same instructions (every LDS read is one broadcast per half-wave):
+// 688 group updates per pair instead of 1088, and the per-step overhead (reciprocal, multipliers, posts, right-hand
+// side) once per pair.  The first neighbourhood of a pair runs its gather / distance / covariance phases on all 64
+// lanes as before, parks its two rows per lane in lanes 0 .. 31 (96 registers) and the wave goes on to the second.
+// Nothing is masked during the elimination: finished rows keep computing on dead entries (their posts only ever
+// reach columns that are finished too), the right-hand side of a row is captured the step it is broadcast, the
+// multipliers stay in place (W3) and are dumped once per neighbourhood for the two interleaved back-substitutions.
+template <typename T, int RC, bool BACK = false, bool GRAM = false, bool W3 = false, bool FOLD = false>  // RC: compiled number of response columns (run-time R <= RC)
 __global__ __launch_bounds__(64, (sizeof(T) == 4 ? (W3 ? MGP_RHS_W3_WAVES : 2) : 1)) MGP_RHS_ATTR void fused_rhs_kernel(FusedArgs a, RhsGeom g) {
   static_assert(!W3 || (sizeof(T) == 4 && BACK), "W3: the fp32 prediction variant");
+  static_assert(!FOLD || (sizeof(T) == 4 && BACK && GRAM && !W3), "FOLD: the fp32 prediction variant with the Gram form");
   constexpr int NP = 64;
   constexpr int NS = NP / 2;
   // register blocking of the pair scheme (mgp_fused_wave.hip, phase 2): BA own rows x BP partners
@@ -101,20 +150,29 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? (W3 ? MGP_RHS_W3_WAVES : 2) :
       return r * KS;
     }
   };
-  constexpr int KMAT = W3 ? E * ((NP - 1) / E + 1) * (E * ((NP - 1) / E) / 2 + (NP - 1) % E) + NP + E : NP * KS;
+  auto troff = [](int r) { return E * (r / E + 1) * (E * (r / E) / 2 + r % E); };  // the packed layout, whatever the variant
+  constexpr int KTRI = E * ((NP - 1) / E + 1) * (E * ((NP - 1) / E) / 2 + (NP - 1) % E) + NP + E;
+  constexpr int KMAT = W3 ? KTRI : (FOLD && 2 * KTRI > NP * KS ? 2 * KTRI : NP * KS);  // (FOLD: later the two packed L)
+  constexpr int HALF = NP / 2;
+  constexpr int NSYS = FOLD ? 2 : 1;  // neighbourhoods per pass of the persistent loop
   constexpr int NR = 1 + RC;                       // rhs columns: cross-covariance + responses
   constexpr int NRV = (NR + E - 1) / E;            // ... in 16-byte groups
   using V = typename v16<T>::type;
   using ACC = typename v16<T>::acc;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#if MGP_RHS_TIMING
+  unsigned long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast_ = __builtin_readcyclecounter();
+#endif
   const int k = a.k, d = a.d, R = a.R, xs = g.xs, dst = g.dst;
   const int rows_x = NP + 1;                       // tile rows: 64 slots + the query
-  const int tile_elems = rows_x * xs > KMAT ? rows_x * xs : KMAT;
+  const int tile_need = rows_x * xs + (FOLD ? HALF * HALF : 0);  // (FOLD: + the parked short rows)
+  const int tile_elems = tile_need > KMAT ? tile_need : KMAT;
   T* tile = reinterpret_cast<T*>(smem);            // feature tile, later the exchange matrix
-  T* colbuf = tile + tile_elems;                   // 64 (W3: two column buffers)
-  T* rhsbuf = colbuf + (W3 ? 2 * NP : NP);         // NRV * E
-  T* ilbuf = rhsbuf + NRV * E;                     // dst
+  T* colbuf = tile + tile_elems;                   // 64 (W3: two column buffers; FOLD: one per neighbourhood)
+  T* rhsbuf = colbuf + (FOLD ? 4 * NP : W3 ? 2 * NP : NP); // NRV * E (FOLD: 2 * 64 -- the cross-covariances on their way to the row owners)
+  T* ilbuf = rhsbuf + (FOLD ? 2 * NP : NRV * E);   // dst
   int64_t* idxbuf = reinterpret_cast<int64_t*>(ilbuf + dst + (dst & 1));  // 65
 
   const T* feat_q = static_cast<const T*>(a.feat_q);
@@ -132,22 +190,49 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? (W3 ? MGP_RHS_W3_WAVES : 2) :
   // Index prefetch (as in the wave kernels): the neighbour index of task t + 1 is requested at the top of task t, so
   // that the row gather of a task does not start with a dependent global round trip (two waves per SIMD: ~1.5 us of a
   // ~22 us task that nothing hid).  One branch-free load per lane (lanes behind k read a valid dummy entry).
+  // (FOLD) a pass takes the pair of tasks 2 un, 2 un + 1; an odd last task is paired with itself (and written once)
+  const int64_t nunits = FOLD ? (g.ntasks + 1) / 2 : g.ntasks;
+  auto task_of = [&](int64_t un, int sys) {
+    const int64_t t = un * NSYS + sys;
+    return t < g.ntasks ? t : g.ntasks - 1;
+  };
   int64_t next_idx = 0, next_q = 0;
-  if ((int64_t)blockIdx.x < g.ntasks) {
-    next_idx = a.nn_idx[(int64_t)blockIdx.x * k + ((int)threadIdx.x < k ? (int)threadIdx.x : 0)];
-    next_q = a.batch_idx ? a.batch_idx[blockIdx.x] : (int64_t)blockIdx.x;
+  if ((int64_t)blockIdx.x < nunits) {
+    const int64_t t0 = task_of(blockIdx.x, 0);
+    next_idx = a.nn_idx[t0 * k + ((int)threadIdx.x < k ? (int)threadIdx.x : 0)];
+    next_q = a.batch_idx ? a.batch_idx[t0] : t0;
   }
-  for (int64_t nb = blockIdx.x; nb < g.ntasks; nb += gridDim.x) {
+  for (int64_t un = blockIdx.x; un < nunits; un += gridDim.x) {
     int i = threadIdx.x;
     asm volatile("" : "+v"(i));  // keep per-lane addresses out of LICM (register pressure)
+    T rhs[NR];
+    V A[FOLD ? 1 : NP / E];
+    // (FOLD) the folded rows of the lane's neighbourhood -- FS: row l, columns 0 .. 31; FL: row 32 + l -- their
+    // right-hand sides, and the rows of the response table of the two neighbourhoods
+    V FL[FOLD ? NP / E : 1], FS[FOLD ? HALF / E : 1];
+    T rvS = T(0), rvL = T(0);
+    int64_t yrow0 = 0, yrow1 = 0;
+    int64_t nb = 0;
+#if MGP_RHS_FOLD_UNROLL
+#pragma unroll
+#else
+#pragma nounroll
+#endif
+    for (int sys = 0; sys < NSYS; ++sys) {
+    nb = task_of(un, sys);
 
     // ---- indices, nugget, responses ------------------------------------------------------
     const int64_t myidx = i < k ? next_idx : 0;
     const int64_t qidx = next_q;
-    if (nb + gridDim.x < g.ntasks) {
-      const int64_t nn = nb + gridDim.x;
-      next_idx = a.nn_idx[nn * k + (i < k ? i : 0)];
-      next_q = a.batch_idx ? a.batch_idx[nn] : nn;
+    {
+      // the next task of this workgroup's sequence: the pair's second, or the first of the next pass
+      const bool in_unit = sys + 1 < NSYS;
+      const int64_t un2 = in_unit ? un : un + gridDim.x;
+      if (un2 < nunits) {
+        const int64_t nn = task_of(un2, in_unit ? sys + 1 : 0);
+        next_idx = a.nn_idx[nn * k + (i < k ? i : 0)];
+        next_q = a.batch_idx ? a.batch_idx[nn] : nn;
+      }
     }
     __syncthreads();
     idxbuf[i] = myidx * (int64_t)d;
@@ -210,6 +295,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? (W3 ? MGP_RHS_W3_WAVES : 2) :
       if (aniso)
         for (int c = i; c < wp; c += 64) ilbuf[c] = c < w ? T(1) / ls[d0 + c] : T(0);
       __syncthreads();
+      MGP_RHS_T(0)
       const T* xq = tile + NP * xs;
       if constexpr (GRAM) {
         // centre row i on the query (times the inverse length scales), in place; |a'|^2 behind the row (column dst)
@@ -332,10 +418,14 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? (W3 ? MGP_RHS_W3_WAVES : 2) :
 
     // ---- responses of the lane's row: requested only now (1 + R registers the distance phase has
     // no room for); the loads fly while the covariances are evaluated and exchanged -----------------
-    T rhs[NR];
+    MGP_RHS_T(1)
 #pragma unroll
     for (int r = 0; r < NR; ++r) rhs[r] = T(0);
-    if (i < k) {
+    if constexpr (FOLD) {  // (requested after both neighbourhoods are parked: no room for them here)
+      const int64_t yr = a.targets_batch ? nb * k + i : myidx;
+      if (sys == 0) yrow0 = yr;
+      else yrow1 = yr;
+    } else if (i < k) {
       const T* ty = targets + (a.targets_batch ? nb * k + i : myidx) * (int64_t)R;
       if (g.resp_vec) {  // (uniform) RC / E loads of 16 bytes instead of RC single ones under RC tests
 #pragma unroll
@@ -383,6 +473,15 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? (W3 ? MGP_RHS_W3_WAVES : 2) :
         }
         kq = cov_from_sqdist<T>(sqd(accq), KID, MID, cscale);
       });
+      if constexpr (FOLD) {
+        // the short rows of the pair's first neighbourhood come back from their parking space (below) before the
+        // exchange matrix takes it; every lane reads, so that the registers were free during the distance phase
+        if (sys == 1) {
+#pragma unroll
+          for (int c4 = 0; c4 < HALF / E; ++c4)
+            FS[c4] = *reinterpret_cast<const V*>(tile + rows_x * xs + (c4 * HALF + (i & (HALF - 1))) * E);
+        }
+      }
       static_for<NS>([&](auto sc) {
         constexpr int s = decltype(sc)::value + 1;
         const int r1 = (i + own_offset((s - 1) / BP)) & (NP - 1);  // pair j * BP + p - 1: (own row j, partner p)
@@ -392,11 +491,225 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? (W3 ? MGP_RHS_W3_WAVES : 2) :
       });
       tile[rowoff(i) + i] = i < k ? T(1) + myeps : T(1);
       rhs[0] = i < k ? kq : T(0);
+      if constexpr (FOLD) rhsbuf[i] = rhs[0];
     }
     __syncthreads();
-    V A[NP / E];
+    if constexpr (FOLD) {
+      // the half-wave of this neighbourhood picks its rows up (what lies right of a row's diagonal was never written:
+      // junk that only ever meets dead entries)
+      // (the first of a pair: BOTH half-waves read -- no merge with older register contents -- and the short rows
+      // are parked in LDS behind the feature rows of the second neighbourhood: 32 registers less under its distance
+      // phase, which otherwise spills)
+      if (sys == 0 || (i >> 5) == 1) {
+        const int lh = i & (HALF - 1);
+#pragma unroll
+        for (int c4 = 0; c4 < HALF / E; ++c4) FS[c4] = *reinterpret_cast<const V*>(tile + rowoff(lh) + c4 * E);
+#pragma unroll
+        for (int c4 = 0; c4 < NP / E; ++c4) FL[c4] = *reinterpret_cast<const V*>(tile + rowoff(HALF + lh) + c4 * E);
+        rvS = rhsbuf[lh];
+        rvL = rhsbuf[HALF + lh];
+      }
+      if (sys == 0 && i < HALF) {
+#pragma unroll
+        for (int c4 = 0; c4 < HALF / E; ++c4) *reinterpret_cast<V*>(tile + rows_x * xs + (c4 * HALF + i) * E) = FS[c4];
+      }
+    } else {
 #pragma unroll
     for (int c4 = 0; c4 < NP / E; ++c4) A[c4] = *reinterpret_cast<const V*>(tile + rowoff(i) + c4 * E);  // (W3: beyond the diagonal belongs to later rows -- never used)
+    }
+    MGP_RHS_T(2)
+    }  // (sys)
+
+    if constexpr (FOLD) {
+      // ---- folded elimination of the pair, back-substitutions, outputs ----------------------------------------
+      const int sub = i >> 5, lh = i & (HALF - 1);
+      const int64_t nbA = un * 2, nbB = un * 2 + 1;
+      const bool have_b = nbB < g.ntasks;
+      T yA[RC], yB[RC];  // the responses of row i of both neighbourhoods
+      auto load_y = [&](T (&y)[RC], int64_t row) {
+#pragma unroll
+        for (int r = 0; r < RC; ++r) y[r] = T(0);
+        if (i < k) {
+          const T* ty = targets + row * (int64_t)R;
+          if (g.resp_vec) {
+#pragma unroll
+            for (int r4 = 0; r4 < RC / E; ++r4) {
+              const V v = *reinterpret_cast<const V*>(ty + r4 * E);
+#pragma unroll
+              for (int e = 0; e < E; ++e) y[r4 * E + e] = v[e];
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < RC; ++r)
+              if (r < R) y[r] = ty[r];
+          }
+        }
+      };
+
+      T* colq = colbuf + sub * 2 * NP;  // the neighbourhood's two column buffers
+      T* Lq = tile + sub * KTRI;    // ... and its packed L
+      colq[HALF + lh] = FL[0][0];
+      colq[lh] = FS[0][0];
+      V piv = *reinterpret_cast<const V*>(colq);
+      V mL = V(0), mS = V(0);  // the multipliers of the current 16-byte group of columns
+      f2 rv2 = f2{rvL, rvS};
+      T uS = T(0), uL = T(0), wS = T(0), wL = T(0);  // u_r = (L^-1 c)_r and u_r / p_r of the lane's two rows
+      T pmin = num<T>::inf();
+      const int bpa = (i & 32) << 2;  // ds_bpermute: byte address of lane 0 of the half-wave
+      constexpr int JB = 8;
+#pragma unroll
+      for (int jb = 0; jb < NP; jb += JB) {
+        if (jb < k)
+#pragma unroll
+        for (int j = jb; j < jb + JB; ++j) {
+          constexpr int NG = NP / E, NGS = HALF / E;
+          const int g0 = j / E, e0 = j % E;
+          const bool sh = j < HALF;  // (compile-time after unrolling) the short rows are still being eliminated
+          const T aL = FL[g0][e0];
+          const T aS = sh ? FS[g0 < NGS ? g0 : 0][e0] : T(0);
+          // right-hand side of row j, to every lane of its half-wave
+          const T bj = __builtin_bit_cast(T, __builtin_amdgcn_ds_bpermute(bpa + 4 * (sh ? j : j - HALF),
+                                                                         __builtin_bit_cast(int, sh ? rv2.y : rv2.x)));
+          // the column in chunks of HG groups (a whole-column copy on top of the 96 row registers spills); column j
+          // lives in buffer j & 1, so its later chunks can still be read after the look-ahead has posted column j + 1
+          constexpr int HG = MGP_RHS_FOLD_HG;
+          T* cb = colq + (j & 1) * NP;
+          T* cbn = colq + ((j + 1) & 1) * NP;
+          const T p = piv[e0];
+          pmin = __builtin_fminf(pmin, p);
+          const T rp = pivot_rcp(p);
+          const T tL = aL * rp, tS = aS * rp;
+          const V ntL = V(-tL), ntS = V(-tS);
+          const bool own = lh == (sh ? j : j - HALF);  // this lane owns row j
+          const T w0 = bj * rp;
+          if (sh) {
+            uS = own ? bj : uS;
+            wS = own ? w0 : wS;
+          } else {
+            uL = own ? bj : uL;
+            wL = own ? w0 : wL;
+          }
+          const int g1 = (j + 1 < NP ? j + 1 : j) / E;
+          {
+            V col[HG];
+            col[0] = piv;
+#pragma unroll
+            for (int u = 1; u < HG; ++u)
+              if (g0 + u < NG) col[u] = *reinterpret_cast<const V*>(cb + (g0 + u) * E);
+            FL[g1] = col[g1 - g0] * ntL + FL[g1];
+            if (sh && g1 < NGS) FS[g1 < NGS ? g1 : 0] = col[g1 - g0] * ntS + FS[g1 < NGS ? g1 : 0];
+            if (j + 1 < NP) {  // look-ahead: column j + 1 is complete, post it and ask for its pivot group
+              cbn[HALF + lh] = FL[g1][(j + 1) % E];
+              if (j + 1 < HALF) cbn[lh] = FS[g1 < NGS ? g1 : 0][(j + 1) % E];
+              piv = *reinterpret_cast<const V*>(cbn + g1 * E);
+            }
+#pragma unroll
+            for (int u = 0; u < HG; ++u)
+              if (g0 + u < NG && g0 + u != g1) {
+                FL[g0 + u] = col[u] * ntL + FL[g0 + u];
+                if (sh && g0 + u < NGS) FS[g0 + u < NGS ? g0 + u : 0] = col[u] * ntS + FS[g0 + u < NGS ? g0 + u : 0];
+              }
+          }
+#pragma unroll
+          for (int h = g0 + HG; h < NG; h += HG) {
+            V col[HG];
+#pragma unroll
+            for (int u = 0; u < HG; ++u)
+              if (h + u < NG) col[u] = *reinterpret_cast<const V*>(cb + (h + u) * E);
+#pragma unroll
+            for (int u = 0; u < HG; ++u)
+              if (h + u < NG) {
+                FL[h + u] = col[u] * ntL + FL[h + u];
+                if (sh && h + u < NGS) FS[h + u < NGS ? h + u : 0] = col[u] * ntS + FS[h + u < NGS ? h + u : 0];
+              }
+          }
+          rv2 = f2{bj, bj} * f2{-tL, -tS} + rv2;
+          mL[e0] = tL;
+          mS[e0] = tS;
+          if (e0 == E - 1) {
+            // group g0 is finished: nobody updates it again.  Its multipliers go to the packed L of the neighbourhood
+            // (row r: the groups that hold columns < r; the exchange matrix is dead) and its registers are free.
+            // (branch-free: a lane whose row ends left of the group writes to the 16 spare bytes behind the last row)
+            T* dump = Lq + KTRI - E;
+            *reinterpret_cast<V*>(g0 * E < HALF || g0 * E < HALF + lh ? Lq + troff(HALF + lh) + g0 * E : dump) = mL;
+            if (sh) *reinterpret_cast<V*>(g0 * E < lh ? Lq + troff(lh) + g0 * E : dump) = mS;
+          }
+#if MGP_RHS_FOLD_SCHED
+          __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+      }
+#if MGP_RHS_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
+      MGP_RHS_T(3)
+      __syncthreads();
+      {
+        colbuf[sub * NP + lh] = wS;
+        colbuf[sub * NP + HALF + lh] = wL;
+        rhsbuf[sub * NP + lh] = uS;
+        rhsbuf[sub * NP + HALF + lh] = uL;
+      }
+      __syncthreads();
+      // from here lane i is row i of BOTH neighbourhoods; its responses fly under the back-substitution
+      load_y(yA, yrow0);
+      load_y(yB, yrow1);
+      T wA = colbuf[i], wB = colbuf[NP + i];
+      const T uA = rhsbuf[i], uB = rhsbuf[NP + i];
+      T* mean = static_cast<T*>(a.mean);
+      T* var = static_cast<T*>(a.var);
+      const T svA = wave_sum_lane63(uA * wA), svB = wave_sum_lane63(uB * wB);
+      const bool badA = !(lane_value(pmin, 0) > T(0)) || !(svA == svA);  // (lane 63's is the one that counts)
+      const bool badB = !(lane_value(pmin, 32) > T(0)) || !(svB == svB);
+      if (i == NP - 1) {
+        var[nbA] = badA ? num<T>::nan() : T(1) - svA;
+        if (badA && a.info) atomicAdd(a.info, 1);
+        if (have_b) {
+          var[nbB] = badB ? num<T>::nan() : T(1) - svB;
+          if (badB && a.info) atomicAdd(a.info, 1);
+        }
+      }
+      MGP_RHS_T(4)
+      // L^T w = D^-1 u from the last row up, two independent chains interleaved
+      constexpr int BB = MGP_RHS_FOLD_BLOCK;
+      const T* LA = tile;
+      const T* LB = tile + KTRI;
+#pragma unroll
+      for (int mb = NP - BB; mb >= 0; mb -= BB) {
+        if (mb < k) {  // (uniform)
+          T la[BB], lb[BB];
+#pragma unroll
+          for (int e = 0; e < BB; ++e) {  // multipliers of row mb + e at step i (junk for i >= mb + e or i >= k: masked below)
+            la[e] = LA[troff(mb + e) + i];
+            lb[e] = LB[troff(mb + e) + i];
+          }
+#pragma unroll
+          for (int e = BB - 1; e >= 0; --e) {
+            const int m = mb + e;
+            if (m >= 1) {
+              const T wmA = lane_value(wA, m), wmB = lane_value(wB, m);
+              if (i < min(m, k)) {
+                wA = fma_t(-la[e], wmA, wA);
+                wB = fma_t(-lb[e], wmB, wB);
+              }
+            }
+          }
+        }
+      }
+      MGP_RHS_T(5)
+#pragma unroll
+      for (int r = 0; r < RC; ++r) {
+        if (r < R) {
+          const T smA = wave_sum_lane63(wA * yA[r]), smB = wave_sum_lane63(wB * yB[r]);
+          if (i == NP - 1) {
+            mean[nbA * R + r] = badA ? num<T>::nan() : smA;
+            if (have_b) mean[nbB * R + r] = badB ? num<T>::nan() : smB;
+          }
+        }
+      }
+      MGP_RHS_T(6)
+      continue;
+    }
 
 #if MGP_RHS_PRIO
     __builtin_amdgcn_s_setprio(MGP_RHS_PRIO);
@@ -535,6 +848,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? (W3 ? MGP_RHS_W3_WAVES : 2) :
     }
 #pragma unroll
     for (int r = 0; r < (BACK ? 1 : NR); ++r) rhs[r] = rv[r / E][r % E];
+    MGP_RHS_T(3)
 
 #if MGP_RHS_PRIO
     __builtin_amdgcn_s_setprio(0);
@@ -611,16 +925,22 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? (W3 ? MGP_RHS_W3_WAVES : 2) :
       }
     }
     }
+    MGP_RHS_T(6)
   }
+#if MGP_RHS_TIMING
+  if (threadIdx.x == 0)
+    for (int t = 0; t < 8; ++t) atomicAdd(&g_rhs_timing[t], tacc_[t]);
+#endif
 }
 
-template <typename T, int RC, bool BACK = false, bool GRAM = false, bool W3 = false>
+template <typename T, int RC, bool BACK = false, bool GRAM = false, bool W3 = false, bool FOLD = false>
 static int launch_rhs_impl(const FusedArgs& a, hipStream_t stream) {
   constexpr int NP = 64;
   constexpr int E = v16<T>::N;
   constexpr int CH = 2 * E;
   constexpr int KS = NP + E;
-  constexpr int KMAT = W3 ? E * ((NP - 1) / E + 1) * (E * ((NP - 1) / E) / 2 + (NP - 1) % E) + NP + E : NP * KS;
+  constexpr int KTRI = E * ((NP - 1) / E + 1) * (E * ((NP - 1) / E) / 2 + (NP - 1) % E) + NP + E;
+  constexpr int KMAT = W3 ? KTRI : (FOLD && 2 * KTRI > NP * KS ? 2 * KTRI : NP * KS);
   constexpr int NRV = (1 + RC + E - 1) / E;
   RhsGeom g;
   const int dpad = (a.d + CH - 1) / CH * CH;
@@ -630,23 +950,26 @@ static int launch_rhs_impl(const FusedArgs& a, hipStream_t stream) {
   g.vec_ok = (a.d % E == 0) && (align % 16 == 0);
   g.resp_vec = a.R == RC && RC % E == 0 && (uintptr_t)a.targets % 16 == 0;
   g.ntasks = a.b;
-  const size_t tile_elems = (size_t)((NP + 1) * g.xs > KMAT ? (NP + 1) * g.xs : KMAT);
-  size_t lds = (tile_elems + (W3 ? 2 * NP : NP) + NRV * E + g.dst + (g.dst & 1)) * sizeof(T) + 66 * sizeof(int64_t);
+  const size_t tile_need = (size_t)(NP + 1) * g.xs + (FOLD ? (NP / 2) * (NP / 2) : 0);
+  const size_t tile_elems = tile_need > (size_t)KMAT ? tile_need : (size_t)KMAT;
+  size_t lds = (tile_elems + (FOLD ? 4 * NP : W3 ? 2 * NP : NP) + (FOLD ? 2 * NP : NRV * E) + g.dst + (g.dst & 1)) * sizeof(T) + 66 * sizeof(int64_t);
   lds = (lds + 15) & ~(size_t)15;
   static Residency res;
   int per_cu = 0, cus = 0;
-  const int rc = res.lookup(reinterpret_cast<const void*>(&fused_rhs_kernel<T, RC, BACK, GRAM, W3>), 64, lds, &per_cu, &cus);
+  const int rc = res.lookup(reinterpret_cast<const void*>(&fused_rhs_kernel<T, RC, BACK, GRAM, W3, FOLD>), 64, lds, &per_cu, &cus);
   if (rc != MGP_OK) return rc;
   static const int env_per_cu = getenv("MGP_RHS_PER_CU") ? atoi(getenv("MGP_RHS_PER_CU")) : 0;  // occupancy experiments
   if (env_per_cu > 0 && env_per_cu < per_cu) per_cu = env_per_cu;
   static const bool trace = getenv("MGP_TRACE") != nullptr;
-  if (trace) fprintf(stderr, "[mgp] fused_rhs_kernel<%d,%d,%d,%d>: lds %zu B, %d workgroups per CU\n", RC, (int)BACK, (int)GRAM, (int)W3, lds, per_cu);
+  if (trace)
+    fprintf(stderr, "[mgp] fused_rhs_kernel<%d,%d,%d,%d,%d>: lds %zu B, %d workgroups per CU\n", RC, (int)BACK, (int)GRAM, (int)W3, (int)FOLD, lds, per_cu);
   int64_t grid = (int64_t)cus * per_cu;
-  if (grid > g.ntasks) grid = g.ntasks;
-  hipLaunchKernelGGL((fused_rhs_kernel<T, RC, BACK, GRAM, W3>), dim3((unsigned)grid), dim3(64), lds, stream, a, g);
+  const int64_t nunits = FOLD ? (g.ntasks + 1) / 2 : g.ntasks;  // (FOLD: a pass of the persistent loop takes two tasks)
+  if (grid > nunits) grid = nunits;
+  hipLaunchKernelGGL((fused_rhs_kernel<T, RC, BACK, GRAM, W3, FOLD>), dim3((unsigned)grid), dim3(64), lds, stream, a, g);
   MGP_HIP_CHECK_LAUNCH();
   note_launch("mgp::fused_rhs_kernel<%s,%d,%s,%s%s>", sizeof(T) == 4 ? "float" : "double", RC, BACK ? "true" : "false",
-              GRAM ? "true" : "false", W3 ? ",w3" : "");
+              GRAM ? "true" : "false", W3 ? ",w3" : (FOLD ? ",fold" : ""));
   return MGP_OK;
 }
 
@@ -665,6 +988,14 @@ static int launch_rhs(const FusedArgs& a, hipStream_t stream) {
 #ifndef MGP_RHS_W3
 #define MGP_RHS_W3 1
 #endif
+#ifndef MGP_RHS_FOLD
+#define MGP_RHS_FOLD 1
+#endif
+      // (FOLD: whole 16-byte rows -- the vector gather -- and a batch that gives every workgroup some pairs)
+      if constexpr (BACK && MGP_RHS_FOLD) {
+        const uintptr_t align = (uintptr_t)a.feat_q | (uintptr_t)a.feat_nn;
+        if (align % 16 == 0 && a.b >= 2) return launch_rhs_impl<T, RC, BACK, true, false, true>(a, stream);
+      }
       if constexpr (BACK && MGP_RHS_W3) return launch_rhs_impl<T, RC, BACK, true, true>(a, stream);
       return launch_rhs_impl<T, RC, BACK, true>(a, stream);
     }
