@@ -108,6 +108,9 @@ struct RhsGeom {
 #ifndef MGP_RHS_FOLD_UNROLL
 #define MGP_RHS_FOLD_UNROLL 1
 #endif
+#ifndef MGP_RHS_FOLD_U
+#define MGP_RHS_FOLD_U 6
+#endif
 #ifndef MGP_RHS_FOLD_HG
 #define MGP_RHS_FOLD_HG 8
 #endif
@@ -264,7 +267,10 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? (W3 ? MGP_RHS_W3_WAVES : 2) :
         const int sub = (int)(((unsigned)i * ((1u << 16) / (unsigned)c16p + 1u)) >> 16);
         const int c = i - sub * c16p;
         const bool lane_on = sub < rpr;
-        constexpr int U = 6;
+        // rows in flight per lane and round.  (FOLD: twelve would make the 65 rows of d = 40 ONE round trip instead of
+        // two -- measured 93.1 against 98.4 M/s with six: the gather's share of a wave's life, a fifth
+        // (tools/rhs_timing.py), is time the other wave uses, and the 24 extra registers spill elsewhere)
+        constexpr int U = FOLD ? MGP_RHS_FOLD_U : 6;
         for (int r0 = 0; r0 <= k; r0 += U * rpr) {  // row k of this loop is the query (tile row NP)
           V v[U];
 #pragma unroll
@@ -697,15 +703,32 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? (W3 ? MGP_RHS_W3_WAVES : 2) :
         }
       }
       MGP_RHS_T(5)
+      // all the sums first (independent chains the scheduler can interleave), then one block of stores by lane 63
+      T smA[RC], smB[RC];
 #pragma unroll
       for (int r = 0; r < RC; ++r) {
-        if (r < R) {
-          const T smA = wave_sum_lane63(wA * yA[r]), smB = wave_sum_lane63(wB * yB[r]);
-          if (i == NP - 1) {
-            mean[nbA * R + r] = badA ? num<T>::nan() : smA;
-            if (have_b) mean[nbB * R + r] = badB ? num<T>::nan() : smB;
+        smA[r] = wave_sum_lane63(wA * yA[r]);  // (rows >= k and responses >= R carry zeros)
+        smB[r] = wave_sum_lane63(wB * yB[r]);
+      }
+      if (i == NP - 1) {
+        const bool vec = g.resp_vec && (reinterpret_cast<uintptr_t>(mean) % 16 == 0);  // (then R == RC, whole 16-byte groups)
+        auto put_row = [&](int64_t nbx, const T (&sm)[RC], bool bad) {
+          if (vec) {
+#pragma unroll
+            for (int r4 = 0; r4 < RC / E; ++r4) {
+              V v;
+#pragma unroll
+              for (int e = 0; e < E; ++e) v[e] = bad ? num<T>::nan() : sm[r4 * E + e];
+              *reinterpret_cast<V*>(mean + nbx * R + r4 * E) = v;
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < RC; ++r)
+              if (r < R) mean[nbx * R + r] = bad ? num<T>::nan() : sm[r];
           }
-        }
+        };
+        put_row(nbA, smA, badA);
+        if (have_b) put_row(nbB, smB, badB);
       }
       MGP_RHS_T(6)
       continue;
@@ -991,10 +1014,11 @@ static int launch_rhs(const FusedArgs& a, hipStream_t stream) {
 #ifndef MGP_RHS_FOLD
 #define MGP_RHS_FOLD 1
 #endif
-      // (FOLD: whole 16-byte rows -- the vector gather -- and a batch that gives every workgroup some pairs)
+      // (FOLD: aligned rows -- the vector gather -- at least one pair, and rows short enough for eight workgroups per CU
+      // with the parked half rows behind them: d <= 48; longer rows take the three-wave variant)
       if constexpr (BACK && MGP_RHS_FOLD) {
         const uintptr_t align = (uintptr_t)a.feat_q | (uintptr_t)a.feat_nn;
-        if (align % 16 == 0 && a.b >= 2) return launch_rhs_impl<T, RC, BACK, true, false, true>(a, stream);
+        if (align % 16 == 0 && a.b >= 2 && (a.d + CH - 1) / CH * CH <= 48) return launch_rhs_impl<T, RC, BACK, true, false, true>(a, stream);
       }
       if constexpr (BACK && MGP_RHS_W3) return launch_rhs_impl<T, RC, BACK, true, true>(a, stream);
       return launch_rhs_impl<T, RC, BACK, true>(a, stream);

@@ -336,6 +336,52 @@ def test_rhs_prediction_variant_matches_oracle(case):
     assert_close(var.cpu().numpy(), v2.cpu().numpy(), 10 * rtol if dtype == "float32" else rtol, "BACK vs forward-only (var)")
 
 
+@pytest.mark.parametrize("b", [2, 3, 7, 1201])
+@pytest.mark.parametrize("shape", [(64, 40, 16), (37, 24, 7), (64, 48, 16), (64, 64, 16)], ids=lambda s: f"k{s[0]}-d{s[1]}-R{s[2]}")
+def test_rhs_fold_pairs_odd_tails_and_the_three_wave_variant(shape, b):
+    """The folded variant eliminates the tasks of a launch in PAIRS (an odd last task is paired with itself and written
+    once); rows of more than twelve 16-byte groups go to the three-wave variant instead.  Odd and tiny batches, a batch
+    index that is not the identity, a per-row noise table and per-batch targets, against the oracle."""
+    from muygpys_amd import _lib
+    from muygpys_amd.fused import KernelSpec, posterior_mean_var
+
+    k, d, R = shape
+    rng = np.random.default_rng(77 + b + k)
+    N = 5_000
+    X = rng.normal(size=(N, d))
+    Y = np.sin(X @ rng.normal(size=(d, R)) / np.sqrt(d)) + 0.1 * rng.normal(size=(N, R))
+    bi = rng.integers(0, N, size=b)
+    ni = rng.integers(0, N - 1, size=(b, k))
+    ni = ni + (ni >= bi[:, None])
+    ls = float(np.sqrt(2 * d))
+    Xd, Yd, bid, nid = to_dev(X, torch.float32), to_dev(Y, torch.float32), to_dev(bi), to_dev(ni)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    mean, var = posterior_mean_var(KernelSpec("matern25", "l2", ls, 1e-2), Xd, Xd, bid, nid, Yd, info=info, path="rhs", packed=False)
+    torch.cuda.synchronize()
+    served = _lib.last_kernel()
+    want = "fold>" if d <= 48 else "w3>"
+    assert served.startswith("mgp::fused_rhs_kernel<float,16,true,true") and served.endswith(want), served
+    assert int(info.item()) == 0
+    m_ref, v_ref = orc.posterior_mean_var(orc.Spec("matern25", "l2", ls, 1e-2), X, X, bi, ni, Y)
+    assert_close(mean.cpu().numpy(), m_ref.reshape(b, R), RTOL["float32"], f"mean [{served}]")
+    assert_close(var.cpu().numpy(), v_ref, RTOL["float32"], f"var [{served}]")
+    # a non-positive-definite neighbourhood in the FIRST and one in the SECOND half of a pair: NaN rows, counted, neighbours untouched
+    if b >= 7:
+        ni2 = ni.copy()
+        ni2[2, 1] = ni2[2, 0]  # duplicate neighbour with a tiny nugget: singular
+        ni2[5, 3] = ni2[5, 2]
+        info.zero_()
+        m3, v3 = posterior_mean_var(KernelSpec("matern25", "l2", ls, 0.0), Xd, Xd, bid, to_dev(ni2), Yd, info=info, path="rhs", packed=False)
+        torch.cuda.synchronize()
+        m0, v0 = posterior_mean_var(KernelSpec("matern25", "l2", ls, 0.0), Xd, Xd, bid, nid, Yd, path="rhs", packed=False)
+        torch.cuda.synchronize()
+        ok = np.ones(b, dtype=bool)
+        ok[[2, 5]] = False
+        assert int(info.item()) >= 0
+        np.testing.assert_array_equal(m3.cpu().numpy()[ok], m0.cpu().numpy()[ok])
+        np.testing.assert_array_equal(v3.cpu().numpy()[ok], v0.cpu().numpy()[ok])
+
+
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_config5_fixture_through_the_prediction_variant(dtype):
     """The reference-generated config-5 fixture (RBF, k = 64, R = 16, d = 40) through the exact call bench.py's
