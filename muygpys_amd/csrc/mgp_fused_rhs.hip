@@ -261,7 +261,32 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? (W3 ? MGP_RHS_W3_WAVES : 2) :
       const int w = min(dst, d - d0);
       const int wp = (w + CH - 1) / CH * CH;
       __syncthreads();
-      if (g.vec_ok) {
+      if constexpr (FOLD) {
+        // Rows straight from global memory into LDS (global_load_lds, as the wave kernels: no VGPR round trip, no
+        // ds_write, and every 1-KiB piece of the tile in flight at once -- one round trip instead of two dependent ones).
+        // 16-byte slot sigma = 64 n + lane of the tile: row = sigma / SPR, column = sigma % SPR; the slots behind the
+        // features of a row re-read its last group (the norm overwrites the first of them), the slots of unused rows
+        // and behind the query row are masked off (what lies behind the tile rows are parked half rows).
+        const int SPR = xs / E;
+        const unsigned total = (unsigned)(rows_x * SPR);
+        const unsigned smagic = (1u << 20) / (unsigned)SPR + 1u;
+        const int c16 = w / E;
+        for (unsigned n = 0; n * 64u < total; ++n) {
+          const unsigned sigma = 64u * n + (unsigned)i;
+          const unsigned row = (sigma * smagic) >> 20;
+          const unsigned c = sigma - row * (unsigned)SPR;
+          const bool on = sigma < total && ((int)row < k || row == (unsigned)NP);
+          const T* src = ((int)row < k ? feat_nn : feat_q) + idxbuf[(int)row < k ? row : NP] + d0 + min((int)c, c16 - 1) * E;
+          if (on) glds16_lds(src, smem, (int)n * 1024);
+        }
+        for (int t = i; t < (NP - k) * SPR; t += NP)  // zero rows for the unused slots
+          *reinterpret_cast<V*>(tile + (k + t / SPR) * xs + (t % SPR) * E) = V(0);
+        if (wp > w) {  // (uniform) the padding group of the 8-wide inner loop: zero, once the rows have landed
+          lds_dma_wait();
+          *reinterpret_cast<V*>(tile + i * xs + w) = V(0);
+          if (i == 0) *reinterpret_cast<V*>(tile + NP * xs + w) = V(0);
+        }
+      } else if (g.vec_ok) {
         const int c16 = w / E, c16p = wp / E;
         const int rpr = NP / c16p;
         const int sub = (int)(((unsigned)i * ((1u << 16) / (unsigned)c16p + 1u)) >> 16);
@@ -300,6 +325,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? (W3 ? MGP_RHS_W3_WAVES : 2) :
       }
       if (aniso)
         for (int c = i; c < wp; c += 64) ilbuf[c] = c < w ? T(1) / ls[d0 + c] : T(0);
+      if constexpr (FOLD) lds_dma_wait();  // the rows have landed
       __syncthreads();
       MGP_RHS_T(0)
       const T* xq = tile + NP * xs;
