@@ -285,3 +285,14 @@ template int launch_fused_wave<float>(const FusedArgs&, hipStream_t);
 template int launch_fused_wave<double>(const FusedArgs&, hipStream_t);
 
 }  // namespace mgp
+
+#if MGP_WAVE_TIMING
+extern "C" int mgp_debug_wave_timing(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mgp::g_wave_timing), sizeof(mgp::g_wave_timing)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(mgp::g_wave_timing), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif

@@ -294,6 +294,21 @@ __device__ const DltMeta<NPL_> g_dlt_meta{};
 //        K_nu of mgp_wave_common.h in software exp: a body of its own, kept out of the fixed-smoothness kernels, where
 //        it cost the config-4 kernel spilled registers).  fp32 kernels carry their (hardware-exp) form in every
 //        instantiation.
+#ifndef MGP_WAVE_TIMING
+#define MGP_WAVE_TIMING 0
+#endif
+#if MGP_WAVE_TIMING
+// phase timing (experiments only; tools/wave_timing.py): s_memtime differences summed per wave and phase
+__device__ unsigned long long g_wave_timing[8];
+#define MGP_WAVE_T(slot)                                           \
+  {                                                                \
+    const unsigned long long tnow_ = __builtin_readcyclecounter(); \
+    tacc_[slot] += tnow_ - tlast_;                                 \
+    tlast_ = tnow_;                                                \
+  }
+#else
+#define MGP_WAVE_T(slot)
+#endif
 template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF = false, bool PACKED = false,
           bool GRAM = false, bool GEN64 = false>
 __global__ __launch_bounds__(64, wave_min_waves(sizeof(T), NP, KFIX, RFIX, DFIX))
@@ -354,6 +369,10 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   using ACC = typename v16<T>::acc;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#if MGP_WAVE_TIMING
+  unsigned long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast_ = __builtin_readcyclecounter();
+#endif
   const int k = KFIX > 0 ? KFIX : a.k;
   const int R = RFIX > 0 ? RFIX : a.R;
   const int d = DFIX > 0 ? DFIX : a.d;
@@ -631,6 +650,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       if (PIPE) lds_dma_wait();  // this task's tile (requested during the previous task's elimination) has landed
 #endif
       __syncthreads();
+      MGP_WAVE_T(0)
       if (PIPE) {
         if constexpr (PACKED) {
           // the slot behind the features carries the row's responses (before it is zeroed as padding)
@@ -806,6 +826,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
           }
         }
         __syncthreads();
+        MGP_WAVE_T(1)
         // ---- phase 2 (Gram form): acc = a'.b' per pair ------------------------------------------
         if (MGP_PHASE(g, 2)) {
 #pragma unroll
@@ -941,6 +962,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       }
     }
 
+    MGP_WAVE_T(2)
     // ---- phase 3: covariances, nugget, responses -> exchange matrix -> row per lane ----
 #if MGP_XCHG_PRIO || MGP_DIST_PRIO
     __builtin_amdgcn_s_setprio(sizeof(T) == 4 || MGP_F64_SAME_PRIO ? MGP_XCHG_PRIO : MGP_DIST_PRIO);
@@ -1138,6 +1160,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       // The first task of a pair parks its rows in lanes 0 .. 31 and goes on to the second; the elimination
       // runs when both are there (or the workgroup has no task left).
       const bool lastt = !(task + t_step < t_end);
+      MGP_WAVE_T(3)
       if (fold_sub == 0 && !lastt) {
         fold_sub = 1;
         fold_task_a = task;
@@ -1226,6 +1249,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 #if MGP_CHOL_PRIO
       __builtin_amdgcn_s_setprio(0);
 #endif
+      MGP_WAVE_T(4)
       // Schur block: the query row KFIX and the response rows behind it are long rows (lanes KFIX - HALF ...)
       if constexpr (RFIX > 1) {
         constexpr int QF = KFIX;
@@ -1272,6 +1296,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
           }
         }
       }
+      MGP_WAVE_T(5)
       continue;
     }
     if constexpr (DLT) {
@@ -1562,6 +1587,10 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       }
     }
   }
+#if MGP_WAVE_TIMING
+  if (threadIdx.x == 0)
+    for (int t = 0; t < 8; ++t) atomicAdd(&g_wave_timing[t], tacc_[t]);
+#endif
 }
 
 }  // namespace mgp
