@@ -91,6 +91,10 @@ static int launch_np_impl(const FusedArgs& a, hipStream_t stream) {
 #ifdef MGP_DEBUG_HOOKS
   if (g_grid_per_cu > 0) per_cu = g_grid_per_cu;
 #endif
+  // (fp64, 32 slots, run-time shape: two waves per SIMD although three would fit -- measured, mgp_fused_wave_kernel.h)
+  if (sizeof(T) == 8 && NP == 32 && KFIX == 0 && per_cu > 8) per_cu = 8;
+  static const int env_per_cu = getenv("MGP_WAVE_PER_CU") ? atoi(getenv("MGP_WAVE_PER_CU")) : 0;  // occupancy experiments
+  if (env_per_cu > 0 && env_per_cu < per_cu) per_cu = env_per_cu;
   int64_t grid = (int64_t)cus * per_cu / 8 * 8;
   if (grid < 8) grid = 8;
   if (grid > g.ntasks) grid = (g.ntasks + 7) / 8 * 8;

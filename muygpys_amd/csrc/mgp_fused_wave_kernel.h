@@ -230,8 +230,16 @@ constexpr int wave_stage_elems(const WaveDims& w) { return w.DLT ? 2 * (32 + 128
 // waves per SIMD the register allocation is held to
 // (fp64, 64 slots: the dealt-lower-triangle kernels -- 44 instead of 104 registers of matrix -- fit three waves:
 // config 4 158.0 vs 153.1 M/s; the row-per-lane ones spill there, measured 10 % slower)
+// (run-time shapes, round 4: without the accumulators' phantom live range -- sec. 4.1b (v) -- the fp32 64-slot kernels
+// need 155..176 registers: held to three waves, MGP_RT_W3: k = 45, d = 24: 121 -> 134 M/s, k = 40, d = 8: 132 -> 157.
+// The fp64 32-slot ones would fit three waves as well (152..164) and are SLOWER there -- k = 20, d = 8 / 24 / 32: 340 /
+// 255 / 223 M/s at twelve workgroups per CU against 377 / 297 / 269 at eight, the same from d = 40 on: their launcher
+// caps the residency at eight, mgp_fused_wave.hip)
+#ifndef MGP_RT_W3
+#define MGP_RT_W3 1
+#endif
 constexpr int wave_min_waves(int es, int NP, int KFIX, int RFIX = 0, int DFIX = 0) {
-  return es == 4 ? (NP <= 32 ? (KFIX == 30 && MGP_W4 ? 4 : 3) : 2)
+  return es == 4 ? (NP <= 32 ? (KFIX == 30 && MGP_W4 ? 4 : 3) : (MGP_RT_W3 && KFIX == 0 ? 3 : 2))
                  : (NP <= 32 ? 2 : (MGP_C4_W3 && wave_dims(es, NP, KFIX, RFIX, DFIX, false, false).DLT ? 3 : 2));
 }
 

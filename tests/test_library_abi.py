@@ -60,3 +60,12 @@ def test_headline_kernels_hold_their_register_budget():
         r = res[name]
         assert r["VGPRs Spill"] == 0 and r["ScratchSize [bytes/lane]"] == 0, (name, r)
         assert r["Occupancy [waves/SIMD]"] >= 3, (name, r)
+    # run-time-shape wave kernels: no accumulator live range around the persistent loop (round 4: zeroing the distance
+    # accumulators under `d0 == 0` inside the feature-stage loop kept 64 registers live through the whole task: 219
+    # instead of 156..176 VGPRs for the fp32 64-slot kernels, 20 spilled in the fp64 one)
+    runtime64 = [k for k in res if re.search(r"fused_wave_kernelIfLi64ELi0ELi0ELi0E", k)]
+    assert len(runtime64) >= 5, sorted(res)
+    for name in runtime64:
+        assert res[name]["VGPRs"] <= 180 and res[name]["VGPRs Spill"] == 0, (name, res[name])
+    for name in (k for k in res if re.search(r"fused_wave_kernelIdLi(32|64)ELi0ELi0ELi0E", k)):
+        assert res[name]["VGPRs Spill"] == 0, (name, res[name])
