@@ -407,9 +407,13 @@ def roofline_of(cfg, w, avg_ms: float, kernel_name: str, objective: bool):
     tflops = F * b / (avg_ms * 1e-3) / 1e12
     vpeak = FP32_VECTOR_TFLOPS if cfg["dtype"] == "f32" else FP64_VECTOR_TFLOPS
     traffic, source = measured_traffic(b, k, d, cfg["dtype"])
+    # what the memory system actually moved per second (PMC bytes of the committed profile over this run's kernel time):
+    # gathered rows come in whole 128-byte lines, so this sits above `achieved` -- the headline kernel's is ~0.65 of peak
+    traffic_rate = traffic / (avg_ms * 1e-3) / 1e9 if traffic else None
     return {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
+        "traffic_rate_GBps": traffic_rate, "traffic_frac": traffic_rate / HBM_PEAK_GBS if traffic_rate else None,
         "kernel": kernel_name,
         "algorithmic_bytes_per_neighbourhood": B, "algorithmic_bytes_per_launch": B * b,
         "kernel_ms": avg_ms,
