@@ -1308,6 +1308,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       continue;
     }
     if constexpr (DLT) {
+      MGP_WAVE_T(3)
       // ---- phase 4D: elimination on the DEALT lower triangle (fp64, one neighbourhood per wave) --------------
       // Row-per-lane elimination issues an FMA for every column right of the pivot in every lane: 3.8 x the
       // arithmetic of the factorisation (finished rows idle, the upper triangle is updated too), and a 104-register
@@ -1398,6 +1399,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 #if MGP_CHOL_PRIO
       __builtin_amdgcn_s_setprio(0);
 #endif
+      MGP_WAVE_T(4)
       {
         // the Schur block sits in compile-time lanes: (q, q) = variance, (q + 1 + r, q) = -mean_r, (q + 1 + r, q + 1 + r) = -y_r^T K^-1 y_r
         constexpr int QF = KFIX;
@@ -1420,6 +1422,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
           }
         }
       }
+      MGP_WAVE_T(5)
       continue;
     }
     // ---- phase 4: Cholesky, row per lane, column broadcast through LDS ----------------
