@@ -83,13 +83,14 @@ struct RhsGeom {
 // GRAM (fp32, one feature stage, not Matern-1/2): rows centred on the query in place, pair
 // distances as |a'|^2 + |b'|^2 - 2 a'.b' -- one packed FMA per two features of a pair instead of a packed
 // subtract and a packed FMA -- and the crosswise distance of a lane is its row's norm, exactly.
-// W3 (round 4; fp32 prediction variant with the Gram form -- BASELINE config 5): held to three waves per SIMD.  The
-// kernel is bound by its two waves (occupancy sweep), and BOTH limits sat at eight workgroups
-// per CU: 254 registers and 18.5 KB of LDS.  Here (i) the exchange matrix is packed lower-triangular (8.7 instead of
-// 17.4 KB: a lane's row of the system only ever needs its lower triangle), (ii) the multipliers are not stored to LDS
-// step by step but kept IN PLACE -- entry (i, j) of a lane's row is dead once column j is eliminated -- and the rows
-// are dumped once, in the same packed layout, where the back-substitution reads L column-wise with consecutive lanes
-// on consecutive addresses, (iii) the column of a step is consumed in two halves instead of copied whole.
+// W3 (round 4; fp32 prediction variant with the Gram form; serves rows longer than d = 48, FOLD below the others):
+// held to three waves per SIMD.  BOTH limits of the plain kernel sat at eight workgroups per CU (registers and 18.5 KB
+// of LDS).  Here (i) the exchange matrix is packed lower-triangular (8.7 instead of 17.4 KB: a lane's row of the
+// system only ever needs its lower triangle), (ii) the multipliers are not stored to LDS step by step but kept IN PLACE
+// -- entry (i, j) of a lane's row is dead once column j is eliminated -- and the rows are dumped once, in the same
+// packed layout, where the back-substitution reads L column-wise with consecutive lanes on consecutive addresses,
+// (iii) the column of a step is consumed in two halves instead of copied whole.  Measured on config 5 (MGP_RHS_PER_CU
+// = 4 / 6 / 8 / 10 / 12 workgroups per CU): 54.0 / 68.2 / 85.8 / 80.7 / 91.5 M/s -- the third wave is worth 6.6 %.
 #ifndef MGP_RHS_W3_WAVES
 #define MGP_RHS_W3_WAVES 3
 #endif
