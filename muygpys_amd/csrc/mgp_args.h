@@ -113,6 +113,7 @@ int64_t jit_cached_min_batch();
 int prepare_fused_wave(int elem_size, int d, int k, int R, int packed, int kernel_id);  // compile into the disk cache
 // k <= 64 with up to 16 responses carried as right-hand-side columns (mgp_fused_rhs.hip)
 template <typename T> int launch_fused_rhs(const FusedArgs&, hipStream_t);
+int launch_fused_rhs_mf(const FusedArgs&, hipStream_t);  // fp32 prediction variant on the matrix cores' layout (mgp_fused_rhs_mf.hip)
 // 64 < k + 1 + R <= 128, fp32: two waves per neighbourhood, rows in registers (mgp_fused_wide.hip)
 template <typename T> int launch_fused_wide(const FusedArgs&, hipStream_t);
 int launch_fused_wide64(const FusedArgs&, hipStream_t);  // fp64, two lanes per row

@@ -1059,6 +1059,16 @@ int launch_fused_rhs(const FusedArgs& a, hipStream_t stream) {
   if (a.k > 64 || a.packed_nn != nullptr) return MGP_EUNSUPPORTED;
   if (a.R <= 4) return launch_rhs<T, 4>(a, stream);
   // many responses without y^T K^-1 y (prediction): one right-hand side + back-substitution
+#ifndef MGP_RHS_MF
+#define MGP_RHS_MF 1
+#endif
+  if constexpr (sizeof(T) == 4 && MGP_RHS_MF) {
+    // fp32: the kernel built on the matrix cores' output layout first (mgp_fused_rhs_mf.hip); shapes it declines go on
+    if (a.R <= 16 && a.ykinvy == nullptr && MGP_RHS_BACK) {
+      const int rc = launch_fused_rhs_mf(a, stream);
+      if (rc != MGP_EUNSUPPORTED) return rc;
+    }
+  }
   if (a.R <= 16 && a.ykinvy == nullptr && MGP_RHS_BACK) return launch_rhs<T, 16, true>(a, stream);
   if (a.R <= 16) return launch_rhs<T, 16>(a, stream);
   return MGP_EUNSUPPORTED;

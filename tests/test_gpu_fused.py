@@ -336,12 +336,13 @@ def test_rhs_prediction_variant_matches_oracle(case):
     assert_close(var.cpu().numpy(), v2.cpu().numpy(), 10 * rtol if dtype == "float32" else rtol, "BACK vs forward-only (var)")
 
 
-@pytest.mark.parametrize("b", [2, 3, 7, 1201])
-@pytest.mark.parametrize("shape", [(64, 40, 16), (37, 24, 7), (64, 48, 16), (64, 64, 16)], ids=lambda s: f"k{s[0]}-d{s[1]}-R{s[2]}")
-def test_rhs_fold_pairs_odd_tails_and_the_three_wave_variant(shape, b):
-    """The folded variant eliminates the tasks of a launch in PAIRS (an odd last task is paired with itself and written
-    once); rows of more than twelve 16-byte groups go to the three-wave variant instead.  Odd and tiny batches, a batch
-    index that is not the identity, a per-row noise table and per-batch targets, against the oracle."""
+@pytest.mark.parametrize("b", [1, 2, 3, 7, 1201])
+@pytest.mark.parametrize("shape", [(64, 40, 16), (37, 24, 7), (64, 48, 16), (64, 64, 16), (33, 8, 16)], ids=lambda s: f"k{s[0]}-d{s[1]}-R{s[2]}")
+def test_rhs_prediction_variants_by_shape(shape, b):
+    """The fp32 prediction variants of the rhs-column kernel by shape: the kernel on the matrix cores' layout
+    (mgp_fused_rhs_mf.hip) everywhere except rows of 41..48 features, which the folded variant takes -- it eliminates the
+    tasks of a launch in PAIRS (an odd last task is paired with itself and written once) -- and, for a single task of
+    that width, the three-wave variant.  Odd and tiny batches against the oracle."""
     from muygpys_amd import _lib
     from muygpys_amd.fused import KernelSpec, posterior_mean_var
 
@@ -359,7 +360,7 @@ def test_rhs_fold_pairs_odd_tails_and_the_three_wave_variant(shape, b):
     mean, var = posterior_mean_var(KernelSpec("matern25", "l2", ls, 1e-2), Xd, Xd, bid, nid, Yd, info=info, path="rhs", packed=False)
     torch.cuda.synchronize()
     served = _lib.last_kernel()
-    want = "fold>" if d <= 48 else "w3>"
+    want = "mfma>" if d != 48 or b < 2 else "fold>"
     assert served.startswith("mgp::fused_rhs_kernel<float,16,true,true") and served.endswith(want), served
     assert int(info.item()) == 0
     m_ref, v_ref = orc.posterior_mean_var(orc.Spec("matern25", "l2", ls, 1e-2), X, X, bi, ni, Y)
@@ -380,6 +381,35 @@ def test_rhs_fold_pairs_odd_tails_and_the_three_wave_variant(shape, b):
         assert int(info.item()) >= 0
         np.testing.assert_array_equal(m3.cpu().numpy()[ok], m0.cpu().numpy()[ok])
         np.testing.assert_array_equal(v3.cpu().numpy()[ok], v0.cpu().numpy()[ok])
+
+
+def test_rhs_three_wave_variant_serves_tables_off_the_16_byte_grid():
+    """A feature table whose rows do not start on 16-byte boundaries (a view one element into a larger buffer): neither
+    the matrix-core kernel nor the folded variant takes it (their gathers are 16-byte transfers); the three-wave variant
+    does, with its element-wise gather."""
+    from muygpys_amd import _lib
+    from muygpys_amd.fused import KernelSpec, posterior_mean_var
+
+    k, d, R, b, N = 64, 40, 16, 333, 4_000
+    rng = np.random.default_rng(5)
+    X = rng.normal(size=(N, d))
+    Y = np.sin(X @ rng.normal(size=(d, R)) / np.sqrt(d)) + 0.1 * rng.normal(size=(N, R))
+    bi = rng.integers(0, N, size=b)
+    ni = rng.integers(0, N - 1, size=(b, k))
+    ni = ni + (ni >= bi[:, None])
+    ls = float(np.sqrt(2 * d))
+    flat = torch.zeros(N * d + 1, device="cuda", dtype=torch.float32)
+    flat[1:] = to_dev(X, torch.float32).reshape(-1)
+    Xd = flat[1:].view(N, d)
+    assert Xd.data_ptr() % 16 == 4
+    mean, var = posterior_mean_var(KernelSpec("matern25", "l2", ls, 1e-2), Xd, Xd, to_dev(bi), to_dev(ni), to_dev(Y, torch.float32),
+                                   path="rhs", packed=False)
+    torch.cuda.synchronize()
+    served = _lib.last_kernel()
+    assert served.endswith("w3>"), served
+    m_ref, v_ref = orc.posterior_mean_var(orc.Spec("matern25", "l2", ls, 1e-2), X, X, bi, ni, Y)
+    assert_close(mean.cpu().numpy(), m_ref.reshape(b, R), RTOL["float32"], f"mean [{served}]")
+    assert_close(var.cpu().numpy(), v_ref, RTOL["float32"], f"var [{served}]")
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
