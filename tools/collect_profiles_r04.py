@@ -11,7 +11,7 @@ import shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RAW = os.path.join(ROOT, "gpurun_out", "r04", "prof")
 OUT = os.path.join(ROOT, "profiles")
-KERNELS = {2: "fused_wave_kernel<float, 32, 30, 1, 40", 4: "fused_wave_kernel<double, 64, 50, 1, 8", 5: "fused_rhs_kernel<float, 16"}
+KERNELS = {2: "fused_wave_kernel<float, 32, 30, 1, 40", 4: "fused_wave_kernel<double, 64, 50, 1, 8", 5: "fused_rhs_mf_kernel<16"}
 SHAPES = {2: {"k": 30, "d": 40, "dtype": "f32"}, 4: {"k": 50, "d": 8, "dtype": "f64"}, 5: {"k": 64, "d": 40, "dtype": "f32"}}
 CORRECTION = ("gfx950: FETCH_SIZE = TCC_EA0_RDREQ x 64 B tallies 128-byte requests at 64 B -> doubled "
               "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE taken as is")
