@@ -43,6 +43,9 @@ struct RhsMfGeom {
 #ifndef MGP_RHS_MF_SCHED
 #define MGP_RHS_MF_SCHED 1
 #endif
+#ifndef MGP_RHS_MF_PRIO
+#define MGP_RHS_MF_PRIO 2  // issue priority raised: covariances .. elimination (1), elimination (2), never (0), (3) / (4): as 1 / 2 + the back-substitution
+#endif
 #ifndef MGP_RHS_MF_WAVES
 #define MGP_RHS_MF_WAVES 3
 #endif
@@ -229,7 +232,11 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
 
     // ---- covariances where the entries are: KS = row c at columns 8 q + 4 h + e, KL = row 32 + c at the same
     //      columns (groups 0 .. 3) and at 32 + them (groups 4 .. 7) ------------------------------------------------
+#if MGP_RHS_MF_PRIO == 1
     __builtin_amdgcn_s_setprio(2);
+#elif MGP_RHS_MF_PRIO == 3
+    __builtin_amdgcn_s_setprio(1);
+#endif
     V KS[4], KL[8];
     T rvS, rvL;
     {
@@ -281,6 +288,9 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
     // column j: held by the lanes with h == (j / 4) % 2 -- short rows KS[(j % 32) / 8][j % 4] while j < 32, long rows
     // KL[4 (j / 32) + (j % 32) / 8][j % 4].  Column buffer j & 1 holds it: the look-ahead posts column j + 1 into the
     // other one while this step's groups are still being read.
+#if MGP_RHS_MF_PRIO >= 2
+    __builtin_amdgcn_s_setprio(2);
+#endif
     T myu = T(0), myw = T(0);  // u_i = (L^-1 c)_i and u_i / p_i of row i = this lane
     T pmin = num<T>::inf();
     V mL = V(0), mS = V(0);
@@ -353,7 +363,9 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
 #endif
       }
     }
+#if MGP_RHS_MF_PRIO < 3
     __builtin_amdgcn_s_setprio(0);
+#endif
     __syncthreads();
 
     // ---- outputs: lane i is row i again -------------------------------------------------------------------------
@@ -398,6 +410,9 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
         }
       }
     }
+#if MGP_RHS_MF_PRIO >= 3
+    __builtin_amdgcn_s_setprio(0);
+#endif
     T sm[RC];
 #pragma unroll
     for (int r = 0; r < RC; ++r) sm[r] = wave_sum_lane63(wv * y[r]);  // (rows >= k and responses >= R carry zeros)
