@@ -383,6 +383,37 @@ def test_rhs_prediction_variants_by_shape(shape, b):
         np.testing.assert_array_equal(v3.cpu().numpy()[ok], v0.cpu().numpy()[ok])
 
 
+@pytest.mark.parametrize("d", [40, 48, 64, 12])
+@pytest.mark.parametrize("kernel,metric", [("rbf", "F2"), ("matern25", "l2"), ("matern15", "l2")])  # (a Matern of SQUARED distances is not positive definite in general)
+def test_rhs_prediction_variants_anisotropy_noise_table_and_query_table(d, kernel, metric):
+    """Anisotropy, a per-training-point noise table, a separate table of queries and k short of the 64 slots through the
+    fp32 prediction variants (matrix-core layout: d = 40, 64, 12; folded: d = 48), against the oracle."""
+    from muygpys_amd import _lib
+    from muygpys_amd.fused import KernelSpec, posterior_mean_var
+
+    k, R, b, N, M = 57, 11, 515, 6_000, 900
+    rng = np.random.default_rng(100 + d)
+    X = rng.normal(size=(N, d))
+    Q = rng.normal(size=(M, d))
+    Y = np.sin(X @ rng.normal(size=(d, R)) / np.sqrt(d)) + 0.1 * rng.normal(size=(N, R))
+    bi = rng.integers(0, M, size=b)
+    ni = np.stack([rng.choice(N, size=k, replace=False) for _ in range(b)])
+    ls = np.sqrt(2 * d) * 10.0 ** rng.uniform(-0.2, 0.2, size=d)
+    if metric == "F2":
+        ls = np.sqrt(ls) * 1.5
+    eps = 10.0 ** rng.uniform(-3, -1.5, size=N)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    mean, var = posterior_mean_var(KernelSpec(kernel, metric, [float(v) for v in ls], to_dev(eps, torch.float32)), to_dev(Q, torch.float32),
+                                   to_dev(X, torch.float32), to_dev(bi), to_dev(ni), to_dev(Y, torch.float32), info=info, packed=False)
+    torch.cuda.synchronize()
+    served = _lib.last_kernel()
+    assert served.endswith("fold>" if d == 48 else "mfma>"), served
+    assert int(info.item()) == 0
+    m_ref, v_ref = orc.posterior_mean_var(orc.Spec(kernel, metric, ls, eps), Q, X, bi, ni, Y)
+    assert_close(mean.cpu().numpy(), m_ref.reshape(b, R), RTOL["float32"], f"mean [{served}]")
+    assert_close(var.cpu().numpy(), v_ref, RTOL["float32"], f"var [{served}]")
+
+
 def test_rhs_three_wave_variant_serves_tables_off_the_16_byte_grid():
     """A feature table whose rows do not start on 16-byte boundaries (a view one element into a larger buffer): neither
     the matrix-core kernel nor the folded variant takes it (their gathers are 16-byte transfers); the three-wave variant
