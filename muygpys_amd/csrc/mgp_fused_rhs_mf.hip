@@ -46,6 +46,9 @@ struct RhsMfGeom {
 #ifndef MGP_RHS_MF_PRIO
 #define MGP_RHS_MF_PRIO 2  // issue priority raised: covariances .. elimination (1), elimination (2), never (0), (3) / (4): as 1 / 2 + the back-substitution
 #endif
+#ifndef MGP_RHS_MF_WRITELANE
+#define MGP_RHS_MF_WRITELANE 1
+#endif
 #ifndef MGP_RHS_MF_WAVES
 #define MGP_RHS_MF_WAVES 3
 #endif
@@ -315,8 +318,19 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
         const T rp = pivot_rcp(p);
         const T tL = aL * rp, tS = sh ? aS * rp : T(0);
         const V ntL = V(-tL), ntS = V(-tS);
+#if MGP_RHS_MF_WRITELANE
+        // u_j and p_j are wave-uniform: into lane j of the capture registers by v_writelane (u_j / p_j follows after
+        // the loop) instead of a compare, two selects and a multiply
+        {
+          const int ub = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, bj));
+          const int pb = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p));
+          asm("v_writelane_b32 %0, %1, %2" : "+v"(myu) : "s"(ub), "n"(j));
+          asm("v_writelane_b32 %0, %1, %2" : "+v"(myw) : "s"(pb), "n"(j));
+        }
+#else
         myu = i == j ? bj : myu;
         myw = i == j ? bj * rp : myw;
+#endif
         // the lane's column groups: long group G covers columns 32 (G / 4) + 8 (G % 4) + 4 h + (0..3), short group q
         // the same below 32.  A group is touched while one of its columns (in either half) lies right of the pivot.
         const int j1 = j + 1 < NP ? j + 1 : j;
@@ -344,8 +358,11 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
             if (sh && G < 4) KS[G < 4 ? G : 0] = cv * ntS + KS[G < 4 ? G : 0];
           }
         }
-        rvL = bj * ntL[0] + rvL;
-        if (sh) rvS = bj * ntS[0] + rvS;
+        {
+          const f2 r2 = f2{bj, bj} * f2{ntL[0], ntS[0]} + f2{rvL, rvS};  // (ntS = 0 once the short rows are done)
+          rvL = r2.x;
+          rvS = r2.y;
+        }
         mL[j % E] = tL;
         mS[j % E] = tS;
         if (j % E == E - 1) {
@@ -365,6 +382,9 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
     }
 #if MGP_RHS_MF_PRIO < 3
     __builtin_amdgcn_s_setprio(0);
+#endif
+#if MGP_RHS_MF_WRITELANE
+    myw = i < k ? myu * pivot_rcp(myw) : T(0);  // (unused slots: their steps may have been skipped)
 #endif
     __syncthreads();
 
