@@ -314,7 +314,9 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
         T* cbn = colbuf + ((j + 1) & 1) * NP;
         const T bj = lane_value(sh ? rvS : rvL, j % HALF);  // right-hand side of row j (both halves carry both rows')
         const T p = pg[j % E];
+#if !MGP_RHS_MF_WRITELANE
         pmin = __builtin_fminf(pmin, p);
+#endif
         const T rp = pivot_rcp(p);
         const T tL = aL * rp, tS = sh ? aS * rp : T(0);
         const V ntL = V(-tL), ntS = V(-tS);
@@ -384,6 +386,8 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
     __builtin_amdgcn_s_setprio(0);
 #endif
 #if MGP_RHS_MF_WRITELANE
+    // lane i holds its row's pivot: a non-positive (or NaN) one anywhere marks the neighbourhood (no running minimum)
+    if (__builtin_amdgcn_ballot_w64(i < k && !(myw > T(0))) != 0) pmin = T(-1);
     myw = i < k ? myu * pivot_rcp(myw) : T(0);  // (unused slots: their steps may have been skipped)
 #endif
     __syncthreads();
