@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Phase timing of the rhs-column kernel (a library built with -DMGP_RHS_TIMING=1: tools/mkvariant.sh timing
-mgp_fused_rhs.hip -DMGP_RHS_TIMING=1).  Prints the share of a wave's life spent per phase on BASELINE config 5.
+"""Phase timing of the rhs-column kernel's FOLDED variant (a library built with -DMGP_RHS_TIMING=1 -DMGP_RHS_MF=0:
+tools/mkvariant.sh timing mgp_fused_rhs.hip -DMGP_RHS_TIMING=1 -DMGP_RHS_MF=0 -- with MGP_RHS_MF the config-5 shape goes
+to mgp_fused_rhs_mf.hip, which carries no stamps).  Prints the share of a wave's life spent per phase on BASELINE config 5.
 
     MUYGPYS_HIP_LIB=variants/lib_timing.so python tools/rhs_timing.py
 """
