@@ -29,6 +29,30 @@
 #include <cstdlib>
 #include "mgp_wave_common.h"
 
+#ifndef MGP_RHS_MF_TIMING
+#define MGP_RHS_MF_TIMING 0
+#endif
+#if MGP_RHS_MF_TIMING
+// phase timing (experiments only; tools/rhs_timing.py --mf): s_memtime differences summed per wave and phase
+__device__ unsigned long long g_rhs_mf_timing[8];
+#define MGP_MF_T(slot)                                             \
+  {                                                                \
+    const unsigned long long tnow_ = __builtin_readcyclecounter(); \
+    tacc_[slot] += tnow_ - tlast_;                                 \
+    tlast_ = tnow_;                                                \
+  }
+extern "C" int mgp_debug_rhs_mf_timing(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rhs_mf_timing), sizeof(g_rhs_mf_timing)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_rhs_mf_timing), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#else
+#define MGP_MF_T(slot)
+#endif
+
 namespace mgp {
 
 struct RhsMfGeom {
@@ -64,6 +88,10 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
   constexpr int KTRI = E * ((NP - 1) / E + 1) * (E * ((NP - 1) / E) / 2 + (NP - 1) % E) + NP + E;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#if MGP_RHS_MF_TIMING
+  unsigned long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast_ = __builtin_readcyclecounter();
+#endif
   const int k = a.k, d = a.d, R = a.R, xs = g.xs, dst = g.dst;
   const int rows_x = NP + 1;  // 64 slots + the query
   const int tile_elems = rows_x * xs > KTRI ? rows_x * xs : KTRI;
@@ -145,6 +173,7 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
       lds_dma_wait();
     }
     __syncthreads();
+    MGP_MF_T(0)
 
     // ---- centre row i on the query (times the inverse length scales), in place; squared norms ------------
     T nrm;
@@ -188,6 +217,7 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
       }
     }
     __syncthreads();
+    MGP_MF_T(1)
     // squared distances |a'|^2 + |b'|^2 - 2 a'.b' with the cancellation guard (mgp_wave_common.h); the two diagonal
     // entries a lane may hold (distance zero against twice the norm) stay out of the guard
     const int rdiag = ((c >> 2) & 1) == h ? 4 * (c >> 3) + (c & 3) : -1;  // the register with row == column (tiles 00, 11)
@@ -287,6 +317,7 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
       rvL = cq[HALF + c];
     }
 
+    MGP_MF_T(2)
     // ---- elimination ------------------------------------------------------------------------------------------
     // column j: held by the lanes with h == (j / 4) % 2 -- short rows KS[(j % 32) / 8][j % 4] while j < 32, long rows
     // KL[4 (j / 32) + (j % 32) / 8][j % 4].  Column buffer j & 1 holds it: the look-ahead posts column j + 1 into the
@@ -392,6 +423,7 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
 #endif
     __syncthreads();
 
+    MGP_MF_T(3)
     // ---- outputs: lane i is row i again -------------------------------------------------------------------------
     T y[RC];
 #pragma unroll
@@ -437,6 +469,7 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
 #if MGP_RHS_MF_PRIO >= 3
     __builtin_amdgcn_s_setprio(0);
 #endif
+    MGP_MF_T(4)
     T sm[RC];
 #pragma unroll
     for (int r = 0; r < RC; ++r) sm[r] = wave_sum_lane63(wv * y[r]);  // (rows >= k and responses >= R carry zeros)
@@ -458,7 +491,12 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
           if (r < R) mean[nb * R + r] = bad ? num<T>::nan() : sm[r];
       }
     }
+    MGP_MF_T(5)
   }
+#if MGP_RHS_MF_TIMING
+  if (threadIdx.x == 0)
+    for (int t = 0; t < 8; ++t) atomicAdd(&g_rhs_mf_timing[t], tacc_[t]);
+#endif
 }
 
 // -> MGP_OK, or MGP_EUNSUPPORTED when the shape is not this kernel's (the caller goes on to the other variants)

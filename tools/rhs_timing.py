@@ -26,12 +26,15 @@ bi, ni = torch.from_numpy(bi).to(dev), torch.from_numpy(ni).to(dev)
 spec = KernelSpec("rbf", "l2", 5.0, 1e-3)
 lib = ctypes.CDLL(_lib.LIB_PATH)
 out = (ctypes.c_ulonglong * 8)()
+mf = "--mf" in sys.argv  # the matrix-core-layout kernel (a library built with -DMGP_RHS_MF_TIMING=1 on mgp_fused_rhs_mf.hip)
+read = lib.mgp_debug_rhs_mf_timing if mf else lib.mgp_debug_rhs_timing
 for it in range(3):
     posterior_mean_var(spec, Xd, Xd, bi, ni, yd, packed=False)
     torch.cuda.synchronize()
-    lib.mgp_debug_rhs_timing(out, 1)
+    read(out, 1)
 print(_lib.last_kernel())
-names = ["gather", "distances", "cov+exchange+readback", "elimination", "dump/redistribute", "back-substitution", "outputs", "-"]
+names = (["indices + gather", "centring + Gram (MFMA)", "distances + covariances", "elimination", "back-substitution", "outputs", "-", "-"]
+         if mf else ["gather", "distances", "cov+exchange+readback", "elimination", "dump/redistribute", "back-substitution", "outputs", "-"])
 tot = sum(out)
 for nm, v in zip(names, out):
     print(f"{nm:24s} {v / tot * 100:6.1f} %   {v / b:10.1f} ticks per neighbourhood")
