@@ -330,8 +330,13 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
     V mL = V(0), mS = V(0);
     const bool h0 = h == 0;
     auto colgrp = [&](int j) { return 4 * (j / HALF) + (j % HALF) / 8; };  // index into KL (KS: the same without the 4)
-    (h0 ? colbuf : cq)[c] = KS[0][0];  // column 0 (held by the lower half)
-    (h0 ? colbuf : cq)[HALF + c] = KL[0][0];
+    // where a half posts its entries of a column: into the column buffer when it holds the column, else into the dead
+    // cross-covariance / nugget arrays (branch-free; two per-lane bases, everything else immediate offsets)
+    T* const post0 = (h0 ? colbuf : cq) + c;  // columns held by the lower half
+    T* const post1 = (h0 ? cq : colbuf) + c;  // ... by the upper half
+    post0[0] = KS[0][0];  // column 0
+    post0[HALF] = KL[0][0];
+    f2 rv2 = f2{rvL, rvS};
     V pg = *reinterpret_cast<const V*>(colbuf);
     T aS = colbuf[c], aL = colbuf[HALF + c];
     constexpr int JB = 8;
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
         const bool sh = j < HALF;  // (compile-time after unrolling) the short rows are still being eliminated
         T* cb = colbuf + (j & 1) * NP;
         T* cbn = colbuf + ((j + 1) & 1) * NP;
-        const T bj = lane_value(sh ? rvS : rvL, j % HALF);  // right-hand side of row j (both halves carry both rows')
+        const T bj = lane_value(sh ? rv2.y : rv2.x, j % HALF);  // right-hand side of row j (both halves carry both rows')
         const T p = pg[j % E];
 #if !MGP_RHS_MF_WRITELANE
         pmin = __builtin_fminf(pmin, p);
@@ -375,10 +380,9 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
           if (sh && G1 < 4) KS[G1 < 4 ? G1 : 0] = cv * ntS + KS[G1 < 4 ? G1 : 0];
         }
         if (j + 1 < NP) {  // look-ahead: column j + 1 is complete -- post it, ask for its pivot group and own entries
-          // (branch-free: the half that does not hold the column writes into the dead cross-covariance array)
-          const bool mine = (j1 / E) % 2 == 0 ? h0 : !h0;
-          (mine ? cbn : cq)[HALF + c] = KL[G1][j1 % E];
-          if (j1 < HALF) (mine ? cbn : cq)[c] = KS[G1 < 4 ? G1 : 0][j1 % E];
+          T* const post = (j1 / E) % 2 == 0 ? post0 : post1;
+          post[(j1 & 1) * NP + HALF] = KL[G1][j1 % E];
+          if (j1 < HALF) post[(j1 & 1) * NP] = KS[G1 < 4 ? G1 : 0][j1 % E];
           pg = *reinterpret_cast<const V*>(cbn + (j1 / E) * E);
           aL = cbn[HALF + c];
           if (j1 < HALF) aS = cbn[c];
@@ -391,11 +395,7 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
             if (sh && G < 4) KS[G < 4 ? G : 0] = cv * ntS + KS[G < 4 ? G : 0];
           }
         }
-        {
-          const f2 r2 = f2{bj, bj} * f2{ntL[0], ntS[0]} + f2{rvL, rvS};  // (ntS = 0 once the short rows are done)
-          rvL = r2.x;
-          rvS = r2.y;
-        }
+        rv2 = rv2 - f2{tL, tS} * f2{bj, bj};  // (tS = 0 once the short rows are done)
         mL[j % E] = tL;
         mS[j % E] = tS;
         if (j % E == E - 1) {
