@@ -73,6 +73,9 @@ struct RhsMfGeom {
 #ifndef MGP_RHS_MF_WRITELANE
 #define MGP_RHS_MF_WRITELANE 1
 #endif
+#ifndef MGP_RHS_MF_TRAIL
+#define MGP_RHS_MF_TRAIL 1
+#endif
 #ifndef MGP_RHS_MF_WAVES
 #define MGP_RHS_MF_WAVES 3
 #endif
@@ -336,6 +339,19 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
     T* const post1 = (h0 ? cq : colbuf) + c;  // ... by the upper half
     post0[0] = KS[0][0];  // column 0
     post0[HALF] = KL[0][0];
+#if MGP_RHS_MF_TRAIL
+    // The first 32 steps' updates of the trailing block (rows and columns 32 .. 63) are a rank-32 update, A22 -= W L^T with
+    // W the numerators and L the multipliers of the long rows: GEMM-shaped, and KL[4 .. 7] IS a 32 x 32 accumulator in
+    // the matrix instruction's layout (that is how it was made).  One v_mfma_f32_32x32x2_f32 per two steps -- the lower
+    // half supplies the even step's (numerator, -multiplier), the upper half the odd step's -- instead of 16 packed FMAs
+    // and 8 column-group reads: -256 VALU and -128 LDS instructions per neighbourhood, on a pipe that idles.
+    F16 KH;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < E; ++e) KH[4 * q + e] = KL[4 + q][e];
+    T aE = T(0), tE = T(0);
+#endif
     f2 rv2 = f2{rvL, rvS};
     V pg = *reinterpret_cast<const V*>(colbuf);
     T aS = colbuf[c], aL = colbuf[HALF + c];
@@ -373,15 +389,35 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
         // the same below 32.  A group is touched while one of its columns (in either half) lies right of the pivot.
         const int j1 = j + 1 < NP ? j + 1 : j;
         const int G1 = colgrp(j1);
+#if MGP_RHS_MF_TRAIL
+        if (j == HALF) {  // the trailing block is complete: back to the row groups
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < E; ++e) KL[4 + q][e] = KH[4 * q + e];
+        }
+        if (sh) {
+          if (j % 2 == 0) {
+            aE = aL;
+            tE = tL;
+          } else {
+            KH = __builtin_amdgcn_mfma_f32_32x32x2f32(h0 ? aE : aL, h0 ? -tE : -tL, KH, 0, 0, 0);
+          }
+        }
+        constexpr bool TRAIL = true;
+#else
+        constexpr bool TRAIL = false;
+#endif
         auto colv = [&](int G) { return *reinterpret_cast<const V*>(cb + HALF * (G / 4) + 8 * (G % 4) + 4 * h); };
-        {
+        if (!(TRAIL && sh && G1 >= 4)) {  // (TRAIL, step 31: column 32 belongs to the trailing block -- the MFMA above)
           const V cv = colv(G1);
           KL[G1] = cv * ntL + KL[G1];
           if (sh && G1 < 4) KS[G1 < 4 ? G1 : 0] = cv * ntS + KS[G1 < 4 ? G1 : 0];
         }
         if (j + 1 < NP) {  // look-ahead: column j + 1 is complete -- post it, ask for its pivot group and own entries
           T* const post = (j1 / E) % 2 == 0 ? post0 : post1;
-          post[(j1 & 1) * NP + HALF] = KL[G1][j1 % E];
+          if (TRAIL && sh && G1 >= 4) post[(j1 & 1) * NP + HALF] = KH[4 * (G1 - 4) + j1 % E];
+          else post[(j1 & 1) * NP + HALF] = KL[G1][j1 % E];
           if (j1 < HALF) post[(j1 & 1) * NP] = KS[G1 < 4 ? G1 : 0][j1 % E];
           pg = *reinterpret_cast<const V*>(cbn + (j1 / E) * E);
           aL = cbn[HALF + c];
@@ -389,7 +425,7 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
         }
 #pragma unroll
         for (int G = 0; G < 8; ++G) {
-          if (G != G1 && HALF * (G / 4) + 8 * (G % 4) + 7 > j) {
+          if (G != G1 && HALF * (G / 4) + 8 * (G % 4) + 7 > j && !(TRAIL && sh && G >= 4)) {
             const V cv = colv(G);
             KL[G] = cv * ntL + KL[G];
             if (sh && G < 4) KS[G < 4 ? G : 0] = cv * ntS + KS[G < 4 ? G : 0];
