@@ -333,47 +333,56 @@ __global__ __launch_bounds__(64, 2) void backward_wave_kernel(BackwardArgs g, in
     // ---- phase 7: feature cotangents: gx_i = 2 sum_j q_ij (x_i - x_j) (the metric's 1/l^2 is in q) ------
     const bool want_gl = gls && aniso;
     if (gq || gnn || want_gl) {
-      V xi[DG], sv[DG], s2[DG], qrow[NP / E];
+      // (rows of more than ten 16-byte groups: the sweep in two passes over half the groups each -- its own row, the
+      // sums and a row j in flight are 3 DG registers x 4, and at DG = 12 / 16 the single pass spilled 441 / 2 199
+      // registers: 9.0 / 18.4 ms per 500 k neighbourhoods at d = 48 / 64 where d = 40 takes 6.2)
+      constexpr int NPASS = DG > 10 ? 2 : 1, DGH = DG / NPASS;
+      V s2[DG], qrow[NP / E];
 #pragma unroll
-      for (int c4 = 0; c4 < DG; ++c4) {
-        sv[c4] = V(0);
-        s2[c4] = V(0);
-        xi[c4] = *reinterpret_cast<const V*>(Xh + i * xs + c4 * E);
-      }
+      for (int c4 = 0; c4 < DG; ++c4) s2[c4] = V(0);
 #pragma unroll
       for (int c4 = 0; c4 < NP / E; ++c4) qrow[c4] = *reinterpret_cast<const V*>(Mh + i * KS + c4 * E);
       const int k_rt = a.k;  // (the run-time value on purpose: with every test folded the compiler hoists the 310
                              //  row reads of the unrolled sweep to its top and spills -- measured 88 instead of 13 ms)
 #pragma unroll
-      for (int j = 0; j < (KFIX > 0 ? KFIX + 1 : NP - 1); ++j) {
-        if (j <= k_rt) {  // uniform; the DG reads of a row are issued together
-          const V qv = V(qrow[j / E][j % E]);
-          const T* xj = Xh + j * xs;
-          V xr[DG];
+      for (int ps = 0; ps < NPASS; ++ps) {
+        V xi[DGH], sv[DGH];
 #pragma unroll
-          for (int c4 = 0; c4 < DG; ++c4) xr[c4] = *reinterpret_cast<const V*>(xj + c4 * E);
-          if (want_gl) {  // (uniform)
+        for (int c4 = 0; c4 < DGH; ++c4) {
+          sv[c4] = V(0);
+          xi[c4] = *reinterpret_cast<const V*>(Xh + i * xs + (ps * DGH + c4) * E);
+        }
 #pragma unroll
-            for (int c4 = 0; c4 < DG; ++c4) {
-              const V t = (xi[c4] - xr[c4]) * qv;
-              sv[c4] = sv[c4] + t;
-              s2[c4] = t * (xi[c4] - xr[c4]) + s2[c4];
+        for (int j = 0; j < (KFIX > 0 ? KFIX + 1 : NP - 1); ++j) {
+          if (j <= k_rt) {  // uniform; the DGH reads of a row are issued together
+            const V qv = V(qrow[j / E][j % E]);
+            const T* xj = Xh + j * xs + ps * DGH * E;
+            V xr[DGH];
+#pragma unroll
+            for (int c4 = 0; c4 < DGH; ++c4) xr[c4] = *reinterpret_cast<const V*>(xj + c4 * E);
+            if (want_gl) {  // (uniform)
+#pragma unroll
+              for (int c4 = 0; c4 < DGH; ++c4) {
+                const V t = (xi[c4] - xr[c4]) * qv;
+                sv[c4] = sv[c4] + t;
+                s2[ps * DGH + c4] = t * (xi[c4] - xr[c4]) + s2[ps * DGH + c4];
+              }
+            } else {
+#pragma unroll
+              for (int c4 = 0; c4 < DGH; ++c4) sv[c4] = (xi[c4] - xr[c4]) * qv + sv[c4];
             }
-          } else {
-#pragma unroll
-            for (int c4 = 0; c4 < DG; ++c4) sv[c4] = (xi[c4] - xr[c4]) * qv + sv[c4];
           }
         }
-      }
-      // out through the tile (every lane is done reading it): consecutive lanes then add consecutive
-      // features of a row -- a lane adding its own row's features one by one touches 62 different cache
-      // lines per instruction (measured: 57 ms of a 65 ms launch)
-      __syncthreads();
+        // out through the tile (every lane is done reading this pass's columns; a later pass reads other columns):
+        // consecutive lanes then add consecutive features of a row -- a lane adding its own row's features one by one
+        // touches 62 different cache lines per instruction (measured: 57 ms of a 65 ms launch)
+        __syncthreads();
 #pragma unroll
-      for (int c4 = 0; c4 < DG; ++c4) {
-        V o = (skip || i > k) ? V(0) : V(T(2)) * sv[c4];
-        if (aniso) o = o * *reinterpret_cast<const V*>(ilb + c4 * E);  // dz/dx = 1 / l
-        *reinterpret_cast<V*>(Xh + i * xs + c4 * E) = o;
+        for (int c4 = 0; c4 < DGH; ++c4) {
+          V o = (skip || i > k) ? V(0) : V(T(2)) * sv[c4];
+          if (aniso) o = o * *reinterpret_cast<const V*>(ilb + (ps * DGH + c4) * E);  // dz/dx = 1 / l
+          *reinterpret_cast<V*>(Xh + i * xs + (ps * DGH + c4) * E) = o;
+        }
       }
       __syncthreads();
       // consecutive lanes add consecutive features (row-major over the rows of the task): an atomic

@@ -127,6 +127,30 @@ def test_backward_wave_kernel_anisotropy_fp32():
     assert_close(out2["ls"], ref2["length_scale"], 1e-5, "g_length_scale (fp64)")
 
 
+@pytest.mark.parametrize("aniso", [False, True])
+@pytest.mark.parametrize("d,k", [(48, 30), (64, 30), (64, 45), (44, 20)])
+def test_backward_wave_kernel_long_rows_fp32(d, k, aniso):
+    """Rows of more than ten 16-byte groups: the feature-cotangent sweep of the wave kernel runs in two passes over half
+    the groups each (round 4; the single pass spilled hundreds of registers at d = 48 / 64).  32- and 64-slot
+    instantiations, iso- and anisotropic, every gradient against the fp64 oracle's vector-Jacobian product."""
+    rng = np.random.default_rng(1000 + d + k + int(aniso))
+    n, R, b = 1200, 2, 257
+    X = rng.normal(size=(n, d))
+    Y = np.sin(X @ rng.normal(size=(d, R)) / np.sqrt(d)) + 0.1 * rng.normal(size=(n, R))
+    bi = rng.choice(n, size=b, replace=False)
+    ni = np.stack([rng.choice(np.setdiff1d(np.arange(n), [i]), size=k, replace=False) for i in bi])
+    ls = np.sqrt(d) * rng.uniform(0.7, 1.5, size=d) if aniso else float(np.sqrt(d))
+    spec = orc.Spec("matern25", "l2", ls, 1e-2)
+    gm, gv = rng.normal(size=(b, R)), rng.normal(size=b)
+    ref = orc.posterior_vjp(spec, X, X, bi, ni, Y, gm, gv)
+    out = _run(spec, X, X, bi, ni, Y, gm, gv, "float32", True)
+    rtol = RTOL["float32"] * 3
+    assert_close(out["x"], ref["train_features"] + ref["test_features"], rtol, "g_features")
+    assert_close(out["y"], ref["targets"], rtol, "g_targets")
+    assert_close(out["ls"], ref["length_scale"], rtol, "g_length_scale")
+    assert_close(out["noise"].reshape(()), ref["noise"], rtol, "g_noise")
+
+
 def test_backward_only_mean_or_only_var():
     """A loss that reads only one output hands the kernel a NULL cotangent for the other."""
     from muygpys_amd.autograd import posterior
