@@ -414,6 +414,45 @@ def test_rhs_prediction_variants_anisotropy_noise_table_and_query_table(d, kerne
     assert_close(var.cpu().numpy(), v_ref, RTOL["float32"], f"var [{served}]")
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_rhs_prediction_variants_random_shapes(seed):
+    """Seeded random shapes through the fp32 prediction path (`path="rhs"`: nn_count 2..64, 8..64 features in whole
+    16-byte groups, 5..16 responses, homoscedastic or per-point noise, shared or separate query table), against the
+    oracle -- whichever variant the dispatcher picks."""
+    from muygpys_amd import _lib
+    from muygpys_amd.fused import KernelSpec, posterior_mean_var
+
+    rng = np.random.default_rng(9000 + seed)
+    k = int(rng.integers(2, 65))
+    d = 4 * int(rng.integers(2, 17))
+    R = int(rng.integers(5, 17))
+    b = int(rng.integers(1, 400))
+    N, M = 3_000, 500
+    kernel = ["rbf", "matern15", "matern25", "maternInf"][seed % 4]
+    metric = "F2" if kernel == "rbf" else "l2"
+    X = rng.normal(size=(N, d))
+    separate = bool(seed % 3 == 0)
+    Q = rng.normal(size=(M, d)) if separate else X
+    Y = np.sin(X @ rng.normal(size=(d, R)) / np.sqrt(d)) + 0.1 * rng.normal(size=(N, R))
+    bi = rng.integers(0, Q.shape[0], size=b)
+    ni = np.stack([rng.choice(N, size=k, replace=False) for _ in range(b)])
+    if not separate:
+        ni = np.where(ni == bi[:, None], (ni + 1) % N, ni)
+    ls = float(np.sqrt(2 * d)) if metric == "l2" else float(np.sqrt(np.sqrt(2 * d)) * 1.5)
+    eps = 10.0 ** rng.uniform(-3, -1.5, size=N) if seed % 2 else 1e-2
+    noise = to_dev(eps, torch.float32) if seed % 2 else eps
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    mean, var = posterior_mean_var(KernelSpec(kernel, metric, ls, noise), to_dev(Q, torch.float32), to_dev(X, torch.float32), to_dev(bi),
+                                   to_dev(ni), to_dev(Y, torch.float32), info=info, path="rhs", packed=False)
+    torch.cuda.synchronize()
+    served = _lib.last_kernel()
+    assert served.startswith("mgp::fused_rhs_kernel<float,16,true"), served
+    assert int(info.item()) == 0, served
+    m_ref, v_ref = orc.posterior_mean_var(orc.Spec(kernel, metric, ls, eps), Q, X, bi, ni, Y)
+    assert_close(mean.cpu().numpy(), m_ref.reshape(b, R), RTOL["float32"], f"mean [{served}; k={k} d={d} R={R} b={b}]")
+    assert_close(var.cpu().numpy(), v_ref, RTOL["float32"], f"var [{served}; k={k} d={d} R={R} b={b}]")
+
+
 def test_rhs_three_wave_variant_serves_tables_off_the_16_byte_grid():
     """A feature table whose rows do not start on 16-byte boundaries (a view one element into a larger buffer): neither
     the matrix-core kernel nor the folded variant takes it (their gathers are 16-byte transfers); the three-wave variant
