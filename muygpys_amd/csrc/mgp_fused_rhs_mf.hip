@@ -19,6 +19,9 @@
 //     waves per SIMD (the row-per-lane kernels: 64-row registers + a 17.4 KB exchange matrix, two waves),
 //   * per elimination step 344 / 64 group updates on average instead of 544 / 64 (the folded two-neighbourhood variant
 //     reaches the same count at 96 registers per lane and two waves).
+//   * the first 32 steps' updates of the trailing block (rows and columns 32 .. 63) are a rank-32 update whose
+//     accumulator those registers already are: one matrix instruction per two steps (MGP_RHS_MF_TRAIL) instead of 16
+//     packed FMAs and 8 column-group reads.
 // Elimination: column j is posted to LDS by the half that holds it (look-ahead: right after the group with column
 // j + 1 is updated), every lane reads the pivot's group (broadcast), its two rows' entries of the column (they are
 // the multipliers' numerators; the partner half holds them) and the column groups its own registers need.  The
