@@ -280,33 +280,61 @@ int mgp_posterior_packed_gathered_f64(const void* packed_q, int64_t q_stride_byt
  * partials[1] + b log sigma^2 (mse = partials[2] / b) follow on the host -- and,
  * sharded, after ONE all-reduce of the six numbers (_src/optimize/loss/mpi.py:
  * 57-70, scale/mpi.py:35-36).  One response (the losses' domain).  mean / var /
- * ykinvy (b each) are written as by mgp_posterior_*; scratch =
- * mgp_reduce_scratch_doubles() doubles; the reduction is a fixed-order two-stage
- * one (bit-reproducible).  mgp_loocv_packed_* reads one prepared table
- * (MGP_EUNSUPPORTED where mgp_posterior_packed_* is).
+ * ykinvy (b each) are written as by mgp_posterior_*.
+ *
+ * ONE launch (round 5): for every shape the register-resident wave kernels serve
+ * (k + 2 <= 64) the fused kernel hands its tasks out through per-XCD dequeue
+ * heads and walks the reduction tree itself -- the workgroup that completes a
+ * block of 64 neighbourhoods reduces it, the one that completes 64 such blocks
+ * reduces those, the last one writes partials[] (csrc/mgp_loocv_tree.h: agent-
+ * scope tickets, write-through hand-off, nobody waits).  Behind the other kernel
+ * families the SAME tree is walked by three small launches (mgp_loocv_tree_*,
+ * also callable on the outputs of any mgp_posterior_*): equal sums bit for bit,
+ * independent of which workgroup finished what when.
+ *
+ * scratch: mgp_loocv_scratch_bytes(b) bytes of device memory, 128-byte aligned,
+ * whose first mgp_loocv_scratch_zero_bytes(b) bytes are ZERO when the call
+ * starts; every call leaves them zero again, so one buffer serves any number of
+ * consecutive calls with the same b on one stream (zero it once; zero it again
+ * after a call with another b, or after a failed launch).  mgp_loocv_packed_*
+ * reads one prepared table (MGP_EUNSUPPORTED where mgp_posterior_packed_* is).
  * ------------------------------------------------------------------------- */
+int64_t mgp_loocv_scratch_bytes(int64_t b);
+int64_t mgp_loocv_scratch_zero_bytes(int64_t b);
 int mgp_loocv_f32(const float* features, int d, const int64_t* batch_idx, const int64_t* nn_idx, int64_t b, int k,
                   const float* targets, int noise_mode, double noise_scalar, const float* noise_dev,
                   int kernel_id, int metric_id, const float* length_scale, int ls_count,
                   float* mean, float* var, float* ykinvy, int* info,
-                  double huber_delta, double* partials, double* scratch, void* stream);
+                  double huber_delta, double* partials, void* scratch, void* stream);
 int mgp_loocv_f64(const double* features, int d, const int64_t* batch_idx, const int64_t* nn_idx, int64_t b, int k,
                   const double* targets, int noise_mode, double noise_scalar, const double* noise_dev,
                   int kernel_id, int metric_id, const double* length_scale, int ls_count,
                   double* mean, double* var, double* ykinvy, int* info,
-                  double huber_delta, double* partials, double* scratch, void* stream);
+                  double huber_delta, double* partials, void* scratch, void* stream);
 int mgp_loocv_packed_f32(const void* packed, int64_t stride_bytes, int d, const int64_t* batch_idx,
                          const int64_t* nn_idx, int64_t b, int k,
                          int noise_mode, double noise_scalar, const float* noise_dev,
                          int kernel_id, int metric_id, const float* length_scale, int ls_count,
                          float* mean, float* var, float* ykinvy, int* info,
-                         double huber_delta, double* partials, double* scratch, void* stream);
+                         double huber_delta, double* partials, void* scratch, void* stream);
 int mgp_loocv_packed_f64(const void* packed, int64_t stride_bytes, int d, const int64_t* batch_idx,
                          const int64_t* nn_idx, int64_t b, int k,
                          int noise_mode, double noise_scalar, const double* noise_dev,
                          int kernel_id, int metric_id, const double* length_scale, int ls_count,
                          double* mean, double* var, double* ykinvy, int* info,
-                         double huber_delta, double* partials, double* scratch, void* stream);
+                         double huber_delta, double* partials, void* scratch, void* stream);
+
+/* The reduction tree alone, over finished outputs (mean / var / ykinvy of b neighbourhoods as written by any
+ * mgp_posterior_* call with one response): partials[6] as above.  resp + row * resp_stride_bytes is the response
+ * of table row `row` (the response tensor: stride sizeof(T); a prepared table: its row stride, resp = table +
+ * d * sizeof(T)); batch_idx may be NULL (row = neighbourhood index).  Same scratch as mgp_loocv_* (its counters
+ * are not used here: no zeroing needed).  Reference: _src/optimize/loss/numpy.py:22-72, scale/numpy.py:9-15. */
+int mgp_loocv_tree_f32(const float* mean, const float* var, const float* ykinvy, const void* resp,
+                       int64_t resp_stride_bytes, const int64_t* batch_idx, int64_t b, double huber_delta,
+                       double* partials, void* scratch, void* stream);
+int mgp_loocv_tree_f64(const double* mean, const double* var, const double* ykinvy, const void* resp,
+                       int64_t resp_stride_bytes, const int64_t* batch_idx, int64_t b, double huber_delta,
+                       double* partials, void* scratch, void* stream);
 
 /* Fused coefficient precompute of the fast posterior mean: coeffs (b, k) = (K_b + eps)^-1 y_b
  * for the neighbourhoods nn_idx (b, k) of one table (gather -> distances -> kernel -> nugget ->

@@ -74,8 +74,10 @@ def _fast_mean_fused(Kcross, coeffs_tensor):
     """A lazy crosswise covariance handle and the gathered coefficients ``coeffs[closest_index]`` (b, k[, R]) --
     what the reference's workflow hands over (examples/from_indices.py:113-118) -- through the fused prediction kernel
     (``mgp_fast_posterior_mean_*``: gather, distances, kernel, dot product in one launch; nothing of size (b, k) is
-    formed).  None when the handle is not a plain crosswise covariance the kernel evaluates."""
-    from muygpys_amd.fused import KernelSpec, fast_posterior_mean
+    formed).  None when the handle is not a plain crosswise covariance the kernel evaluates, or the neighbourhood has
+    more slots than a wavefront (``k + 1 > 64``: mgp_fast_mean.hip serves one test point per 32 or 64 lanes) -- the
+    caller then materialises the handle and takes the reference's einsum."""
+    from muygpys_amd.fused import FusedUnsupported, KernelSpec, fast_posterior_mean
 
     c = Kcross.diffs
     if not (c.kind == "crosswise" and c.reduced and c.metric in ("l2", "F2") and Kcross.kernel != "matern_gen"):
@@ -83,11 +85,14 @@ def _fast_mean_fused(Kcross, coeffs_tensor):
     if not (isinstance(coeffs_tensor, torch.Tensor) and coeffs_tensor.is_cuda and coeffs_tensor.ndim in (2, 3)):
         return None
     b, k = c.nn_indices.shape
-    if tuple(coeffs_tensor.shape[:2]) != (b, k) or coeffs_tensor.dtype != c.dtype:
+    if tuple(coeffs_tensor.shape[:2]) != (b, k) or coeffs_tensor.dtype != c.dtype or k + 1 > 64:
         return None
     spec = KernelSpec(Kcross.kernel, c.metric, 1.0 if c.length_scale is None else c.length_scale, 0.0)
     rows = torch.arange(b, device=coeffs_tensor.device)
-    out = fast_posterior_mean(spec, c.data, c.nn_data, c.data_indices, c.nn_indices, coeffs_tensor, rows)
+    try:
+        out = fast_posterior_mean(spec, c.data, c.nn_data, c.data_indices, c.nn_indices, coeffs_tensor, rows)
+    except FusedUnsupported:
+        return None
     return torch.squeeze(out)
 
 

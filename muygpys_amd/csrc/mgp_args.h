@@ -2,6 +2,7 @@
 #pragma once
 
 #include "mgp_device.h"
+#include "mgp_loocv_tree.h"
 
 namespace mgp {
 
@@ -30,6 +31,11 @@ struct FusedArgs {
   const void* packed_nn = nullptr;
   int64_t q_stride = 0, nn_stride = 0;
   double smoothness = 0.0;  // kernel_id == MGP_KERNEL_MATERN_GEN: the Matern smoothness nu
+  // One-launch LOOCV evaluation (mgp_loocv_*; wave kernels): tree.out != nullptr -- tasks are handed out by per-XCD
+  // dequeue heads in tree.ctrl instead of a static stride, outputs are stored write-through, and the workgroup that
+  // completes a block of the reduction tree reduces it (mgp_loocv_tree.h).  Only launch_fused_wave serves it; behind
+  // every other kernel family the caller walks the same tree with launch_loocv_tree (mgp_tensor_ops.hip).
+  LoocvTree tree;
 };
 
 #ifndef __HIPCC_RTC__  // the rest is host side: other argument blocks and the launcher declarations
@@ -137,9 +143,11 @@ template <typename T> int launch_perturb(const T*, int64_t, int, int, double, co
 template <typename T>
 int launch_loss_sums(const T*, const T*, const T*, int64_t, const double*, double, double, double*, double*, hipStream_t);
 template <typename T> int launch_column_sums(const T*, int64_t, int, double*, double*, hipStream_t);
+// the reduction tree of mgp_loocv_tree.h over finished outputs, as three small launches (same functions, same bits
+// as the walk inside the fused wave kernels)
 template <typename T>
-int launch_loocv_partials(const T*, const T*, const T*, const void*, int64_t, const int64_t*, int64_t, double, double*,
-                          double*, hipStream_t);
+int launch_loocv_tree(const LoocvTree&, const T* mean, const T* var, const T* yk, const int64_t* batch_idx, int64_t b, hipStream_t);
+LoocvTree loocv_tree_layout(void* scratch, int64_t b, double* out, const void* resp, int64_t resp_stride, double huber_delta);
 int reduce_scratch_doubles();
 int allreduce_partials(double* partials_dev, int count, void* nccl_comm, hipStream_t stream);  // mgp_collective.hip
 template <typename T> int launch_matern_gen(const T*, int64_t, double, double, T*, hipStream_t);

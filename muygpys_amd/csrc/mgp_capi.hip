@@ -36,7 +36,7 @@ int posterior(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t*
               int R, int noise_mode, double eps, const T* nd, int kernel_id, int metric_id, const T* ls,
               int ls_count, T* mean, T* var, T* yk, int* info, void* stream, int path = PATH_AUTO,
               const void* packed_q = nullptr, int64_t q_stride = 0, const void* packed_nn = nullptr,
-              int64_t nn_stride = 0, int targets_batch = 0) {
+              int64_t nn_stride = 0, int targets_batch = 0, const LoocvTree* tree = nullptr, bool* tree_served = nullptr) {
   if (b < 0 || k < 1 || d < 1 || R < 1) return MGP_EINVAL;
   if (b == 0) return MGP_OK;  // empty shard: nothing to read or write (outputs may be NULL)
   const bool packed = packed_nn != nullptr;
@@ -62,11 +62,19 @@ int posterior(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t*
   a.q_stride = q_stride;
   a.nn_stride = nn_stride;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (packed) return launch_fused_wave<T>(a, s);  // MGP_EUNSUPPORTED: the caller uses the plain tables
+  // a LOOCV evaluation (mgp_loocv_*): the wave kernels walk the reduction tree themselves (one launch); behind the
+  // other families the caller does
+  if (tree) a.tree = *tree;
+  if (tree_served) *tree_served = false;
+  if (packed || path == PATH_AUTO) {
+    const int rc = launch_fused_wave<T>(a, s);
+    if (rc == MGP_OK && tree && tree_served) *tree_served = true;
+    if (packed || rc != MGP_EUNSUPPORTED) return rc;  // (prepared tables, MGP_EUNSUPPORTED: the caller uses the plain tables)
+  }
+  a.tree = LoocvTree{};
   if (path == PATH_RHS) return launch_fused_rhs<T>(a, s);
   if (path == PATH_AUTO) {
-    int rc = launch_fused_wave<T>(a, s);
-    if (rc != MGP_EUNSUPPORTED) return rc;
+    int rc;
     rc = launch_fused_rhs<T>(a, s);
     if (rc != MGP_EUNSUPPORTED) return rc;
     rc = launch_fused_wide<T>(a, s);
@@ -180,6 +188,8 @@ extern "C" {
 const char* mgp_version(void) { return "muygpys_amd-hip 0.1 (gfx950)"; }
 int mgp_max_nn_count(int elem_size, int R) { return max_nn_count(elem_size, R); }
 int mgp_reduce_scratch_doubles(void) { return reduce_scratch_doubles(); }
+int64_t mgp_loocv_scratch_bytes(int64_t b) { return b < 0 ? 0 : tree_scratch_bytes(b); }
+int64_t mgp_loocv_scratch_zero_bytes(int64_t b) { return b < 0 ? 0 : tree_zero_bytes(b); }
 int mgp_matern_gen_constants(double smoothness, double* out7) {
   if (!out7 || !(smoothness > 0.0)) return MGP_EINVAL;
   matern_gen_constants_host(smoothness, out7);
@@ -293,24 +303,35 @@ int mgp_posterior_f64(const double* fq, const double* fn, int d, const int64_t* 
   }                                                                                                                  \
   int mgp_loocv_##SUF(const T* feat, int d, const int64_t* bi, const int64_t* ni, int64_t b, int k, const T* tg,     \
                       int nm, double eps, const T* nd, int kid, int mid, const T* ls, int lsc, T* mean, T* var,      \
-                      T* yk, int* info, double huber_delta, double* partials, double* scratch, void* st) {           \
+                      T* yk, int* info, double huber_delta, double* partials, void* scratch, void* st) {             \
     if ((b > 0 && (!mean || !var || !yk)) || !partials || !scratch || !(huber_delta > 0)) return MGP_EINVAL;         \
+    const LoocvTree tr = loocv_tree_layout(scratch, b, partials, tg, (int64_t)sizeof(T), huber_delta);               \
+    bool served = false;                                                                                             \
     const int rc = posterior<T>(feat, feat, d, bi, ni, b, k, tg, 1, nm, eps, nd, kid, mid, ls, lsc, mean, var, yk,  \
-                                info, st);                                                                           \
-    if (rc != MGP_OK) return rc;                                                                                     \
-    return launch_loocv_partials<T>(mean, var, yk, tg, (int64_t)sizeof(T), bi, b, huber_delta, partials, scratch,    \
-                                    S_(st));                                                                         \
+                                info, st, PATH_AUTO, nullptr, 0, nullptr, 0, 0, &tr, &served);                                                                           \
+    if (rc != MGP_OK || served) return rc;                                                                           \
+    return launch_loocv_tree<T>(tr, mean, var, yk, bi, b, S_(st));                                                   \
+  }                                                                                                                  \
+  int mgp_loocv_tree_##SUF(const T* mean, const T* var, const T* yk, const void* resp, int64_t resp_stride,          \
+                           const int64_t* bi, int64_t b, double huber_delta, double* partials, void* scratch,        \
+                           void* st) {                                                                               \
+    if (b < 0 || (b > 0 && (!mean || !var || !yk || !resp)) || !partials || !scratch || !(huber_delta > 0))          \
+      return MGP_EINVAL;                                                                                             \
+    return launch_loocv_tree<T>(loocv_tree_layout(scratch, b, partials, resp, resp_stride, huber_delta), mean, var,  \
+                                yk, bi, b, S_(st));                                                                  \
   }                                                                                                                  \
   int mgp_loocv_packed_##SUF(const void* packed, int64_t stride, int d, const int64_t* bi, const int64_t* ni,        \
                              int64_t b, int k, int nm, double eps, const T* nd, int kid, int mid, const T* ls,       \
                              int lsc, T* mean, T* var, T* yk, int* info, double huber_delta, double* partials,       \
-                             double* scratch, void* st) {                                                            \
+                             void* scratch, void* st) {                                                              \
     if ((b > 0 && (!mean || !var || !yk)) || !partials || !scratch || !(huber_delta > 0)) return MGP_EINVAL;         \
+    const LoocvTree tr = loocv_tree_layout(scratch, b, partials, static_cast<const char*>(packed) + (size_t)d * sizeof(T), \
+                                           stride, huber_delta);                                                     \
+    bool served = false;                                                                                             \
     const int rc = posterior<T>(nullptr, nullptr, d, bi, ni, b, k, nullptr, 1, nm, eps, nd, kid, mid, ls, lsc, mean, \
-                                var, yk, info, st, PATH_AUTO, packed, stride, packed, stride);                       \
-    if (rc != MGP_OK) return rc;                                                                                     \
-    return launch_loocv_partials<T>(mean, var, yk, static_cast<const char*>(packed) + (size_t)d * sizeof(T), stride, \
-                                    bi, b, huber_delta, partials, scratch, S_(st));                                  \
+                                var, yk, info, st, PATH_AUTO, packed, stride, packed, stride, 0, &tr, &served);      \
+    if (rc != MGP_OK || served) return rc;                                                                           \
+    return launch_loocv_tree<T>(tr, mean, var, yk, bi, b, S_(st));                                                   \
   }
 MGP_DEFINE_PATHS(f32, float)
 MGP_DEFINE_PATHS(f64, double)

@@ -571,7 +571,7 @@ int launch_fused_rhs_mf(const FusedArgs& a, hipStream_t stream) {
   if (grid > g.ntasks) grid = g.ntasks;
   hipLaunchKernelGGL((fused_rhs_mf_kernel<RC>), dim3((unsigned)grid), dim3(64), lds, stream, a, g);
   MGP_HIP_CHECK_LAUNCH();
-  note_launch("mgp::fused_rhs_kernel<float,%d,true,true,mfma>", RC);
+  note_launch("mgp::fused_rhs_mf_kernel<%d>", RC);  // (the symbol rocprofv3 and lib/kernel_resources.json list)
   return MGP_OK;
 }
 

@@ -38,6 +38,15 @@ static void gen_geometry(const FusedArgs& a, WaveGeom* g, size_t* lds, int elem_
   }
 }
 
+// one-launch LOOCV evaluation (FusedArgs::tree): the workgroup's list of completed level-1 blocks goes behind
+// everything else in LDS
+static void tree_geometry(const FusedArgs& a, WaveGeom* g, size_t* lds) {
+  g->tree_list = 0;
+  if (!a.tree.out) return;
+  g->tree_list = (int)*lds;
+  *lds += kTreeListBytes;
+}
+
 template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF = false, bool PACKED = false,
           bool GRAM = false, bool GEN64 = false>
 static int launch_np_impl(const FusedArgs& a, hipStream_t stream) {
@@ -75,6 +84,7 @@ static int launch_np_impl(const FusedArgs& a, hipStream_t stream) {
   if (a.kernel_id == MGP_KERNEL_MATERN_GEN && !((NP <= 32 || KFIX > 0) && !COEFF && (sizeof(T) == 4 || GEN64))) return MGP_EUNSUPPORTED;
   if (GEN64 && a.kernel_id != MGP_KERNEL_MATERN_GEN) return MGP_EUNSUPPORTED;
   gen_geometry(a, &g, &lds, (int)sizeof(T));
+  tree_geometry(a, &g, &lds);
 #ifdef MGP_DEBUG_HOOKS
   lds += (size_t)g_lds_pad;
 #endif
@@ -179,6 +189,7 @@ static int launch_jit(const FusedArgs& a, hipStream_t stream) {
   size_t lds = tile_elems * sizeof(T) + wave_colbuf_bytes(sizeof(T), NP, wave_fold(sizeof(T), NP, a.k, a.R, a.d, true, false, gram));
   lds = (lds + 15) & ~(size_t)15;
   gen_geometry(a, &g, &lds, (int)sizeof(T));
+  tree_geometry(a, &g, &lds);
   static Residency res;
   int per_cu = 0, cus = 0;
   const int rrc = res.lookup(fn, 64, lds, &per_cu, &cus);
@@ -208,6 +219,8 @@ static int launch_jit(const FusedArgs& a, hipStream_t stream) {
 template <typename T>
 int launch_fused_wave(const FusedArgs& a, hipStream_t stream) {
   const int rows = a.k + 1 + a.R;
+  if (a.b >= (int64_t)1 << 31) return MGP_EUNSUPPORTED;  // (task and chunk numbers are 32-bit in the kernel)
+  if (a.tree.out && (a.R != 1 || a.coeffs || !a.ykinvy || !a.tree.ctrl)) return MGP_EINVAL;
   if (a.coeffs != nullptr) {  // fused fast-mean precompute: one response
     if (a.packed_nn != nullptr) return MGP_EUNSUPPORTED;
     if (a.R == 1 && rows <= 32) return launch_np<T, 32, 0, 0, 0, false, true>(a, stream);

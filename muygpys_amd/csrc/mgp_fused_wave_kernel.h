@@ -142,6 +142,9 @@ struct WaveGeom {
   float gen_h, gen_lc;
   // ... and in fp64 (2 x MGP_GEN_NODES64 doubles; natural logarithms; smallest scaled distance the table covers)
   double gen_h64, gen_lc64, gen_xmin64;
+  // one-launch LOOCV evaluation (FusedArgs::tree.out): byte offset in LDS of the workgroup's list of completed
+  // level-1 blocks (kTreeListBytes, behind everything else)
+  int tree_list = 0;
 };
 
 // Sizes shared by the kernel and its launchers.  Plain constexpr functions of the shape (element size es,
@@ -437,16 +440,16 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   // can stay in flight across the task (loads under divergent branches that write the same
   // register make the compiler wait for the first before issuing the second).  Slots without
   // an index read a valid dummy element and are zeroed when the value is consumed.
-  auto load_index = [&](int64_t task, int h, int i) -> int64_t {
-    const int64_t nb0 = task * NH;                       // uniform
+  auto load_index = [&](int task, int h, int i) -> int64_t {
+    const int64_t nb0 = (int64_t)task * NH;                       // uniform
     const int hh = (NH > 1 && nb0 + h >= a.b) ? 0 : h;   // odd tail: replay the first half
     const int64_t* row = a.nn_idx + nb0 * k;
     const int64_t* p = row + (hh * k + (i < k ? i : 0));
     if (a.batch_idx != nullptr && i == q) p = a.batch_idx + nb0 + hh;
     return *p;
   };
-  auto fix_index = [&](int64_t raw, int64_t task, int h, int i) -> int64_t {
-    const int64_t nb0 = task * NH;
+  auto fix_index = [&](int64_t raw, int task, int h, int i) -> int64_t {
+    const int64_t nb0 = (int64_t)task * NH;
     const int hh = (NH > 1 && nb0 + h >= a.b) ? 0 : h;
     if (i < k) return raw;
     if (i == q) return a.batch_idx != nullptr ? raw : nb0 + hh;
@@ -454,8 +457,95 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   };
 
   const int64_t task0 = xcd * per_xcd + (blockIdx.x >> 3);
+
+  // ---- the workgroup's task sequence T0, T1, ... ---------------------------------------------------------------
+  // Static (no control block): T_n = task0 + n t_step inside the XCD's eighth, as ever.
+  // Dynamic (a.tree.ctrl, round 5): tasks go out in CHUNKS of CT consecutive tasks (a folded pair; otherwise one) --
+  // the first two chunks of a workgroup are static (the XCD's range start + its rank, + the workgroups per XCD), every
+  // further one is drawn from the XCD's dequeue head, so a launch of a few tasks per workgroup does not end on
+  // workgroups with one task more than the others (config 3's strong-scaling shards: 20.3 tasks per workgroup).  The
+  // pipeline needs T_{n+1} (rows requested during T_n) and T_{n+2} (indices), so the draw for the chunk after the
+  // next happens when the generator enters a chunk -- in the same agent-scope atomic instruction as the arrival ticket
+  // of the reduction tree (lane 0 arrives, lane 1 draws: one round trip per chunk).
+  constexpr int CT = wave_fold(sizeof(T), NP, KFIX, RFIX, DFIX, PIPED, COEFF, GRAM) ? 2 : 1;
+  const bool dyn = a.tree.ctrl != nullptr;
+  const bool tree_on = a.tree.out != nullptr;  // (implies dyn)
+  // (chunk and block numbers are 32-bit: 2^31 chunks are beyond any index tensor that fits the device)
+  const int nchunks = (int)((ntasks + CT - 1) / CT), cpx = (nchunks + 7) / 8;
+  const int ch_lo = xcd * cpx, ch_hi = min((xcd + 1) * cpx, nchunks);
+  int g_chunk = ch_lo + (int)(blockIdx.x >> 3), g_next = g_chunk + (int)t_step;  // dynamic: chunk being dealt, the one after
+  if (g_chunk >= ch_hi) g_chunk = -1;
+  if (g_next >= ch_hi) g_next = -1;
+  int g_pos = 0;
+  int arr_blk = 0;  // level-1 block and count of the neighbourhoods stored since the last arrival ticket
+  unsigned arr_n = 0;
+  // level-1 blocks of the reduction tree this workgroup completed (its ticket was the block's last): reduced after the
+  // task loop, so that nothing of the tree is live in it (inlined at the ticket, the walk cost the headline kernel 20
+  // spilled registers; as a function call, spills around the call all over the loop)
+  int* tlist = reinterpret_cast<int*>(smem + g.tree_list);
+  int tlist_n = 0;
+  auto seq_next = [&](bool arrive) -> int {
+    int t;
+    bool draw = false;
+    if (!dyn) {
+      // (static: g_pos counts the tasks dealt)
+      const int64_t ts = task0 + (int64_t)g_pos * t_step;
+      t = ts < t_end ? (int)ts : -1;
+      ++g_pos;
+    } else {
+      if (g_chunk >= 0 && (g_pos == CT || g_chunk * CT + g_pos >= (int)ntasks)) {
+        g_chunk = g_next;
+        g_next = -1;
+        g_pos = 0;
+        draw = g_chunk >= 0;
+      }
+      t = g_chunk >= 0 ? g_chunk * CT + g_pos : -1;
+      ++g_pos;
+    }
+    arrive = arrive && arr_n > 0;
+    if (draw || arrive) {
+      if (arrive) drain_stores();  // the outputs behind the ticket have left the CU
+      unsigned old = 0;
+      if ((threadIdx.x == 0 && arrive) || (threadIdx.x == 1 && draw)) {
+        // (one uniform base + a per-lane word offset: the level-1 counters lie behind the control block)
+        const unsigned word = threadIdx.x == 0 ? (unsigned)(kTreeCtrlBytes / 4) + (unsigned)arr_blk : 32u * (unsigned)xcd;
+        old = __hip_atomic_fetch_add(a.tree.ctrl + word, threadIdx.x == 0 ? arr_n : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      const unsigned tk_arr = __builtin_amdgcn_readlane(old, 0), tk_draw = __builtin_amdgcn_readlane(old, 1);
+      if (draw) {
+        const unsigned c = (unsigned)ch_lo + 2u * (unsigned)t_step + tk_draw;
+        g_next = c < (unsigned)ch_hi ? (int)c : -1;
+      }
+      if (arrive) {
+        const int64_t left = a.b - ((int64_t)arr_blk << 6);
+        if (tk_arr + arr_n == (left < 64 ? (unsigned)left : 64u)) {  // this ticket completed the block
+          if (tlist_n < kTreeListCap) {
+            if (threadIdx.x == 0) tlist[tlist_n] = arr_blk;
+            ++tlist_n;
+          } else if (threadIdx.x == 0) {  // (list full: the scratch's deferred list, reduced by the last workgroup out)
+            const unsigned slot = __hip_atomic_fetch_add(a.tree.ctrl + kTreeWordDeferred, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            st_agent(a.tree.deferred + slot, (unsigned)arr_blk);
+          }
+        }
+        arr_n = 0;
+      }
+    }
+    return t;
+  };
+  // `slots` neighbourhoods from `first` on have just been stored (write-through): note them for the next ticket
+  auto note_stored = [&](int64_t first, int slots) {
+    const int64_t left = a.b - first;
+    arr_blk = (int)(first >> 6);
+    arr_n = left <= 0 ? 0u : (left < slots ? (unsigned)left : (unsigned)slots);
+  };
+  // an output element: write-through when other workgroups will read it in this launch (the tree's level 1)
+  auto st_out = [&](T* p, T v) {
+    if (tree_on) st_agent_f(p, v);
+    else *p = v;
+  };
+  int task = seq_next(false), t1 = seq_next(false), t2 = -1;  // (task numbers are 32-bit: the launcher refuses more)
   int64_t next_idx = 0;
-  if (task0 < t_end) next_idx = load_index(task0, NH == 1 ? 0 : (int)threadIdx.x / NP, threadIdx.x & (NP - 1));
+  if (task >= 0) next_idx = load_index(task, NH == 1 ? 0 : (int)threadIdx.x / NP, threadIdx.x & (NP - 1));
 
   // Software-pipelined gather (static shapes, one feature stage): the feature tile of task
   // t+1 is requested right before the factorisation of task t -- by then the tile region of
@@ -470,7 +560,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   const unsigned spr_magic = (1u << 20) / (unsigned)SPR + 1u;  // sigma / SPR for sigma < 64 * 33
   T pre_y = T(0), pre_eps = T(0);
   int64_t pre_idx = 0, pre_tg = 0;  // pre_tg: row of the response tensor (table row, or b * k + slot when gathered)
-  auto pipe_issue = [&](int64_t task_n, int64_t idx_n, int lane_) {
+  auto pipe_issue = [&](int task_n, int64_t idx_n, int lane_) {
     const int h = NH == 1 ? 0 : lane_ / NP;
     const int i = lane_ & (NP - 1);
     // pointer to this slot's feature row; slots without one (idx_n = 0) point at row 0 -- any
@@ -514,7 +604,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     // response and nugget of the slot's row: unconditional single loads (idx_n is 0, a valid
     // row, for slots without one; the values are masked where they are consumed)
     {
-      const int64_t nb0 = task_n * NH;
+      const int64_t nb0 = (int64_t)task_n * NH;
       const int hh = (NH > 1 && nb0 + h >= a.b) ? 0 : h;
       // (only neighbour slots index the response / noise tables: the query slot's row number belongs to
       // the QUERY table, which may be the longer one)
@@ -524,17 +614,16 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     if (!PACKED || a.targets_batch) pre_y = targets[pre_tg * (int64_t)R];
     pre_eps = (T)a.noise_scalar;
     if (a.noise_mode != MGP_NOISE_SCALAR) {
-      const int64_t nb0 = task_n * NH;
+      const int64_t nb0 = (int64_t)task_n * NH;
       const int hh = (NH > 1 && nb0 + h >= a.b) ? 0 : h;
       const T* pn = a.noise_mode == MGP_NOISE_TABLE ? noise_dev + (i < k ? idx_n : 0) : noise_dev + nb0 * k + (hh * k + (i < k ? i : 0));
       pre_eps = *pn;
     }
   };
-  if (PIPE && task0 < t_end) {
-    pipe_issue(task0, fix_index(next_idx, task0, NH == 1 ? 0 : (int)threadIdx.x / NP, threadIdx.x & (NP - 1)),
+  if (PIPE && task >= 0) {
+    pipe_issue(task, fix_index(next_idx, task, NH == 1 ? 0 : (int)threadIdx.x / NP, threadIdx.x & (NP - 1)),
                threadIdx.x);
-    if (task0 + t_step < t_end)
-      next_idx = load_index(task0 + t_step, NH == 1 ? 0 : (int)threadIdx.x / NP, threadIdx.x & (NP - 1));
+    if (t1 >= 0) next_idx = load_index(t1, NH == 1 ? 0 : (int)threadIdx.x / NP, threadIdx.x & (NP - 1));
   }
 
   // Exchange-matrix slot of each of the lane's NS pairs (phase 3) and which of them are real
@@ -594,8 +683,8 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   // quarter; quarters 0 / 1 belong to the first task of a pair, 2 / 3 to the second
   V FL[FOLD ? NG : 1], FS[FOLD ? NGS : 1];
   int fold_sub = 0;
-  int64_t fold_task_a = 0;
-  for (int64_t task = task0; task < t_end; task += t_step) {
+  int fold_task_a = 0;
+  for (; task >= 0; task = t1, t1 = t2) {
     // The lane id is made opaque per task: otherwise LICM hoists every per-lane address, mask
     // and index of the unrolled phases out of this loop and the kernel runs out of registers.
     int lane = threadIdx.x;
@@ -606,7 +695,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     T* Kh = tile + h * KMAT;
     T* colh = colbuf + h * NP;
     int64_t* idxh = idxbuf + h * NP;
-    const int64_t nb0 = task * NH;
+    const int64_t nb0 = (int64_t)task * NH;
     const bool live = nb0 + h < a.b;
     const int hh = live ? h : 0;
 
@@ -623,7 +712,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       myeps = pre_eps;
     } else {
       myidx = fix_index(next_idx, task, h, i);
-      if (task + t_step < t_end) next_idx = load_index(task + t_step, h, i);
+      if (t1 >= 0) next_idx = load_index(t1, h, i);
       __syncthreads();  // previous task's LDS reads are complete
       idxh[i] = myidx * (int64_t)d;  // element offset of the row
       mytg = a.targets_batch ? (nb0 + hh) * k + (i < k ? i : 0) : myidx;
@@ -649,6 +738,11 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     // covariances, few distance instructions at small d): elimination (2) > exchange (1) > distances (0)
     __builtin_amdgcn_s_setprio(sizeof(T) == 4 || MGP_F64_SAME_PRIO ? MGP_DIST_PRIO : MGP_XCHG_PRIO);
 #endif
+
+    // the task after the next (a draw from the XCD's queue when it opens a chunk) and the arrival ticket of the outputs
+    // stored at the end of the previous iteration: behind the stores' drain, which the wait for this task's rows
+    // (below) would pay anyway
+    t2 = seq_next(true);
 
     // ---- phases 1+2: stage features, accumulate squared distances ---------------------
     for (int d0 = 0; d0 < d; d0 += dst) {
@@ -1154,9 +1248,9 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 
     // the next task's rows are requested now: their latency hides behind the factorisation, and
     // the registers they land in are not live during the (register-hungry) distance phase
-    if (PIPE && task + t_step < t_end) {
-      pipe_issue(task + t_step, fix_index(next_idx, task + t_step, h, i), lane);
-      if (task + 2 * t_step < t_end) next_idx = load_index(task + 2 * t_step, h, i);
+    if (PIPE && t1 >= 0) {
+      pipe_issue(t1, fix_index(next_idx, t1, h, i), lane);
+      if (t2 >= 0) next_idx = load_index(t2, h, i);
     }
 
     if constexpr (FOLD) {
@@ -1167,7 +1261,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       // neighbourhood half the column reads and, summed over the steps, 182 instead of 284 group updates.
       // The first task of a pair parks its rows in lanes 0 .. 31 and goes on to the second; the elimination
       // runs when both are there (or the workgroup has no task left).
-      const bool lastt = !(task + t_step < t_end);
+      const bool lastt = t1 < 0;
       MGP_WAVE_T(3)
       if (fold_sub == 0 && !lastt) {
         fold_sub = 1;
@@ -1263,7 +1357,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         constexpr int QF = KFIX;
         const int l16 = lane & (HALF - 1);
         const bool second = (lane >> 5) != 0;
-        const int64_t nbq = (second ? task : fold_task_a) * NH + (NH == 1 ? 0 : (lane >> LOGH) & (NH - 1));
+        const int64_t nbq = (int64_t)(second ? task : fold_task_a) * NH + (NH == 1 ? 0 : (lane >> LOGH) & (NH - 1));
         const bool liveq = nbq < a.b && (!second || have_b);
         T* mean = static_cast<T*>(a.mean);
         T* var = static_cast<T*>(a.var);
@@ -1276,19 +1370,19 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         }
         if (liveq) {
           if (l16 == QF - HALF) {
-            var[nbq] = bad ? num<T>::nan() : sq;
+            st_out(var + nbq, bad ? num<T>::nan() : sq);
             if (bad && a.info) atomicAdd(a.info, 1);
           } else if (l16 > QF - HALF && l16 <= QF - HALF + RFIX) {
             const int r = l16 - (QF - HALF) - 1;
-            mean[nbq * RFIX + r] = bad ? num<T>::nan() : -sq;
-            if (yk) yk[nbq * RFIX + r] = bad ? num<T>::nan() : -sd;
+            st_out(mean + (nbq * RFIX + r), bad ? num<T>::nan() : -sq);
+            if (yk) st_out(yk + (nbq * RFIX + r), bad ? num<T>::nan() : -sd);
           }
         }
       } else {
         constexpr int QF = KFIX, YF = KFIX + 1;
         const int l16 = lane & (HALF - 1);
         const bool second = (lane >> 5) != 0;
-        const int64_t nbq = (second ? task : fold_task_a) * NH + (NH == 1 ? 0 : (lane >> LOGH) & (NH - 1));
+        const int64_t nbq = (int64_t)(second ? task : fold_task_a) * NH + (NH == 1 ? 0 : (lane >> LOGH) & (NH - 1));
         const bool liveq = nbq < a.b && (!second || have_b);
         T* mean = static_cast<T*>(a.mean);
         T* var = static_cast<T*>(a.var);
@@ -1296,14 +1390,16 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         const T sq = FL[QF / E][QF % E], sy = FL[YF / E][YF % E];
         if (liveq) {
           if (l16 == QF - HALF) {
-            var[nbq] = bad ? num<T>::nan() : sq;
+            st_out(var + nbq, bad ? num<T>::nan() : sq);
             if (bad && a.info) atomicAdd(a.info, 1);
           } else if (l16 == YF - HALF) {
-            mean[nbq] = bad ? num<T>::nan() : -sq;
-            if (yk) yk[nbq] = bad ? num<T>::nan() : -sy;
+            st_out(mean + nbq, bad ? num<T>::nan() : -sq);
+            if (yk) st_out(yk + nbq, bad ? num<T>::nan() : -sy);
           }
         }
       }
+      // (dynamic sequence: the pair is one chunk -- consecutive tasks, 2 NH consecutive neighbourhoods of one block)
+      if (tree_on) note_stored((int64_t)fold_task_a * NH, have_b ? 2 * NH : NH);
       MGP_WAVE_T(5)
       continue;
     }
@@ -1410,17 +1506,18 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         const int64_t nb = nb0;
         if (live) {
           if (lane == (eq & 63)) {
-            var[nb] = bad ? num<T>::nan() : Dp[eq >> 6][QF & 1];
+            st_out(var + nb, bad ? num<T>::nan() : Dp[eq >> 6][QF & 1]);
             if (bad && a.info) atomicAdd(a.info, 1);
           }
 #pragma unroll
           for (int r = 0; r < RFIX; ++r) {
             const int YF = QF + 1 + r;
             const int em = cs2(QF) + (YF >> 1) - (QF >> 1), ey = cs2(YF);
-            if (lane == (em & 63)) mean[nb * RFIX + r] = bad ? num<T>::nan() : -Dp[em >> 6][YF & 1];
-            if (yk && lane == (ey & 63)) yk[nb * RFIX + r] = bad ? num<T>::nan() : -Dp[ey >> 6][YF & 1];
+            if (lane == (em & 63)) st_out(mean + (nb * RFIX + r), bad ? num<T>::nan() : -Dp[em >> 6][YF & 1]);
+            if (yk && lane == (ey & 63)) st_out(yk + (nb * RFIX + r), bad ? num<T>::nan() : -Dp[ey >> 6][YF & 1]);
           }
         }
+        if (tree_on) note_stored(nb0, NH);
       }
       MGP_WAVE_T(5)
       continue;
@@ -1552,11 +1649,11 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       const T sq = A[QF / E][QF % E], sy = A[YF / E][YF % E];
       if (live) {
         if (i == QF) {
-          var[nb] = bad ? num<T>::nan() : sq;
+          st_out(var + nb, bad ? num<T>::nan() : sq);
           if (bad && a.info) atomicAdd(a.info, 1);
         } else if (i == YF) {
-          mean[nb] = bad ? num<T>::nan() : -sq;
-          if (yk) yk[nb] = bad ? num<T>::nan() : -sy;
+          st_out(mean + nb, bad ? num<T>::nan() : -sq);
+          if (yk) st_out(yk + nb, bad ? num<T>::nan() : -sy);
         }
       }
     } else if constexpr (PIPED || TRI) {
@@ -1573,12 +1670,12 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       }
       if (live) {
         if (i == q) {
-          var[nb] = bad ? num<T>::nan() : aq;
+          st_out(var + nb, bad ? num<T>::nan() : aq);
           if (bad && a.info) atomicAdd(a.info, 1);
         } else if (i > q && i <= q + R) {  // (static shapes: lanes behind the last response row are idle)
           const int r = i - q - 1;
-          mean[nb * R + r] = bad ? num<T>::nan() : -aq;
-          if (yk) yk[nb * R + r] = bad ? num<T>::nan() : -aii;
+          st_out(mean + (nb * R + r), bad ? num<T>::nan() : -aq);
+          if (yk) st_out(yk + (nb * R + r), bad ? num<T>::nan() : -aii);
         }
       }
     } else {
@@ -1588,14 +1685,46 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       __syncthreads();
       if (live) {
         if (i == q) {
-          var[nb] = bad ? num<T>::nan() : Kh[q * KS + q];
+          st_out(var + nb, bad ? num<T>::nan() : Kh[q * KS + q]);
           if (bad && a.info) atomicAdd(a.info, 1);
         } else if (i > q && i <= q + R) {  // (static shapes: lanes behind the last response row are idle)
           const int r = i - q - 1;
-          mean[nb * R + r] = bad ? num<T>::nan() : -Kh[i * KS + q];
-          if (yk) yk[nb * R + r] = bad ? num<T>::nan() : -Kh[i * KS + i];
+          st_out(mean + (nb * R + r), bad ? num<T>::nan() : -Kh[i * KS + q]);
+          if (yk) st_out(yk + (nb * R + r), bad ? num<T>::nan() : -Kh[i * KS + i]);
         }
       }
+    }
+    if constexpr (!COEFF) {
+      if (tree_on) note_stored(nb0, NH);
+    }
+  }
+  // ---- the workgroup is out of tasks ---------------------------------------------------------------------------
+  if (dyn) {
+    if (tree_on) {
+      seq_next(true);  // the ticket of its last outputs (the sequence is exhausted: no draw)
+      // reduce the level-1 blocks this workgroup completed, each as far up the tree as its tickets are the last ones
+      const T* o_mean = static_cast<const T*>(a.mean);
+      const T* o_var = static_cast<const T*>(a.var);
+      const T* o_yk = static_cast<const T*>(a.ykinvy);
+      __syncthreads();
+      for (int e = 0; e < tlist_n; ++e)
+        tree_reduce_block<T>(a.tree, o_mean, o_var, o_yk, a.batch_idx, a.b, tlist[e], (int)threadIdx.x);
+      drain_stores();
+    }
+    // the last workgroup out reduces what overflowed the lists and rewinds the task queues (every draw of the launch
+    // has returned by then: a workgroup leaves its loop only after its last draw came back)
+    unsigned outc = 0;
+    if (threadIdx.x == 0) outc = __hip_atomic_fetch_add(a.tree.ctrl + kTreeWordOut, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    outc = __builtin_amdgcn_readfirstlane(outc);
+    if (outc + 1u == gridDim.x) {
+      if (tree_on) {
+        const unsigned nd = ld_agent(a.tree.ctrl + kTreeWordDeferred);
+        for (unsigned e = 0; e < nd; ++e)
+          tree_reduce_block<T>(a.tree, static_cast<const T*>(a.mean), static_cast<const T*>(a.var), static_cast<const T*>(a.ykinvy),
+                               a.batch_idx, a.b, ld_agent(a.tree.deferred + e), (int)threadIdx.x);
+      }
+      if (threadIdx.x < 10)
+        st_agent(a.tree.ctrl + (threadIdx.x < 8 ? 32 * (int)threadIdx.x : (threadIdx.x == 8 ? kTreeWordOut : kTreeWordDeferred)), 0u);
     }
   }
 #if MGP_WAVE_TIMING

@@ -92,7 +92,7 @@ uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
 // the options every kernel file of the library is built with (muygpys_amd/build.py) -- part of the key
 const char* const kOptions[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm",
                                 "-pragma-unroll-threshold=1000000", "-Wno-pass-failed"};
-const char* const kSources[] = {"mgp_fused_wave_kernel.h", "mgp_wave_common.h", "mgp_args.h", "mgp_device.h"};
+const char* const kSources[] = {"mgp_fused_wave_kernel.h", "mgp_wave_common.h", "mgp_args.h", "mgp_device.h", "mgp_loocv_tree.h"};
 
 struct Env {
   Rtc rtc;

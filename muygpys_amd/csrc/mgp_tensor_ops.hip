@@ -5,6 +5,7 @@
 #include <cmath>
 
 #include "mgp_device.h"
+#include "mgp_loocv_tree.h"
 
 namespace mgp {
 
@@ -483,26 +484,33 @@ __global__ void loss_sums_kernel(const T* pred, const T* target, const T* var, i
 }
 
 // LOOCV partial sums of one shard (optimize/loss.py:159-168 with scale/numpy.py:11-18 folded in):
-// [sum r^2/v, sum log v, sum r^2, n, sum pseudo-Huber(r), sum y^T K^-1 y], r = mean - y(batch row).
-// The batch row's response is read where the fused launch read it: resp + row * stride (bytes) --
-// the response tensor (stride = sizeof T) or a prepared table (stride = row bytes, resp offset d).
+// [sum r^2/v, sum log v, sum r^2, n, sum pseudo-Huber(r), sum y^T K^-1 y], r = mean - y(batch row), as the fixed
+// reduction tree of mgp_loocv_tree.h.  The fused wave kernels walk that tree themselves (one launch per evaluation);
+// these three kernels walk it behind any other kernel family: one wave per block, the same device functions.
 template <typename T>
-__global__ void loocv_partials_kernel(const T* mean, const T* var, const T* yk, const char* resp, int64_t stride,
-                                      const int64_t* batch_idx, int64_t n, double hd, double* scratch) {
-  double acc[6] = {0, 0, 0, 0, 0, 0};
-  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = batch_idx ? batch_idx[t] : t;
-    const double y = (double)*reinterpret_cast<const T*>(resp + row * stride);
-    const double r = (double)mean[t] - y, v = (double)var[t];
-    const double r2 = r * r;
-    acc[0] += r2 / v;
-    acc[1] += ::log(v);
-    acc[2] += r2;
-    acc[3] += 1.0;
-    acc[4] += hd * hd * (::sqrt(1.0 + (r / hd) * (r / hd)) - 1.0);
-    acc[5] += (double)yk[t];
-  }
-  block_reduce_store<6>(acc, nullptr, scratch);
+__global__ void loocv_level1_kernel(LoocvTree tr, const T* mean, const T* var, const T* yk, const int64_t* batch_idx, int64_t b) {
+  const int64_t j1 = blockIdx.x * (int64_t)(kBlock / MGP_WAVE) + (threadIdx.x >> 6);
+  if (j1 >= tree_nb1(b)) return;
+  const int lane = threadIdx.x & 63;
+  double t[6];
+  tree_level1<T, false>(tr, mean, var, yk, batch_idx, b, j1, lane, t);
+  if (lane == 0)
+    for (int i = 0; i < 6; ++i) tr.part1[6 * j1 + i] = t[i];
+}
+__global__ void loocv_level2_kernel(LoocvTree tr, int64_t b) {
+  const int64_t j2 = blockIdx.x * (int64_t)(kBlock / MGP_WAVE) + (threadIdx.x >> 6);
+  if (j2 >= tree_nb2(b)) return;
+  const int lane = threadIdx.x & 63;
+  double t[6];
+  tree_level2<false>(tr, tree_nb1(b), j2, lane, t);
+  if (lane == 0)
+    for (int i = 0; i < 6; ++i) tr.part2[6 * j2 + i] = t[i];
+}
+__global__ void loocv_level3_kernel(LoocvTree tr, int64_t b) {
+  double t[6];
+  tree_level3<false>(tr, tree_nb2(b), (int)threadIdx.x, t);
+  if (threadIdx.x == 0)
+    for (int i = 0; i < 6; ++i) tr.out[i] = t[i];
 }
 
 template <typename T>
@@ -677,20 +685,36 @@ int launch_column_sums(const T* x, int64_t n, int R, double* out, double* scratc
   }
   return MGP_OK;
 }
+LoocvTree loocv_tree_layout(void* scratch, int64_t b, double* out, const void* resp, int64_t resp_stride, double huber_delta) {
+  char* base = static_cast<char*>(scratch);
+  LoocvTree tr;
+  tr.out = out;
+  tr.ctrl = reinterpret_cast<unsigned*>(base);
+  tr.cnt1 = reinterpret_cast<unsigned*>(base + tree_off_cnt1(b));
+  tr.cnt2 = reinterpret_cast<unsigned*>(base + tree_off_cnt2(b));
+  tr.part1 = reinterpret_cast<double*>(base + tree_off_part1(b));
+  tr.part2 = reinterpret_cast<double*>(base + tree_off_part2(b));
+  tr.deferred = reinterpret_cast<unsigned*>(base + tree_off_deferred(b));
+  tr.resp = static_cast<const char*>(resp);
+  tr.resp_stride = resp_stride;
+  tr.huber_delta = huber_delta;
+  return tr;
+}
 template <typename T>
-int launch_loocv_partials(const T* mean, const T* var, const T* yk, const void* resp, int64_t stride,
-                          const int64_t* batch_idx, int64_t n, double hd, double* out, double* scratch, hipStream_t s) {
-  if (!scratch || !out) return MGP_EINVAL;
-  if (n == 0) {
-    hipError_t e = hipMemsetAsync(out, 0, 6 * sizeof(double), s);
+int launch_loocv_tree(const LoocvTree& tr, const T* mean, const T* var, const T* yk, const int64_t* batch_idx, int64_t b,
+                      hipStream_t s) {
+  if (!tr.out || !tr.part1 || !tr.part2) return MGP_EINVAL;
+  if (b == 0) {
+    hipError_t e = hipMemsetAsync(tr.out, 0, 6 * sizeof(double), s);
     return e == hipSuccess ? MGP_OK : -(1000 + (int)e);
   }
-  int g = grid_1d(n);
-  if (g > kReduceBlocks) g = kReduceBlocks;
-  hipLaunchKernelGGL(loocv_partials_kernel<T>, dim3(g), dim3(kBlock), 0, s, mean, var, yk,
-                     static_cast<const char*>(resp), stride, batch_idx, n, hd, scratch);
+  constexpr int W = kBlock / MGP_WAVE;
+  hipLaunchKernelGGL(loocv_level1_kernel<T>, dim3((unsigned)((tree_nb1(b) + W - 1) / W)), dim3(kBlock), 0, s, tr, mean, var, yk,
+                     batch_idx, b);
   MGP_HIP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kBlock), 0, s, scratch, g, 6, out);
+  hipLaunchKernelGGL(loocv_level2_kernel, dim3((unsigned)((tree_nb2(b) + W - 1) / W)), dim3(kBlock), 0, s, tr, b);
+  MGP_HIP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(loocv_level3_kernel, dim3(1), dim3(MGP_WAVE), 0, s, tr, b);
   MGP_HIP_CHECK_LAUNCH();
   return MGP_OK;
 }
@@ -754,8 +778,7 @@ int launch_table_pack(const T* feat, const T* targets, int64_t n, int d, int R, 
   template int launch_loss_sums<T>(const T*, const T*, const T*, int64_t, const double*, double, double, double*,  \
                                    double*, hipStream_t);                                                          \
   template int launch_column_sums<T>(const T*, int64_t, int, double*, double*, hipStream_t);                        \
-  template int launch_loocv_partials<T>(const T*, const T*, const T*, const void*, int64_t, const int64_t*, int64_t, \
-                                        double, double*, double*, hipStream_t);                                     \
+  template int launch_loocv_tree<T>(const LoocvTree&, const T*, const T*, const T*, const int64_t*, int64_t, hipStream_t); \
   template int launch_table_pack<T>(const T*, const T*, int64_t, int, int, void*, int64_t, hipStream_t);          \
   template int launch_matern_gen<T>(const T*, int64_t, double, double, T*, hipStream_t);
 MGP_INSTANTIATE(float)

@@ -358,6 +358,12 @@ __device__ __forceinline__ T cov_from_sqdist(T acc, int kernel_id, int metric_id
 // correction and a class test: 18 instructions; here 9): its argument is a squared distance -- zero (identical rows)
 // is lifted by adding 1e-280 (a no-op for every x >= 1e-264), whose root, 1e-140, is zero for every covariance function; relative error < 2^-50.  The exp is
 // exp_neg() above without the clamp on the exponent (v_cvt_i32_f64 saturates, v_ldexp_f64 underflows to zero).
+// v_cvt_i32_f64 saturates; the C cast `(int)x` of an out-of-range double is poison to the optimiser (advisor, round 4).
+__device__ __forceinline__ int cvt_i32_sat(double x) {
+  int i;
+  asm("v_cvt_i32_f64 %0, %1" : "=v"(i) : "v"(x));
+  return i;
+}
 template <int CB, int KID, int MID>
 __device__ __forceinline__ void cov_batch64(double (&v)[CB], double post_scale) {
   constexpr auto C = [](unsigned long long bits) { return __builtin_bit_cast(double, bits); };
@@ -404,7 +410,12 @@ __device__ __forceinline__ void cov_batch64(double (&v)[CB], double post_scale) 
       w[u] = 1.0;
     }
   }
+  // exp(-800) = 0 in fp64: the clamp keeps an extreme scaled distance (length scale at a 1e-5 bound, an infinite
+  // feature) a plain number through the range reduction below (inf - inf otherwise) and returns covariance 0 like the
+  // reference's exp(-inf); v_min_f64 also drops a NaN from inf * rsq(inf) = inf * 0.
   double n[CB], r[CB], q[CB];
+#pragma unroll
+  for (int u = 0; u < CB; ++u) t[u] = __builtin_fmin(t[u], 800.0);
 #pragma unroll
   for (int u = 0; u < CB; ++u) n[u] = __builtin_rint(t[u] * -1.4426950408889634074);
 #pragma unroll
@@ -424,7 +435,7 @@ __device__ __forceinline__ void cov_batch64(double (&v)[CB], double post_scale) 
 #pragma unroll
   for (int u = 0; u < CB; ++u) q[u] = __builtin_fma(q[u], r[u], 1.0);
 #pragma unroll
-  for (int u = 0; u < CB; ++u) q[u] = __builtin_amdgcn_ldexp(q[u], (int)n[u]);
+  for (int u = 0; u < CB; ++u) q[u] = __builtin_amdgcn_ldexp(q[u], cvt_i32_sat(n[u]));
 #pragma unroll
   for (int u = 0; u < CB; ++u) {
     if constexpr (KID == MGP_KERNEL_MATERN_15 || KID == MGP_KERNEL_MATERN_25) v[u] = w[u] * q[u];
@@ -643,7 +654,7 @@ __device__ __forceinline__ void matern_gen_batch64(double (&v)[CB], unsigned liv
 #pragma unroll
     for (int u = 0; u < CB; ++u) q[u] = __builtin_fma(q[u], r[u], 1.0);
 #pragma unroll
-    for (int u = 0; u < CB; ++u) acc[u] += __builtin_amdgcn_ldexp(q[u], (int)m[u]);
+    for (int u = 0; u < CB; ++u) acc[u] += __builtin_amdgcn_ldexp(q[u], cvt_i32_sat(m[u]));
   }
 #pragma unroll
   for (int u = 0; u < CB; ++u) v[u] = acc[u];

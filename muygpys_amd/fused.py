@@ -401,7 +401,7 @@ def loocv_partials(
     var = torch.empty((b,), device=fn.device, dtype=dtype)
     yk = torch.empty((b,), device=fn.device, dtype=dtype)
     partials = torch.empty(6, device=fn.device, dtype=torch.float64)
-    scratch = _lib.reduce_scratch(fn.device)
+    scratch = _lib.loocv_scratch(fn.device, b)
     tail = (mode, eps, _lib.ptr(nz), spec.kernel_id(), spec.metric_id(), _lib.ptr(ls), ls.numel(), _lib.ptr(mean),
             _lib.ptr(var), _lib.ptr(yk), _lib.ptr(info), float(huber_delta), _lib.ptr(partials), _lib.ptr(scratch),
             _lib.stream_ptr())
@@ -413,12 +413,34 @@ def loocv_partials(
     if use_packed:
         pn = pack_table(train_features, train_targets)
         lsk = pn.kernel_length_scale(ls)
-        tail = tail[:5] + (_lib.ptr(lsk), lsk.numel()) + tail[7:]
-        rc = _lib.fn("loocv_packed", dtype)(_lib.ptr(pn.data), pn.stride, pn.d_kernel, _lib.ptr(bi), _lib.ptr(ni), b, k, *tail)
+        tail_packed = tail[:5] + (_lib.ptr(lsk), lsk.numel()) + tail[7:]  # (`tail` stays the plain-table call's)
+        rc = _lib.fn("loocv_packed", dtype)(_lib.ptr(pn.data), pn.stride, pn.d_kernel, _lib.ptr(bi), _lib.ptr(ni), b, k,
+                                            *tail_packed)
     if rc == -2:
         rc = _lib.fn("loocv", dtype)(_lib.ptr(fn), d, _lib.ptr(bi), _lib.ptr(ni), b, k, _lib.ptr(tg), *tail)
+    if rc != 0:
+        _lib.loocv_scratch_reset()
     _lib.check(rc, "mgp_loocv")
     return partials, mean, var
+
+
+def loocv_tree_sums(mean: torch.Tensor, var: torch.Tensor, ykinvy: torch.Tensor, train_targets: torch.Tensor,
+                    batch_indices: Optional[torch.Tensor], huber_delta: float = 1.5) -> torch.Tensor:
+    """The LOOCV partial sums from finished outputs (``mgp_loocv_tree_*``): the reduction tree ``mgp_loocv_*`` walks
+    inside its fused launch, as three small launches -- equal bits (csrc/mgp_loocv_tree.h).  ``mean`` / ``var`` /
+    ``ykinvy`` ``(b,)`` as returned by :func:`posterior_mean_var` with ``want_ykinvy``; one response."""
+    _lib.require_cuda(mean, var, ykinvy, train_targets, batch_indices)
+    dtype = mean.dtype
+    b = mean.numel()
+    tg = train_targets.reshape(-1).to(dtype).contiguous()
+    bi = None if batch_indices is None else batch_indices.to(torch.int64).contiguous()
+    out = torch.empty(6, device=mean.device, dtype=torch.float64)
+    scratch = torch.empty(max(int(_lib.load().mgp_loocv_scratch_bytes(b)), 16), dtype=torch.uint8, device=mean.device)
+    rc = _lib.fn("loocv_tree", dtype)(_lib.ptr(mean.contiguous()), _lib.ptr(var.contiguous()), _lib.ptr(ykinvy.contiguous()),
+                                      _lib.ptr(tg), tg.element_size(), _lib.ptr(bi), b, float(huber_delta), _lib.ptr(out),
+                                      _lib.ptr(scratch), _lib.stream_ptr())
+    _lib.check(rc, "mgp_loocv_tree")
+    return out
 
 
 def fast_posterior_mean(
@@ -457,6 +479,8 @@ def fast_posterior_mean(
         _lib.ptr(fq), _lib.ptr(fn), d, _lib.ptr(bi), _lib.ptr(ni), b, k, _lib.ptr(co), _lib.ptr(crow), R,
         spec.kernel_id(), spec.metric_id(), _lib.ptr(ls), ls.numel(), _lib.ptr(mean), _lib.stream_ptr(),
     )
+    if rc == -2:
+        raise FusedUnsupported(f"mgp_fast_posterior_mean serves k + 1 <= 64 slots; got nn_count = {k}")
     _lib.check(rc, "mgp_fast_posterior_mean")
     return mean.reshape(b) if squeeze else mean
 

@@ -63,7 +63,7 @@ def main():
     out = {}
     for path in sorted(glob.glob(os.path.join(HERE, "*.npz"))):
         name = os.path.basename(path)[:-4]
-        if name.startswith(("grad_", "fast_", "gen_", "fp32_")):
+        if name.startswith(("grad_", "fast_", "gen_", "fp32_", "scale_")):
             continue
         g = np.load(path)
         meta = json.loads(str(g["meta"]))

@@ -68,7 +68,7 @@ def test_bench_step_of_every_config_matches_the_oracle(cid):
     name = _oracle_checked_kernel(cid)
     assert name.startswith("mgp::fused_"), name
     if cid == 5:  # the prediction variant of the rhs-column kernel (the round-3 parity gap)
-        assert name.startswith("mgp::fused_rhs_kernel<float,16,true"), name
+        assert name.startswith(("mgp::fused_rhs_mf_kernel<16", "mgp::fused_rhs_kernel<float,16,true")), name
 
 
 def _run(cmd, timeout=900):

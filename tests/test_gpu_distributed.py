@@ -52,10 +52,12 @@ def test_partials_and_finish(golden, dtype):
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 @pytest.mark.parametrize("packed", [False, True])
 def test_loocv_call_equals_the_three_call_composition(dtype, packed):
-    """``mgp_loocv_*`` (one call) against ``mgp_posterior_*`` + ``mgp_loss_sums_*`` + ``mgp_column_sums_*``:
-    the same kernels and the same fixed-order reductions, so the six sums agree to the last bit."""
+    """``mgp_loocv_*`` (one call, since round 5 one LAUNCH: the fused kernel walks the reduction tree itself) against
+    ``mgp_posterior_*`` + ``mgp_loocv_tree_*`` (the same tree walked by three small launches over the finished outputs):
+    the six sums agree to the last bit; and against the other fixed-order reductions of the library
+    (``mgp_loss_sums_*`` / ``mgp_column_sums_*``: another summation order) to fp64 rounding."""
     from muygpys_amd import _lib
-    from muygpys_amd.fused import KernelSpec, loocv_partials, posterior_mean_var
+    from muygpys_amd.fused import KernelSpec, loocv_partials, loocv_tree_sums, posterior_mean_var
 
     td = getattr(torch, dtype)
     g = torch.Generator(device="cuda").manual_seed(11)
@@ -69,11 +71,13 @@ def test_loocv_call_equals_the_three_call_composition(dtype, packed):
     p, mean, var = loocv_partials(spec, X, y, bi, ni, huber_delta=1.5, packed=packed)
     m2, v2, yk2 = posterior_mean_var(spec, X, X, bi, ni, y, want_ykinvy=True, packed=packed)
     assert torch.equal(mean, m2) and torch.equal(var, v2)
+    expect = loocv_tree_sums(m2, v2, yk2, y, bi, 1.5)
+    assert torch.equal(p, expect), (p.tolist(), expect.tolist())
     sums = _lib.loss_sums(m2.contiguous(), y[bi].contiguous(), v2, None, 1.5, 3.0)
     yks = _lib.column_sums(yk2.reshape(b, 1).contiguous())
-    expect = torch.stack([sums[4], sums[5], sums[0], torch.tensor(float(b), device="cuda", dtype=torch.float64),
-                          sums[2], yks[0]])
-    assert torch.equal(p, expect), (p.tolist(), expect.tolist())
+    other = torch.stack([sums[4], sums[5], sums[0], torch.tensor(float(b), device="cuda", dtype=torch.float64),
+                         sums[2], yks[0]])
+    torch.testing.assert_close(p, other, rtol=1e-12, atol=1e-9)
     # and against plain fp64 torch arithmetic on the same outputs
     r = m2.double() - y[bi].double()
     ref = torch.stack([(r * r / v2.double()).sum(), v2.double().log().sum(), (r * r).sum()])

@@ -166,3 +166,29 @@ def test_family_level_fast_mean_on_lazy_handles_is_one_fused_launch(name, dtype,
     # the materialised route (the reference's tensors) agrees
     dense = m.fast_posterior_mean(Kcross.materialize(), coeffs[closest])
     assert_close(dense.cpu().numpy(), g["fast_mean"], 3 * RTOL[dtype], "fast posterior mean (materialised)")
+
+
+@pytest.mark.parametrize("k", [63, 64, 70])
+def test_family_level_fast_mean_on_lazy_handles_beyond_a_wavefront(k):
+    """nn_count + 1 > 64 is more than mgp_fast_mean.hip serves (one test point per 32 / 64 lanes): the family function
+    must fall back to the materialised covariance + the reference's einsum (_src/gp/muygps/numpy.py:70-77) instead of
+    raising; k = 63 still takes the fused kernel."""
+    from muygpys_amd._src.gp.muygps.hip import _muygps_fast_posterior_mean
+    from muygpys_amd.gp.deformation import Isotropy, l2
+    from muygpys_amd.gp.hyperparameter import Parameter
+    from muygpys_amd.gp.kernels import Matern
+
+    rng = np.random.default_rng(300 + k)
+    n, b, d = 400, 57, 8
+    X, Q = rng.normal(size=(n, d)), rng.normal(size=(b, d))
+    cset = np.stack([rng.choice(n, size=k, replace=False) for _ in range(b)]).astype(np.int64)
+    co = rng.normal(size=(b, k))
+    kernel = Matern(smoothness=Parameter(1.5), deformation=Isotropy(l2, Parameter(2.0)))
+    Xd, Qd = to_dev(X, torch.float64), to_dev(Q, torch.float64)
+    crosswise = kernel.deformation.crosswise_tensor(Qd, Xd, torch.arange(b, device="cuda"), to_dev(cset), lazy=True)
+    Kcross = kernel(crosswise)
+    got = _muygps_fast_posterior_mean(Kcross, to_dev(co, torch.float64))
+    torch.cuda.synchronize()
+    r = np.sqrt(((Q[:, None, :] - X[cset]) ** 2).sum(-1)) / 2.0
+    Kc = (1 + np.sqrt(3) * r) * np.exp(-np.sqrt(3) * r)
+    assert_close(got.cpu().numpy(), (Kc * co).sum(1), RTOL["float64"], f"fast mean, k = {k}")

@@ -1,0 +1,124 @@
+"""One LOOCV objective evaluation = ONE launch (round 5): the fused wave kernels hand their tasks out through per-XCD
+dequeue heads and walk the reduction tree of the partial sums themselves (csrc/mgp_loocv_tree.h).  Pinned here:
+
+* the sums equal -- bit for bit -- the same tree walked by three small launches over the finished outputs
+  (mgp_loocv_tree_*), for every kernel family that serves a LOOCV call, whatever workgroup finished what when;
+* they equal the oracle's losses / sigma^2 (reference: _src/optimize/loss/numpy.py:22-72, scale/numpy.py:9-34);
+* the scratch's counters are left zero: the same buffer serves call after call;
+* the dynamic task queue deals every neighbourhood exactly once (outputs equal the prediction launch's, bit for bit).
+"""
+
+import numpy as np
+import pytest
+
+from oracle import muygps_oracle as orc
+from tests.util import RTOL, assert_close, to_dev
+
+torch = pytest.importorskip("torch")
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a ROCm device")]
+
+
+def _problem(seed, n, b, k, d, dtype):
+    rng = np.random.default_rng(seed)
+    X = rng.normal(size=(n, d))
+    y = np.sin(X @ rng.normal(size=d) / np.sqrt(d)) + 0.1 * rng.normal(size=n)
+    bi = rng.choice(n, size=b, replace=b > n)
+    ni = rng.integers(0, n - 1, size=(b, k))
+    ni = ni + (ni >= bi[:, None])  # never the batch row itself
+    td = getattr(torch, dtype)
+    return X, y, bi, ni, to_dev(X, td), to_dev(y, td), to_dev(bi), to_dev(ni)
+
+
+# (dtype, k, d, packed, b): the built-in static shapes (folded pairs / dealt triangle), run-time compiled ones,
+# run-time-shape kernels with 4 / 2 / 1 neighbourhoods per wave, and shapes the wave kernels do not serve (the tree is
+# then walked behind the rhs-column kernel).  Batch sizes on and off every block boundary of the tree.
+CASES = [
+    ("float32", 30, 40, True, 1), ("float32", 30, 40, True, 63), ("float32", 30, 40, True, 64), ("float32", 30, 40, True, 65),
+    ("float32", 30, 40, True, 4097), ("float32", 30, 40, True, 70_001), ("float32", 30, 40, "auto", 262_147),
+    ("float32", 30, 40, False, 9_999),
+    ("float64", 50, 8, True, 4_100), ("float64", 50, 8, True, 66_003), ("float64", 30, 40, True, 8_200),
+    ("float32", 10, 8, True, 5_003), ("float32", 20, 16, False, 66_000), ("float32", 45, 24, True, 4_099),
+    ("float64", 12, 6, False, 3_001), ("float32", 62, 16, True, 2_050),
+    ("float32", 64, 40, False, 1_030), ("float64", 70, 8, False, 517),
+]
+
+
+@pytest.mark.parametrize("dtype,k,d,packed,b", CASES, ids=lambda v: str(v))
+def test_one_launch_sums_equal_the_tree_walked_by_kernels_and_the_oracle(dtype, k, d, packed, b):
+    from muygpys_amd import _lib
+    from muygpys_amd.fused import KernelSpec, loocv_partials, loocv_tree_sums, posterior_mean_var
+
+    n = 5_000
+    X, y, bi, ni, Xd, yd, bid, nid = _problem(11 + k + b % 97, n, b, k, d, dtype)
+    spec = KernelSpec("matern15", "l2", 3.0 if d >= 16 else 1.5, 1e-2)
+    runs = []
+    for rep in range(3):  # (the same scratch: every call must leave its counters zero)
+        p, mean, var = loocv_partials(spec, Xd, yd, bid, nid, huber_delta=1.5, packed=packed)
+        served = _lib.last_kernel()
+        torch.cuda.synchronize()
+        runs.append((p.cpu().numpy().copy(), mean.cpu().numpy().copy(), var.cpu().numpy().copy()))
+    for p, m, v in runs[1:]:
+        assert np.array_equal(p.view(np.int64), runs[0][0].view(np.int64)), f"sums differ between calls [{served}]: {p} vs {runs[0][0]}"
+        assert np.array_equal(m, runs[0][1]) and np.array_equal(v, runs[0][2])
+    p0 = runs[0][0]
+    # the prediction launch (static task stride, plain stores) returns the same bits per neighbourhood
+    m2, v2, yk2 = posterior_mean_var(spec, Xd, Xd, bid, nid, yd, want_ykinvy=True, packed=packed)
+    torch.cuda.synchronize()
+    assert np.array_equal(m2.cpu().numpy(), runs[0][1]) and np.array_equal(v2.cpu().numpy(), runs[0][2]), served
+    # ... and the tree walked by the three small launches over those outputs returns the same sums, bit for bit
+    p_tree = loocv_tree_sums(m2, v2, yk2, yd, bid, 1.5).cpu().numpy()
+    assert np.array_equal(p_tree.view(np.int64), p0.view(np.int64)), f"[{served}] in-kernel {p0} vs kernels {p_tree}"
+    assert p0[3] == b
+    # oracle (fp64 numpy restatement of the reference)
+    pick = np.arange(b) if b <= 3000 else np.random.default_rng(5).choice(b, size=3000, replace=False)
+    ospec = orc.Spec("matern15", "l2", spec.length_scale, 1e-2)
+    m_ref, v_ref = orc.posterior_mean_var(ospec, X, X, bi[pick], ni[pick], y)
+    assert_close(runs[0][1][pick], m_ref, RTOL[dtype], f"mean [{served}]")
+    # the sums against the per-neighbourhood outputs in numpy fp64
+    mm, vv = runs[0][1].astype(np.float64), runs[0][2].astype(np.float64)
+    r = mm - y.astype(getattr(np, dtype)).astype(np.float64)[bi]
+    ref = np.array([np.sum(r * r / vv), np.sum(np.log(vv)), np.sum(r * r), b,
+                    np.sum(1.5**2 * (np.sqrt(1 + (r / 1.5) ** 2) - 1)), np.sum(yk2.cpu().numpy().astype(np.float64))])
+    np.testing.assert_allclose(p0, ref, rtol=1e-11, atol=1e-9)
+
+
+def test_scratch_is_reusable_across_batch_sizes_and_interleaved_shapes():
+    """The Python layer keeps one zeroed scratch per (stream, batch size); alternating batch sizes and kernels must not
+    see each other's counters."""
+    from muygpys_amd.fused import KernelSpec, loocv_partials
+
+    spec = KernelSpec("matern15", "l2", 3.0, 1e-2)
+    ref = {}
+    for rep in range(3):
+        for b in (200, 4_097, 200, 33_000):
+            _, _, _, _, Xd, yd, bid, nid = _problem(3, 4_000, b, 30, 40, "float32")
+            p, _, _ = loocv_partials(spec, Xd, yd, bid, nid, packed=True)
+            torch.cuda.synchronize()
+            got = p.cpu().numpy()
+            assert got[3] == b
+            if b in ref:
+                assert np.array_equal(got.view(np.int64), ref[b].view(np.int64)), (rep, b, got, ref[b])
+            ref[b] = got
+
+
+def test_one_launch_under_uneven_load_with_warm_caches():
+    """Hand-offs must hold when the reducing CU has the handed-off lines in its L1 (it READ them before they were
+    rewritten) and while other work runs: fill mean / var / ykinvy with garbage through plain loads and stores of a
+    torch kernel, start a long unrelated kernel on a second stream, then evaluate; many times."""
+    from muygpys_amd.fused import KernelSpec, loocv_partials
+
+    spec = KernelSpec("matern15", "l2", 3.0, 1e-2)
+    _, _, _, _, Xd, yd, bid, nid = _problem(8, 20_000, 150_001, 30, 40, "float32")
+    p_ref, m_ref, v_ref = loocv_partials(spec, Xd, yd, bid, nid, packed=True)
+    torch.cuda.synchronize()
+    p_ref = p_ref.cpu().numpy()
+    side = torch.cuda.Stream()
+    junk = torch.randn(64 << 20, device="cuda")
+    for rep in range(25):
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                junk.mul_(1.0000001)
+        p, m, v = loocv_partials(spec, Xd, yd, bid, nid, packed=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(p.cpu().numpy().view(np.int64), p_ref.view(np.int64)), (rep, p.cpu().numpy(), p_ref)
+        assert torch.equal(m, m_ref) and torch.equal(v, v_ref)

@@ -106,7 +106,7 @@ def test_config5_properties_at_full_size():
     ni = ni + (ni >= bi[:, None])
     spec = KernelSpec("rbf", "F2", 5.0, 1e-3)
     m1, v1 = _run(spec, X, bi, ni, Y1)
-    assert _lib.last_kernel().startswith("mgp::fused_rhs_kernel<float,16,true"), _lib.last_kernel()
+    assert _lib.last_kernel().startswith(("mgp::fused_rhs_mf_kernel<16", "mgp::fused_rhs_kernel<float,16,true")), _lib.last_kernel()
     m2, v2 = _run(spec, X, bi, ni, Y2)
     m3, v3 = _run(spec, X, bi, ni, 2.0 * Y1 - 0.5 * Y2)
     assert torch.equal(v1, v2) and torch.equal(v1, v3)
