@@ -283,24 +283,35 @@ int mgp_posterior_packed_gathered_f64(const void* packed_q, int64_t q_stride_byt
  * ykinvy (b each) are written as by mgp_posterior_*.
  *
  * ONE launch (round 5): for every shape the register-resident wave kernels serve
- * (k + 2 <= 64) the fused kernel hands its tasks out through per-XCD dequeue
- * heads and walks the reduction tree itself -- the workgroup that completes a
- * block of 64 neighbourhoods reduces it, the one that completes 64 such blocks
- * reduces those, the last one writes partials[] (csrc/mgp_loocv_tree.h: agent-
- * scope tickets, write-through hand-off, nobody waits).  Behind the other kernel
+ * (k + 2 <= 64) the fused kernel walks the reduction tree of the sums itself
+ * (csrc/mgp_loocv_tree.h).  A leaf of the tree is what ONE workgroup of the
+ * persistent launch evaluates: out of tasks, it reads its own outputs back and
+ * reduces them; the workgroup that completes a block of 64 leaves reduces those,
+ * the last one writes partials[] (agent-scope tickets, write-through hand-off,
+ * nobody waits; nothing of it inside the task loop).  Behind the other kernel
  * families the SAME tree is walked by three small launches (mgp_loocv_tree_*,
- * also callable on the outputs of any mgp_posterior_*): equal sums bit for bit,
- * independent of which workgroup finished what when.
+ * also callable on the outputs of any mgp_posterior_*): equal sums bit for bit
+ * for equal leaves (mgp_last_loocv_geometry).  The last bits of the sums depend
+ * on the leaves, i.e. on the kernel and the device -- not on timing.
  *
- * scratch: mgp_loocv_scratch_bytes(b) bytes of device memory, 128-byte aligned,
- * whose first mgp_loocv_scratch_zero_bytes(b) bytes are ZERO when the call
+ * partials may be DEVICE memory or PINNED HOST memory mapped into the device's
+ * address space: the count, partials[3], is written last, behind a drain of the
+ * other five, so a host that zeroed it before the call and polls it reading b
+ * has all six without a stream synchronisation or a copy.
+ *
+ * scratch: mgp_loocv_scratch_bytes() bytes of device memory, 128-byte aligned,
+ * whose first mgp_loocv_scratch_zero_bytes() bytes are ZERO when the call
  * starts; every call leaves them zero again, so one buffer serves any number of
- * consecutive calls with the same b on one stream (zero it once; zero it again
- * after a call with another b, or after a failed launch).  mgp_loocv_packed_*
- * reads one prepared table (MGP_EUNSUPPORTED where mgp_posterior_packed_* is).
+ * consecutive calls on one stream (zero it once; again after a failed launch).
+ * mgp_loocv_packed_* reads one prepared table (MGP_EUNSUPPORTED where
+ * mgp_posterior_packed_* is).
  * ------------------------------------------------------------------------- */
-int64_t mgp_loocv_scratch_bytes(int64_t b);
-int64_t mgp_loocv_scratch_zero_bytes(int64_t b);
+int64_t mgp_loocv_scratch_bytes(void);
+int64_t mgp_loocv_scratch_zero_bytes(void);
+/* the leaves of the tree the calling thread's most recent mgp_loocv_* call walked inside its fused launch
+ * (persistent workgroups, neighbourhoods per task); grid = 0: it walked none (the three-launch walk on the
+ * canonical leaves served it) */
+int mgp_last_loocv_geometry(int* grid, int* nh);
 int mgp_loocv_f32(const float* features, int d, const int64_t* batch_idx, const int64_t* nn_idx, int64_t b, int k,
                   const float* targets, int noise_mode, double noise_scalar, const float* noise_dev,
                   int kernel_id, int metric_id, const float* length_scale, int ls_count,
@@ -327,14 +338,16 @@ int mgp_loocv_packed_f64(const void* packed, int64_t stride_bytes, int d, const 
 /* The reduction tree alone, over finished outputs (mean / var / ykinvy of b neighbourhoods as written by any
  * mgp_posterior_* call with one response): partials[6] as above.  resp + row * resp_stride_bytes is the response
  * of table row `row` (the response tensor: stride sizeof(T); a prepared table: its row stride, resp = table +
- * d * sizeof(T)); batch_idx may be NULL (row = neighbourhood index).  Same scratch as mgp_loocv_* (its counters
- * are not used here: no zeroing needed).  Reference: _src/optimize/loss/numpy.py:22-72, scale/numpy.py:9-15. */
+ * d * sizeof(T)); batch_idx may be NULL (row = neighbourhood index).  (grid, nh): the leaves -- what
+ * mgp_last_loocv_geometry reported, for the bits of that call's own walk; 0, 0: the canonical ones.  Same scratch
+ * as mgp_loocv_* (its counters are not used here: no zeroing needed).
+ * Reference: _src/optimize/loss/numpy.py:22-72, scale/numpy.py:9-15. */
 int mgp_loocv_tree_f32(const float* mean, const float* var, const float* ykinvy, const void* resp,
                        int64_t resp_stride_bytes, const int64_t* batch_idx, int64_t b, double huber_delta,
-                       double* partials, void* scratch, void* stream);
+                       int grid, int nh, double* partials, void* scratch, void* stream);
 int mgp_loocv_tree_f64(const double* mean, const double* var, const double* ykinvy, const void* resp,
                        int64_t resp_stride_bytes, const int64_t* batch_idx, int64_t b, double huber_delta,
-                       double* partials, void* scratch, void* stream);
+                       int grid, int nh, double* partials, void* scratch, void* stream);
 
 /* Fused coefficient precompute of the fast posterior mean: coeffs (b, k) = (K_b + eps)^-1 y_b
  * for the neighbourhoods nn_idx (b, k) of one table (gather -> distances -> kernel -> nugget ->

@@ -70,7 +70,7 @@ _SIGS = {
     "table_pack": [_p, _p, _l, _i, _i, _p, _l, _p],
     "loocv": [_p, _i, _p, _p, _l, _i, _p, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p, _p, _d, _p, _p, _p],
     "loocv_packed": [_p, _l, _i, _p, _p, _l, _i, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p, _p, _d, _p, _p, _p],
-    "loocv_tree": [_p, _p, _p, _p, _l, _p, _l, _d, _p, _p, _p],
+    "loocv_tree": [_p, _p, _p, _p, _l, _p, _l, _d, _i, _i, _p, _p, _p],
     "loss_sums": [_p, _p, _p, _l, _p, _d, _d, _p, _p, _p],
     "column_sums": [_p, _l, _i, _p, _p, _p],
     "posterior_backward": [_p, _p, _i, _p, _p, _l, _i, _p, _i, _i, _d, _p, _i, _i, _p, _i,
@@ -115,8 +115,10 @@ def load():
     lib.mgp_last_kernel_name.restype = _i
     lib.mgp_reduce_scratch_doubles.restype = _i
     for name in ("mgp_loocv_scratch_bytes", "mgp_loocv_scratch_zero_bytes"):
-        getattr(lib, name).argtypes = [_l]
+        getattr(lib, name).argtypes = []
         getattr(lib, name).restype = _l
+    lib.mgp_last_loocv_geometry.argtypes = [C.POINTER(_i), C.POINTER(_i)]
+    lib.mgp_last_loocv_geometry.restype = _i
     lib.mgp_matern_gen_constants.argtypes = [_d, C.POINTER(C.c_double)]
     lib.mgp_matern_gen_constants.restype = _i
     lib.mgp_jit_prepare.argtypes = [_i, _i, _i, _i, _i, _i]
@@ -182,23 +184,31 @@ def reduce_scratch(device):
 
 
 # scratch of the one-launch LOOCV evaluation (mgp_loocv_*): its counters must be zero when a call starts and every call
-# leaves them zero, so a buffer is zeroed ONCE and then reused by every later evaluation of the same batch size on the
-# same stream (the inner loop of a hyper-parameter search: no allocation, no memset, one launch per evaluation).
+# leaves them zero, so a buffer is zeroed ONCE and then reused by every later evaluation on the same
+# stream (the inner loop of a hyper-parameter search: no allocation, no memset, one launch per evaluation).
 _LOOCV_SCRATCH: "dict" = {}
 
 
-def loocv_scratch(device, b: int) -> "torch.Tensor":
-    """The zero-initialised, per-(device, stream, batch size) scratch of ``mgp_loocv_*`` (uint8, 256-byte aligned by
-    torch's allocator).  Streams never share one (two evaluations in flight would share counters)."""
+def loocv_scratch(device, b: int = 0) -> "torch.Tensor":
+    """The zero-initialised, per-(device, stream) scratch of ``mgp_loocv_*`` (uint8, 256-byte aligned by torch's
+    allocator).  Streams never share one (two evaluations in flight would share counters)."""
     dev = torch.device(device)
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(torch.cuda.current_stream().cuda_stream), int(b))
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(torch.cuda.current_stream().cuda_stream))
     buf = _LOOCV_SCRATCH.get(key)
     if buf is None:
         if len(_LOOCV_SCRATCH) >= 16:  # (a search evaluates one batch size; keep the cache from growing without bound)
             _LOOCV_SCRATCH.pop(next(iter(_LOOCV_SCRATCH)))
-        buf = torch.zeros(max(int(load().mgp_loocv_scratch_bytes(int(b))), 16), dtype=torch.uint8, device=dev)
+        buf = torch.zeros(int(load().mgp_loocv_scratch_bytes()), dtype=torch.uint8, device=dev)
         _LOOCV_SCRATCH[key] = buf
     return buf
+
+
+def last_loocv_geometry():
+    """(grid, nh): the leaves of the reduction tree the last ``mgp_loocv_*`` call of this thread walked inside its fused
+    launch; (0, 0): the three-launch walk on the canonical leaves served it."""
+    g, n = C.c_int(0), C.c_int(0)
+    check(load().mgp_last_loocv_geometry(C.byref(g), C.byref(n)), "mgp_last_loocv_geometry")
+    return g.value, n.value
 
 
 def loocv_scratch_reset() -> None:

@@ -29,7 +29,9 @@ PER_FILE_FLAGS = {
     "mgp_fused_rhs_mf.hip": ["-mllvm", "-pragma-unroll-threshold=1000000", "-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     # (+ the register report of every instantiation -> lib/kernel_resources.json: the headline kernels sit at
     # the 168-register cap of three waves per SIMD, and a spill there costs 30 %)
-    "mgp_fused_wave.hip": ["-mllvm", "-pragma-unroll-threshold=1000000", "-Rpass-analysis=kernel-resource-usage"],
+    "mgp_fused_wave.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
+    **{f"mgp_fused_wave_inst_{n}.hip": ["-mllvm", "-pragma-unroll-threshold=1000000", "-Rpass-analysis=kernel-resource-usage"]
+       for n in ("f32", "f64")},
     "mgp_solve_wave.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
     "mgp_backward.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
     "mgp_backward_wave.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],

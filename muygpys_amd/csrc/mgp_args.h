@@ -31,10 +31,10 @@ struct FusedArgs {
   const void* packed_nn = nullptr;
   int64_t q_stride = 0, nn_stride = 0;
   double smoothness = 0.0;  // kernel_id == MGP_KERNEL_MATERN_GEN: the Matern smoothness nu
-  // One-launch LOOCV evaluation (mgp_loocv_*; wave kernels): tree.out != nullptr -- tasks are handed out by per-XCD
-  // dequeue heads in tree.ctrl instead of a static stride, outputs are stored write-through, and the workgroup that
-  // completes a block of the reduction tree reduces it (mgp_loocv_tree.h).  Only launch_fused_wave serves it; behind
-  // every other kernel family the caller walks the same tree with launch_loocv_tree (mgp_tensor_ops.hip).
+  // One-launch LOOCV evaluation (mgp_loocv_*; wave kernels): tree.out != nullptr -- a workgroup that has run out of
+  // tasks reduces its own outputs (its leaf of the reduction tree) and walks up as far as its tickets are the last
+  // ones (mgp_loocv_tree.h).  Only launch_fused_wave serves it (and fills in tree.grid / tree.nh); behind every other
+  // kernel family the caller walks the same tree with launch_loocv_tree (mgp_tensor_ops.hip).
   LoocvTree tree;
 };
 
@@ -111,6 +111,9 @@ template <typename T> int launch_fused_wave(const FusedArgs&, hipStream_t);
 int jit_wave_function(int es, int np, int k, int R, int d, bool packed, bool gram, hipFunction_t* fn, bool allow_compile = true,
                       bool gen64 = false);
 int jit_wave_prepare(int es, int np, int k, int R, int d, bool packed, bool gram, bool gen64 = false);
+// one instantiation of the wave kernel (mgp_fused_wave_launch.h; instantiated in mgp_fused_wave_inst_*.hip)
+template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF, bool PACKED, bool GRAM, bool GEN64>
+int launch_np_impl(const FusedArgs& a, hipStream_t stream);
 int jit_mode();
 int jit_loaded_count();
 uint64_t jit_source_hash();
@@ -129,6 +132,8 @@ int describe_fused_wave(int elem_size, int d, int k, int R, int packed, char* bu
 // what served a call depends on more than the shape (batch thresholds of the run-time compiler, its disk cache,
 // alignment, the kernel's Gram-form eligibility), so tests and bench.py report THIS, not a description of the shape
 void note_launch(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+// ... and the leaves of the reduction tree it walked (grid = 0: it walked none; mgp_last_loocv_geometry)
+void note_tree_geometry(int grid, int nh);
 
 template <typename T>
 int launch_crosswise_diffs(const T*, const T*, int, const int64_t*, const int64_t*, int64_t, int, T*, hipStream_t);
@@ -146,8 +151,9 @@ template <typename T> int launch_column_sums(const T*, int64_t, int, double*, do
 // the reduction tree of mgp_loocv_tree.h over finished outputs, as three small launches (same functions, same bits
 // as the walk inside the fused wave kernels)
 template <typename T>
-int launch_loocv_tree(const LoocvTree&, const T* mean, const T* var, const T* yk, const int64_t* batch_idx, int64_t b, hipStream_t);
-LoocvTree loocv_tree_layout(void* scratch, int64_t b, double* out, const void* resp, int64_t resp_stride, double huber_delta);
+int launch_loocv_tree(const LoocvTree&, int grid, int nh, const T* mean, const T* var, const T* yk, const int64_t* batch_idx, int64_t b,
+                      hipStream_t);
+LoocvTree loocv_tree_layout(void* scratch, double* out, const void* resp, int64_t resp_stride, double huber_delta);
 int reduce_scratch_doubles();
 int allreduce_partials(double* partials_dev, int count, void* nccl_comm, hipStream_t stream);  // mgp_collective.hip
 template <typename T> int launch_matern_gen(const T*, int64_t, double, double, T*, hipStream_t);

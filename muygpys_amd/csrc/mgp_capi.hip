@@ -10,6 +10,8 @@
 namespace mgp {
 
 static thread_local char g_last_kernel[256] = "";
+static thread_local int g_tree_grid = 0, g_tree_nh = 0;
+void note_tree_geometry(int grid, int nh) { g_tree_grid = grid, g_tree_nh = nh; }
 void note_launch(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -67,8 +69,12 @@ int posterior(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t*
   if (tree) a.tree = *tree;
   if (tree_served) *tree_served = false;
   if (packed || path == PATH_AUTO) {
-    const int rc = launch_fused_wave<T>(a, s);
+    int rc = launch_fused_wave<T>(a, s);
     if (rc == MGP_OK && tree && tree_served) *tree_served = true;
+    if (rc == MGP_EUNSUPPORTED && tree) {  // (a grid beyond the tree's leaves: the plain launch, the tree by kernels)
+      a.tree = LoocvTree{};
+      rc = launch_fused_wave<T>(a, s);
+    }
     if (packed || rc != MGP_EUNSUPPORTED) return rc;  // (prepared tables, MGP_EUNSUPPORTED: the caller uses the plain tables)
   }
   a.tree = LoocvTree{};
@@ -188,8 +194,13 @@ extern "C" {
 const char* mgp_version(void) { return "muygpys_amd-hip 0.1 (gfx950)"; }
 int mgp_max_nn_count(int elem_size, int R) { return max_nn_count(elem_size, R); }
 int mgp_reduce_scratch_doubles(void) { return reduce_scratch_doubles(); }
-int64_t mgp_loocv_scratch_bytes(int64_t b) { return b < 0 ? 0 : tree_scratch_bytes(b); }
-int64_t mgp_loocv_scratch_zero_bytes(int64_t b) { return b < 0 ? 0 : tree_zero_bytes(b); }
+int64_t mgp_loocv_scratch_bytes(void) { return tree_scratch_bytes(); }
+int64_t mgp_loocv_scratch_zero_bytes(void) { return tree_zero_bytes(); }
+int mgp_last_loocv_geometry(int* grid, int* nh) {
+  if (!grid || !nh) return MGP_EINVAL;
+  *grid = g_tree_grid, *nh = g_tree_nh;
+  return MGP_OK;
+}
 int mgp_matern_gen_constants(double smoothness, double* out7) {
   if (!out7 || !(smoothness > 0.0)) return MGP_EINVAL;
   matern_gen_constants_host(smoothness, out7);
@@ -305,33 +316,35 @@ int mgp_posterior_f64(const double* fq, const double* fn, int d, const int64_t* 
                       int nm, double eps, const T* nd, int kid, int mid, const T* ls, int lsc, T* mean, T* var,      \
                       T* yk, int* info, double huber_delta, double* partials, void* scratch, void* st) {             \
     if ((b > 0 && (!mean || !var || !yk)) || !partials || !scratch || !(huber_delta > 0)) return MGP_EINVAL;         \
-    const LoocvTree tr = loocv_tree_layout(scratch, b, partials, tg, (int64_t)sizeof(T), huber_delta);               \
+    LoocvTree tr = loocv_tree_layout(scratch, partials, tg, (int64_t)sizeof(T), huber_delta);                        \
     bool served = false;                                                                                             \
+    note_tree_geometry(0, 0);                                                                                        \
     const int rc = posterior<T>(feat, feat, d, bi, ni, b, k, tg, 1, nm, eps, nd, kid, mid, ls, lsc, mean, var, yk,  \
-                                info, st, PATH_AUTO, nullptr, 0, nullptr, 0, 0, &tr, &served);                                                                           \
+                                info, st, PATH_AUTO, nullptr, 0, nullptr, 0, 0, &tr, &served);                       \
     if (rc != MGP_OK || served) return rc;                                                                           \
-    return launch_loocv_tree<T>(tr, mean, var, yk, bi, b, S_(st));                                                   \
+    return launch_loocv_tree<T>(tr, 0, 0, mean, var, yk, bi, b, S_(st));                                             \
   }                                                                                                                  \
   int mgp_loocv_tree_##SUF(const T* mean, const T* var, const T* yk, const void* resp, int64_t resp_stride,          \
-                           const int64_t* bi, int64_t b, double huber_delta, double* partials, void* scratch,        \
-                           void* st) {                                                                               \
+                           const int64_t* bi, int64_t b, double huber_delta, int grid, int nh, double* partials,     \
+                           void* scratch, void* st) {                                                                \
     if (b < 0 || (b > 0 && (!mean || !var || !yk || !resp)) || !partials || !scratch || !(huber_delta > 0))          \
       return MGP_EINVAL;                                                                                             \
-    return launch_loocv_tree<T>(loocv_tree_layout(scratch, b, partials, resp, resp_stride, huber_delta), mean, var,  \
-                                yk, bi, b, S_(st));                                                                  \
+    return launch_loocv_tree<T>(loocv_tree_layout(scratch, partials, resp, resp_stride, huber_delta), grid, nh,      \
+                                mean, var, yk, bi, b, S_(st));                                                       \
   }                                                                                                                  \
   int mgp_loocv_packed_##SUF(const void* packed, int64_t stride, int d, const int64_t* bi, const int64_t* ni,        \
                              int64_t b, int k, int nm, double eps, const T* nd, int kid, int mid, const T* ls,       \
                              int lsc, T* mean, T* var, T* yk, int* info, double huber_delta, double* partials,       \
                              void* scratch, void* st) {                                                              \
     if ((b > 0 && (!mean || !var || !yk)) || !partials || !scratch || !(huber_delta > 0)) return MGP_EINVAL;         \
-    const LoocvTree tr = loocv_tree_layout(scratch, b, partials, static_cast<const char*>(packed) + (size_t)d * sizeof(T), \
-                                           stride, huber_delta);                                                     \
+    LoocvTree tr = loocv_tree_layout(scratch, partials, static_cast<const char*>(packed) + (size_t)d * sizeof(T),    \
+                                     stride, huber_delta);                                                           \
     bool served = false;                                                                                             \
+    note_tree_geometry(0, 0);                                                                                        \
     const int rc = posterior<T>(nullptr, nullptr, d, bi, ni, b, k, nullptr, 1, nm, eps, nd, kid, mid, ls, lsc, mean, \
                                 var, yk, info, st, PATH_AUTO, packed, stride, packed, stride, 0, &tr, &served);      \
     if (rc != MGP_OK || served) return rc;                                                                           \
-    return launch_loocv_tree<T>(tr, mean, var, yk, bi, b, S_(st));                                                   \
+    return launch_loocv_tree<T>(tr, 0, 0, mean, var, yk, bi, b, S_(st));                                             \
   }
 MGP_DEFINE_PATHS(f32, float)
 MGP_DEFINE_PATHS(f64, double)

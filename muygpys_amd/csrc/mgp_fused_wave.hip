@@ -3,7 +3,7 @@
 #include <cstdio>
 #include <cstdlib>
 
-#include "mgp_fused_wave_kernel.h"
+#include "mgp_fused_wave_launch.h"
 
 namespace mgp {
 
@@ -12,116 +12,6 @@ int g_phase_mask = 0xF;
 int g_grid_per_cu = 0;  // override of resident workgroups per CU
 int g_lds_pad = 0;      // extra dynamic LDS bytes per workgroup
 #endif
-
-// general-smoothness Matern: the node table (2 x MGP_GEN_NODES floats) goes behind everything else in
-// LDS; spacing and the log2 of h 2^(1-nu)/Gamma(nu) are launch constants
-static void gen_geometry(const FusedArgs& a, WaveGeom* g, size_t* lds, int elem_size) {
-  g->gen_tab = 0;
-  g->gen_h = 0.5f;
-  g->gen_lc = 0.0f;
-  g->gen_h64 = 0.3;
-  g->gen_lc64 = 0.0;
-  g->gen_xmin64 = 1e-12;
-  if (a.kernel_id != MGP_KERNEL_MATERN_GEN) return;
-  const double nu = a.smoothness, h = gen_step(nu);
-  g->gen_tab = (int)*lds;
-  g->gen_h = (float)h;
-  g->gen_lc = (float)((log(h) + (1.0 - nu) * log(2.0) - lgamma(nu)) / log(2.0));
-  if (elem_size == 8) {  // fp64: finer step, natural logarithms, a larger table
-    const double h64 = gen_step64(nu);
-    g->gen_h64 = h64;
-    g->gen_lc64 = log(h64) + (1.0 - nu) * log(2.0) - lgamma(nu);
-    g->gen_xmin64 = gen_xmin64(nu);
-    *lds += 2 * MGP_GEN_NODES64 * sizeof(double);
-  } else {
-    *lds += 2 * MGP_GEN_NODES * sizeof(float);
-  }
-}
-
-// one-launch LOOCV evaluation (FusedArgs::tree): the workgroup's list of completed level-1 blocks goes behind
-// everything else in LDS
-static void tree_geometry(const FusedArgs& a, WaveGeom* g, size_t* lds) {
-  g->tree_list = 0;
-  if (!a.tree.out) return;
-  g->tree_list = (int)*lds;
-  *lds += kTreeListBytes;
-}
-
-template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF = false, bool PACKED = false,
-          bool GRAM = false, bool GEN64 = false>
-static int launch_np_impl(const FusedArgs& a, hipStream_t stream) {
-  constexpr WaveDims WD = wave_dims(sizeof(T), NP, KFIX, RFIX, DFIX, COEFF, GRAM);
-  constexpr int NH = WD.NH;
-  constexpr int E = WD.E;
-  constexpr int CH = WD.CH;
-  constexpr int KMAT = WD.KMAT;
-  WaveGeom g;
-#ifdef MGP_DEBUG_HOOKS
-  g.mask = g_phase_mask;
-#else
-  g.mask = 0xF;
-#endif
-  g.q = NP - 1 - a.R;
-  const int dpad = (a.d + CH - 1) / CH * CH;
-  g.dst = dpad < 64 ? dpad : 64;
-  g.xs = g.dst + E;  // dst/E is even -> dst/E + 1 slots: odd
-  const uintptr_t align = PACKED ? ((uintptr_t)a.packed_q | (uintptr_t)a.packed_nn | (uintptr_t)a.q_stride | (uintptr_t)a.nn_stride)
-                                 : ((uintptr_t)a.feat_q | (uintptr_t)a.feat_nn);
-  g.vec_ok = (a.d % E == 0) && (align % 16 == 0);
-  if (PACKED && a.R > E && !a.targets_batch) return MGP_EUNSUPPORTED;  // the responses ride in one 16-byte slot
-  if ((DFIX > 0 || PIPED) && !g.vec_ok) return MGP_EUNSUPPORTED;
-  if (PIPED && a.d > g.dst) return MGP_EUNSUPPORTED;  // more than one feature stage
-  g.ntasks = (a.b + NH - 1) / NH;
-  const size_t tile_feat = (size_t)wave_tile_rows(WD, NP, KFIX, g.xs) * g.xs + wave_stage_elems(WD), tile_mat = (size_t)NH * KMAT;
-  const size_t tile_elems = tile_feat > tile_mat ? tile_feat : tile_mat;
-  constexpr bool PIPE = PIPED;
-  size_t lds = PIPE ? tile_elems * sizeof(T) +
-                          wave_colbuf_bytes(sizeof(T), NP, wave_fold(sizeof(T), NP, KFIX, RFIX, DFIX, PIPED, COEFF, GRAM))
-                    : (tile_elems + 64 + g.dst + (g.dst & 1)) * sizeof(T) + 64 * sizeof(int64_t);
-  lds = (lds + 15) & ~(size_t)15;
-  // (the general Matern needs the per-lane pair tables: 32-slot or static shapes; fp64 -- round 4 -- in the GEN64
-  // instantiations only)
-  if (a.kernel_id == MGP_KERNEL_MATERN_GEN && !((NP <= 32 || KFIX > 0) && !COEFF && (sizeof(T) == 4 || GEN64))) return MGP_EUNSUPPORTED;
-  if (GEN64 && a.kernel_id != MGP_KERNEL_MATERN_GEN) return MGP_EUNSUPPORTED;
-  gen_geometry(a, &g, &lds, (int)sizeof(T));
-  tree_geometry(a, &g, &lds);
-#ifdef MGP_DEBUG_HOOKS
-  lds += (size_t)g_lds_pad;
-#endif
-  // Persistent grid = exactly the resident capacity: every workgroup owns a fixed share of the
-  // tasks, so one workgroup more than fits runs as a second, nearly empty round (measured: 13
-  // instead of 12 per CU costs 40 %).  Residency comes from the occupancy query for this kernel
-  // at this LDS size; the CU count from the device.
-  static Residency res;
-  int per_cu = 0, cus = 0;
-  const int rrc = res.lookup(
-      reinterpret_cast<const void*>(&fused_wave_kernel<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF, PACKED, GRAM, GEN64>), 64, lds, &per_cu,
-      &cus);
-  if (rrc != MGP_OK) return rrc;
-#ifdef MGP_DEBUG_HOOKS
-  if (g_grid_per_cu > 0) per_cu = g_grid_per_cu;
-#endif
-  // (fp64, 32 slots, run-time shape: two waves per SIMD although three would fit -- measured, mgp_fused_wave_kernel.h)
-  if (sizeof(T) == 8 && NP == 32 && KFIX == 0 && per_cu > 8) per_cu = 8;
-  static const int env_per_cu = getenv("MGP_WAVE_PER_CU") ? atoi(getenv("MGP_WAVE_PER_CU")) : 0;  // occupancy experiments
-  if (env_per_cu > 0 && env_per_cu < per_cu) per_cu = env_per_cu;
-  int64_t grid = (int64_t)cus * per_cu / 8 * 8;
-  if (grid < 8) grid = 8;
-  if (grid > g.ntasks) grid = (g.ntasks + 7) / 8 * 8;
-  static const bool trace = getenv("MGP_TRACE") != nullptr;  // which instantiation served a call
-  if (trace)
-    fprintf(stderr, "mgp: fused_wave_kernel<%s,%d,%d,%d,%d,%s%s%s> b=%lld k=%d d=%d R=%d grid=%lld lds=%zu\n",
-            sizeof(T) == 4 ? "float" : "double", NP, KFIX, RFIX, DFIX, PIPED ? "pipe" : "stage", PACKED ? ",packed" : "",
-            GRAM ? ",gram" : "",
-            (long long)a.b, a.k, a.d, a.R, (long long)grid, lds);
-  hipLaunchKernelGGL((fused_wave_kernel<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF, PACKED, GRAM, GEN64>), dim3((unsigned)grid), dim3(64),
-                     lds, stream, a, g);
-  MGP_HIP_CHECK_LAUNCH();
-  note_launch("mgp::fused_wave_kernel<%s,%d,%d,%d,%d,%s,%s,%s,%s%s>", sizeof(T) == 4 ? "float" : "double", NP, KFIX, RFIX, DFIX,
-              PIPED ? "true" : "false", COEFF ? "true" : "false", PACKED ? "true" : "false", GRAM ? "true" : "false",
-              GEN64 ? ",gen64" : "");
-  return MGP_OK;
-}
 
 // fp32 pipelined kernels compute the squared distances in the Gram form, except for the Matern-1/2
 // kernel (and the general Matern below nu = 1): exp(-r) has a kink at r = 0, so the absolute error a
@@ -135,20 +25,26 @@ static bool gram_allowed(const FusedArgs& a) {
   return a.kernel_id != MGP_KERNEL_MATERN_05 && !(a.kernel_id == MGP_KERNEL_MATERN_GEN && a.smoothness < 1.0);
 }
 
+// (launch_np_impl is instantiated in mgp_fused_wave_inst_*.hip; here only the calls)
+template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF, bool PACKED, bool GRAM, bool GEN64 = false>
+static int launch_inst(const FusedArgs& a, hipStream_t stream) {
+  return launch_np_impl<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF, PACKED, GRAM, GEN64>(a, stream);
+}
+
 template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF = false, bool PACKED = false>
 static int launch_np(const FusedArgs& a, hipStream_t stream) {
   // fp64 general-smoothness Matern: its own instantiations, for the run-time-shape 32-slot kernels (static shapes:
   // compiled at run time, launch_jit); the difference form throughout
   if constexpr (sizeof(T) == 8) {
     if (a.kernel_id == MGP_KERNEL_MATERN_GEN) {
-      if constexpr (NP == 32 && KFIX == 0 && !COEFF) return launch_np_impl<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF, PACKED, false, true>(a, stream);
+      if constexpr (NP == 32 && KFIX == 0 && !COEFF) return launch_inst<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF, PACKED, false, true>(a, stream);
       else return MGP_EUNSUPPORTED;
     }
   }
   if constexpr (PIPED && !COEFF && MGP_GRAM && (sizeof(T) == 4 || MGP_GRAM64)) {
-    if (gram_allowed<T>(a)) return launch_np_impl<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF, PACKED, true>(a, stream);
+    if (gram_allowed<T>(a)) return launch_inst<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF, PACKED, true>(a, stream);
   }
-  return launch_np_impl<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF, PACKED, false>(a, stream);
+  return launch_inst<T, NP, KFIX, RFIX, DFIX, PIPED, COEFF, PACKED, false>(a, stream);
 }
 
 // Slots per neighbourhood of the static instantiation that serves a shape (0: none does): 16 / 32 / 64,
@@ -189,7 +85,6 @@ static int launch_jit(const FusedArgs& a, hipStream_t stream) {
   size_t lds = tile_elems * sizeof(T) + wave_colbuf_bytes(sizeof(T), NP, wave_fold(sizeof(T), NP, a.k, a.R, a.d, true, false, gram));
   lds = (lds + 15) & ~(size_t)15;
   gen_geometry(a, &g, &lds, (int)sizeof(T));
-  tree_geometry(a, &g, &lds);
   static Residency res;
   int per_cu = 0, cus = 0;
   const int rrc = res.lookup(fn, 64, lds, &per_cu, &cus);
@@ -202,17 +97,21 @@ static int launch_jit(const FusedArgs& a, hipStream_t stream) {
   int64_t grid = (int64_t)cus * per_cu / 8 * 8;
   if (grid < 8) grid = 8;
   if (grid > g.ntasks) grid = (g.ntasks + 7) / 8 * 8;
+  if (a.tree.out && grid > kTreeMaxLeaves) return MGP_EUNSUPPORTED;  // (as launch_np_impl)
   static const bool trace = getenv("MGP_TRACE") != nullptr;
   if (trace)
     fprintf(stderr, "mgp: [run-time compiled] fused_wave_kernel<%s,%d,%d,%d,%d,pipe%s%s> b=%lld grid=%lld lds=%zu\n",
             sizeof(T) == 4 ? "float" : "double", NP, a.k, a.R, a.d, packed ? ",packed" : "", gram ? ",gram" : "", (long long)a.b,
             (long long)grid, lds);
   FusedArgs args = a;
+  args.tree.grid = (int)grid;  // (the leaves of the reduction tree are this launch's workgroups)
+  args.tree.nh = WD.NH;
   void* params[] = {&args, &g};
   const hipError_t err = hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 64, 1, 1, (unsigned)lds, stream, params, nullptr);
   if (err != hipSuccess) return -(1000 + (int)err);
   note_launch("mgp::fused_wave_kernel<%s,%d,%d,%d,%d,true,false,%s,%s%s> [run-time compiled]", sizeof(T) == 4 ? "float" : "double", NP,
               a.k, a.R, a.d, packed ? "true" : "false", gram ? "true" : "false", gen64 ? ",gen64" : "");
+  note_tree_geometry(a.tree.out ? (int)grid : 0, WD.NH);
   return MGP_OK;
 }
 
@@ -220,7 +119,7 @@ template <typename T>
 int launch_fused_wave(const FusedArgs& a, hipStream_t stream) {
   const int rows = a.k + 1 + a.R;
   if (a.b >= (int64_t)1 << 31) return MGP_EUNSUPPORTED;  // (task and chunk numbers are 32-bit in the kernel)
-  if (a.tree.out && (a.R != 1 || a.coeffs || !a.ykinvy || !a.tree.ctrl)) return MGP_EINVAL;
+  if (a.tree.out && (a.R != 1 || a.coeffs || !a.ykinvy || !a.tree.ctrl || !a.tree.resp)) return MGP_EINVAL;
   if (a.coeffs != nullptr) {  // fused fast-mean precompute: one response
     if (a.packed_nn != nullptr) return MGP_EUNSUPPORTED;
     if (a.R == 1 && rows <= 32) return launch_np<T, 32, 0, 0, 0, false, true>(a, stream);

@@ -142,9 +142,6 @@ struct WaveGeom {
   float gen_h, gen_lc;
   // ... and in fp64 (2 x MGP_GEN_NODES64 doubles; natural logarithms; smallest scaled distance the table covers)
   double gen_h64, gen_lc64, gen_xmin64;
-  // one-launch LOOCV evaluation (FusedArgs::tree.out): byte offset in LDS of the workgroup's list of completed
-  // level-1 blocks (kTreeListBytes, behind everything else)
-  int tree_list = 0;
 };
 
 // Sizes shared by the kernel and its launchers.  Plain constexpr functions of the shape (element size es,
@@ -458,92 +455,18 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 
   const int64_t task0 = xcd * per_xcd + (blockIdx.x >> 3);
 
-  // ---- the workgroup's task sequence T0, T1, ... ---------------------------------------------------------------
-  // Static (no control block): T_n = task0 + n t_step inside the XCD's eighth, as ever.
-  // Dynamic (a.tree.ctrl, round 5): tasks go out in CHUNKS of CT consecutive tasks (a folded pair; otherwise one) --
-  // the first two chunks of a workgroup are static (the XCD's range start + its rank, + the workgroups per XCD), every
-  // further one is drawn from the XCD's dequeue head, so a launch of a few tasks per workgroup does not end on
-  // workgroups with one task more than the others (config 3's strong-scaling shards: 20.3 tasks per workgroup).  The
-  // pipeline needs T_{n+1} (rows requested during T_n) and T_{n+2} (indices), so the draw for the chunk after the
-  // next happens when the generator enters a chunk -- in the same agent-scope atomic instruction as the arrival ticket
-  // of the reduction tree (lane 0 arrives, lane 1 draws: one round trip per chunk).
-  constexpr int CT = wave_fold(sizeof(T), NP, KFIX, RFIX, DFIX, PIPED, COEFF, GRAM) ? 2 : 1;
-  const bool dyn = a.tree.ctrl != nullptr;
-  const bool tree_on = a.tree.out != nullptr;  // (implies dyn)
-  // (chunk and block numbers are 32-bit: 2^31 chunks are beyond any index tensor that fits the device)
-  const int nchunks = (int)((ntasks + CT - 1) / CT), cpx = (nchunks + 7) / 8;
-  const int ch_lo = xcd * cpx, ch_hi = min((xcd + 1) * cpx, nchunks);
-  int g_chunk = ch_lo + (int)(blockIdx.x >> 3), g_next = g_chunk + (int)t_step;  // dynamic: chunk being dealt, the one after
-  if (g_chunk >= ch_hi) g_chunk = -1;
-  if (g_next >= ch_hi) g_next = -1;
-  int g_pos = 0;
-  int arr_blk = 0;  // level-1 block and count of the neighbourhoods stored since the last arrival ticket
-  unsigned arr_n = 0;
-  // level-1 blocks of the reduction tree this workgroup completed (its ticket was the block's last): reduced after the
-  // task loop, so that nothing of the tree is live in it (inlined at the ticket, the walk cost the headline kernel 20
-  // spilled registers; as a function call, spills around the call all over the loop)
-  int* tlist = reinterpret_cast<int*>(smem + g.tree_list);
-  int tlist_n = 0;
-  auto seq_next = [&](bool arrive) -> int {
-    int t;
-    bool draw = false;
-    if (!dyn) {
-      // (static: g_pos counts the tasks dealt)
-      const int64_t ts = task0 + (int64_t)g_pos * t_step;
-      t = ts < t_end ? (int)ts : -1;
-      ++g_pos;
-    } else {
-      if (g_chunk >= 0 && (g_pos == CT || g_chunk * CT + g_pos >= (int)ntasks)) {
-        g_chunk = g_next;
-        g_next = -1;
-        g_pos = 0;
-        draw = g_chunk >= 0;
-      }
-      t = g_chunk >= 0 ? g_chunk * CT + g_pos : -1;
-      ++g_pos;
-    }
-    arrive = arrive && arr_n > 0;
-    if (draw || arrive) {
-      if (arrive) drain_stores();  // the outputs behind the ticket have left the CU
-      unsigned old = 0;
-      if ((threadIdx.x == 0 && arrive) || (threadIdx.x == 1 && draw)) {
-        // (one uniform base + a per-lane word offset: the level-1 counters lie behind the control block)
-        const unsigned word = threadIdx.x == 0 ? (unsigned)(kTreeCtrlBytes / 4) + (unsigned)arr_blk : 32u * (unsigned)xcd;
-        old = __hip_atomic_fetch_add(a.tree.ctrl + word, threadIdx.x == 0 ? arr_n : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      const unsigned tk_arr = __builtin_amdgcn_readlane(old, 0), tk_draw = __builtin_amdgcn_readlane(old, 1);
-      if (draw) {
-        const unsigned c = (unsigned)ch_lo + 2u * (unsigned)t_step + tk_draw;
-        g_next = c < (unsigned)ch_hi ? (int)c : -1;
-      }
-      if (arrive) {
-        const int64_t left = a.b - ((int64_t)arr_blk << 6);
-        if (tk_arr + arr_n == (left < 64 ? (unsigned)left : 64u)) {  // this ticket completed the block
-          if (tlist_n < kTreeListCap) {
-            if (threadIdx.x == 0) tlist[tlist_n] = arr_blk;
-            ++tlist_n;
-          } else if (threadIdx.x == 0) {  // (list full: the scratch's deferred list, reduced by the last workgroup out)
-            const unsigned slot = __hip_atomic_fetch_add(a.tree.ctrl + kTreeWordDeferred, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            st_agent(a.tree.deferred + slot, (unsigned)arr_blk);
-          }
-        }
-        arr_n = 0;
-      }
-    }
-    return t;
+  // ---- the workgroup's task sequence T0, T1, ...: T_n = task0 + n t_step inside the XCD's eighth; the index row of
+  // T_{n+2} is requested while T_n runs.  (Round 5 also built a dynamic sequence for the LOOCV instantiations -- chunks
+  // of a folded pair drawn from per-XCD dequeue heads, draws consumed a task later -- and measured it out: at config 3's
+  // strong-scaling shard, ten pairs per workgroup, whole pairs quantise worse than 20-or-21 tasks do, +12 us on 196;
+  // at 1 M neighbourhoods -0.5 %.)
+  int g_pos = 0;  // tasks dealt
+  auto seq_gen = [&]() -> int {
+    const int64_t ts = task0 + (int64_t)g_pos * t_step;
+    ++g_pos;
+    return ts < t_end ? (int)ts : -1;
   };
-  // `slots` neighbourhoods from `first` on have just been stored (write-through): note them for the next ticket
-  auto note_stored = [&](int64_t first, int slots) {
-    const int64_t left = a.b - first;
-    arr_blk = (int)(first >> 6);
-    arr_n = left <= 0 ? 0u : (left < slots ? (unsigned)left : (unsigned)slots);
-  };
-  // an output element: write-through when other workgroups will read it in this launch (the tree's level 1)
-  auto st_out = [&](T* p, T v) {
-    if (tree_on) st_agent_f(p, v);
-    else *p = v;
-  };
-  int task = seq_next(false), t1 = seq_next(false), t2 = -1;  // (task numbers are 32-bit: the launcher refuses more)
+  int task = seq_gen(), t1 = seq_gen(), t2 = -1;  // (task numbers are 32-bit: the launcher refuses more)
   int64_t next_idx = 0;
   if (task >= 0) next_idx = load_index(task, NH == 1 ? 0 : (int)threadIdx.x / NP, threadIdx.x & (NP - 1));
 
@@ -699,6 +622,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     const bool live = nb0 + h < a.b;
     const int hh = live ? h : 0;
 
+
     // ---- phase 0: indices, responses, nugget -------------------------------------------
     int64_t myidx = 0, mytg = 0;
     T myeps = T(0), myy0 = T(0);
@@ -738,11 +662,6 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     // covariances, few distance instructions at small d): elimination (2) > exchange (1) > distances (0)
     __builtin_amdgcn_s_setprio(sizeof(T) == 4 || MGP_F64_SAME_PRIO ? MGP_DIST_PRIO : MGP_XCHG_PRIO);
 #endif
-
-    // the task after the next (a draw from the XCD's queue when it opens a chunk) and the arrival ticket of the outputs
-    // stored at the end of the previous iteration: behind the stores' drain, which the wait for this task's rows
-    // (below) would pay anyway
-    t2 = seq_next(true);
 
     // ---- phases 1+2: stage features, accumulate squared distances ---------------------
     for (int d0 = 0; d0 < d; d0 += dst) {
@@ -1248,6 +1167,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 
     // the next task's rows are requested now: their latency hides behind the factorisation, and
     // the registers they land in are not live during the (register-hungry) distance phase
+    t2 = seq_gen();  // the task after the next: its index row is requested now
     if (PIPE && t1 >= 0) {
       pipe_issue(t1, fix_index(next_idx, t1, h, i), lane);
       if (t2 >= 0) next_idx = load_index(t2, h, i);
@@ -1370,12 +1290,12 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         }
         if (liveq) {
           if (l16 == QF - HALF) {
-            st_out(var + nbq, bad ? num<T>::nan() : sq);
+            *(var + nbq) = bad ? num<T>::nan() : sq;
             if (bad && a.info) atomicAdd(a.info, 1);
           } else if (l16 > QF - HALF && l16 <= QF - HALF + RFIX) {
             const int r = l16 - (QF - HALF) - 1;
-            st_out(mean + (nbq * RFIX + r), bad ? num<T>::nan() : -sq);
-            if (yk) st_out(yk + (nbq * RFIX + r), bad ? num<T>::nan() : -sd);
+            *(mean + (nbq * RFIX + r)) = bad ? num<T>::nan() : -sq;
+            if (yk) *(yk + (nbq * RFIX + r)) = bad ? num<T>::nan() : -sd;
           }
         }
       } else {
@@ -1390,16 +1310,14 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         const T sq = FL[QF / E][QF % E], sy = FL[YF / E][YF % E];
         if (liveq) {
           if (l16 == QF - HALF) {
-            st_out(var + nbq, bad ? num<T>::nan() : sq);
+            *(var + nbq) = bad ? num<T>::nan() : sq;
             if (bad && a.info) atomicAdd(a.info, 1);
           } else if (l16 == YF - HALF) {
-            st_out(mean + nbq, bad ? num<T>::nan() : -sq);
-            if (yk) st_out(yk + nbq, bad ? num<T>::nan() : -sy);
+            *(mean + nbq) = bad ? num<T>::nan() : -sq;
+            if (yk) *(yk + nbq) = bad ? num<T>::nan() : -sy;
           }
         }
       }
-      // (dynamic sequence: the pair is one chunk -- consecutive tasks, 2 NH consecutive neighbourhoods of one block)
-      if (tree_on) note_stored((int64_t)fold_task_a * NH, have_b ? 2 * NH : NH);
       MGP_WAVE_T(5)
       continue;
     }
@@ -1506,18 +1424,17 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         const int64_t nb = nb0;
         if (live) {
           if (lane == (eq & 63)) {
-            st_out(var + nb, bad ? num<T>::nan() : Dp[eq >> 6][QF & 1]);
+            *(var + nb) = bad ? num<T>::nan() : Dp[eq >> 6][QF & 1];
             if (bad && a.info) atomicAdd(a.info, 1);
           }
 #pragma unroll
           for (int r = 0; r < RFIX; ++r) {
             const int YF = QF + 1 + r;
             const int em = cs2(QF) + (YF >> 1) - (QF >> 1), ey = cs2(YF);
-            if (lane == (em & 63)) st_out(mean + (nb * RFIX + r), bad ? num<T>::nan() : -Dp[em >> 6][YF & 1]);
-            if (yk && lane == (ey & 63)) st_out(yk + (nb * RFIX + r), bad ? num<T>::nan() : -Dp[ey >> 6][YF & 1]);
+            if (lane == (em & 63)) *(mean + (nb * RFIX + r)) = bad ? num<T>::nan() : -Dp[em >> 6][YF & 1];
+            if (yk && lane == (ey & 63)) *(yk + (nb * RFIX + r)) = bad ? num<T>::nan() : -Dp[ey >> 6][YF & 1];
           }
         }
-        if (tree_on) note_stored(nb0, NH);
       }
       MGP_WAVE_T(5)
       continue;
@@ -1649,11 +1566,11 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       const T sq = A[QF / E][QF % E], sy = A[YF / E][YF % E];
       if (live) {
         if (i == QF) {
-          st_out(var + nb, bad ? num<T>::nan() : sq);
+          *(var + nb) = bad ? num<T>::nan() : sq;
           if (bad && a.info) atomicAdd(a.info, 1);
         } else if (i == YF) {
-          st_out(mean + nb, bad ? num<T>::nan() : -sq);
-          if (yk) st_out(yk + nb, bad ? num<T>::nan() : -sy);
+          *(mean + nb) = bad ? num<T>::nan() : -sq;
+          if (yk) *(yk + nb) = bad ? num<T>::nan() : -sy;
         }
       }
     } else if constexpr (PIPED || TRI) {
@@ -1670,12 +1587,12 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       }
       if (live) {
         if (i == q) {
-          st_out(var + nb, bad ? num<T>::nan() : aq);
+          *(var + nb) = bad ? num<T>::nan() : aq;
           if (bad && a.info) atomicAdd(a.info, 1);
         } else if (i > q && i <= q + R) {  // (static shapes: lanes behind the last response row are idle)
           const int r = i - q - 1;
-          st_out(mean + (nb * R + r), bad ? num<T>::nan() : -aq);
-          if (yk) st_out(yk + (nb * R + r), bad ? num<T>::nan() : -aii);
+          *(mean + (nb * R + r)) = bad ? num<T>::nan() : -aq;
+          if (yk) *(yk + (nb * R + r)) = bad ? num<T>::nan() : -aii;
         }
       }
     } else {
@@ -1685,48 +1602,27 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       __syncthreads();
       if (live) {
         if (i == q) {
-          st_out(var + nb, bad ? num<T>::nan() : Kh[q * KS + q]);
+          *(var + nb) = bad ? num<T>::nan() : Kh[q * KS + q];
           if (bad && a.info) atomicAdd(a.info, 1);
         } else if (i > q && i <= q + R) {  // (static shapes: lanes behind the last response row are idle)
           const int r = i - q - 1;
-          st_out(mean + (nb * R + r), bad ? num<T>::nan() : -Kh[i * KS + q]);
-          if (yk) st_out(yk + (nb * R + r), bad ? num<T>::nan() : -Kh[i * KS + i]);
+          *(mean + (nb * R + r)) = bad ? num<T>::nan() : -Kh[i * KS + q];
+          if (yk) *(yk + (nb * R + r)) = bad ? num<T>::nan() : -Kh[i * KS + i];
         }
       }
     }
-    if constexpr (!COEFF) {
-      if (tree_on) note_stored(nb0, NH);
-    }
   }
-  // ---- the workgroup is out of tasks ---------------------------------------------------------------------------
-  if (dyn) {
-    if (tree_on) {
-      seq_next(true);  // the ticket of its last outputs (the sequence is exhausted: no draw)
-      // reduce the level-1 blocks this workgroup completed, each as far up the tree as its tickets are the last ones
-      const T* o_mean = static_cast<const T*>(a.mean);
-      const T* o_var = static_cast<const T*>(a.var);
-      const T* o_yk = static_cast<const T*>(a.ykinvy);
-      __syncthreads();
-      for (int e = 0; e < tlist_n; ++e)
-        tree_reduce_block<T>(a.tree, o_mean, o_var, o_yk, a.batch_idx, a.b, tlist[e], (int)threadIdx.x);
+  // ---- one-launch LOOCV evaluation (mgp_loocv_*): the workgroup is out of tasks -- its leaf of the reduction tree (its
+  // own outputs, read back) and up the tree as far as its tickets are the last ones (mgp_loocv_tree.h) ---------------
+#ifndef MGP_EXP_NO_TREE  // (-DMGP_EXP_NO_TREE: A/B control, tools/loocv_ab.py -- the kernel without the walk)
+  if constexpr (!COEFF) {
+    if (a.tree.out != nullptr) {
       drain_stores();
-    }
-    // the last workgroup out reduces what overflowed the lists and rewinds the task queues (every draw of the launch
-    // has returned by then: a workgroup leaves its loop only after its last draw came back)
-    unsigned outc = 0;
-    if (threadIdx.x == 0) outc = __hip_atomic_fetch_add(a.tree.ctrl + kTreeWordOut, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    outc = __builtin_amdgcn_readfirstlane(outc);
-    if (outc + 1u == gridDim.x) {
-      if (tree_on) {
-        const unsigned nd = ld_agent(a.tree.ctrl + kTreeWordDeferred);
-        for (unsigned e = 0; e < nd; ++e)
-          tree_reduce_block<T>(a.tree, static_cast<const T*>(a.mean), static_cast<const T*>(a.var), static_cast<const T*>(a.ykinvy),
-                               a.batch_idx, a.b, ld_agent(a.tree.deferred + e), (int)threadIdx.x);
-      }
-      if (threadIdx.x < 10)
-        st_agent(a.tree.ctrl + (threadIdx.x < 8 ? 32 * (int)threadIdx.x : (threadIdx.x == 8 ? kTreeWordOut : kTreeWordDeferred)), 0u);
+      tree_leaf_done<T>(a.tree, static_cast<const T*>(a.mean), static_cast<const T*>(a.var), static_cast<const T*>(a.ykinvy),
+                        a.batch_idx, a.b, (int)blockIdx.x, (int)threadIdx.x);
     }
   }
+#endif
 #if MGP_WAVE_TIMING
   if (threadIdx.x == 0)
     for (int t = 0; t < 8; ++t) atomicAdd(&g_wave_timing[t], tacc_[t]);

@@ -486,31 +486,30 @@ __global__ void loss_sums_kernel(const T* pred, const T* target, const T* var, i
 // LOOCV partial sums of one shard (optimize/loss.py:159-168 with scale/numpy.py:11-18 folded in):
 // [sum r^2/v, sum log v, sum r^2, n, sum pseudo-Huber(r), sum y^T K^-1 y], r = mean - y(batch row), as the fixed
 // reduction tree of mgp_loocv_tree.h.  The fused wave kernels walk that tree themselves (one launch per evaluation);
-// these three kernels walk it behind any other kernel family: one wave per block, the same device functions.
+// these three kernels walk it behind any other kernel family: one wave per leaf / block, the same device functions.
 template <typename T>
 __global__ void loocv_level1_kernel(LoocvTree tr, const T* mean, const T* var, const T* yk, const int64_t* batch_idx, int64_t b) {
-  const int64_t j1 = blockIdx.x * (int64_t)(kBlock / MGP_WAVE) + (threadIdx.x >> 6);
-  if (j1 >= tree_nb1(b)) return;
+  const int w = blockIdx.x * (kBlock / MGP_WAVE) + (threadIdx.x >> 6);
+  if (w >= tr.grid) return;
   const int lane = threadIdx.x & 63;
   double t[6];
-  tree_level1<T, false>(tr, mean, var, yk, batch_idx, b, j1, lane, t);
+  tree_level1<T>(tr, mean, var, yk, batch_idx, b, w, lane, t);
   if (lane == 0)
-    for (int i = 0; i < 6; ++i) tr.part1[6 * j1 + i] = t[i];
+    for (int i = 0; i < 6; ++i) tr.part1[6 * w + i] = t[i];
 }
-__global__ void loocv_level2_kernel(LoocvTree tr, int64_t b) {
-  const int64_t j2 = blockIdx.x * (int64_t)(kBlock / MGP_WAVE) + (threadIdx.x >> 6);
-  if (j2 >= tree_nb2(b)) return;
+__global__ void loocv_level2_kernel(LoocvTree tr) {
+  const int j2 = blockIdx.x * (kBlock / MGP_WAVE) + (threadIdx.x >> 6);
+  if (j2 >= (int)tree_nb2(tr.grid)) return;
   const int lane = threadIdx.x & 63;
   double t[6];
-  tree_level2<false>(tr, tree_nb1(b), j2, lane, t);
+  tree_level2<false>(tr, j2, lane, t);
   if (lane == 0)
     for (int i = 0; i < 6; ++i) tr.part2[6 * j2 + i] = t[i];
 }
-__global__ void loocv_level3_kernel(LoocvTree tr, int64_t b) {
+__global__ void loocv_level3_kernel(LoocvTree tr) {
   double t[6];
-  tree_level3<false>(tr, tree_nb2(b), (int)threadIdx.x, t);
-  if (threadIdx.x == 0)
-    for (int i = 0; i < 6; ++i) tr.out[i] = t[i];
+  tree_level3<false>(tr, (int)threadIdx.x, t);
+  tree_result(tr.out, t, (int)threadIdx.x);  // (`out` may be mapped host memory: the count last)
 }
 
 template <typename T>
@@ -685,36 +684,40 @@ int launch_column_sums(const T* x, int64_t n, int R, double* out, double* scratc
   }
   return MGP_OK;
 }
-LoocvTree loocv_tree_layout(void* scratch, int64_t b, double* out, const void* resp, int64_t resp_stride, double huber_delta) {
+LoocvTree loocv_tree_layout(void* scratch, double* out, const void* resp, int64_t resp_stride, double huber_delta) {
   char* base = static_cast<char*>(scratch);
   LoocvTree tr;
   tr.out = out;
   tr.ctrl = reinterpret_cast<unsigned*>(base);
-  tr.cnt1 = reinterpret_cast<unsigned*>(base + tree_off_cnt1(b));
-  tr.cnt2 = reinterpret_cast<unsigned*>(base + tree_off_cnt2(b));
-  tr.part1 = reinterpret_cast<double*>(base + tree_off_part1(b));
-  tr.part2 = reinterpret_cast<double*>(base + tree_off_part2(b));
-  tr.deferred = reinterpret_cast<unsigned*>(base + tree_off_deferred(b));
+  tr.cnt2 = reinterpret_cast<unsigned*>(base + tree_off_cnt2());
+  tr.part1 = reinterpret_cast<double*>(base + tree_off_part1());
+  tr.part2 = reinterpret_cast<double*>(base + tree_off_part2());
   tr.resp = static_cast<const char*>(resp);
   tr.resp_stride = resp_stride;
   tr.huber_delta = huber_delta;
   return tr;
 }
+// (grid, nh): the leaves -- those of the fused launch whose outputs these are, for equal bits with its own walk; 0, 0:
+// the canonical ones (kTreeCanonGrid leaves of one neighbourhood per task)
 template <typename T>
-int launch_loocv_tree(const LoocvTree& tr, const T* mean, const T* var, const T* yk, const int64_t* batch_idx, int64_t b,
-                      hipStream_t s) {
+int launch_loocv_tree(const LoocvTree& tr0, int grid, int nh, const T* mean, const T* var, const T* yk, const int64_t* batch_idx,
+                      int64_t b, hipStream_t s) {
+  LoocvTree tr = tr0;
   if (!tr.out || !tr.part1 || !tr.part2) return MGP_EINVAL;
+  if (grid == 0 && nh == 0) grid = kTreeCanonGrid, nh = 1;
+  if (grid < 8 || grid % 8 != 0 || grid > kTreeMaxLeaves || (nh != 1 && nh != 2 && nh != 4)) return MGP_EINVAL;
+  tr.grid = grid;
+  tr.nh = nh;
   if (b == 0) {
     hipError_t e = hipMemsetAsync(tr.out, 0, 6 * sizeof(double), s);
     return e == hipSuccess ? MGP_OK : -(1000 + (int)e);
   }
   constexpr int W = kBlock / MGP_WAVE;
-  hipLaunchKernelGGL(loocv_level1_kernel<T>, dim3((unsigned)((tree_nb1(b) + W - 1) / W)), dim3(kBlock), 0, s, tr, mean, var, yk,
-                     batch_idx, b);
+  hipLaunchKernelGGL(loocv_level1_kernel<T>, dim3((unsigned)((grid + W - 1) / W)), dim3(kBlock), 0, s, tr, mean, var, yk, batch_idx, b);
   MGP_HIP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(loocv_level2_kernel, dim3((unsigned)((tree_nb2(b) + W - 1) / W)), dim3(kBlock), 0, s, tr, b);
+  hipLaunchKernelGGL(loocv_level2_kernel, dim3((unsigned)((tree_nb2(grid) + W - 1) / W)), dim3(kBlock), 0, s, tr);
   MGP_HIP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(loocv_level3_kernel, dim3(1), dim3(MGP_WAVE), 0, s, tr, b);
+  hipLaunchKernelGGL(loocv_level3_kernel, dim3(1), dim3(MGP_WAVE), 0, s, tr);
   MGP_HIP_CHECK_LAUNCH();
   return MGP_OK;
 }
@@ -778,7 +781,7 @@ int launch_table_pack(const T* feat, const T* targets, int64_t n, int d, int R, 
   template int launch_loss_sums<T>(const T*, const T*, const T*, int64_t, const double*, double, double, double*,  \
                                    double*, hipStream_t);                                                          \
   template int launch_column_sums<T>(const T*, int64_t, int, double*, double*, hipStream_t);                        \
-  template int launch_loocv_tree<T>(const LoocvTree&, const T*, const T*, const T*, const int64_t*, int64_t, hipStream_t); \
+  template int launch_loocv_tree<T>(const LoocvTree&, int, int, const T*, const T*, const T*, const int64_t*, int64_t, hipStream_t); \
   template int launch_table_pack<T>(const T*, const T*, int64_t, int, int, void*, int64_t, hipStream_t);          \
   template int launch_matern_gen<T>(const T*, int64_t, double, double, T*, hipStream_t);
 MGP_INSTANTIATE(float)

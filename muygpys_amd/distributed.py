@@ -171,14 +171,55 @@ P_R2_OVER_V, P_LOG_V, P_R2, P_COUNT, P_HUBER, P_YKY0 = 0, 1, 2, 3, 4, 5
 LOSSES = ("lool", "mse", "looph", "pseudo_huber")
 
 
-def hip_local_partials(spec, features, targets, batch_indices, nn_indices, packed="auto", huber_delta: float = 1.5):
-    """The local shard's partial sums on the GPU: ONE library call (``mgp_loocv_*``: the fused launch
-    and a fixed-order fp64 reduction on the same stream; nothing returns to the host in between).
+# Prepared evaluations (fused.LoocvPlan) of the optimisers' inner loop: one per (tables, shard, model structure).  The
+# tensors are referenced by the plan, so their ids stay theirs while the entry lives.
+_PLANS: "Dict[tuple, object]" = {}
+_PLANS_MAX = 8
 
-    Returns ``(partials float64 [6], mean, var)`` -- all device tensors."""
-    from muygpys_amd.fused import loocv_partials
 
-    return loocv_partials(spec, features, targets, batch_indices, nn_indices, huber_delta=huber_delta, packed=packed)
+def _loocv_plan(spec, features, targets, batch_indices, nn_indices, packed, huber_delta: float, host_result: bool):
+    from muygpys_amd.fused import LoocvPlan
+
+    noise_t = spec.noise if isinstance(spec.noise, torch.Tensor) and spec.noise.ndim >= 1 else None
+    ls = spec.length_scale
+    aniso = not isinstance(ls, (int, float)) and not (isinstance(ls, torch.Tensor) and ls.numel() == 1)
+    key = (spec.kernel, spec.metric, aniso, id(features), features._version, id(targets), targets._version,
+           id(batch_indices), id(nn_indices), None if noise_t is None else id(noise_t), str(packed), float(huber_delta),
+           bool(host_result), int(torch.cuda.current_stream().cuda_stream))
+    plan = _PLANS.get(key)
+    if plan is None:
+        if len(_PLANS) >= _PLANS_MAX:
+            _PLANS.pop(next(iter(_PLANS)))
+        plan = LoocvPlan(spec.kernel, spec.metric, features, targets, batch_indices, nn_indices, anisotropic=aniso,
+                         noise_tensor=noise_t, huber_delta=huber_delta, packed=packed, host_result=host_result)
+        _PLANS[key] = plan
+    return plan
+
+
+def clear_plans() -> None:
+    _PLANS.clear()
+
+
+def hip_local_partials(spec, features, targets, batch_indices, nn_indices, packed="auto", huber_delta: float = 1.5,
+                       host_result: bool = False):
+    """The local shard's partial sums on the GPU: ONE launch (``mgp_loocv_*``: the fused kernel walks the fixed-order
+    fp64 reduction tree itself) through a prepared evaluation (:class:`muygpys_amd.fused.LoocvPlan`: tables, buffers
+    and the argument list are set up once per search, an evaluation costs one ctypes call).
+
+    Returns ``(partials float64 [6], mean, var)``: ``partials`` a device tensor, or -- ``host_result``: a single
+    process needs no all-reduce -- a numpy array read from the pinned host memory the kernel wrote it to."""
+    general = spec.kernel == "matern_gen"
+    if general:  # (the general-smoothness model is not on the prepared-evaluation path)
+        from muygpys_amd.fused import loocv_partials
+
+        return loocv_partials(spec, features, targets, batch_indices, nn_indices, huber_delta=huber_delta, packed=packed)
+    plan = _loocv_plan(spec, features, targets, batch_indices, nn_indices, packed, huber_delta, host_result)
+    ls = spec.length_scale
+    if isinstance(ls, torch.Tensor):
+        ls = ls.detach().cpu().tolist() if ls.numel() > 1 else float(ls)
+    noise = 0.0 if isinstance(spec.noise, torch.Tensor) and spec.noise.ndim >= 1 else float(spec.noise)
+    plan.launch(ls, noise)
+    return (plan.wait() if host_result else plan.partials), plan.mean, plan.var
 
 
 def hip_local_looph(mean, targets_b, var, sigma_sq: float, looph_delta: float = 3.0) -> torch.Tensor:
@@ -237,10 +278,13 @@ def sharded_loocv(
         nn_indices = shard_rows(nn_indices, rank, size)
     kw = {}
     if local_fn is hip_local_partials:
-        kw = dict(packed=packed, huber_delta=float(loss_kwargs.get("boundary_scale", 1.5)))
+        # (one process: the kernel writes the sums to pinned host memory and nothing is all-reduced)
+        kw = dict(packed=packed, huber_delta=float(loss_kwargs.get("boundary_scale", 1.5)), host_result=size == 1)
     partials, mean, var = local_fn(spec, features, targets, batch_indices, nn_indices, **kw)
-    allreduce_sum_(partials, group)
-    out = finish_objective(partials.tolist(), nn_indices.shape[1], loss)
+    if isinstance(partials, torch.Tensor):
+        allreduce_sum_(partials, group)
+        partials = partials.tolist()
+    out = finish_objective(partials, nn_indices.shape[1], loss)
     if loss == "looph":
         part = looph_fn(mean, targets[batch_indices], var, out["sigma_sq"], float(loss_kwargs.get("boundary_scale", 3.0)))
         allreduce_sum_(part, group)

@@ -53,7 +53,8 @@ def test_partials_and_finish(golden, dtype):
 @pytest.mark.parametrize("packed", [False, True])
 def test_loocv_call_equals_the_three_call_composition(dtype, packed):
     """``mgp_loocv_*`` (one call, since round 5 one LAUNCH: the fused kernel walks the reduction tree itself) against
-    ``mgp_posterior_*`` + ``mgp_loocv_tree_*`` (the same tree walked by three small launches over the finished outputs):
+    ``mgp_posterior_*`` + ``mgp_loocv_tree_*`` (the same tree, the same leaves, walked by three small launches over the
+    finished outputs):
     the six sums agree to the last bit; and against the other fixed-order reductions of the library
     (``mgp_loss_sums_*`` / ``mgp_column_sums_*``: another summation order) to fp64 rounding."""
     from muygpys_amd import _lib
@@ -69,9 +70,10 @@ def test_loocv_call_equals_the_three_call_composition(dtype, packed):
     ni = ni + (ni >= bi[:, None])
     spec = KernelSpec("matern15", "l2", 5.0, 1e-3)
     p, mean, var = loocv_partials(spec, X, y, bi, ni, huber_delta=1.5, packed=packed)
+    leaves = _lib.last_loocv_geometry()  # (the workgroups of the fused launch: the leaves of its tree)
     m2, v2, yk2 = posterior_mean_var(spec, X, X, bi, ni, y, want_ykinvy=True, packed=packed)
     assert torch.equal(mean, m2) and torch.equal(var, v2)
-    expect = loocv_tree_sums(m2, v2, yk2, y, bi, 1.5)
+    expect = loocv_tree_sums(m2, v2, yk2, y, bi, 1.5, leaves=leaves)
     assert torch.equal(p, expect), (p.tolist(), expect.tolist())
     sums = _lib.loss_sums(m2.contiguous(), y[bi].contiguous(), v2, None, 1.5, 3.0)
     yks = _lib.column_sums(yk2.reshape(b, 1).contiguous())
