@@ -183,6 +183,13 @@ def _loocv_plan(spec, features, targets, batch_indices, nn_indices, packed, hube
     noise_t = spec.noise if isinstance(spec.noise, torch.Tensor) and spec.noise.ndim >= 1 else None
     ls = spec.length_scale
     aniso = not isinstance(ls, (int, float)) and not (isinstance(ls, torch.Tensor) and ls.numel() == 1)
+    # (an optimiser's loop asks for the same plan thousands of times: one identity check before the dictionary)
+    global _LAST_PLAN
+    lp = _LAST_PLAN
+    if (lp is not None and lp[0] is features and lp[1] is targets and lp[2] is batch_indices and lp[3] is nn_indices
+            and lp[4] == (spec.kernel, spec.metric, aniso, packed, huber_delta, host_result) and lp[5] is noise_t
+            and lp[6] == (features._version, targets._version) and lp[7] == torch.cuda.current_stream().cuda_stream):
+        return lp[8]
     key = (spec.kernel, spec.metric, aniso, id(features), features._version, id(targets), targets._version,
            id(batch_indices), id(nn_indices), None if noise_t is None else id(noise_t), str(packed), float(huber_delta),
            bool(host_result), int(torch.cuda.current_stream().cuda_stream))
@@ -193,11 +200,18 @@ def _loocv_plan(spec, features, targets, batch_indices, nn_indices, packed, hube
         plan = LoocvPlan(spec.kernel, spec.metric, features, targets, batch_indices, nn_indices, anisotropic=aniso,
                          noise_tensor=noise_t, huber_delta=huber_delta, packed=packed, host_result=host_result)
         _PLANS[key] = plan
+    _LAST_PLAN = (features, targets, batch_indices, nn_indices, (spec.kernel, spec.metric, aniso, packed, huber_delta, host_result),
+                  noise_t, (features._version, targets._version), torch.cuda.current_stream().cuda_stream, plan)
     return plan
 
 
+_LAST_PLAN = None
+
+
 def clear_plans() -> None:
+    global _LAST_PLAN
     _PLANS.clear()
+    _LAST_PLAN = None
 
 
 def hip_local_partials(spec, features, targets, batch_indices, nn_indices, packed="auto", huber_delta: float = 1.5,

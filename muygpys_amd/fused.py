@@ -493,7 +493,8 @@ class LoocvPlan:
         self._ls_dev = torch.ones(dk, device=dev, dtype=dtype) if anisotropic else None
         ls_ptr = _lib.ptr(self._ls_dev if anisotropic else self._ls_host)
         ls_count = dk if anisotropic else 1
-        tail = [mode, 0.0, _lib.ptr(nz), self.spec.kernel_id(), self.spec.metric_id(), ls_ptr, ls_count, _lib.ptr(self.mean),
+        self._eps = _lib.C.c_double(0.0)  # (the one argument that changes per evaluation: set in place)
+        tail = [mode, self._eps, _lib.ptr(nz), self.spec.kernel_id(), self.spec.metric_id(), ls_ptr, ls_count, _lib.ptr(self.mean),
                 _lib.ptr(self.var), _lib.ptr(self.ykinvy), _lib.ptr(self.info), float(huber_delta), _lib.ptr(self.partials),
                 _lib.ptr(self.scratch)]
         if use_packed:
@@ -502,8 +503,11 @@ class LoocvPlan:
         else:
             self._fn = _lib.fn("loocv", dtype)
             head = [_lib.ptr(fn), d, _lib.ptr(self.bi), _lib.ptr(self.ni), b, k, _lib.ptr(tg)]
-        self._args = head + tail
-        self._eps_at = len(head) + 1
+        # (every argument converted once: an evaluation is one foreign call on ready-made objects; the stream is the
+        # one current when the plan was made -- the plan's scratch must not serve two streams anyway)
+        self._stream = _lib.stream_ptr()
+        sig = self._fn.argtypes
+        self._args = tuple(a if isinstance(a, _lib.C._SimpleCData) or a is None else t(a) for a, t in zip(head + tail + [self._stream], sig))
         self._np = np
         self._launched = False
 
@@ -517,10 +521,10 @@ class LoocvPlan:
             self._ls_dev.copy_(self._ls_host, non_blocking=True)
         else:
             self._ls_np[0] = length_scale
-        self._args[self._eps_at] = float(noise)
+        self._eps.value = noise
         if self.host_result:
             self._res[3] = 0.0  # (the kernel writes the count last)
-        rc = self._fn(*self._args, _lib.stream_ptr())
+        rc = self._fn(*self._args)
         if rc != 0:
             self.scratch.zero_()
         _lib.check(rc, "mgp_loocv")
