@@ -64,13 +64,41 @@ def _world(group=None):
     return 0, 1
 
 
+def _collectives_on(group=None) -> bool:
+    """A process group of more than one rank -- or of ONE rank with ``MUYGPYS_HIP_FORCE_COLLECTIVES=1``: a single-GPU
+    box then runs every collective of the path through torch's RCCL (``nccl``) for real, on device tensors
+    (tests/test_gpu_distributed.py), instead of short-circuiting them."""
+    import os
+
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("MUYGPYS_HIP_FORCE_COLLECTIVES") == "1"
+
+
 def allreduce_sum_(partials: torch.Tensor, group=None) -> torch.Tensor:
     """In-place SUM all-reduce of the partial-sum vector (RCCL over xGMI on GPUs; gloo on CPU)."""
     import torch.distributed as dist
 
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _collectives_on(group):
         dist.all_reduce(partials, op=dist.ReduceOp.SUM, group=group)
     return partials
+
+
+def gather_rows(local: torch.Tensor, sizes: Sequence[int], group=None) -> torch.Tensor:
+    """Every rank's block of rows, concatenated in rank order, on every rank (the reference's test-time
+    ``_consistent_unchunk_tensor``, _src/mpi_utils.py:118-141: a pickled allgather of unequal chunks).  The blocks of
+    the reference's chunk rule differ by one row when the batch does not divide: they are padded to the longest and
+    gathered as ONE equal-sized ``all_gather_into_tensor`` (RCCL's all-gather takes equal counts), then trimmed."""
+    import torch.distributed as dist
+
+    size, longest = len(sizes), max(sizes)
+    padded = local.new_zeros((longest,) + tuple(local.shape[1:]))
+    padded[: local.shape[0]] = local
+    out = local.new_empty((size * longest,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
+    return torch.cat([out[r * longest: r * longest + sizes[r]] for r in range(size)])
 
 
 # ---------------------------------------------------------------------------------------------
@@ -115,7 +143,7 @@ def disable_sharded_mode() -> None:
 
 
 def reductions_active() -> bool:
-    return bool(_ACTIVE["on"]) and _world(_ACTIVE["group"])[1] > 1
+    return bool(_ACTIVE["on"]) and _collectives_on(_ACTIVE["group"])
 
 
 def active_group():
@@ -135,7 +163,7 @@ def broadcast_scalar(value: float, group=None, root: int = 0) -> float:
     gp/hyperparameter/scalar.py:145-146)."""
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+    if not _collectives_on(group):
         return float(value)
     # nccl (= RCCL) needs a device tensor: this rank's current device (ranks set it from LOCAL_RANK)
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
@@ -150,7 +178,7 @@ def broadcast_vector(values, group=None, root: int = 0):
     import torch.distributed as dist
 
     values = np.asarray(values, dtype=np.float64)
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+    if not _collectives_on(group):
         return values
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
     t = torch.as_tensor(values, dtype=torch.float64).to(dev)
@@ -293,7 +321,7 @@ def sharded_loocv(
     kw = {}
     if local_fn is hip_local_partials:
         # (one process: the kernel writes the sums to pinned host memory and nothing is all-reduced)
-        kw = dict(packed=packed, huber_delta=float(loss_kwargs.get("boundary_scale", 1.5)), host_result=size == 1)
+        kw = dict(packed=packed, huber_delta=float(loss_kwargs.get("boundary_scale", 1.5)), host_result=not _collectives_on(group))
     partials, mean, var = local_fn(spec, features, targets, batch_indices, nn_indices, **kw)
     if isinstance(partials, torch.Tensor):
         allreduce_sum_(partials, group)
@@ -359,15 +387,9 @@ def sharded_posterior(spec, test_features, train_features, train_targets, batch_
     bi = shard_rows(batch_indices, rank, size)
     ni = shard_rows(nn_indices, rank, size)
     mean, var = posterior_mean_var(spec, test_features, train_features, bi, ni, train_targets)
-    if gather and size > 1:
-        import torch.distributed as dist
-
+    if gather and _collectives_on(group):
         sizes = chunk_sizes(nn_indices.shape[0], size)
-        means = [torch.empty((s,) + tuple(mean.shape[1:]), device=mean.device, dtype=mean.dtype) for s in sizes]
-        vars_ = [torch.empty((s,), device=var.device, dtype=var.dtype) for s in sizes]
-        dist.all_gather(means, mean.contiguous(), group=group)
-        dist.all_gather(vars_, var.contiguous(), group=group)
-        mean, var = torch.cat(means), torch.cat(vars_)
+        mean, var = gather_rows(mean, sizes, group), gather_rows(var, sizes, group)
     return mean, var
 
 

@@ -262,3 +262,40 @@ def test_two_rank_bayes_driver_proposes_the_same_points():
         assert p.exitcode == 0
     assert got[0][1] == got[1][1]
     assert 0.5 <= got[0][1] <= 8.0
+
+
+def _gather_worker(rank, world, port, b, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from muygpys_amd import distributed as D
+
+        sizes = D.chunk_sizes(b, world)
+        lo, hi = D.shard_bounds(b, rank, world)
+        whole = torch.arange(b * 3, dtype=torch.float64).reshape(b, 3) * 0.5
+        got2 = D.gather_rows(whole[lo:hi].clone(), sizes)
+        got1 = D.gather_rows(whole[lo:hi, 0].clone(), sizes)
+        q.put((rank, sizes, bool(torch.equal(got2, whole)), bool(torch.equal(got1, whole[:, 0]))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("b", [10, 11, 2, 3])  # 10 = 3 + 3 + 4, 11 = 3 + 4 + 4, 2 = 0 + 1 + 1 (an empty block)
+def test_three_rank_gather_of_unequal_blocks_is_padded_and_trimmed(b):
+    """sharded_posterior(gather=True) used to call all_gather with per-rank shapes that differ whenever the batch does
+    not divide (the reference's chunk rule gives the remainder to the last ranks, _src/mpi_utils.py:36-41); RCCL's
+    all-gather takes equal counts.  gather_rows pads every block to the longest, gathers once into one tensor and
+    trims: world size 3 over gloo, batch sizes with remainders 1 and 2 and an empty block."""
+    world, port = 3, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, b, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    for rank, sizes, ok2, ok1 in res:
+        assert sum(sizes) == b and sizes == sorted(sizes), sizes  # the remainder sits on the last ranks
+        assert ok2 and ok1, (rank, sizes)

@@ -227,3 +227,90 @@ def test_mgp_allreduce_partials_over_a_real_rccl_communicator():
     finally:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+def _nccl_one_rank(port, q):
+    """torch.distributed over RCCL (`nccl`) with ONE rank on cuda:0, every collective of the path forced on
+    (MUYGPYS_HIP_FORCE_COLLECTIVES): what the 8-GPU scaling run executes, minus the other seven GPUs."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MUYGPYS_HIP_FORCE_COLLECTIVES="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        import bench
+        from muygpys_amd import distributed as D
+        from muygpys_amd.fused import KernelSpec
+        from muygpys_amd.gp import MuyGPS
+        from muygpys_amd.gp.deformation import Isotropy, l2
+        from muygpys_amd.gp.hyperparameter import AnalyticScale, Parameter
+        from muygpys_amd.gp.kernels import Matern
+        from muygpys_amd.gp.noise import HomoscedasticNoise
+        from tests.conftest import load_golden
+
+        assert D._collectives_on() and dist.get_backend() == "nccl"
+        g = load_golden("m15_iso_knn_k30_d40_c2")
+        td = torch.float64
+        X, y = to_dev(g["features"], td), to_dev(g["targets"], td)
+        bi, ni = to_dev(g["batch_idx"]), to_dev(g["nn_idx"])
+        spec = KernelSpec(g["meta"]["kernel"], g["meta"]["metric"], g["meta"]["length_scale"], g["meta"]["noise"])
+        out = {}
+        # the six sums all-reduced on the device through RCCL, then the second (looph) all-reduce
+        res = D.sharded_loocv(spec, X, y, bi, ni, loss="looph")
+        out["lool"], out["sigma_sq"], out["looph"] = res["lool"], res["sigma_sq"], res["looph"]
+        # broadcasts (sampled hyper-parameters / start points / the Bayes driver's seed): device tensors under nccl
+        out["bcast"] = D.broadcast_scalar(3.25)
+        out["bvec"] = D.broadcast_vector([1.0, 2.5, -4.0]).tolist()
+        out["seed"] = D.synchronized_seed()
+        # the functor layer's L-BFGS-B under sharded reductions (every loss / scale sum all-reduced over RCCL)
+        model = MuyGPS(Matern(smoothness=Parameter(1.5), deformation=Isotropy(l2, length_scale=Parameter(3.0, (0.5, 20.0)))),
+                       noise=HomoscedasticNoise(g["meta"]["noise"]), scale=AnalyticScale())
+        opt = D.optimize_sharded(model, X, y, bi, ni, optimizer="lbfgsb")
+        out["ls"] = float(opt.kernel.deformation.length_scale())
+        # prediction with the padded equal-size gather
+        mean, var = D.sharded_posterior(spec, X, X, y, bi, ni, gather=True)
+        out["mean"], out["var"] = mean.cpu().numpy(), var.cpu().numpy()
+        # bench.py's own collectives (barrier, MAX all-reduce of the elapsed time, the ranks-seen all-reduce)
+        elapsed, kern_ms, ranks_seen, _ = bench.time_steps(lambda: D.sharded_loocv(spec, X, y, bi, ni, presharded=True), 2, 3, dist,
+                                                           "nccl", torch.device("cuda", 0))
+        out["ranks_seen"], out["steps"] = ranks_seen, len(kern_ms)
+        q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_every_collective_of_the_path_through_torchs_rccl_with_one_rank():
+    """RCCL has only ever run where there is more than one GPU -- the driver's scaling bench.  A world-size-1 ``nccl``
+    process group on this box's GPU executes the same calls on device tensors: init_process_group(device_id=...), the
+    all-reduce of the partial sums, the broadcasts, L-BFGS-B under sharded reductions, the padded all_gather_into_tensor
+    of sharded_posterior(gather=True), and bench.py's barrier / MAX / ranks-seen collectives.  Values: the fixture's."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from tests.conftest import load_golden
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_one_rank, args=(port, q))
+    p.start()
+    out = q.get(timeout=900)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    g = load_golden("m15_iso_knn_k30_d40_c2")
+    np.testing.assert_allclose(out["lool"], g["lool"], rtol=1e-8)
+    np.testing.assert_allclose(out["sigma_sq"], g["sigma_sq"][0], rtol=1e-8)
+    np.testing.assert_allclose(out["looph"], g["looph"], rtol=1e-8)
+    assert out["bcast"] == 3.25 and out["bvec"] == [1.0, 2.5, -4.0] and 0 <= out["seed"] < 2**31
+    assert 0.5 <= out["ls"] <= 20.0
+    np.testing.assert_allclose(out["mean"], g["mean"], rtol=1e-5, atol=1e-5 * np.sqrt(np.mean(g["mean"] ** 2)))
+    np.testing.assert_allclose(out["var"], g["var_unscaled"], rtol=1e-5)
+    assert out["ranks_seen"] == 1 and out["steps"] == 3
