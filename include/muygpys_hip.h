@@ -445,6 +445,25 @@ int mgp_posterior_backward_f64(const double* feat_q, const double* feat_nn, int 
                                const double* grad_mean, const double* grad_var,
                                double* grad_feat_q, double* grad_feat_nn, double* grad_targets,
                                double* grad_ls, double* grad_noise, int* info, void* stream);
+/* Gradient of a LOOCV objective with respect to the length scale(s) and the noise diagonal (round 5): the
+ * vector-Jacobian product above with the training table on both sides, one response, and a third upstream cotangent
+ * -- grad_ykinvy (b), of y^T K^-1 y, through which the analytic sigma^2 enters every LOOCV loss
+ * (gp/hyperparameter/scale.py:205-217 inside optimize/loss.py:159-176):
+ *     K-bar = gv a a^T - gm a u^T - gyk u u^T,   a = K^-1 c,  u = K^-1 y.
+ * grad_mean / grad_var / grad_ykinvy (b each) are d loss / d (mean_i, var_i, y_i^T K_i^-1 y_i) of the caller's loss;
+ * grad_ls (b, ls_count) and grad_noise (b, k) as above (either may be NULL).  What the reference obtains from
+ * torch autograd over its torch backend (torch/muygps_layer.py:129-164); here it gives scipy's L-BFGS-B an analytic
+ * gradient instead of p + 1 finite-difference evaluations per iteration (_src/optimize/chassis/numpy.py:57-81). */
+int mgp_loocv_backward_f32(const float* features, int d, const int64_t* batch_idx, const int64_t* nn_idx, int64_t b, int k,
+                           const float* targets, int noise_mode, double noise_scalar, const float* noise_dev,
+                           int kernel_id, int metric_id, const float* length_scale, int ls_count,
+                           const float* grad_mean, const float* grad_var, const float* grad_ykinvy,
+                           float* grad_ls, float* grad_noise, int* info, void* stream);
+int mgp_loocv_backward_f64(const double* features, int d, const int64_t* batch_idx, const int64_t* nn_idx, int64_t b, int k,
+                           const double* targets, int noise_mode, double noise_scalar, const double* noise_dev,
+                           int kernel_id, int metric_id, const double* length_scale, int ls_count,
+                           const double* grad_mean, const double* grad_var, const double* grad_ykinvy,
+                           double* grad_ls, double* grad_noise, int* info, void* stream);
 /* Largest nn_count the backward kernel accepts (two LDS-resident k x k triangles). */
 int mgp_max_nn_count_backward(int elem_size);
 

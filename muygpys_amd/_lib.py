@@ -73,6 +73,7 @@ _SIGS = {
     "loocv_tree": [_p, _p, _p, _p, _l, _p, _l, _d, _i, _i, _p, _p, _p],
     "loss_sums": [_p, _p, _p, _l, _p, _d, _d, _p, _p, _p],
     "column_sums": [_p, _l, _i, _p, _p, _p],
+    "loocv_backward": [_p, _i, _p, _p, _l, _i, _p, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p],
     "posterior_backward": [_p, _p, _i, _p, _p, _l, _i, _p, _i, _i, _d, _p, _i, _i, _p, _i,
                            _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "fast_coefficients": [_p, _i, _p, _l, _i, _p, _i, _d, _p, _i, _i, _p, _i, _p, _p, _p],

@@ -69,11 +69,68 @@ def _get_opt_lists(muygps, verbose: bool = False):
     return x0_names, np.asarray(x0, dtype=np.float64), np.asarray(bounds, dtype=np.float64).reshape(-1, 2)
 
 
-def _scipy_optimize(muygps, obj_fn: Callable, verbose: bool = False, **kwargs):
+def _analytic_value_and_grad(muygps, obj_fn, x0_names):
+    """``x -> (loss, d loss / d x)`` for scipy's ``jac=True``: one fused LOOCV evaluation and one backward launch
+    (``muygpys_amd.fused.loocv_value_and_grad``) instead of ``len(x) + 1`` evaluations per iteration.  The objective
+    must be what ``make_loo_crossval_fn`` builds on lazy handles (``obj_fn.loocv_context``), the loss ``lool_fn`` or
+    ``mse_fn``, the free parameters length scales (``length_scale`` / ``length_scale{i}``) of a closed-form kernel
+    with homoscedastic noise -- anything else raises (there is no silent fall-back to finite differences: the caller
+    asked for an analytic gradient).  A free ``noise`` is refused too: inside the reference's objective sigma^2 is
+    computed with the STORED noise while mean and variance take the trial value (gp/hyperparameter/scale.py:206,214
+    against gp/noise/homoscedastic.py:112-113), which is not the function the gradient kernel differentiates."""
+    from muygpys_amd import distributed as D
+    from muygpys_amd import lazy, lazy_eval
+    from muygpys_amd.fused import loocv_value_and_grad
+    from muygpys_amd.optimize.loss import lool_fn, mse_fn
+
+    ctx = getattr(obj_fn, "loocv_context", None)
+    if ctx is None:
+        raise ValueError("analytic_gradient=True: the objective was not built by make_loo_crossval_fn")
+    loss = "lool" if ctx["loss_fn"] is lool_fn else ("mse" if ctx["loss_fn"] is mse_fn else None)
+    if loss is None or ctx["target_mask"] is not None:
+        raise ValueError("analytic_gradient=True: the gradient is written out for lool_fn and mse_fn (no target mask)")
+    pair, cross, nn_t = ctx["pairwise_diffs"], ctx["crosswise_diffs"], ctx["batch_nn_targets"]
+    if not (isinstance(pair, lazy.LazyDiffs) and isinstance(cross, lazy.LazyDiffs) and isinstance(nn_t, lazy.LazyTargets)):
+        raise ValueError("analytic_gradient=True: needs the lazy training tensors (MuyGPS.make_train_tensors under "
+                         "config.state.lazy_tensors / integration.install())")
+    if cross.data is not pair.nn_data and cross.data.data_ptr() != pair.nn_data.data_ptr():
+        raise ValueError("analytic_gradient=True: LOOCV differentiates one table (query rows = training rows)")
+    index = {}
+    for j, name in enumerate(x0_names):
+        if name == "length_scale":
+            index[j] = 0
+        elif name.startswith("length_scale") and name[len("length_scale"):].isdigit():
+            index[j] = int(name[len("length_scale"):])
+        else:
+            raise ValueError(f"analytic_gradient=True: {name!r} is not a length scale (see the docstring for 'noise')")
+    noise = muygps.noise()
+    noise = float(noise.item()) if hasattr(noise, "item") else float(noise)
+    reduce_fn = D.reduce_if_sharded_ if D.reductions_active() else None
+
+    def value_and_grad(x_array, *args):
+        Kin = ctx["kernel_fn"](pair, **{h: float(x_array[i]) for i, h in enumerate(x0_names)})
+        if not isinstance(Kin, lazy.LazyCov):
+            raise ValueError("analytic_gradient=True: the kernel did not stay a lazy handle")
+        spec = lazy_eval._spec(Kin)
+        spec.noise = noise
+        value, g_ls, _ = loocv_value_and_grad(spec, pair.nn_data, nn_t.targets, cross.data_indices, pair.nn_indices,
+                                              loss=loss, reduce_fn=reduce_fn)
+        return value, np.array([g_ls[index[j]] for j in range(len(x0_names))], dtype=np.float64)
+
+    return value_and_grad
+
+
+def _scipy_optimize(muygps, obj_fn: Callable, verbose: bool = False, analytic_gradient: bool = False, **kwargs):
+    """numpy.py:57-81.  ``analytic_gradient`` (round 5, opt-in; default: the reference's finite differences, the same
+    trajectory as the reference's): hand scipy the analytic gradient of the LOOCV loss."""
     from scipy import optimize as opt
 
     x0_names, x0, bounds = _get_opt_lists(muygps, verbose=verbose)
-    optres = opt.minimize(_obj_fn_adapter(obj_fn, x0_names), x0, method="L-BFGS-B", bounds=bounds, **kwargs)
+    if analytic_gradient:
+        optres = opt.minimize(_analytic_value_and_grad(muygps, obj_fn, x0_names), x0, jac=True, method="L-BFGS-B",
+                              bounds=bounds, **kwargs)
+    else:
+        optres = opt.minimize(_obj_fn_adapter(obj_fn, x0_names), x0, method="L-BFGS-B", bounds=bounds, **kwargs)
     if verbose:
         print(f"optimizer results: \n{optres}")
     return _new_muygps(muygps, x0_names, bounds, {n: optres.x[i] for i, n in enumerate(x0_names)})

@@ -65,6 +65,9 @@ struct BackwardArgs {
   void* grad_targets;      // (n_nn, R)  += (atomic)
   void* grad_ls;           // (b, ls_count) per-neighbourhood partials
   void* grad_noise;        // (b, k) per-neighbourhood diagonal cotangent
+  // LOOCV objective (round 5; one response): upstream cotangent of y^T K^-1 y, (b).  When set, the solved right-hand
+  // side is y itself (u = K^-1 y) and grad_mean enters as a factor: K-bar = gv a a^T - gm a u^T - gyk u u^T.
+  const void* grad_yk = nullptr;
 };
 template <typename T> int launch_backward(const BackwardArgs&, hipStream_t);
 template <typename T> int launch_backward_wave(const BackwardArgs&, hipStream_t);  // Isotropy, k + 2 <= 64: on the wave kernel's phases

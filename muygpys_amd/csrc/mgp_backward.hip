@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256) void backward_kernel(BackwardArgs g, int stage
   const T* ls = static_cast<const T*>(a.length_scale);
   const T* gmean = static_cast<const T*>(g.grad_mean);
   const T* gvar = static_cast<const T*>(g.grad_var);
+  const T* gyk = static_cast<const T*>(g.grad_yk);  // (LOOCV, R = 1: the right-hand side is y, w = gm u below)
   T* gq = static_cast<T*>(g.grad_feat_q);
   T* gnn = static_cast<T*>(g.grad_feat_nn);
   T* gtg = static_cast<T*>(g.grad_targets);
@@ -200,7 +201,9 @@ __global__ __launch_bounds__(256) void backward_kernel(BackwardArgs g, int stage
       else eps = noise_dev[nb * k + r];
       S[r * SP + r] = T(1) + eps;
       T yt = T(0);
-      if (gmean)
+      if (gyk)
+        yt = targets[idx[r] * (int64_t)R];
+      else if (gmean)
         for (int q = 0; q < R; ++q) yt += gmean[nb * R + q] * targets[idx[r] * (int64_t)R + q];
       S[(k + 1) * SP + r] = yt;
     }
@@ -237,6 +240,9 @@ __global__ __launch_bounds__(256) void backward_kernel(BackwardArgs g, int stage
     }
     if (stage == 3) continue;
     const T gv = gvar ? gvar[nb] : T(0);
+    // (LOOCV: wv holds u = K^-1 y; the mean's cotangent enters as the factor gm, y^T K^-1 y's as gyv)
+    const T gyv = gyk ? gyk[nb] : T(0);
+    const T gm1 = gyk ? (gmean ? gmean[nb] : T(0)) : T(1);
 
     // ---- cotangent of every pair's acc (overwrites Q), isotropic length-scale partial ----
     T liso = T(0);
@@ -244,8 +250,8 @@ __global__ __launch_bounds__(256) void backward_kernel(BackwardArgs g, int stage
       int a_, c_;
       tri_decode(p, a_, c_);
       T gK;
-      if (a_ < k) gK = T(2) * gv * av[a_] * av[c_] - (av[a_] * wv[c_] + av[c_] * wv[a_]);
-      else gK = wv[c_] - T(2) * gv * av[c_];
+      if (a_ < k) gK = T(2) * gv * av[a_] * av[c_] - gm1 * (av[a_] * wv[c_] + av[c_] * wv[a_]) - T(2) * gyv * wv[a_] * wv[c_];
+      else gK = gm1 * wv[c_] - T(2) * gv * av[c_];
       const T acc = Q[a_ * SP + c_];
       const T x = metric_arg<T>(acc, a.metric_id, post_scale);
       const T kp = kernel_deriv<T>(a.kernel_id, x);
@@ -264,11 +270,11 @@ __global__ __launch_bounds__(256) void backward_kernel(BackwardArgs g, int stage
       if ((tid & 63) == 0) atomicAdd(&red[0], liso);
     }
     if (gnz)
-      for (int r = tid; r < k; r += NT) gnz[nb * k + r] = gv * av[r] * av[r] - av[r] * wv[r];
+      for (int r = tid; r < k; r += NT) gnz[nb * k + r] = gv * av[r] * av[r] - gm1 * av[r] * wv[r] - gyv * wv[r] * wv[r];
     if (gtg && gmean)
       for (int t = tid; t < k * R; t += NT) {
         const int c = t / R, r = t - c * R;
-        unsafeAtomicAdd(gtg + idx[c] * (int64_t)R + r, gmean[nb * R + r] * av[c]);
+        unsafeAtomicAdd(gtg + idx[c] * (int64_t)R + r, gmean[nb * R + r] * av[c] + (gyk ? T(2) * gyv * wv[c] : T(0)));
       }
     __syncthreads();
     if (gls && !aniso && tid == 0) gls[nb] = -(l2 ? T(1) : T(2)) * inv_l * red[0];  // dx/dl = -x/l | -2x/l

@@ -51,6 +51,7 @@ __global__ __launch_bounds__(64, 2) void backward_wave_kernel(BackwardArgs g, in
   const T* noise_dev = static_cast<const T*>(a.noise_dev);
   const T* gmean = static_cast<const T*>(g.grad_mean);
   const T* gvar = static_cast<const T*>(g.grad_var);
+  const T* gyk = static_cast<const T*>(g.grad_yk);  // (LOOCV, R = 1: the right-hand side is y, w = gm u below)
   T* gq = static_cast<T*>(g.grad_feat_q);
   T* gnn = static_cast<T*>(g.grad_feat_nn);
   T* gtg = static_cast<T*>(g.grad_targets);
@@ -89,7 +90,9 @@ __global__ __launch_bounds__(64, 2) void backward_wave_kernel(BackwardArgs g, in
       if (a.noise_mode == MGP_NOISE_SCALAR) myeps = (T)a.noise_scalar;
       else if (a.noise_mode == MGP_NOISE_TABLE) myeps = noise_dev[myidx];
       else myeps = noise_dev[nbb * k + i];
-      if (gmean) {
+      if (gyk) {
+        myyt = targets[(a.targets_batch ? nbb * k + i : myidx) * (int64_t)R];
+      } else if (gmean) {
         const T* ty = targets + (a.targets_batch ? nbb * k + i : myidx) * (int64_t)R;
         for (int r = 0; r < R; ++r) myyt += gmean[nbb * R + r] * ty[r];
       }
@@ -270,8 +273,14 @@ __global__ __launch_bounds__(64, 2) void backward_wave_kernel(BackwardArgs g, in
     }
     __builtin_amdgcn_s_setprio(0);
     __syncthreads();  // every lane is done with the multipliers: M becomes the q matrix
+    // (LOOCV: xw is u = K^-1 y so far; w = gm u from here on, u kept for the y^T K^-1 y terms)
+    const T xu = xw;
+    const T gyv = gyk ? gyk[nbb] : T(0);
+    if (gyk) xw = (gmean ? gmean[nbb] : T(0)) * xu;
+    T* uvec = colbuf;  // (free between the back-substitution and the next task's elimination)
     avec[lane] = i < k ? xa : T(0);
     wvec[lane] = i < k ? xw : T(0);
+    if (gyk) uvec[lane] = i < k ? xu : T(0);
     __syncthreads();
     const bool skip = bad || !live;  // cotangents of a non-SPD neighbourhood are left untouched
 
@@ -291,7 +300,8 @@ __global__ __launch_bounds__(64, 2) void backward_wave_kernel(BackwardArgs g, in
           const int hi = max(r1, c), lo = min(r1, c);
           const bool real = lo < k && hi <= k;
           const T alo = ah[lo], wlo = wh[lo], ahi = ah[hi], whi = wh[hi];
-          const T gK = hi < k ? T(2) * gv * ahi * alo - (ahi * wlo + alo * whi) : wlo - T(2) * gv * alo;
+          T gK = hi < k ? T(2) * gv * ahi * alo - (ahi * wlo + alo * whi) : wlo - T(2) * gv * alo;
+          if (gyk && hi < k) gK -= T(2) * gyv * uvec[h * NP + hi] * uvec[h * NP + lo];
           const T accv = acc_total(acc[s - 1]);
           const T x = (MID == MGP_METRIC_L2 ? sqrt_fast(accv) : accv) * post_scale;
           // d kappa / d x with the fast exponential of the forward kernels (mgp_device.h: kernel_deriv)
@@ -318,9 +328,9 @@ __global__ __launch_bounds__(64, 2) void backward_wave_kernel(BackwardArgs g, in
     }
     // per-neighbourhood outputs that need a and w only
     if (!skip) {
-      if (gnz && i < k) gnz[nb * k + i] = gv * xa * xa - xa * xw;
+      if (gnz && i < k) gnz[nb * k + i] = gv * xa * xa - xa * xw - gyv * xu * xu;
       if (gtg && gmean && i < k)
-        for (int r = 0; r < R; ++r) unsafeAtomicAdd(gtg + myidx * (int64_t)R + r, gmean[nb * R + r] * xa);
+        for (int r = 0; r < R; ++r) unsafeAtomicAdd(gtg + myidx * (int64_t)R + r, gmean[nb * R + r] * xa + (gyk ? T(2) * gyv * xu : T(0)));
     }
     if (gls && !aniso) {
       // sum over the lanes of the half

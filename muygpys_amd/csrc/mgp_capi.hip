@@ -116,11 +116,12 @@ template <typename T>
 int posterior_backward(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t* ni, int64_t b, int k,
                        const T* tg, int R, int noise_mode, double eps, const T* nd, int kernel_id, int metric_id,
                        const T* ls, int ls_count, const T* gmean, const T* gvar, T* gfq, T* gfn, T* gtg, T* gls,
-                       T* gnz, int* info, void* stream) {
+                       T* gnz, int* info, void* stream, const T* gyk = nullptr) {
   if (b < 0 || k < 1 || d < 1 || R < 1) return MGP_EINVAL;
   if (b == 0) return MGP_OK;
   if (!fq || !fn || !ni || !tg || !ls) return MGP_EINVAL;
-  if (!gmean && !gvar) return MGP_EINVAL;
+  if (!gmean && !gvar && !gyk) return MGP_EINVAL;
+  if (gyk && R != 1) return MGP_EINVAL;  // (the LOOCV losses are defined for one response)
   if (!valid_kernel(kernel_id) || !valid_metric(metric_id)) return MGP_EINVAL;
   if (noise_mode < MGP_NOISE_SCALAR || noise_mode > MGP_NOISE_BATCH) return MGP_EINVAL;
   if (noise_mode != MGP_NOISE_SCALAR && !nd) return MGP_EINVAL;
@@ -128,6 +129,7 @@ int posterior_backward(const T* fq, const T* fn, int d, const int64_t* bi, const
   BackwardArgs g{{fq, fn, bi, ni, tg, nd, ls, nullptr, nullptr, nullptr, info, b, eps, d, k, R, noise_mode, kernel_id,
                   metric_id, ls_count, 0},
                  gmean, gvar, gfq, gfn, gtg, gls, gnz};
+  g.grad_yk = gyk;
   static const bool lds_only = getenv("MGP_BACKWARD_LDS") != nullptr;  // A/B switch (timing only)
   if (!lds_only) {
     const int rc = launch_backward_wave<T>(g, static_cast<hipStream_t>(stream));
@@ -389,6 +391,13 @@ MGP_DEFINE_COEF(f64, double)
                                    T* gls, T* gnz, int* info, void* st) {                                            \
     return posterior_backward<T>(fq, fn, d, bi, ni, b, k, tg, R, nm, eps, nd, kid, mid, ls, lsc, gmean, gvar, gfq,  \
                                  gfn, gtg, gls, gnz, info, st);                                                      \
+  }                                                                                                                  \
+  int mgp_loocv_backward_##SUF(const T* feat, int d, const int64_t* bi, const int64_t* ni, int64_t b, int k,        \
+                               const T* tg, int nm, double eps, const T* nd, int kid, int mid, const T* ls, int lsc, \
+                               const T* gmean, const T* gvar, const T* gyk, T* gls, T* gnz, int* info, void* st) {   \
+    if (b > 0 && (!gmean || !gvar || !gyk || (!gls && !gnz))) return MGP_EINVAL;                                     \
+    return posterior_backward<T>(feat, feat, d, bi, ni, b, k, tg, 1, nm, eps, nd, kid, mid, ls, lsc, gmean, gvar,    \
+                                 nullptr, nullptr, nullptr, gls, gnz, info, st, gyk);                                \
   }
 MGP_DEFINE_BWD(f32, float)
 MGP_DEFINE_BWD(f64, double)

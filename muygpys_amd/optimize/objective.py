@@ -35,4 +35,9 @@ def make_loo_crossval_fn(
         Kin, Kcross = kernels_fn(*args, batch_features=batch_features, **kwargs)
         return predict_and_loss_fn(Kin, Kcross, *args, **kwargs)
 
+    # what the objective was built from, for a driver that differentiates it analytically instead of by finite
+    # differences (_src/optimize/chassis/hip.py: _scipy_optimize(..., analytic_gradient=True))
+    obj_fn.loocv_context = dict(loss_fn=loss_fn, kernel_fn=kernel_fn, pairwise_diffs=pairwise_diffs,
+                                crosswise_diffs=crosswise_diffs, batch_nn_targets=batch_nn_targets,
+                                batch_targets=batch_targets, target_mask=target_mask, loss_kwargs=dict(loss_kwargs))
     return obj_fn
