@@ -24,8 +24,15 @@ namespace mgp {
 // loops over features are compile-time and read zeros past d
 // KFIX > 0: nn_count known at compile time (the elimination, the back-substitution and the sweep lose their
 // per-step run-time tests: one basic block each, counted LDS waits)
-template <typename T, int NP, int DG, int KFIX = 0>
-__global__ __launch_bounds__(64, 2) void backward_wave_kernel(BackwardArgs g, int vec_ok) {
+// HYPER (round 5): hyper-parameter gradients only -- no feature cotangents are asked for (the LOOCV gradient of
+// L-BFGS-B, mgp_loocv_backward_*).  The per-feature length-scale partials are then accumulated where the pair
+// cotangents q_ij are formed, by the lane that owns the pair, from the two rows of the tile:
+// dL/dl_f = -(2 / l_f) sum_{pairs} q_ij (z_if - z_jf)^2; the q matrix is not written and the feature sweep -- the one
+// phase that needs the whole q row (NP registers) next to two feature rows -- does not exist in the instantiation.
+template <typename T, int NP, int DG, int KFIX = 0, bool HYPER = false>
+// (fp64 with 64 slots: the system's row -- 64 doubles -- and the 32 kept distance accumulators alone are 256 registers:
+// one wave per SIMD and the whole register file; at two waves it spills 358 .. 793 registers)
+__global__ __launch_bounds__(64, (sizeof(T) == 8 && NP == 64) ? 1 : 2) void backward_wave_kernel(BackwardArgs g, int vec_ok) {
   constexpr int NH = 64 / NP;
   constexpr int NS = NP / 2, BA = 4, BP = NS / BA;
   auto own_offset = [](int j) { return j == 0 ? 0 : (j + 1) * BP + 1; };
@@ -287,6 +294,8 @@ __global__ __launch_bounds__(64, 2) void backward_wave_kernel(BackwardArgs g, in
     // ---- phase 6: pair cotangents q_ij = gK_ij dkappa/dacc_ij, symmetric, zero diagonal ---------------
     const T gv = gvar ? gvar[nbb] : T(0);
     T liso = T(0);
+    V s2h[HYPER ? DG : 1];  // (HYPER) per-feature sums of q_ij dz^2 over the lane's own pairs
+    T qown[HYPER ? NS : 1];  // (HYPER) q of the lane's own pairs (zero for a pair that is not real, or met twice)
     {
       const T* ah = avec + h * NP;
       const T* wh = wvec + h * NP;
@@ -320,11 +329,37 @@ __global__ __launch_bounds__(64, 2) void backward_wave_kernel(BackwardArgs g, in
           // the pair at cyclic distance NP / 2 is met from both ends: count it once
           const bool twice = ((r1 - c) & (NP - 1)) == NP / 2 && r1 < c;
           if (real && !twice) liso += gK * kp * x;
-          Mh[hi <= k ? hi * KS + lo : dump] = q;
-          Mh[hi <= k ? lo * KS + hi : dump] = q;
+          if constexpr (HYPER) {
+            qown[s - 1] = (real && !twice) ? q : T(0);
+          } else {
+            Mh[hi <= k ? hi * KS + lo : dump] = q;
+            Mh[hi <= k ? lo * KS + hi : dump] = q;
+          }
         }
       });
-      Mh[i * KS + i] = T(0);
+      if constexpr (!HYPER) Mh[i * KS + i] = T(0);
+    }
+    if constexpr (HYPER) {
+      // the pairs' shares of the per-feature length-scale partials, pair by pair (the distance accumulators are dead
+      // by now; one copy of this loop, not one per covariance function)
+#pragma unroll
+      for (int c4 = 0; c4 < DG; ++c4) s2h[c4] = V(0);
+      if (gls && aniso) {  // (uniform)
+#pragma unroll
+        for (int s = 1; s <= NS; ++s) {
+          const int r1 = (i + own_offset((s - 1) / BP)) & (NP - 1);
+          const int c = (i + (s - 1) % BP + 1) & (NP - 1);
+          const V qv = V(qown[s - 1]);
+          const T* xa_ = Xh + r1 * xs;
+          const T* xb_ = Xh + c * xs;
+#pragma unroll
+          for (int c4 = 0; c4 < DG; ++c4) {
+            const V dz = *reinterpret_cast<const V*>(xa_ + c4 * E) - *reinterpret_cast<const V*>(xb_ + c4 * E);
+            s2h[c4] = (dz * qv) * dz + s2h[c4];
+          }
+          if ((s & 3) == 0) __builtin_amdgcn_sched_barrier(0);  // (four pairs' reads in flight; all hoisted, they spill)
+        }
+      }
     }
     // per-neighbourhood outputs that need a and w only
     if (!skip) {
@@ -342,6 +377,20 @@ __global__ __launch_bounds__(64, 2) void backward_wave_kernel(BackwardArgs g, in
 
     // ---- phase 7: feature cotangents: gx_i = 2 sum_j q_ij (x_i - x_j) (the metric's 1/l^2 is in q) ------
     const bool want_gl = gls && aniso;
+    if constexpr (HYPER) {
+      if (want_gl) {
+        // every lane's pair sums through the tile, lane f adds column f (each unordered pair once: twice the sum)
+        __syncthreads();
+#pragma unroll
+        for (int c4 = 0; c4 < DG; ++c4) *reinterpret_cast<V*>(Xh + i * xs + c4 * E) = s2h[c4];
+        __syncthreads();
+        for (int f = i; f < d; f += NP) {
+          T acc = T(0);
+          for (int j = 0; j < NP; ++j) acc += Xh[j * xs + f];
+          if (!skip) gls[nb * (int64_t)d + f] = T(-2) * ilb[f] * acc;
+        }
+      }
+    } else
     if (gq || gnn || want_gl) {
       // (rows of more than ten 16-byte groups: the sweep in two passes over half the groups each -- its own row, the
       // sums and a row j in flight are 3 DG registers x 4, and at DG = 12 / 16 the single pass spilled 441 / 2 199
@@ -430,8 +479,8 @@ __global__ __launch_bounds__(64, 2) void backward_wave_kernel(BackwardArgs g, in
   }
 }
 
-template <typename T, int NP, int DG, int KFIX = 0>
-static int launch_bwd_np(const BackwardArgs& g, hipStream_t stream) {
+template <typename T, int NP, int DG, int KFIX = 0, bool HYPER = false>
+static int launch_bwd_np_impl(const BackwardArgs& g, hipStream_t stream) {
   constexpr int NH = 64 / NP;
   constexpr int E = v16<T>::N, KS = NP + E, xs = DG * E + E;
   const uintptr_t align = (uintptr_t)g.f.feat_q | (uintptr_t)g.f.feat_nn;
@@ -439,14 +488,22 @@ static int launch_bwd_np(const BackwardArgs& g, hipStream_t stream) {
   const size_t lds = ((size_t)NH * NP * xs + (size_t)NH * NP * KS + 4 * 64) * sizeof(T) + 64 * sizeof(int64_t);
   static Residency res;
   int per_cu = 0, cus = 0;
-  const int rc = res.lookup(reinterpret_cast<const void*>(&backward_wave_kernel<T, NP, DG, KFIX>), 64, lds, &per_cu, &cus);
+  const int rc = res.lookup(reinterpret_cast<const void*>(&backward_wave_kernel<T, NP, DG, KFIX, HYPER>), 64, lds, &per_cu, &cus);
   if (rc != MGP_OK) return rc;
   const int64_t ntasks = (g.f.b + NH - 1) / NH;
   int64_t grid = (int64_t)cus * per_cu;
   if (grid > ntasks) grid = ntasks;
-  hipLaunchKernelGGL((backward_wave_kernel<T, NP, DG, KFIX>), dim3((unsigned)grid), dim3(64), lds, stream, g, vec_ok);
+  hipLaunchKernelGGL((backward_wave_kernel<T, NP, DG, KFIX, HYPER>), dim3((unsigned)grid), dim3(64), lds, stream, g, vec_ok);
   MGP_HIP_CHECK_LAUNCH();
   return MGP_OK;
+}
+// (no feature cotangent asked for: the instantiation without the sweep)
+template <typename T, int NP, int DG, int KFIX = 0>
+static int launch_bwd_np(const BackwardArgs& g, hipStream_t stream) {
+  // (Anisotropy only: under Isotropy the one length-scale partial needs no sweep in either instantiation, and the
+  // sweep-less one spills more at the headline shape: 6.3 against 4.9 ms per 1 M neighbourhoods)
+  if (!g.grad_feat_q && !g.grad_feat_nn && g.f.ls_count > 1) return launch_bwd_np_impl<T, NP, DG, KFIX, true>(g, stream);
+  return launch_bwd_np_impl<T, NP, DG, KFIX, false>(g, stream);
 }
 
 template <typename T, int NP>
@@ -475,8 +532,15 @@ int launch_backward_wave(const BackwardArgs& g, hipStream_t stream) {
   const int rows = g.f.k + 2;
   if ((g.f.ls_count != 1 && g.f.ls_count != g.f.d) || g.f.d > 16 * (16 / (int)sizeof(T)) || rows > 64) return MGP_EUNSUPPORTED;
   if (rows <= 32) return launch_bwd_dg<T, 32>(g, stream);
-  if constexpr (sizeof(T) == 8) return MGP_EUNSUPPORTED;  // 64 fp64 row registers + the sweep's: spills
-  else return launch_bwd_dg<T, 64>(g, stream);
+  if constexpr (sizeof(T) == 8) {
+    // rows of at most 8 features (round 5; BASELINE config 4: k = 50, d = 8, whose L-BFGS-B gradient is this launch):
+    // hyper-parameter gradients without the sweep at two waves per SIMD; with feature cotangents the sweep's 64-double
+    // q row takes the whole register file (one wave per SIMD) -- still ahead of the LDS workgroup kernel
+    if (g.f.d <= 8) return launch_bwd_np<T, 64, 4>(g, stream);
+    return MGP_EUNSUPPORTED;
+  } else {
+    return launch_bwd_dg<T, 64>(g, stream);
+  }
 }
 
 template int launch_backward_wave<float>(const BackwardArgs&, hipStream_t);
