@@ -47,7 +47,7 @@ FP32_VECTOR_TFLOPS = 157.3  # same guide: peak FP32 (vector)
 FP64_VECTOR_TFLOPS = 78.6   # half the fp32 vector rate (v_fma_f64 at the v_pk_fma_f32 issue cost, tools/ubench)
 # committed PMC passes, newest first (each names the shape(s) it was taken on)
 TRAFFIC_FILES = [(os.path.join(ROOT, "profiles", f), f) for f in (
-    "r04_wave_pmc_traffic.json", "r04_c45_pmc_traffic.json", "r03_wave_pmc_traffic.json", "r03_c45_pmc_traffic.json",
+    "r05_wave_pmc_traffic.json", "r05_c45_pmc_traffic.json", "r04_wave_pmc_traffic.json", "r04_c45_pmc_traffic.json", "r03_wave_pmc_traffic.json", "r03_c45_pmc_traffic.json",
     "r02_wave_pmc_traffic.json", "r02_c45_pmc_traffic.json")]
 
 # BASELINE.json configs: shape, model and what one step does
@@ -411,6 +411,12 @@ def _outputs_of(cfg, w, route: str, last):
     return last[0], last[1]
 
 
+def _launch_geometry():
+    from muygpys_amd import _lib
+
+    return _lib.last_launch_geometry()
+
+
 def roofline_of(cfg, w, avg_ms: float, kernel_name: str, objective: bool):
     s = 4 if cfg["dtype"] == "f32" else 8
     k, d, R, b = w["k"], w["d"], w["R"], w["b"]
@@ -428,6 +434,7 @@ def roofline_of(cfg, w, avg_ms: float, kernel_name: str, objective: bool):
         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
         "traffic_rate_GBps": traffic_rate, "traffic_frac": traffic_rate / HBM_PEAK_GBS if traffic_rate else None,
         "kernel": kernel_name,
+        "launch": dict(zip(("workgroups", "lds_bytes_per_workgroup"), _launch_geometry())),
         "algorithmic_bytes_per_neighbourhood": B, "algorithmic_bytes_per_launch": B * b,
         "kernel_ms": avg_ms,
         "valu": {"achieved": tflops, "peak": vpeak, "unit": "TFLOP/s", "frac": tflops / vpeak,

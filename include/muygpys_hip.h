@@ -312,6 +312,10 @@ int64_t mgp_loocv_scratch_zero_bytes(void);
  * (persistent workgroups, neighbourhoods per task); grid = 0: it walked none (the three-launch walk on the
  * canonical leaves served it) */
 int mgp_last_loocv_geometry(int* grid, int* nh);
+/* launch geometry of the calling thread's most recent wave-kernel / matrix-core-layout launch: workgroups (the
+ * persistent grid) and dynamic LDS bytes per workgroup -- what profiles/ quote next to the compiler's register
+ * record (lib/kernel_resources.json); diagnostic */
+int mgp_last_launch_geometry(int64_t* workgroups, int* lds_bytes);
 int mgp_loocv_f32(const float* features, int d, const int64_t* batch_idx, const int64_t* nn_idx, int64_t b, int k,
                   const float* targets, int noise_mode, double noise_scalar, const float* noise_dev,
                   int kernel_id, int metric_id, const float* length_scale, int ls_count,

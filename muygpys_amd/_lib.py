@@ -118,6 +118,8 @@ def load():
     for name in ("mgp_loocv_scratch_bytes", "mgp_loocv_scratch_zero_bytes"):
         getattr(lib, name).argtypes = []
         getattr(lib, name).restype = _l
+    lib.mgp_last_launch_geometry.argtypes = [C.POINTER(_l), C.POINTER(_i)]
+    lib.mgp_last_launch_geometry.restype = _i
     lib.mgp_last_loocv_geometry.argtypes = [C.POINTER(_i), C.POINTER(_i)]
     lib.mgp_last_loocv_geometry.restype = _i
     lib.mgp_matern_gen_constants.argtypes = [_d, C.POINTER(C.c_double)]
@@ -209,6 +211,13 @@ def last_loocv_geometry():
     launch; (0, 0): the three-launch walk on the canonical leaves served it."""
     g, n = C.c_int(0), C.c_int(0)
     check(load().mgp_last_loocv_geometry(C.byref(g), C.byref(n)), "mgp_last_loocv_geometry")
+    return g.value, n.value
+
+
+def last_launch_geometry():
+    """(workgroups, dynamic LDS bytes per workgroup) of this thread's last wave-kernel launch."""
+    g, n = C.c_int64(0), C.c_int(0)
+    check(load().mgp_last_launch_geometry(C.byref(g), C.byref(n)), "mgp_last_launch_geometry")
     return g.value, n.value
 
 

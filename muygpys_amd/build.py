@@ -26,7 +26,8 @@ PER_FILE_FLAGS = {
     # the 64-step elimination must unroll completely (the fp64 / 16-response body exceeds the default
     # pragma-unroll budget, and a rolled loop indexes the 128-register row at run time = in scratch)
     "mgp_fused_rhs.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
-    "mgp_fused_rhs_mf.hip": ["-mllvm", "-pragma-unroll-threshold=1000000", "-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+    "mgp_fused_rhs_mf.hip": ["-mllvm", "-pragma-unroll-threshold=1000000", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
+                             "-Rpass-analysis=kernel-resource-usage"],
     # (+ the register report of every instantiation -> lib/kernel_resources.json: the headline kernels sit at
     # the 168-register cap of three waves per SIMD, and a spill there costs 30 %)
     "mgp_fused_wave.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
@@ -34,7 +35,7 @@ PER_FILE_FLAGS = {
        for n in ("f32", "f64")},
     "mgp_solve_wave.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
     "mgp_backward.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
-    "mgp_backward_wave.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
+    "mgp_backward_wave.hip": ["-mllvm", "-pragma-unroll-threshold=1000000", "-Rpass-analysis=kernel-resource-usage"],
 }
 
 

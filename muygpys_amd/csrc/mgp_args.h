@@ -137,6 +137,8 @@ int describe_fused_wave(int elem_size, int d, int k, int R, int packed, char* bu
 void note_launch(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 // ... and the leaves of the reduction tree it walked (grid = 0: it walked none; mgp_last_loocv_geometry)
 void note_tree_geometry(int grid, int nh);
+// ... and its launch geometry: workgroups and dynamic LDS bytes per workgroup (mgp_last_launch_geometry)
+void note_launch_geometry(int64_t grid, size_t lds_bytes);
 
 template <typename T>
 int launch_crosswise_diffs(const T*, const T*, int, const int64_t*, const int64_t*, int64_t, int, T*, hipStream_t);

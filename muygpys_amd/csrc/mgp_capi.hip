@@ -12,6 +12,9 @@ namespace mgp {
 static thread_local char g_last_kernel[256] = "";
 static thread_local int g_tree_grid = 0, g_tree_nh = 0;
 void note_tree_geometry(int grid, int nh) { g_tree_grid = grid, g_tree_nh = nh; }
+static thread_local int64_t g_launch_grid = 0;
+static thread_local int g_launch_lds = 0;
+void note_launch_geometry(int64_t grid, size_t lds_bytes) { g_launch_grid = grid, g_launch_lds = (int)lds_bytes; }
 void note_launch(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -74,6 +77,11 @@ int posterior(const T* fq, const T* fn, int d, const int64_t* bi, const int64_t*
     if (rc == MGP_EUNSUPPORTED && tree) {  // (a grid beyond the tree's leaves: the plain launch, the tree by kernels)
       a.tree = LoocvTree{};
       rc = launch_fused_wave<T>(a, s);
+    }
+    // prepared tables with up to sixteen responses behind the features (round 5): the fp32 prediction kernel on the
+    // matrix cores' layout reads them too (BASELINE config 5: two 128-byte lines per neighbour instead of three)
+    if constexpr (sizeof(T) == 4) {
+      if (packed && rc == MGP_EUNSUPPORTED && !tree && !yk) rc = launch_fused_rhs_mf(a, s);
     }
     if (packed || rc != MGP_EUNSUPPORTED) return rc;  // (prepared tables, MGP_EUNSUPPORTED: the caller uses the plain tables)
   }
@@ -198,6 +206,11 @@ int mgp_max_nn_count(int elem_size, int R) { return max_nn_count(elem_size, R); 
 int mgp_reduce_scratch_doubles(void) { return reduce_scratch_doubles(); }
 int64_t mgp_loocv_scratch_bytes(void) { return tree_scratch_bytes(); }
 int64_t mgp_loocv_scratch_zero_bytes(void) { return tree_zero_bytes(); }
+int mgp_last_launch_geometry(int64_t* workgroups, int* lds_bytes) {
+  if (!workgroups || !lds_bytes) return MGP_EINVAL;
+  *workgroups = g_launch_grid, *lds_bytes = g_launch_lds;
+  return MGP_OK;
+}
 int mgp_last_loocv_geometry(int* grid, int* nh) {
   if (!grid || !nh) return MGP_EINVAL;
   *grid = g_tree_grid, *nh = g_tree_nh;

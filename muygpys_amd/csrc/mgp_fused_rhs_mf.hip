@@ -62,6 +62,14 @@ struct RhsMfGeom {
   int dst, xs;
   int resp_vec;  // all RC responses of a row in 16-byte loads (R == RC, rows 16-byte aligned)
   int64_t ntasks;
+  // element strides of the feature rows and of the response rows, and where they start: the plain tables (d, d, R) or
+  // -- round 5 -- prepared tables (mgp_table_pack_*: rows [features d | responses R | pad] at a 64-byte multiple
+  // stride, 256 B at d = 40, R = 16): a neighbour's sixteen responses then lie in the second of the two 128-byte lines
+  // its feature row is gathered from, where the plain tables cost a third line per neighbour
+  int64_t row_nn, row_q, row_resp;
+  const float* feat_q;
+  const float* feat_nn;
+  const float* resp;
 };
 
 #ifndef MGP_RHS_MF_BLOCK
@@ -109,9 +117,9 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
   int64_t* idxbuf = reinterpret_cast<int64_t*>(colbuf);  // 65 row offsets: only alive during the gather
   T* normb = colbuf + NP;
 
-  const T* feat_q = static_cast<const T*>(a.feat_q);
-  const T* feat_nn = static_cast<const T*>(a.feat_nn);
-  const T* targets = static_cast<const T*>(a.targets);
+  const T* feat_q = g.feat_q;
+  const T* feat_nn = g.feat_nn;
+  const T* targets = g.resp;
   const T* noise_dev = static_cast<const T*>(a.noise_dev);
   const T* ls = static_cast<const T*>(a.length_scale);
   const bool aniso = a.ls_count > 1;
@@ -141,8 +149,8 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
       next_q = a.batch_idx ? a.batch_idx[nn] : nn;
     }
     __syncthreads();  // the previous task's LDS reads are done
-    idxbuf[i] = myidx * (int64_t)d;
-    if (i == 0) idxbuf[NP] = qidx * (int64_t)d;
+    idxbuf[i] = myidx * g.row_nn;
+    if (i == 0) idxbuf[NP] = qidx * g.row_q;
     T myeps = T(0);
     if (i < k) {
       if (a.noise_mode == MGP_NOISE_SCALAR) myeps = (T)a.noise_scalar;
@@ -468,7 +476,7 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
 #pragma unroll
     for (int r = 0; r < RC; ++r) y[r] = T(0);
     if (i < k) {  // the responses fly under the back-substitution
-      const T* ty = targets + yrow * (int64_t)R;
+      const T* ty = targets + yrow * g.row_resp;
       if (g.resp_vec) {
 #pragma unroll
         for (int r4 = 0; r4 < RC / E; ++r4) {
@@ -543,10 +551,13 @@ int launch_fused_rhs_mf(const FusedArgs& a, hipStream_t stream) {
   constexpr int NP = 64, E = 4, CH = 8, RC = 16;
   constexpr int KTRI = E * ((NP - 1) / E + 1) * (E * ((NP - 1) / E) / 2 + (NP - 1) % E) + NP + E;
   const int dpad = (a.d + CH - 1) / CH * CH;
-  const uintptr_t align = (uintptr_t)a.feat_q | (uintptr_t)a.feat_nn;
-  if (a.k > NP || a.R > RC || a.ykinvy != nullptr || a.packed_nn != nullptr || a.d % E != 0 || a.d < CH || dpad > 64 ||
+  const bool packed = a.packed_nn != nullptr;
+  const uintptr_t align = packed ? ((uintptr_t)a.packed_q | (uintptr_t)a.packed_nn | (uintptr_t)a.q_stride | (uintptr_t)a.nn_stride)
+                                 : ((uintptr_t)a.feat_q | (uintptr_t)a.feat_nn);
+  if (a.k > NP || a.R > RC || a.ykinvy != nullptr || a.d % E != 0 || a.d < CH || dpad > 64 ||
       align % 16 != 0 || a.kernel_id == MGP_KERNEL_MATERN_05 || a.kernel_id == MGP_KERNEL_MATERN_GEN)
     return MGP_EUNSUPPORTED;
+  if (packed && (!a.packed_q || (!a.targets_batch && a.nn_stride < (int64_t)((a.d + a.R) * sizeof(float))))) return MGP_EINVAL;
   // rows of 41 .. 48 features: the tile is 13.5 KB, eleven workgroups per CU (one SIMD a wave short) -- measured 86.8
   // M/s against 94.2 of the folded variant (mgp_fused_rhs.hip), which takes them; d <= 40: 104.6 against 101.9; d = 64
   // (eight workgroups per CU either way): 79.8 against 74.5 of the three-wave variant
@@ -554,8 +565,25 @@ int launch_fused_rhs_mf(const FusedArgs& a, hipStream_t stream) {
   RhsMfGeom g;
   g.dst = dpad;
   g.xs = g.dst + E;
-  g.resp_vec = a.R == RC && (uintptr_t)a.targets % 16 == 0;
   g.ntasks = a.b;
+  if (packed) {
+    g.feat_nn = static_cast<const float*>(a.packed_nn);
+    g.feat_q = static_cast<const float*>(a.packed_q);
+    g.row_nn = a.nn_stride / (int64_t)sizeof(float);
+    g.row_q = a.q_stride / (int64_t)sizeof(float);
+  } else {
+    g.feat_nn = static_cast<const float*>(a.feat_nn);
+    g.feat_q = static_cast<const float*>(a.feat_q);
+    g.row_nn = g.row_q = a.d;
+  }
+  if (packed && !a.targets_batch) {  // the responses ride behind the features of the neighbour's row
+    g.resp = g.feat_nn + a.d;
+    g.row_resp = g.row_nn;
+  } else {
+    g.resp = static_cast<const float*>(a.targets);
+    g.row_resp = a.R;
+  }
+  g.resp_vec = a.R == RC && (uintptr_t)g.resp % 16 == 0 && (g.row_resp * sizeof(float)) % 16 == 0;
   const size_t tile_elems = (size_t)(NP + 1) * g.xs > (size_t)KTRI ? (size_t)(NP + 1) * g.xs : (size_t)KTRI;
   size_t lds = (tile_elems + 4 * NP + g.dst + (g.dst & 1)) * sizeof(float);
   lds = (lds + 15) & ~(size_t)15;
@@ -571,7 +599,8 @@ int launch_fused_rhs_mf(const FusedArgs& a, hipStream_t stream) {
   if (grid > g.ntasks) grid = g.ntasks;
   hipLaunchKernelGGL((fused_rhs_mf_kernel<RC>), dim3((unsigned)grid), dim3(64), lds, stream, a, g);
   MGP_HIP_CHECK_LAUNCH();
-  note_launch("mgp::fused_rhs_mf_kernel<%d>", RC);  // (the symbol rocprofv3 and lib/kernel_resources.json list)
+  note_launch("mgp::fused_rhs_mf_kernel<%d>%s", RC, packed ? " [prepared tables]" : "");  // (the symbol rocprofv3 lists)
+  note_launch_geometry(grid, lds);
   return MGP_OK;
 }
 

@@ -112,6 +112,7 @@ static int launch_jit(const FusedArgs& a, hipStream_t stream) {
   note_launch("mgp::fused_wave_kernel<%s,%d,%d,%d,%d,true,false,%s,%s%s> [run-time compiled]", sizeof(T) == 4 ? "float" : "double", NP,
               a.k, a.R, a.d, packed ? "true" : "false", gram ? "true" : "false", gen64 ? ",gen64" : "");
   note_tree_geometry(a.tree.out ? (int)grid : 0, WD.NH);
+  note_launch_geometry(grid, lds);
   return MGP_OK;
 }
 

@@ -119,6 +119,7 @@ int launch_np_impl(const FusedArgs& a, hipStream_t stream) {
               PIPED ? "true" : "false", COEFF ? "true" : "false", PACKED ? "true" : "false", GRAM ? "true" : "false",
               GEN64 ? ",gen64" : "");
   note_tree_geometry(a.tree.out ? (int)grid : 0, NH);
+  note_launch_geometry(grid, lds);
   return MGP_OK;
 }
 

@@ -131,7 +131,13 @@ class PackedTable:
     def supported(d: int, R: int, k: int, dtype) -> bool:
         es = 4 if dtype == torch.float32 else 8
         dk = (d * es + 15) // 16 * 16 // es  # (rows are padded to whole 16-byte groups)
-        return dk <= 64 and R * es <= 16 and k + 1 + R <= 64
+        if dk > 64:
+            return False
+        if R * es <= 16 and k + 1 + R <= 64:  # the wave kernels: the responses of a row in one 16-byte slot
+            return True
+        # fp32 predictions with up to sixteen responses and nn_count <= 64 (BASELINE config 5; round 5): the kernel on the
+        # matrix cores' layout reads rows [features | 16 responses] at a 256-byte stride (d = 40)
+        return es == 4 and 4 < R <= 16 and k <= 64 and dk >= 8 and (dk + 7) // 8 * 8 != 48
 
     def kernel_length_scale(self, ls: torch.Tensor) -> torch.Tensor:
         """Per-feature length scales padded to ``d_kernel`` entries (ones: the padded features are all zero)."""

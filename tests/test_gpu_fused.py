@@ -696,3 +696,38 @@ def test_dispatcher_agrees_with_the_lds_workgroup_kernel(shape):
     assert_close(m1.cpu().numpy().reshape(b, R), m2.cpu().numpy().reshape(b, R), rtol, f"mean [{_lib.served_by(d, k, R, td, False, 'auto')}]")
     assert_close(v1.cpu().numpy(), v2.cpu().numpy(), rtol, "var")
     assert_close(y1.cpu().numpy().reshape(b, R), y2.cpu().numpy().reshape(b, R), rtol, "ykinvy")
+
+
+@pytest.mark.parametrize("k,d,R,b", [(64, 40, 16, 5003), (56, 24, 12, 1001), (60, 8, 16, 257), (64, 64, 5, 130)])
+def test_prepared_tables_with_up_to_sixteen_responses_give_identical_bits(k, d, R, b):
+    """Round 5 (BASELINE config 5): rows [features | 16 responses | pad] at a 64-byte multiple stride (256 B at d = 40)
+    read by the fp32 prediction kernel on the matrix cores' layout -- a neighbour's responses come with the second
+    128-byte line of its feature row instead of from a third line of a separate response tensor
+    (reference gather: gp/muygps.py:474).  Same kernel, same arithmetic: the same bits as from the plain tables; and
+    the oracle's values."""
+    from muygpys_amd import _lib
+    from muygpys_amd.fused import KernelSpec, PackedTable, posterior_mean_var
+
+    rng = np.random.default_rng(500 + k + R)
+    n = 3000
+    X, Q = rng.normal(size=(n, d)), rng.normal(size=(700, d))
+    Y = np.sin(X @ rng.normal(size=(d, R)) / np.sqrt(d)) + 0.05 * rng.normal(size=(n, R))
+    bi = rng.integers(0, 700, size=b)
+    ni = np.stack([rng.choice(n, size=k, replace=False) for _ in range(b)])
+    assert PackedTable.supported(d, R, k, torch.float32)
+    Xd, Qd, Yd = to_dev(X, torch.float32), to_dev(Q, torch.float32), to_dev(Y, torch.float32)
+    spec = KernelSpec("rbf", "F2", 4.0 if d >= 24 else 2.0, 1e-2)
+    out = {}
+    for packed in (True, False):
+        info = torch.zeros(1, dtype=torch.int32, device="cuda")
+        mean, var = posterior_mean_var(spec, Qd, Xd, to_dev(bi), to_dev(ni), Yd, info=info, packed=packed)
+        torch.cuda.synchronize()
+        served = _lib.last_kernel()
+        assert served.startswith("mgp::fused_rhs_mf_kernel<16>") and served.endswith("[prepared tables]") == packed, served
+        assert int(info.item()) == 0
+        out[packed] = (mean.clone(), var.clone())
+    assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
+    pick = np.arange(min(b, 400))
+    m_ref, v_ref = orc.posterior_mean_var(orc.Spec("rbf", "F2", spec.length_scale, 1e-2), Q, X, bi[pick], ni[pick], Y)
+    assert_close(out[True][0].cpu().numpy()[pick], m_ref.reshape(len(pick), R), RTOL["float32"], "mean")
+    assert_rel_close(out[True][1].cpu().numpy()[pick], v_ref, RTOL["float32"], "var")
