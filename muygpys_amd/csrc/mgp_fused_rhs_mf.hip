@@ -28,6 +28,7 @@
 // multipliers of four steps are collected in registers and written to the packed L (the feature tile is dead by then)
 // where the back-substitution reads them column-wise; right-hand side, back-substitution and outputs as in
 // mgp_fused_rhs.hip (prediction variant).
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include "mgp_wave_common.h"
@@ -66,10 +67,9 @@ struct RhsMfGeom {
   // -- round 5 -- prepared tables (mgp_table_pack_*: rows [features d | responses R | pad] at a 64-byte multiple
   // stride, 256 B at d = 40, R = 16): a neighbour's sixteen responses then lie in the second of the two 128-byte lines
   // its feature row is gathered from, where the plain tables cost a third line per neighbour
-  int64_t row_nn, row_q, row_resp;
-  const float* feat_q;
-  const float* feat_nn;
-  const float* resp;
+  // (32-bit, and the bases in FusedArgs' own feat_q / feat_nn / targets fields -- the launcher hands the kernel a copy
+  // with the prepared tables' addresses there: scalar registers are what this kernel spills)
+  int row_nn, row_q, row_resp;
 };
 
 #ifndef MGP_RHS_MF_BLOCK
@@ -117,9 +117,9 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
   int64_t* idxbuf = reinterpret_cast<int64_t*>(colbuf);  // 65 row offsets: only alive during the gather
   T* normb = colbuf + NP;
 
-  const T* feat_q = g.feat_q;
-  const T* feat_nn = g.feat_nn;
-  const T* targets = g.resp;
+  const T* feat_q = static_cast<const T*>(a.feat_q);
+  const T* feat_nn = static_cast<const T*>(a.feat_nn);
+  const T* targets = static_cast<const T*>(a.targets);
   const T* noise_dev = static_cast<const T*>(a.noise_dev);
   const T* ls = static_cast<const T*>(a.length_scale);
   const bool aniso = a.ls_count > 1;
@@ -149,8 +149,8 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
       next_q = a.batch_idx ? a.batch_idx[nn] : nn;
     }
     __syncthreads();  // the previous task's LDS reads are done
-    idxbuf[i] = myidx * g.row_nn;
-    if (i == 0) idxbuf[NP] = qidx * g.row_q;
+    idxbuf[i] = myidx * (int64_t)g.row_nn;
+    if (i == 0) idxbuf[NP] = qidx * (int64_t)g.row_q;
     T myeps = T(0);
     if (i < k) {
       if (a.noise_mode == MGP_NOISE_SCALAR) myeps = (T)a.noise_scalar;
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
 #pragma unroll
     for (int r = 0; r < RC; ++r) y[r] = T(0);
     if (i < k) {  // the responses fly under the back-substitution
-      const T* ty = targets + yrow * g.row_resp;
+      const T* ty = targets + yrow * (int64_t)g.row_resp;
       if (g.resp_vec) {
 #pragma unroll
         for (int r4 = 0; r4 < RC / E; ++r4) {
@@ -566,24 +566,23 @@ int launch_fused_rhs_mf(const FusedArgs& a, hipStream_t stream) {
   g.dst = dpad;
   g.xs = g.dst + E;
   g.ntasks = a.b;
+  FusedArgs ak = a;  // (the kernel's copy: table bases in feat_q / feat_nn / targets whatever the table form)
   if (packed) {
-    g.feat_nn = static_cast<const float*>(a.packed_nn);
-    g.feat_q = static_cast<const float*>(a.packed_q);
-    g.row_nn = a.nn_stride / (int64_t)sizeof(float);
-    g.row_q = a.q_stride / (int64_t)sizeof(float);
+    if (a.nn_stride / 4 > INT32_MAX || a.q_stride / 4 > INT32_MAX) return MGP_EUNSUPPORTED;
+    ak.feat_nn = a.packed_nn;
+    ak.feat_q = a.packed_q;
+    g.row_nn = (int)(a.nn_stride / (int64_t)sizeof(float));
+    g.row_q = (int)(a.q_stride / (int64_t)sizeof(float));
   } else {
-    g.feat_nn = static_cast<const float*>(a.feat_nn);
-    g.feat_q = static_cast<const float*>(a.feat_q);
     g.row_nn = g.row_q = a.d;
   }
   if (packed && !a.targets_batch) {  // the responses ride behind the features of the neighbour's row
-    g.resp = g.feat_nn + a.d;
+    ak.targets = static_cast<const float*>(a.packed_nn) + a.d;
     g.row_resp = g.row_nn;
   } else {
-    g.resp = static_cast<const float*>(a.targets);
     g.row_resp = a.R;
   }
-  g.resp_vec = a.R == RC && (uintptr_t)g.resp % 16 == 0 && (g.row_resp * sizeof(float)) % 16 == 0;
+  g.resp_vec = a.R == RC && (uintptr_t)ak.targets % 16 == 0 && ((size_t)g.row_resp * sizeof(float)) % 16 == 0;
   const size_t tile_elems = (size_t)(NP + 1) * g.xs > (size_t)KTRI ? (size_t)(NP + 1) * g.xs : (size_t)KTRI;
   size_t lds = (tile_elems + 4 * NP + g.dst + (g.dst & 1)) * sizeof(float);
   lds = (lds + 15) & ~(size_t)15;
@@ -597,7 +596,7 @@ int launch_fused_rhs_mf(const FusedArgs& a, hipStream_t stream) {
   if (trace) fprintf(stderr, "[mgp] fused_rhs_mf_kernel<%d>: lds %zu B, %d workgroups per CU\n", RC, lds, per_cu);
   int64_t grid = (int64_t)cus * per_cu;
   if (grid > g.ntasks) grid = g.ntasks;
-  hipLaunchKernelGGL((fused_rhs_mf_kernel<RC>), dim3((unsigned)grid), dim3(64), lds, stream, a, g);
+  hipLaunchKernelGGL((fused_rhs_mf_kernel<RC>), dim3((unsigned)grid), dim3(64), lds, stream, ak, g);
   MGP_HIP_CHECK_LAUNCH();
   note_launch("mgp::fused_rhs_mf_kernel<%d>%s", RC, packed ? " [prepared tables]" : "");  // (the symbol rocprofv3 lists)
   note_launch_geometry(grid, lds);
