@@ -238,27 +238,28 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
     f2 D2[24];
     {
       const T nc0 = normb[c], nc1 = normb[HALF + c];
-      V nra[4], nrb[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        nra[q] = *reinterpret_cast<const V*>(normb + 8 * q + 4 * h);
-        nrb[q] = *reinterpret_cast<const V*>(normb + HALF + 8 * q + 4 * h);
-      }
       T guard = T(1);
-      static_for<24>([&](auto pc) {
-        constexpr int pr = decltype(pc)::value, tl = pr / 8, r = 2 * (pr % 8);
-        const F16& gg = tl == 0 ? g00 : (tl == 1 ? g01 : g11);
-        const V& nr = tl == 2 ? nrb[r / 4] : nra[r / 4];
-        const T nc = tl == 0 ? nc0 : nc1;
-        const f2 ns = f2{nr[r % 4] + nc, nr[r % 4 + 1] + nc};
-        const f2 dd = f2{gg[r], gg[r + 1]} * f2{-2.0f, -2.0f} + ns;
-        f2 tt = dd * f2{MGP_GRAM_GUARD, MGP_GRAM_GUARD} - ns;
-        if constexpr (tl != 1) {
-          tt.x = rdiag == r ? T(1) : tt.x;
-          tt.y = rdiag == r + 1 ? T(1) : tt.y;
-        }
-        guard = __builtin_fminf(__builtin_fminf(guard, tt.x), tt.y);
-        D2[pr] = f2{__builtin_fmaxf(dd.x, 0.0f), __builtin_fmaxf(dd.y, 0.0f)};
+      // (the norms of the columns one 16-byte group at a time, right where they are used: all eight groups up front are
+      // 32 registers on top of the three accumulators and the distances -- that was what spilled at three waves per SIMD)
+      static_for<4>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        const V nra = *reinterpret_cast<const V*>(normb + 8 * q + 4 * h);
+        const V nrb = *reinterpret_cast<const V*>(normb + HALF + 8 * q + 4 * h);
+        static_for<6>([&](auto pc) {
+          constexpr int tl = decltype(pc)::value / 2, r = 4 * q + 2 * (decltype(pc)::value % 2), pr = 8 * tl + r / 2;
+          const F16& gg = tl == 0 ? g00 : (tl == 1 ? g01 : g11);
+          const V& nr = tl == 2 ? nrb : nra;
+          const T nc = tl == 0 ? nc0 : nc1;
+          const f2 ns = f2{nr[r % 4] + nc, nr[r % 4 + 1] + nc};
+          const f2 dd = f2{gg[r], gg[r + 1]} * f2{-2.0f, -2.0f} + ns;
+          f2 tt = dd * f2{MGP_GRAM_GUARD, MGP_GRAM_GUARD} - ns;
+          if constexpr (tl != 1) {
+            tt.x = rdiag == r ? T(1) : tt.x;
+            tt.y = rdiag == r + 1 ? T(1) : tt.y;
+          }
+          guard = __builtin_fminf(__builtin_fminf(guard, tt.x), tt.y);
+          D2[pr] = f2{__builtin_fmaxf(dd.x, 0.0f), __builtin_fmaxf(dd.y, 0.0f)};
+        });
       });
       if (gram_guard_tripped(guard)) {
         // this neighbourhood's distances again in the difference form, entry by entry (rare: registers before speed)

@@ -38,6 +38,8 @@ def main():
     print(f"[{args.scan}] kNN {args.queries} queries x {args.n} points, d={args.d}, k={args.k}: {dt * 1e3:.1f} ms "
           f"-> {args.queries / dt / 1e3:.1f} k queries/s, {pairs / dt / 1e12:.2f} T pair-distances/s, "
           f"{2 * pairs * args.d / dt / 1e12:.1f} TFLOP/s")
+    # (for A/B runs of kernel variants: the same lists whatever the tiling)
+    print(f"checksum: indices {int(idx.sort(dim=1).values.to(torch.int64).sum().item())}, distances {float(dist.double().sum().item()):.9e}")
 
 
 if __name__ == "__main__":
