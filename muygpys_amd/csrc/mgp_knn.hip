@@ -131,15 +131,17 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(KnnArgs a) {
   // whatever the arithmetic), staggered they spread over the memory system.
   const int64_t ntiles = (a.n - a.start + KNN_TN - 1) / KNN_TN;
   const int64_t tile_off = ((int64_t)blockIdx.x * 7919) % ntiles;
-  auto tile_row = [&](int64_t j) { return a.start + ((j + tile_off) % ntiles) * KNN_TN; };
-  issue_tile(0, tile_row(0));
+  // (running tile index instead of (tj + tile_off) % ntiles: see knn_scan_bf16x3_kernel)
+  auto tile_after = [&](int64_t t) { return t + 1 == ntiles ? (int64_t)0 : t + 1; };
+  int64_t tcur = tile_off;
+  issue_tile(0, a.start + tcur * KNN_TN);
   int buf = 0;
   int64_t next_drain = 0;
-  for (int64_t tj = 0; tj < ntiles; ++tj, buf ^= 1) {
-    const int64_t t0 = tile_row(tj);
+  for (int64_t tj = 0; tj < ntiles; ++tj, buf ^= 1, tcur = tile_after(tcur)) {
+    const int64_t t0 = a.start + tcur * KNN_TN;
     __builtin_amdgcn_s_waitcnt(0);  // this wave's share of tile `buf` has landed
     __syncthreads();                // ... everyone's has, and nobody still reads the other buffer
-    if (tj + 1 < ntiles) issue_tile(buf ^ 1, tile_row(tj + 1));
+    if (tj + 1 < ntiles) issue_tile(buf ^ 1, a.start + tile_after(tcur) * KNN_TN);
     const float* tl = tile0 + buf * KNN_TN * XS;
     const float* xnt = xn0 + buf * KNN_TN;
 
@@ -284,12 +286,56 @@ int launch_knn_scan(const KnnArgs& a, hipStream_t stream) {
 // A workgroup owns 256 queries (64 per wave, two MFMA row blocks).
 // ------------------------------------------------------------------------------------------------
 
+#ifndef MGP_KNN_TIMING
+#define MGP_KNN_TIMING 0
+#endif
+#if MGP_KNN_TIMING
+// phase timing (experiments only; tools/knn_timing.py): cycle-counter differences summed per wave and phase --
+// 0 tile wait + barrier, 1 tile issue, 2 matrix blocks + survivor queues, 3 drain, 4 prologue
+__device__ unsigned long long g_knn_timing[8];
+#define MGP_KNN_T(slot)                                            \
+  {                                                                \
+    const unsigned long long tnow_ = __builtin_readcyclecounter(); \
+    tacc_[slot] += tnow_ - tlast_;                                 \
+    tlast_ = tnow_;                                                \
+  }
+}  // namespace mgp
+extern "C" int mgp_debug_knn_timing(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mgp::g_knn_timing), sizeof(mgp::g_knn_timing)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(mgp::g_knn_timing), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+namespace mgp {
+#else
+#define MGP_KNN_T(slot)
+#endif
+
 typedef __bf16 bf8x __attribute__((ext_vector_type(8)));
 typedef unsigned int u4x __attribute__((ext_vector_type(4)));
 
 constexpr int KB_QW = 64;     // queries per wave
-constexpr int KB_QB = 256;    // queries per workgroup
 constexpr int KB_CAP = 16;    // queue entries per query
+#ifndef MGP_KNN_STAGGER
+#define MGP_KNN_STAGGER 64      // 0: every workgroup starts at the first tile, 1: scattered over the table, n > 1: over a window of n tiles
+#endif
+#ifndef MGP_KNN_SCAN_BLOCK
+#define MGP_KNN_SCAN_BLOCK 16   // list entries loaded together when a survivor is inserted (32: the drain spills more, slower)
+#endif
+#ifndef MGP_KNN_CADENCE
+#define MGP_KNN_CADENCE 64      // drain interval = rows seen / this (0: the fixed schedule of rounds 1-4)
+#endif
+#ifndef MGP_KNN_SWIZZLE
+#define MGP_KNN_SWIZZLE 1
+#endif
+#ifndef MGP_KNN_PIPE_KP
+#define MGP_KNN_PIPE_KP 16     // packed row lengths up to this run the survivor test one column block behind the matrix instructions
+#endif
+#ifndef MGP_KNN_CADENCE_MAX
+#define MGP_KNN_CADENCE_MAX 16384
+#endif
 
 __device__ __forceinline__ unsigned bf16_rne(float x) {  // bits of bf16(x), round to nearest even
   const unsigned u = __float_as_uint(x);
@@ -307,17 +353,23 @@ __device__ __forceinline__ void neg_thr_split(float qn, float tau, unsigned& hi,
 // TN: training rows per staged tile.  64 for the wider rows; 128 at KP = 16 (d <= 14: BASELINE config 4's d = 8), where a
 // 64-row tile is only 12 MFMAs per wave between two workgroup barriers (round 4: the 10 M-point search of config 4 ran at
 // 18 % matrix-pipe occupancy, barrier-bound).
-template <int KP, int TN>
-__global__ __launch_bounds__(256, (KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void knn_scan_bf16x3_kernel(KnnPackedArgs a) {
+template <int KP, int TN, int NW, int NBUF>
+__global__ __launch_bounds__(64 * NW, (KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void knn_scan_bf16x3_kernel(KnnPackedArgs a) {
+  constexpr int KB_QB = KB_QW * NW;     // queries per workgroup
   constexpr int RB = 4 * KP;            // bytes of a packed row: KP bf16 hi + KP bf16 lo
-  constexpr int SPR = RB / 16 + 1;      // 16-byte slots of a staged row (odd)
+  // KP = 16 (MGP_KNN_SWIZZLE): the staged row is its four 16-byte slots and nothing else -- slot s of row r lies at
+  // slot s ^ ((r >> 2) & 3), the transfer's SOURCE address does the permuting (its LDS side is lane-linear) -- which
+  // reads as conflict-free as the padded rows (lanes r, r + 4, r + 8, r + 12 of a 16-lane phase share a 16-bank group
+  // and now take its four different slots) at 8 transfers per 128-row tile instead of 10 (12 issued)
+  constexpr bool SWZ = MGP_KNN_SWIZZLE && KP == 16;
+  constexpr int SPR = SWZ ? RB / 16 : RB / 16 + 1;  // 16-byte slots of a staged row (odd when padded)
   constexpr int XSB = SPR * 16;         // LDS row stride in bytes
   constexpr int NQ = KP / 16;           // 16-byte operand pieces per half row = MFMAs per chain
   constexpr int NPASS = TN * SPR / 64;
   static_assert(TN * SPR % 64 == 0, "tile must be whole wave passes");
   extern __shared__ __attribute__((aligned(16))) char smem[];  // carved by hand, see knn_scan_kernel
-  char* tile0 = smem;                                                     // [2][TN * XSB]
-  int* q_i = reinterpret_cast<int*>(smem + 2 * TN * XSB);             // [KB_QB * KB_CAP]
+  char* tile0 = smem;                                                     // [NBUF][TN * XSB]
+  int* q_i = reinterpret_cast<int*>(smem + NBUF * TN * XSB);           // [KB_QB * KB_CAP]
   int* q_cnt = q_i + KB_QB * KB_CAP;                                      // [KB_QB]
   float* tau_s = reinterpret_cast<float*>(q_cnt + KB_QB);                 // [KB_QB]
 
@@ -362,40 +414,84 @@ __global__ __launch_bounds__(256, (KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void knn_sc
     }
   }
 
+  // more than two buffers: every wave issues the same number of transfers per tile (a pass index past the end repeats
+  // the last pass: the same bytes to the same place), so "all but the NBUF - 2 newest tiles have landed" is one
+  // immediate vmcnt; two buffers (the build's setting: three measured slower at every row length) wait for everything
+  constexpr int IPW = (NPASS + NW - 1) / NW;
   auto issue_tile = [&](int buf, int64_t t0) {
-    for (int p = w; p < NPASS; p += 4) {
+#pragma unroll
+    for (int it = 0; it < IPW; ++it) {
+      if (NBUF == 2 && w + NW * it >= NPASS) break;
+      const int p = min(w + NW * it, NPASS - 1);
       const int sigma = 64 * p + lane;
       const int row = sigma / SPR;
-      const int c = min(sigma - row * SPR, SPR - 2);
+      const int c = SWZ ? (sigma - row * SPR) ^ ((row >> 2) & 3) : min(sigma - row * SPR, SPR - 2);
       const int64_t grow = min(t0 + row, a.n - 1);
       lds_dma16(reinterpret_cast<const char*>(a.packed_train) + grow * (int64_t)RB + c * 16,
                 lds_offset(tile0 + buf * TN * XSB) + p * 1024);
     }
   };
   const int64_t ntiles = (a.n - a.start + TN - 1) / TN;  // staggered walk, see knn_scan_kernel
+#if MGP_KNN_STAGGER == 1
   const int64_t tile_off = ((int64_t)blockIdx.x * 7919) % ntiles;
-  auto tile_row = [&](int64_t j) { return a.start + ((j + tile_off) % ntiles) * TN; };
-  issue_tile(0, tile_row(0));
+#elif MGP_KNN_STAGGER > 1
+  // a window of MGP_KNN_STAGGER tiles: neighbours in the grid start a tile apart, so the workgroups of an XCD are spread
+  // over the memory channels but walk the same few hundred KB at any time -- the tile one of them brought in is in L2
+  // (or the Infinity Cache) for the ones behind it
+  const int64_t tile_off = (int64_t)(blockIdx.x % MGP_KNN_STAGGER) % ntiles;
+#else
+  const int64_t tile_off = 0;
+#endif
+  // (the tile of step j is (j + tile_off) mod ntiles, kept as two running indices: the 64-bit remainder is ~150 scalar
+  // instructions, twice per tile -- most of the 19 % of a wave's cycles the tile issue took at KP = 16, round 5)
+  auto tile_after = [&](int64_t t) { return t + 1 == ntiles ? (int64_t)0 : t + 1; };
+  int64_t tcur = tile_off, tahead = tile_off;  // tile index of step tj / of the next tile to request
+  for (int t = 0; t < NBUF - 1; ++t)
+    if (t < ntiles) {
+      issue_tile(t, a.start + tahead * TN);
+      tahead = tile_after(tahead);
+    }
   int buf = 0;
   int64_t next_drain = 0;
-  for (int64_t tj = 0; tj < ntiles; ++tj, buf ^= 1) {
-    const int64_t t0 = tile_row(tj);
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    if (tj + 1 < ntiles) issue_tile(buf ^ 1, tile_row(tj + 1));
+#if MGP_KNN_TIMING
+  unsigned long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast_ = __builtin_readcyclecounter();
+#endif
+  for (int64_t tj = 0; tj < ntiles; ++tj, buf = buf + 1 == NBUF ? 0 : buf + 1, tcur = tile_after(tcur)) {
+    const int64_t t0 = a.start + tcur * TN;
+    // tile tj has landed: at most the NBUF - 2 tiles behind it are still on their way
+    if (NBUF > 2 && tj + NBUF - 2 < ntiles) {
+      constexpr int N = (NBUF - 2) * IPW;
+      static_assert(N < 64, "vmcnt is six bits");
+      __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | (0x7 << 4) | (0xF << 8));
+    } else {
+      __builtin_amdgcn_s_waitcnt(0);
+    }
+    __syncthreads();  // ... everyone's share has, and nobody still reads the buffer tile tj - 1 was in
+    MGP_KNN_T(0)
+    if (tj + NBUF - 1 < ntiles) {
+      issue_tile(buf == 0 ? NBUF - 1 : buf - 1, a.start + tahead * TN);
+      tahead = tile_after(tahead);
+    }
+    MGP_KNN_T(1)
     const char* tl = tile0 + buf * TN * XSB;
 
-#pragma unroll
-    for (int ct = 0; ct < TN / 32; ++ct) {
-      const int col = ct * 32 + r32;
-      const char* xrow = tl + col * XSB;
+    const int nvalid = (int)(a.n - t0 < (int64_t)TN ? a.n - t0 : (int64_t)TN);  // rows of this tile that exist
+    // one column block of 32 table rows against the wave's two row blocks of 32 queries: three chains per block
+    auto blocks = [&](int ct, f16x (&accr)[2]) {
+      const char* xrow = tl + (ct * 32 + r32) * XSB;
       u4x bhi[NQ], blo[NQ];
+      if constexpr (SWZ) {  // (NQ == 1; (row >> 2) & 3 == (r32 >> 2) & 3 for every column block)
+        const int off = (half ^ ((r32 >> 2) & 3)) << 4;
+        bhi[0] = *reinterpret_cast<const u4x*>(xrow + off);
+        blo[0] = *reinterpret_cast<const u4x*>(xrow + (off ^ 32));
+      } else {
 #pragma unroll
-      for (int j = 0; j < NQ; ++j) {
-        bhi[j] = *reinterpret_cast<const u4x*>(xrow + half * KP + 16 * j);
-        blo[j] = *reinterpret_cast<const u4x*>(xrow + 2 * KP + half * KP + 16 * j);
+        for (int j = 0; j < NQ; ++j) {
+          bhi[j] = *reinterpret_cast<const u4x*>(xrow + half * KP + 16 * j);
+          blo[j] = *reinterpret_cast<const u4x*>(xrow + 2 * KP + half * KP + 16 * j);
+        }
       }
-      f16x accr[2];
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
         f16x acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -413,6 +509,9 @@ __global__ __launch_bounds__(256, (KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void knn_sc
                                                         __builtin_bit_cast(bf8x, bhi[j]), acc, 0, 0, 0);
         accr[rb] = acc;
       }
+    };
+    auto survivors = [&](int ct, const f16x (&accr)[2]) {
+      const int col = ct * 32 + r32;
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
         const f16x acc = accr[rb];
@@ -421,7 +520,7 @@ __global__ __launch_bounds__(256, (KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void knn_sc
         int mx = max(__float_as_int(acc[0]), __float_as_int(acc[1]));
 #pragma unroll
         for (int v = 2; v < 16; v += 2) mx = max(mx, max(__float_as_int(acc[v]), __float_as_int(acc[v + 1])));
-        if (mx > 0 && t0 + col < a.n) {
+        if (mx > 0 && col < nvalid) {
 #pragma unroll
           for (int v = 0; v < 16; ++v) {
             if (acc[v] > 0.f) {
@@ -432,17 +531,48 @@ __global__ __launch_bounds__(256, (KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void knn_sc
           }
         }
       }
+    };
+    if constexpr (KP <= MGP_KNN_PIPE_KP) {
+      // short rows (one matrix instruction per chain): the vector work on a column block's accumulators -- the max over
+      // 16 registers, the survivor branch -- sits behind the NEXT block's matrix instructions instead of waiting for its
+      // own (a second pair of accumulators: the registers are there at KP <= 16)
+      f16x accp[2][2];
+      blocks(0, accp[0]);
+#pragma unroll
+      for (int ct = 1; ct < TN / 32; ++ct) {
+        blocks(ct, accp[ct & 1]);
+        survivors(ct - 1, accp[(ct - 1) & 1]);
+      }
+      survivors(TN / 32 - 1, accp[(TN / 32 - 1) & 1]);
+    } else {
+#pragma unroll
+      for (int ct = 0; ct < TN / 32; ++ct) {
+        f16x accr[2];
+        blocks(ct, accr);
+        survivors(ct, accr);
+      }
     }
 
+    MGP_KNN_T(2)
     // ---- drain: exact re-measurement of the survivors, then the k-best update ------------------
     // Not after every tile: a drain is a chain of dependent global loads (~2 us), and the four
     // waves of the workgroup meet at the next tile's barrier, so one wave draining stalls all;
     // batching makes the waves drain together.  A query collects ~ 64 k / rows_seen candidates per
     // tile, so the interval grows with the rows already seen (queues hold KB_CAP entries).
     if (tj < next_drain && tj + 1 < ntiles) continue;
-    {  // (cadence in ROWS seen by this workgroup: every 64 up to 4 096, then 256 / 512 / 1 024 -- whatever the tile size)
+    {
+#if MGP_KNN_CADENCE
+      // cadence in ROWS the lists have seen (the a.start rows they were made from + this workgroup's): a query collects
+      // ~ k / rows_seen candidates per row, so an interval of rows_seen / MGP_KNN_CADENCE rows brings k / MGP_KNN_CADENCE
+      // (<= 1) per query -- the queues hold KB_CAP = 16 -- and the whole walk ~ MGP_KNN_CADENCE ln(n / start) drains
+      // instead of n / 1 024
+      const int64_t rows = a.start + tj * TN;
+      const int64_t every = rows / MGP_KNN_CADENCE < 64 ? 64 : rows / MGP_KNN_CADENCE > MGP_KNN_CADENCE_MAX ? MGP_KNN_CADENCE_MAX : rows / MGP_KNN_CADENCE;
+#else
+      // (cadence in ROWS seen by this workgroup: every 64 up to 4 096, then 256 / 512 / 1 024 -- whatever the tile size)
       const int64_t rows = tj * TN;
       const int every = rows < 4096 ? 64 : rows < 16384 ? 256 : rows < 65536 ? 512 : 1024;
+#endif
       next_drain = tj + (every / TN > 1 ? every / TN : 1);
     }
     // Lane-per-query: lane r merges the queue of the wave's query r into that query's k-best list,
@@ -477,14 +607,24 @@ __global__ __launch_bounds__(256, (KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void knn_sc
             if (cd < tau) {
               float m1 = -__builtin_inff(), m2 = -__builtin_inff();
               int at = 0;
-              for (int j = 0; j < k; ++j) {
-                const float v = ld[j];
-                if (v > m1) {
-                  m2 = m1;
-                  m1 = v;
-                  at = j;
-                } else if (v > m2) {
-                  m2 = v;
+              // the list in blocks of MGP_KNN_SCAN_BLOCK loads that are all in flight together: one at a time (k is a
+              // run-time value, the loop stays rolled) an insertion was a chain of k memory latencies -- 50 x ~0.7 us
+              // with every other wave of the workgroup waiting at the next tile's barrier, which was most of the
+              // 10 M-row scan's time (round 5)
+              for (int j0 = 0; j0 < k; j0 += MGP_KNN_SCAN_BLOCK) {
+                float lv[MGP_KNN_SCAN_BLOCK];
+#pragma unroll
+                for (int u = 0; u < MGP_KNN_SCAN_BLOCK; ++u) lv[u] = ld[min(j0 + u, k - 1)];
+#pragma unroll
+                for (int u = 0; u < MGP_KNN_SCAN_BLOCK; ++u) {
+                  const float v = j0 + u < k ? lv[u] : -__builtin_inff();
+                  if (v > m1) {
+                    m2 = m1;
+                    m1 = v;
+                    at = j0 + u;
+                  } else if (v > m2) {
+                    m2 = v;
+                  }
                 }
               }
               ld[at] = cd;
@@ -509,23 +649,36 @@ __global__ __launch_bounds__(256, (KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void knn_sc
         }
       }
     }
+    MGP_KNN_T(3)
   }
+#if MGP_KNN_TIMING
+  if (lane == 0)
+    for (int t = 0; t < 8; ++t) atomicAdd(&g_knn_timing[t], tacc_[t]);
+#endif
 }
 
 #ifndef MGP_KNN_TN16
 #define MGP_KNN_TN16 128
 #endif
+#ifndef MGP_KNN_NW16
+#define MGP_KNN_NW16 4
+#endif
+#ifndef MGP_KNN_NBUF16
+#define MGP_KNN_NBUF16 2
+#endif
 template <int KP>
 static int launch_knn_packed_kp(const KnnPackedArgs& a, hipStream_t stream) {
   constexpr int TN = KP <= 16 ? MGP_KNN_TN16 : KNN_TN;
+  constexpr int NW = KP <= 16 ? MGP_KNN_NW16 : 4, NBUF = KP <= 16 ? MGP_KNN_NBUF16 : 2;
+  constexpr int KB_QB = KB_QW * NW;
   const int64_t grid = (a.m + KB_QB - 1) / KB_QB;
-  const size_t lds = 2 * TN * (4 * KP + 16) + (KB_QB * KB_CAP + 2 * KB_QB) * sizeof(float);
+  const size_t lds = NBUF * TN * (4 * KP + (MGP_KNN_SWIZZLE && KP == 16 ? 0 : 16)) + (KB_QB * KB_CAP + 2 * KB_QB) * sizeof(float);
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_scan_bf16x3_kernel<KP, TN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_scan_bf16x3_kernel<KP, TN, NW, NBUF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return -(1000 + (int)e);
   }
-  hipLaunchKernelGGL((knn_scan_bf16x3_kernel<KP, TN>), dim3((unsigned)grid), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((knn_scan_bf16x3_kernel<KP, TN, NW, NBUF>), dim3((unsigned)grid), dim3(64 * NW), lds, stream, a);
   MGP_HIP_CHECK_LAUNCH();
   return MGP_OK;
 }
