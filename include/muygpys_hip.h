@@ -400,14 +400,27 @@ int mgp_knn_scan_f32(const float* train, const float* train_sqn, int64_t n, int 
  * hi.hi + hi.lo + lo.hi, error < 2^-14 |q||x|, folded into the threshold) and an
  * exact fp32 difference-form re-measurement of every survivor: exact results,
  * ~4.4 x fewer matrix-pipe cycles than mgp_knn_scan_f32.
- *   packed_train (n, 2 KP) / packed_queries (m, 2 KP), KP = 16 ceil(d / 16): per row
- *       [bf16(x) zero-padded to KP | bf16(x - float(bf16(x))) zero-padded to KP]
+ *   packed_train (n, 2 KP) / packed_queries (m, 2 KP), KP = 16 ceil((d + 2) / 16): per row
+ *       [bf16(x) zero-padded to KP | bf16(x - float(bf16(x))) zero-padded to KP]; slots KP - 2, KP - 1 of each part hold
+ *       the split of (c, 1) in a table row, c = -|x|^2/2 + 2^-14 QMAX |x| (raised by its own split error), and of
+ *       (1, 0) in a query row (the kernel writes -thr into the second one)
  *   best_d IN/OUT: exact squared distances (difference form); other arguments and
  *   the overflow contract as for mgp_knn_scan_f32. */
 int mgp_knn_scan_bf16x3(const float* train, const void* packed_train, const float* train_sqn, int64_t n, int d,
                         const float* queries, const void* packed_queries, const float* query_sqn,
                         const int64_t* self_idx, int64_t m, int k, int64_t start,
                         float* best_d, int32_t* best_i, int32_t* overflow, void* stream);
+/* The same for d <= 8 (BASELINE config 4: d = 8) with TWO chains per block: K = 16 takes eight slots from each half of
+ * the wave, so [q_hi | q_lo] x [x_hi | x_hi] and [q_hi | T_q] x [x_lo | T_x] give hi.hi + lo.hi + hi.lo + the threshold
+ * terms in two matrix instructions (round 5).
+ *   packed_train (n, 24) / packed_queries (m, 24) bf16: per row [hi(8) | lo(8) | T(8)], features zero-padded to 8;
+ *       T of a table row = [hi(c), lo(c), 1, 1, 0, 0, 0, 0] with c = -|x|^2/2 + 2^-14 QMAX |x| (raised by its own
+ *       split error), T of a query row = [1, 1, 0, 0, 0, 0, 0, 0] (the kernel fills slots 2, 3 with -thr).
+ *   Everything else as for mgp_knn_scan_bf16x3; MGP_EUNSUPPORTED for d > 8. */
+int mgp_knn_scan_bf16x2_d8(const float* train, const void* packed_train, const float* train_sqn, int64_t n, int d,
+                           const float* queries, const void* packed_queries, const float* query_sqn,
+                           const int64_t* self_idx, int64_t m, int k, int64_t start,
+                           float* best_d, int32_t* best_i, int32_t* overflow, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Backward pass of the fused hot path (vector-Jacobian product).  Replaces what

@@ -102,6 +102,7 @@ struct KnnPackedArgs {
   int* overflow;                // (m)
   int64_t n, m, start;
   int d, k;
+  int layout = 0;               // 0: rows [hi(KP) | lo(KP)], KP = 16 ceil((d + 2) / 16); 1: d <= 8, rows [hi(8) | lo(8) | T(8)]
 };
 int launch_knn_scan_packed(const KnnPackedArgs&, hipStream_t);
 

@@ -388,6 +388,22 @@ int mgp_knn_scan_bf16x3(const float* train, const void* packed_train, const floa
   return launch_knn_scan_packed(a, S_(st));
 }
 
+int mgp_knn_scan_bf16x2_d8(const float* train, const void* packed_train, const float* train_sqn, int64_t n, int d,
+                           const float* queries, const void* packed_queries, const float* query_sqn,
+                           const int64_t* self_idx, int64_t m, int k, int64_t start, float* best_d, int32_t* best_i,
+                           int32_t* overflow, void* st) {
+  if (n < 0 || m < 0 || d < 1 || k < 1 || start < 0) return MGP_EINVAL;
+  if (d > 8) return MGP_EUNSUPPORTED;
+  if (m == 0 || start >= n) return MGP_OK;
+  if (!train || !packed_train || !train_sqn || !queries || !packed_queries || !query_sqn || !best_d || !best_i ||
+      !overflow)
+    return MGP_EINVAL;
+  KnnPackedArgs a{train, packed_train, train_sqn, queries, packed_queries, query_sqn, self_idx, best_d, best_i,
+                  overflow, n, m, start, d, k};
+  a.layout = 1;
+  return launch_knn_scan_packed(a, S_(st));
+}
+
 #define MGP_DEFINE_COEF(SUF, T)                                                                                     \
   int mgp_fast_coefficients_##SUF(const T* fn, int d, const int64_t* ni, int64_t b, int k, const T* tg, int nm,      \
                                   double eps, const T* nd, int kid, int mid, const T* ls, int lsc, T* coeffs,        \

@@ -356,15 +356,21 @@ __device__ __forceinline__ void neg_thr_split(float qn, float tau, unsigned& hi,
 template <int KP, int TN, int NW, int NBUF>
 __global__ __launch_bounds__(64 * NW, (KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void knn_scan_bf16x3_kernel(KnnPackedArgs a) {
   constexpr int KB_QB = KB_QW * NW;     // queries per workgroup
-  constexpr int RB = 4 * KP;            // bytes of a packed row: KP bf16 hi + KP bf16 lo
+  // KP == 8 (d <= 8: BASELINE config 4): rows [hi(8) | lo(8) | T(8)] and TWO chains per block instead of three -- K = 16
+  // takes eight slots from each half of the wave, so  A = [q_hi | q_lo] x B = [x_hi | x_hi]  is q_hi.x_hi + q_lo.x_hi in
+  // one instruction and  A = [q_hi | T_q] x B = [x_lo | T_x]  adds q_hi.x_lo and the threshold terms
+  // (T_q = [1, 1, -thr_hi, -thr_lo, 0 ..], T_x = [c_hi, c_lo, 1, 1, 0 ..]): the same sum as the three-chain form with
+  // six of its sixteen slots padding, a third less matrix work and 48 instead of 64 staged bytes per row
+  constexpr bool K8 = KP == 8;
+  constexpr int RB = K8 ? 48 : 4 * KP;  // bytes of a packed row: KP bf16 hi + KP bf16 lo (K8: + the eight T slots)
   // KP = 16 (MGP_KNN_SWIZZLE): the staged row is its four 16-byte slots and nothing else -- slot s of row r lies at
   // slot s ^ ((r >> 2) & 3), the transfer's SOURCE address does the permuting (its LDS side is lane-linear) -- which
   // reads as conflict-free as the padded rows (lanes r, r + 4, r + 8, r + 12 of a 16-lane phase share a 16-bank group
   // and now take its four different slots) at 8 transfers per 128-row tile instead of 10 (12 issued)
   constexpr bool SWZ = MGP_KNN_SWIZZLE && KP == 16;
-  constexpr int SPR = SWZ ? RB / 16 : RB / 16 + 1;  // 16-byte slots of a staged row (odd when padded)
+  constexpr int SPR = SWZ || K8 ? RB / 16 : RB / 16 + 1;  // 16-byte slots of a staged row (odd when padded; K8: three)
   constexpr int XSB = SPR * 16;         // LDS row stride in bytes
-  constexpr int NQ = KP / 16;           // 16-byte operand pieces per half row = MFMAs per chain
+  constexpr int NQ = K8 ? 1 : KP / 16;  // 16-byte operand pieces per half row = MFMAs per chain
   constexpr int NPASS = TN * SPR / 64;
   static_assert(TN * SPR % 64 == 0, "tile must be whole wave passes");
   extern __shared__ __attribute__((aligned(16))) char smem[];  // carved by hand, see knn_scan_kernel
@@ -395,23 +401,33 @@ __global__ __launch_bounds__(64 * NW, (KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void kn
   // half-word of the last dword of the last piece of the half-1 lanes.
   u4x ahi[2][NQ], alo[2][NQ];
   float myqn[2];
+  auto set_thr = [&](int rb, float tau) {  // (upper-half lanes) -thr of the row block's query into its operand slots
+    unsigned hi, lo;
+    neg_thr_split(myqn[rb], tau, hi, lo);
+    if constexpr (K8) {
+      alo[rb][0].y = hi | (lo << 16);  // T slots 2, 3
+    } else {
+      ahi[rb][NQ - 1].w = (ahi[rb][NQ - 1].w & 0xFFFFu) | (hi << 16);
+      alo[rb][NQ - 1].w = (alo[rb][NQ - 1].w & 0xFFFFu) | (lo << 16);
+    }
+  };
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb) {
     const int row = w * KB_QW + rb * 32 + r32;
     const int64_t q = qbase + row;
     const char* prow = reinterpret_cast<const char*>(a.packed_queries) + (q < a.m ? q : 0) * (int64_t)RB;
+    if constexpr (K8) {  // ahi = [q_hi | q_lo], alo = [q_hi | T_q] (lower half | upper half of the wave)
+      ahi[rb][0] = *reinterpret_cast<const u4x*>(prow + 16 * half);
+      alo[rb][0] = *reinterpret_cast<const u4x*>(prow + 32 * half);
+    } else {
 #pragma unroll
-    for (int j = 0; j < NQ; ++j) {
-      ahi[rb][j] = *reinterpret_cast<const u4x*>(prow + half * KP + 16 * j);
-      alo[rb][j] = *reinterpret_cast<const u4x*>(prow + 2 * KP + half * KP + 16 * j);
+      for (int j = 0; j < NQ; ++j) {
+        ahi[rb][j] = *reinterpret_cast<const u4x*>(prow + half * KP + 16 * j);
+        alo[rb][j] = *reinterpret_cast<const u4x*>(prow + 2 * KP + half * KP + 16 * j);
+      }
     }
     myqn[rb] = q < a.m ? a.query_sqn[q] : 0.f;
-    if (half == 1) {
-      unsigned hi, lo;
-      neg_thr_split(myqn[rb], tau_s[row], hi, lo);
-      ahi[rb][NQ - 1].w = (ahi[rb][NQ - 1].w & 0xFFFFu) | (hi << 16);
-      alo[rb][NQ - 1].w = (alo[rb][NQ - 1].w & 0xFFFFu) | (lo << 16);
-    }
+    if (half == 1) set_thr(rb, tau_s[row]);
   }
 
   // more than two buffers: every wave issues the same number of transfers per tile (a pass index past the end repeats
@@ -425,7 +441,7 @@ __global__ __launch_bounds__(64 * NW, (KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void kn
       const int p = min(w + NW * it, NPASS - 1);
       const int sigma = 64 * p + lane;
       const int row = sigma / SPR;
-      const int c = SWZ ? (sigma - row * SPR) ^ ((row >> 2) & 3) : min(sigma - row * SPR, SPR - 2);
+      const int c = SWZ ? (sigma - row * SPR) ^ ((row >> 2) & 3) : K8 ? sigma - row * SPR : min(sigma - row * SPR, SPR - 2);
       const int64_t grow = min(t0 + row, a.n - 1);
       lds_dma16(reinterpret_cast<const char*>(a.packed_train) + grow * (int64_t)RB + c * 16,
                 lds_offset(tile0 + buf * TN * XSB) + p * 1024);
@@ -481,7 +497,10 @@ __global__ __launch_bounds__(64 * NW, (KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void kn
     auto blocks = [&](int ct, f16x (&accr)[2]) {
       const char* xrow = tl + (ct * 32 + r32) * XSB;
       u4x bhi[NQ], blo[NQ];
-      if constexpr (SWZ) {  // (NQ == 1; (row >> 2) & 3 == (r32 >> 2) & 3 for every column block)
+      if constexpr (K8) {  // bhi = [x_hi | x_hi], blo = [x_lo | T_x]; 48-byte rows read conflict-free as they are
+        bhi[0] = *reinterpret_cast<const u4x*>(xrow);
+        blo[0] = *reinterpret_cast<const u4x*>(xrow + 16 + 16 * half);
+      } else if constexpr (SWZ) {  // (NQ == 1; (row >> 2) & 3 == (r32 >> 2) & 3 for every column block)
         const int off = (half ^ ((r32 >> 2) & 3)) << 4;
         bhi[0] = *reinterpret_cast<const u4x*>(xrow + off);
         blo[0] = *reinterpret_cast<const u4x*>(xrow + (off ^ 32));
@@ -495,18 +514,25 @@ __global__ __launch_bounds__(64 * NW, (KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void kn
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
         f16x acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if constexpr (K8) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8x, ahi[rb][0]),
+                                                        __builtin_bit_cast(bf8x, bhi[0]), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8x, alo[rb][0]),
+                                                        __builtin_bit_cast(bf8x, blo[0]), acc, 0, 0, 0);
+        } else {
 #pragma unroll
-        for (int j = 0; j < NQ; ++j)
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8x, ahi[rb][j]),
-                                                        __builtin_bit_cast(bf8x, bhi[j]), acc, 0, 0, 0);
+          for (int j = 0; j < NQ; ++j)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8x, ahi[rb][j]),
+                                                          __builtin_bit_cast(bf8x, bhi[j]), acc, 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < NQ; ++j)
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8x, ahi[rb][j]),
-                                                        __builtin_bit_cast(bf8x, blo[j]), acc, 0, 0, 0);
+          for (int j = 0; j < NQ; ++j)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8x, ahi[rb][j]),
+                                                          __builtin_bit_cast(bf8x, blo[j]), acc, 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < NQ; ++j)
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8x, alo[rb][j]),
-                                                        __builtin_bit_cast(bf8x, bhi[j]), acc, 0, 0, 0);
+          for (int j = 0; j < NQ; ++j)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8x, alo[rb][j]),
+                                                          __builtin_bit_cast(bf8x, bhi[j]), acc, 0, 0, 0);
+        }
         accr[rb] = acc;
       }
     };
@@ -641,12 +667,7 @@ __global__ __launch_bounds__(64 * NW, (KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void kn
       __builtin_amdgcn_s_waitcnt(0);
       if (half == 1) {
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-          unsigned hi, lo;
-          neg_thr_split(myqn[rb], tau_s[w * KB_QW + rb * 32 + r32], hi, lo);
-          ahi[rb][NQ - 1].w = (ahi[rb][NQ - 1].w & 0xFFFFu) | (hi << 16);
-          alo[rb][NQ - 1].w = (alo[rb][NQ - 1].w & 0xFFFFu) | (lo << 16);
-        }
+        for (int rb = 0; rb < 2; ++rb) set_thr(rb, tau_s[w * KB_QW + rb * 32 + r32]);
       }
     }
     MGP_KNN_T(3)
@@ -672,7 +693,8 @@ static int launch_knn_packed_kp(const KnnPackedArgs& a, hipStream_t stream) {
   constexpr int NW = KP <= 16 ? MGP_KNN_NW16 : 4, NBUF = KP <= 16 ? MGP_KNN_NBUF16 : 2;
   constexpr int KB_QB = KB_QW * NW;
   const int64_t grid = (a.m + KB_QB - 1) / KB_QB;
-  const size_t lds = NBUF * TN * (4 * KP + (MGP_KNN_SWIZZLE && KP == 16 ? 0 : 16)) + (KB_QB * KB_CAP + 2 * KB_QB) * sizeof(float);
+  constexpr int XSB = KP == 8 ? 48 : 4 * KP + (MGP_KNN_SWIZZLE && KP == 16 ? 0 : 16);  // staged row (see the kernel)
+  const size_t lds = NBUF * TN * XSB + (KB_QB * KB_CAP + 2 * KB_QB) * sizeof(float);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_scan_bf16x3_kernel<KP, TN, NW, NBUF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -689,6 +711,7 @@ int launch_knn_scan_packed(const KnnPackedArgs& a, hipStream_t stream) {
                        (uintptr_t)a.packed_queries;
   if (al % 16 != 0) return MGP_EUNSUPPORTED;
   if (a.n >= (int64_t)1 << 31) return MGP_EUNSUPPORTED;
+  if (a.layout == 1) return a.d <= 8 ? launch_knn_packed_kp<8>(a, stream) : MGP_EUNSUPPORTED;
   switch ((a.d + 2 + 15) / 16 * 16) {  // features + the two threshold slots
     case 16: return launch_knn_packed_kp<16>(a, stream);
     case 32: return launch_knn_packed_kp<32>(a, stream);

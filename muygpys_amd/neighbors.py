@@ -20,6 +20,8 @@ distances carry no cancellation error and ties resolve by distance then index or
 
 from __future__ import annotations
 
+import os
+
 from typing import Tuple
 
 import torch
@@ -119,6 +121,21 @@ class NN_Wrapper:
             packed[:, pos], packed[:, kp + pos] = cls._split_bf16(val)
         return packed
 
+    @classmethod
+    def _pack_bf16_d8(cls, x: torch.Tensor, slot_a, slot_b) -> torch.Tensor:
+        """d <= 8 (mgp_knn_scan_bf16x2_d8): rows [hi(8) | lo(8) | T(8)].  The threshold terms are one product of the T
+        parts: a table row (``slot_a`` = c, ``slot_b`` = 1) carries T = [hi(c), lo(c), 1, 1, 0 ...], a query row
+        (``slot_a`` = 1, ``slot_b`` = 0) T = [1, 1, 0, 0, 0 ...] -- the kernel writes the split of -thr into slots 2, 3."""
+        n, d = x.shape
+        packed = torch.zeros((n, 24), device=x.device, dtype=torch.bfloat16)
+        packed[:, :d], packed[:, 8:8 + d] = cls._split_bf16(x)
+        if torch.is_tensor(slot_a):  # table rows
+            packed[:, 16], packed[:, 17] = cls._split_bf16(slot_a.to(torch.float32))
+            packed[:, 18:20] = 1.0
+        else:  # query rows
+            packed[:, 16:18] = 1.0
+        return packed
+
     def _scan_nns(self, samples, nn_count, exclude=None):
         """Fused MFMA scan (see the module docstring); None when the shape is not covered."""
         if not self._scan_supported(samples, nn_count):
@@ -156,13 +173,17 @@ class NN_Wrapper:
             # through to the exact re-measurement): the packed table is rebuilt only when a batch
             # exceeds the bound it was packed for, with head-room so that it rarely does
             qmax = float(qn.max().sqrt())
+            # d <= 8: the two-chain kernel on 24-slot rows (round 5), else three chains on [hi(KP) | lo(KP)]
+            d8 = self.feature_count <= 8 and os.environ.get("MUYGPYS_HIP_KNN_D8", "1") != "0"  # (0: A/B against the three-chain kernel)
+            pack = self._pack_bf16_d8 if d8 else self._pack_bf16
+            scan = _lib.load().mgp_knn_scan_bf16x2_d8 if d8 else _lib.load().mgp_knn_scan_bf16x3
             if self._packed_train is None or qmax > self._packed_qmax:
                 self._packed_qmax = 1.25 * qmax
                 c = -0.5 * self._sq + (2.0**-14 * self._packed_qmax) * self._sq.sqrt()
                 c = c + 2.0**-15 * c.abs()
-                self._packed_train = self._pack_bf16(self.train, c, 1.0)
-            packed_q = self._pack_bf16(q, 1.0, 0.0)
-            rc = _lib.load().mgp_knn_scan_bf16x3(
+                self._packed_train = pack(self.train, c, 1.0)
+            packed_q = pack(q, 1.0, 0.0)
+            rc = scan(
                 _lib.ptr(self.train), _lib.ptr(self._packed_train), _lib.ptr(self._sq_scan), self.train_count,
                 self.feature_count, _lib.ptr(q), _lib.ptr(packed_q), _lib.ptr(qn), _lib.ptr(ex64), m, k,
                 SCAN_INIT_ROWS, _lib.ptr(best_d), _lib.ptr(best_i), _lib.ptr(overflow), _lib.stream_ptr(),

@@ -169,3 +169,27 @@ def test_spatially_sorted_table_stays_on_the_scan_path():
     rd, ri = ref.topk(16, dim=1, largest=False)
     torch.testing.assert_close(dist[:500].double(), rd, rtol=1e-4, atol=1e-7)
     assert float((idx[:500] == ri).float().mean()) > 0.999
+
+
+@pytest.mark.parametrize("d,k,n,m", [(8, 50, 300000, 4000), (4, 10, 150000, 3000)])
+def test_two_chain_d8_scan_returns_the_three_chain_scans_lists(d, k, n, m, monkeypatch):
+    """d <= 8 runs the two-chain kernel on 24-slot rows (mgp_knn_scan_bf16x2_d8, round 5); MUYGPYS_HIP_KNN_D8=0 keeps
+    the three-chain kernel on [hi(16) | lo(16)] rows.  Both pre-filters feed the same exact re-measurement: the same
+    lists, index for index (enough rows for the drain interval to grow past a tile)."""
+    from muygpys_amd.neighbors import NN_Wrapper
+
+    g = torch.Generator().manual_seed(41 + d)
+    X = torch.randn(n, d, generator=g).cuda()
+    Q = torch.randn(m, d, generator=g).cuda()
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MUYGPYS_HIP_KNN_D8", flag)
+        nn = NN_Wrapper(X, k, scan_kind="bf16x3")
+        out[flag] = nn.get_nns(Q)
+        assert nn._packed_train.shape[1] == (24 if flag == "1" else 32)
+        assert int(nn.last_overflow.sum()) == 0
+    assert torch.equal(out["1"][0], out["0"][0])
+    assert torch.equal(out["1"][1], out["0"][1])
+    ref = torch.cdist(Q[:500].double(), X.double()) ** 2
+    d2, _ = ref.topk(k, dim=1, largest=False)
+    torch.testing.assert_close(out["1"][1][:500].double(), d2, rtol=1e-5, atol=1e-6)
