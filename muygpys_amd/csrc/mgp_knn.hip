@@ -316,7 +316,7 @@ namespace mgp {
 typedef __bf16 bf8x __attribute__((ext_vector_type(8)));
 typedef unsigned int u4x __attribute__((ext_vector_type(4)));
 
-constexpr int KB_QW = 64;     // queries per wave
+constexpr int KB_RB = 32;     // queries per row block (one 32 x 32 matrix tile's rows)
 constexpr int KB_CAP = 16;    // queue entries per query
 #ifndef MGP_KNN_STAGGER
 #define MGP_KNN_STAGGER 64      // 0: every workgroup starts at the first tile, 1: scattered over the table, n > 1: over a window of n tiles
@@ -353,8 +353,11 @@ __device__ __forceinline__ void neg_thr_split(float qn, float tau, unsigned& hi,
 // TN: training rows per staged tile.  64 for the wider rows; 128 at KP = 16 (d <= 14: BASELINE config 4's d = 8), where a
 // 64-row tile is only 12 MFMAs per wave between two workgroup barriers (round 4: the 10 M-point search of config 4 ran at
 // 18 % matrix-pipe occupancy, barrier-bound).
-template <int KP, int TN, int NW, int NBUF>
-__global__ __launch_bounds__(64 * NW, (KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void knn_scan_bf16x3_kernel(KnnPackedArgs a) {
+// RBN: row blocks of 32 queries per wave.  Two everywhere but at KP = 8, where four fit the registers: a staged tile, its
+// barrier, its wait and its LDS-DMA instructions -- a third of a wave's cycles at two -- then serve twice the matrix work
+template <int KP, int TN, int NW, int NBUF, int RBN>
+__global__ __launch_bounds__(64 * NW, (RBN > 2 ? 3 : KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void knn_scan_bf16x3_kernel(KnnPackedArgs a) {
+  constexpr int KB_QW = KB_RB * RBN;    // queries per wave
   constexpr int KB_QB = KB_QW * NW;     // queries per workgroup
   // KP == 8 (d <= 8: BASELINE config 4): rows [hi(8) | lo(8) | T(8)] and TWO chains per block instead of three -- K = 16
   // takes eight slots from each half of the wave, so  A = [q_hi | q_lo] x B = [x_hi | x_hi]  is q_hi.x_hi + q_lo.x_hi in
@@ -385,22 +388,22 @@ __global__ __launch_bounds__(64 * NW, (KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void kn
   const int64_t qbase = (int64_t)blockIdx.x * KB_QB;
   const int d = a.d, k = a.k;
 
-  if (tid < KB_QB) {
-    const int64_t q = qbase + tid;
-    float t = -__builtin_inff();
+  for (int t = tid; t < KB_QB; t += 64 * NW) {
+    const int64_t q = qbase + t;
+    float tau = -__builtin_inff();
     if (q < a.m) {
-      t = a.best_d[q * k];
-      for (int j = 1; j < k; ++j) t = fmaxf(t, a.best_d[q * k + j]);
+      tau = a.best_d[q * k];
+      for (int j = 1; j < k; ++j) tau = fmaxf(tau, a.best_d[q * k + j]);
     }
-    tau_s[tid] = t;
-    q_cnt[tid] = 0;
+    tau_s[t] = tau;
+    q_cnt[t] = 0;
   }
   __syncthreads();
   // A operands: row block rb, lane (r32, half): packed slots [half*KP/2, half*KP/2 + KP/2) of query
   // qbase + 64 w + 32 rb + r32, hi and lo parts.  The -thr slot (packed slot KP-1) is the upper
   // half-word of the last dword of the last piece of the half-1 lanes.
-  u4x ahi[2][NQ], alo[2][NQ];
-  float myqn[2];
+  u4x ahi[RBN][NQ], alo[RBN][NQ];
+  float myqn[RBN];
   auto set_thr = [&](int rb, float tau) {  // (upper-half lanes) -thr of the row block's query into its operand slots
     unsigned hi, lo;
     neg_thr_split(myqn[rb], tau, hi, lo);
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(64 * NW, (KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void kn
     }
   };
 #pragma unroll
-  for (int rb = 0; rb < 2; ++rb) {
+  for (int rb = 0; rb < RBN; ++rb) {
     const int row = w * KB_QW + rb * 32 + r32;
     const int64_t q = qbase + row;
     const char* prow = reinterpret_cast<const char*>(a.packed_queries) + (q < a.m ? q : 0) * (int64_t)RB;
@@ -494,7 +497,8 @@ __global__ __launch_bounds__(64 * NW, (KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void kn
 
     const int nvalid = (int)(a.n - t0 < (int64_t)TN ? a.n - t0 : (int64_t)TN);  // rows of this tile that exist
     // one column block of 32 table rows against the wave's two row blocks of 32 queries: three chains per block
-    auto blocks = [&](int ct, f16x (&accr)[2]) {
+    // (rb0: the first of the two row blocks the call serves)
+    auto blocks = [&](int ct, int rb0, f16x (&accr)[2]) {
       const char* xrow = tl + (ct * 32 + r32) * XSB;
       u4x bhi[NQ], blo[NQ];
       if constexpr (K8) {  // bhi = [x_hi | x_hi], blo = [x_lo | T_x]; 48-byte rows read conflict-free as they are
@@ -512,7 +516,8 @@ __global__ __launch_bounds__(64 * NW, (KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void kn
         }
       }
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
+      for (int r2 = 0; r2 < 2; ++r2) {
+        const int rb = rb0 + r2;
         f16x acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if constexpr (K8) {
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8x, ahi[rb][0]),
@@ -533,14 +538,15 @@ __global__ __launch_bounds__(64 * NW, (KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void kn
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8x, alo[rb][j]),
                                                           __builtin_bit_cast(bf8x, bhi[j]), acc, 0, 0, 0);
         }
-        accr[rb] = acc;
+        accr[r2] = acc;
       }
     };
-    auto survivors = [&](int ct, const f16x (&accr)[2]) {
+    auto survivors = [&](int ct, int rb0, const f16x (&accr)[2]) {
       const int col = ct * 32 + r32;
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
-        const f16x acc = accr[rb];
+      for (int r2 = 0; r2 < 2; ++r2) {
+        const int rb = rb0 + r2;
+        const f16x acc = accr[r2];
         // any accumulator positive?  as integers (a positive float is a positive int32): v_max3_i32
         // without the NaN-quieting canonicalisation fmaxf would put in front of every operand
         int mx = max(__float_as_int(acc[0]), __float_as_int(acc[1]));
@@ -558,24 +564,35 @@ __global__ __launch_bounds__(64 * NW, (KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void kn
         }
       }
     };
-    if constexpr (KP <= MGP_KNN_PIPE_KP) {
+    if constexpr (RBN == 4) {
+      // two pairs of row blocks, each pair's vector work behind the other pair's matrix instructions
+      f16x accA[2], accB[2];
+#pragma unroll
+      for (int ct = 0; ct < TN / 32; ++ct) {
+        blocks(ct, 0, accA);
+        if (ct > 0) survivors(ct - 1, 2, accB);
+        blocks(ct, 2, accB);
+        survivors(ct, 0, accA);
+      }
+      survivors(TN / 32 - 1, 2, accB);
+    } else if constexpr (KP <= MGP_KNN_PIPE_KP) {
       // short rows (one matrix instruction per chain): the vector work on a column block's accumulators -- the max over
       // 16 registers, the survivor branch -- sits behind the NEXT block's matrix instructions instead of waiting for its
       // own (a second pair of accumulators: the registers are there at KP <= 16)
       f16x accp[2][2];
-      blocks(0, accp[0]);
+      blocks(0, 0, accp[0]);
 #pragma unroll
       for (int ct = 1; ct < TN / 32; ++ct) {
-        blocks(ct, accp[ct & 1]);
-        survivors(ct - 1, accp[(ct - 1) & 1]);
+        blocks(ct, 0, accp[ct & 1]);
+        survivors(ct - 1, 0, accp[(ct - 1) & 1]);
       }
-      survivors(TN / 32 - 1, accp[(TN / 32 - 1) & 1]);
+      survivors(TN / 32 - 1, 0, accp[(TN / 32 - 1) & 1]);
     } else {
 #pragma unroll
       for (int ct = 0; ct < TN / 32; ++ct) {
         f16x accr[2];
-        blocks(ct, accr);
-        survivors(ct, accr);
+        blocks(ct, 0, accr);
+        survivors(ct, 0, accr);
       }
     }
 
@@ -606,10 +623,14 @@ __global__ __launch_bounds__(64 * NW, (KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void kn
     // queries are pending.  Round e handles every lane's e-th queue entry: exact squared distance
     // (d/4 independent 16-byte loads from each of the two rows), then one pass over the list that
     // finds its largest and second largest entry; a closer candidate replaces the largest.
-    const int qslot = w * KB_QW + lane;
+    bool drained = false;
+#pragma nounroll
+    for (int qh = 0; qh < RBN / 2; ++qh) {  // 64 of the wave's queries at a time
+    const int qslot = w * KB_QW + 64 * qh + lane;
     const int64_t q = qbase + qslot;
     int cnt = q < a.m ? q_cnt[qslot] : 0;
     if (__any(cnt > 0)) {
+      drained = true;
       if (cnt > KB_CAP) {
         a.overflow[q] = 1;
         cnt = KB_CAP;
@@ -664,10 +685,13 @@ __global__ __launch_bounds__(64 * NW, (KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void kn
         tau_s[qslot] = tau;
         q_cnt[qslot] = 0;
       }
+    }
+    }
+    if (drained) {  // (wave-uniform)
       __builtin_amdgcn_s_waitcnt(0);
       if (half == 1) {
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) set_thr(rb, tau_s[w * KB_QW + rb * 32 + r32]);
+        for (int rb = 0; rb < RBN; ++rb) set_thr(rb, tau_s[w * KB_QW + rb * 32 + r32]);
       }
     }
     MGP_KNN_T(3)
@@ -687,20 +711,23 @@ __global__ __launch_bounds__(64 * NW, (KP <= 16 ? 4 : KP <= 48 ? 3 : 2)) void kn
 #ifndef MGP_KNN_NBUF16
 #define MGP_KNN_NBUF16 2
 #endif
-template <int KP>
+#ifndef MGP_KNN_RB4_MIN_QUERIES
+#define MGP_KNN_RB4_MIN_QUERIES (1 << 20)
+#endif
+template <int KP, int RBN = 2>
 static int launch_knn_packed_kp(const KnnPackedArgs& a, hipStream_t stream) {
   constexpr int TN = KP <= 16 ? MGP_KNN_TN16 : KNN_TN;
   constexpr int NW = KP <= 16 ? MGP_KNN_NW16 : 4, NBUF = KP <= 16 ? MGP_KNN_NBUF16 : 2;
-  constexpr int KB_QB = KB_QW * NW;
+  constexpr int KB_QB = KB_RB * RBN * NW;
   const int64_t grid = (a.m + KB_QB - 1) / KB_QB;
   constexpr int XSB = KP == 8 ? 48 : 4 * KP + (MGP_KNN_SWIZZLE && KP == 16 ? 0 : 16);  // staged row (see the kernel)
   const size_t lds = NBUF * TN * XSB + (KB_QB * KB_CAP + 2 * KB_QB) * sizeof(float);
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_scan_bf16x3_kernel<KP, TN, NW, NBUF>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_scan_bf16x3_kernel<KP, TN, NW, NBUF, RBN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return -(1000 + (int)e);
   }
-  hipLaunchKernelGGL((knn_scan_bf16x3_kernel<KP, TN, NW, NBUF>), dim3((unsigned)grid), dim3(64 * NW), lds, stream, a);
+  hipLaunchKernelGGL((knn_scan_bf16x3_kernel<KP, TN, NW, NBUF, RBN>), dim3((unsigned)grid), dim3(64 * NW), lds, stream, a);
   MGP_HIP_CHECK_LAUNCH();
   return MGP_OK;
 }
@@ -711,7 +738,15 @@ int launch_knn_scan_packed(const KnnPackedArgs& a, hipStream_t stream) {
                        (uintptr_t)a.packed_queries;
   if (al % 16 != 0) return MGP_EUNSUPPORTED;
   if (a.n >= (int64_t)1 << 31) return MGP_EUNSUPPORTED;
-  if (a.layout == 1) return a.d <= 8 ? launch_knn_packed_kp<8>(a, stream) : MGP_EUNSUPPORTED;
+  if (a.layout == 1) {
+    if (a.d > 8) return MGP_EUNSUPPORTED;
+    // four row blocks per wave (512 queries per workgroup, three workgroups per CU): 5-6 % faster once the grid is many
+    // rounds of the chip's 768 slots (2 M queries x 10 M rows: 1.78 -> 1.68 s), slower below (400 k queries = 782
+    // workgroups: 387 -> 463 ms, a second round for fourteen of them)
+    const char* e = getenv("MUYGPYS_HIP_KNN_RB4_MIN");  // (tests: 0 forces the four-block kernel)
+    const int64_t rb4_min = e ? atoll(e) : (int64_t)MGP_KNN_RB4_MIN_QUERIES;
+    return a.m >= rb4_min ? launch_knn_packed_kp<8, 4>(a, stream) : launch_knn_packed_kp<8, 2>(a, stream);
+  }
   switch ((a.d + 2 + 15) / 16 * 16) {  // features + the two threshold slots
     case 16: return launch_knn_packed_kp<16>(a, stream);
     case 32: return launch_knn_packed_kp<32>(a, stream);

@@ -193,3 +193,24 @@ def test_two_chain_d8_scan_returns_the_three_chain_scans_lists(d, k, n, m, monke
     ref = torch.cdist(Q[:500].double(), X.double()) ** 2
     d2, _ = ref.topk(k, dim=1, largest=False)
     torch.testing.assert_close(out["1"][1][:500].double(), d2, rtol=1e-5, atol=1e-6)
+
+
+def test_four_row_block_scan_returns_the_same_lists(monkeypatch):
+    """From 2**20 queries on, the d <= 8 scan runs four row blocks of 32 queries per wave (512 per workgroup);
+    MUYGPYS_HIP_KNN_RB4_MIN=0 forces that kernel at any size: the same lists as the two-block kernel, index for index
+    (a query count that is not a multiple of 512: the last workgroup is partly empty)."""
+    from muygpys_amd.neighbors import NN_Wrapper
+
+    g = torch.Generator().manual_seed(77)
+    X = torch.randn(200000, 8, generator=g).cuda()
+    Q = torch.randn(5000 + 37, 8, generator=g).cuda()
+    out = {}
+    for flag in ("0", str(1 << 40)):
+        monkeypatch.setenv("MUYGPYS_HIP_KNN_RB4_MIN", flag)
+        nn = NN_Wrapper(X, 50, scan_kind="bf16x3")
+        out[flag] = nn.get_nns(Q)
+        assert int(nn.last_overflow.sum()) == 0
+    (i4, d4), (i2, d2) = out["0"], out[str(1 << 40)]
+    assert torch.equal(d4, d2) and float((i4 == i2).float().mean()) > 0.9999
+    ref = torch.cdist(Q[:300].double(), X.double()) ** 2
+    torch.testing.assert_close(d4[:300].double(), ref.topk(50, dim=1, largest=False)[0], rtol=1e-5, atol=1e-6)
