@@ -327,6 +327,9 @@ constexpr int KB_CAP = 16;    // queue entries per query
 #ifndef MGP_KNN_CADENCE
 #define MGP_KNN_CADENCE 64      // drain interval = rows seen / this (0: the fixed schedule of rounds 1-4)
 #endif
+#ifndef MGP_KNN_REGSTAGE
+#define MGP_KNN_REGSTAGE 1
+#endif
 #ifndef MGP_KNN_SWIZZLE
 #define MGP_KNN_SWIZZLE 1
 #endif
@@ -450,6 +453,29 @@ __global__ __launch_bounds__(64 * NW, (RBN > 2 ? 3 : KP <= 16 ? 4 : KP <= 48 ? 3
                 lds_offset(tile0 + buf * TN * XSB) + p * 1024);
     }
   };
+  // MGP_KNN_REGSTAGE: the next tile through registers instead -- plain 16-byte loads requested right behind the barrier,
+  // written to the other buffer after this tile's matrix blocks.  An LDS-DMA instruction next to the other waves' matrix
+  // instructions takes a few hundred cycles to ISSUE (tools/knn_timing.py: at d = 40 a wave spent as long issuing its
+  // three or four per tile as in the tile's 36 matrix instructions); a load into registers does not
+  constexpr bool RSTG = MGP_KNN_REGSTAGE && NBUF == 2;
+  u4x stg[RSTG ? IPW : 1];
+  auto load_tile = [&](int64_t t0) {
+#pragma unroll
+    for (int it = 0; it < IPW; ++it) {
+      const int p = min(w + NW * it, NPASS - 1);
+      const int sigma = 64 * p + lane;
+      const int row = sigma / SPR;
+      const int c = SWZ ? (sigma - row * SPR) ^ ((row >> 2) & 3) : K8 ? sigma - row * SPR : min(sigma - row * SPR, SPR - 2);
+      const int64_t grow = min(t0 + row, a.n - 1);
+      stg[RSTG ? it : 0] = *reinterpret_cast<const u4x*>(reinterpret_cast<const char*>(a.packed_train) + grow * (int64_t)RB + c * 16);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < IPW; ++it)
+      if (w + NW * it < NPASS)
+        *reinterpret_cast<u4x*>(tile0 + buf * TN * XSB + (w + NW * it) * 1024 + lane * 16) = stg[RSTG ? it : 0];
+  };
   const int64_t ntiles = (a.n - a.start + TN - 1) / TN;  // staggered walk, see knn_scan_kernel
 #if MGP_KNN_STAGGER == 1
   const int64_t tile_off = ((int64_t)blockIdx.x * 7919) % ntiles;
@@ -465,11 +491,17 @@ __global__ __launch_bounds__(64 * NW, (RBN > 2 ? 3 : KP <= 16 ? 4 : KP <= 48 ? 3
   // instructions, twice per tile -- most of the 19 % of a wave's cycles the tile issue took at KP = 16, round 5)
   auto tile_after = [&](int64_t t) { return t + 1 == ntiles ? (int64_t)0 : t + 1; };
   int64_t tcur = tile_off, tahead = tile_off;  // tile index of step tj / of the next tile to request
-  for (int t = 0; t < NBUF - 1; ++t)
-    if (t < ntiles) {
-      issue_tile(t, a.start + tahead * TN);
-      tahead = tile_after(tahead);
-    }
+  if constexpr (RSTG) {
+    load_tile(a.start + tahead * TN);
+    tahead = tile_after(tahead);
+    store_tile(0);
+  } else {
+    for (int t = 0; t < NBUF - 1; ++t)
+      if (t < ntiles) {
+        issue_tile(t, a.start + tahead * TN);
+        tahead = tile_after(tahead);
+      }
+  }
   int buf = 0;
   int64_t next_drain = 0;
 #if MGP_KNN_TIMING
@@ -479,7 +511,9 @@ __global__ __launch_bounds__(64 * NW, (RBN > 2 ? 3 : KP <= 16 ? 4 : KP <= 48 ? 3
   for (int64_t tj = 0; tj < ntiles; ++tj, buf = buf + 1 == NBUF ? 0 : buf + 1, tcur = tile_after(tcur)) {
     const int64_t t0 = a.start + tcur * TN;
     // tile tj has landed: at most the NBUF - 2 tiles behind it are still on their way
-    if (NBUF > 2 && tj + NBUF - 2 < ntiles) {
+    if constexpr (RSTG) {
+      // (the barrier below orders this wave's LDS writes of the tile before everyone's reads)
+    } else if (NBUF > 2 && tj + NBUF - 2 < ntiles) {
       constexpr int N = (NBUF - 2) * IPW;
       static_assert(N < 64, "vmcnt is six bits");
       __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | (0x7 << 4) | (0xF << 8));
@@ -488,8 +522,10 @@ __global__ __launch_bounds__(64 * NW, (RBN > 2 ? 3 : KP <= 16 ? 4 : KP <= 48 ? 3
     }
     __syncthreads();  // ... everyone's share has, and nobody still reads the buffer tile tj - 1 was in
     MGP_KNN_T(0)
-    if (tj + NBUF - 1 < ntiles) {
-      issue_tile(buf == 0 ? NBUF - 1 : buf - 1, a.start + tahead * TN);
+    const bool more = tj + NBUF - 1 < ntiles;
+    if (more) {
+      if constexpr (RSTG) load_tile(a.start + tahead * TN);
+      else issue_tile(buf == 0 ? NBUF - 1 : buf - 1, a.start + tahead * TN);
       tahead = tile_after(tahead);
     }
     MGP_KNN_T(1)
@@ -596,6 +632,9 @@ __global__ __launch_bounds__(64 * NW, (RBN > 2 ? 3 : KP <= 16 ? 4 : KP <= 48 ? 3
       }
     }
 
+    if constexpr (RSTG) {
+      if (more) store_tile(buf ^ 1);  // (everyone passed this step's barrier: nobody reads that buffer any more)
+    }
     MGP_KNN_T(2)
     // ---- drain: exact re-measurement of the survivors, then the k-best update ------------------
     // Not after every tile: a drain is a chain of dependent global loads (~2 us), and the four
