@@ -293,6 +293,9 @@ def make_step(cfg, w, route: str, path: str, use_packed: bool):
     from muygpys_amd.config import config
 
     config.state.lazy_tensors = True  # what integration.install() switches on
+    # the not-positive-definite counter of a launch is read when the next evaluation arrives instead of right behind
+    # the launch (config.py; one device synchronisation per evaluation otherwise); main() flushes the last one
+    config.state.check_spd = "deferred"
     kfn = {"rbf": K._rbf_fn, "matern05": K._matern_05_fn, "matern15": K._matern_15_fn, "matern25": K._matern_25_fn,
            "matern_inf": K._matern_inf_fn}[cfg["kernel"]]
     metric = T._l2 if cfg["metric"] == "l2" else T._F2
@@ -355,6 +358,9 @@ def time_steps(step, warmup: int, steps: int, dist, backend: str, dev):
         if gc_was:
             gc.enable()
     kern_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+    from muygpys_amd import _lib
+
+    _lib.flush_spd_checks()  # (drop-in routes: the last step's not-positive-definite counter, see make_step)
     ranks_seen = 1
     if dist is not None:
         cdev = dev if backend == "nccl" else "cpu"

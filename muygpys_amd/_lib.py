@@ -261,18 +261,50 @@ def require_cuda(*tensors):
             raise TypeError("hip backend functions take torch tensors on a ROCm device ('cuda')")
 
 
+_SPD_PENDING = []   # deferred mode: [(pinned int32 tensor, event, what)] of the launch not yet looked at
+_SPD_SLOTS = []     # two pinned slots, used in turn
+
+
+def _raise_not_spd(bad: int, what: str) -> None:
+    import numpy as np
+
+    raise np.linalg.LinAlgError(
+        f"{what}: {bad} neighbourhood(s) are not positive definite (singular or indefinite K + noise)"
+    )
+
+
+def flush_spd_checks() -> None:
+    """Deferred mode (config.state.check_spd == "deferred"): look at the counter of the last checked launch now."""
+    while _SPD_PENDING:
+        host, event, what = _SPD_PENDING.pop(0)
+        event.synchronize()
+        bad = int(host[0])
+        if bad:
+            _raise_not_spd(bad, what + " (reported one call late: deferred check)")
+
+
 def raise_if_not_spd(info, what: str) -> None:
     """Reference behaviour for an unsolvable local system: numpy.linalg.LinAlgError from
     ``linalg.solve`` (_src/gp/muygps/numpy.py:37).  ``info`` is the device counter the kernels
     increment per neighbourhood with a non-positive Cholesky pivot."""
     from muygpys_amd.config import config
 
-    if info is None or not config.state.check_spd:
+    mode = config.state.check_spd
+    if info is None or not mode:
+        return
+    if mode == "deferred":
+        import torch
+
+        flush_spd_checks()  # the previous launch's counter: its copy is behind us on the stream
+        if len(_SPD_SLOTS) < 2:
+            _SPD_SLOTS.append(torch.zeros(1, dtype=torch.int32).pin_memory())
+        host = _SPD_SLOTS[0]
+        _SPD_SLOTS.reverse()
+        host.copy_(info, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        _SPD_PENDING.append((host, event, what))
         return
     bad = int(info.item())
     if bad:
-        import numpy as np
-
-        raise np.linalg.LinAlgError(
-            f"{what}: {bad} neighbourhood(s) are not positive definite (singular or indefinite K + noise)"
-        )
+        _raise_not_spd(bad, what)

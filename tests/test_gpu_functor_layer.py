@@ -147,6 +147,47 @@ def test_singular_neighbourhood_raises_linalgerror():
             m.posterior_mean(Kin, Kc, y_nn)
 
 
+def test_deferred_spd_check_raises_one_call_late_or_at_the_flush():
+    """config.state.check_spd = "deferred": the counter of a launch is looked at when the next checked call arrives
+    (or at _lib.flush_spd_checks()), so a loop of evaluations does not wait for every launch; the singular
+    neighbourhood's outputs are NaN meanwhile and the same LinAlgError is raised, one call late."""
+    from muygpys_amd import _lib
+    from muygpys_amd.config import config
+    from muygpys_amd.gp import MuyGPS
+    from muygpys_amd.gp.deformation import F2, Isotropy
+    from muygpys_amd.gp.hyperparameter import Parameter
+    from muygpys_amd.gp.kernels import RBF
+    from muygpys_amd.gp.noise import HomoscedasticNoise
+
+    g = torch.Generator().manual_seed(21)
+    X = torch.randn(50, 4, generator=g, dtype=torch.float64).cuda()
+    y = torch.randn(50, generator=g, dtype=torch.float64).cuda()
+    bad_ni = torch.tensor([[1, 1, 2, 3], [4, 5, 6, 7]], device="cuda")  # duplicate neighbour, zero nugget
+    good_ni = torch.tensor([[1, 9, 2, 3], [4, 5, 6, 7]], device="cuda")
+    bi = torch.tensor([0, 8], device="cuda")
+    m = MuyGPS(kernel=RBF(deformation=Isotropy(F2, length_scale=Parameter(1.0))), noise=HomoscedasticNoise(0.0))
+
+    def mean_of(ni):
+        cross, pair, y_nn = m.make_predict_tensors(bi, ni, None, X, y)
+        return m.posterior_mean(m.kernel(pair), m.kernel(cross), y_nn)
+
+    before = config.state.check_spd
+    config.state.check_spd = "deferred"
+    try:
+        out = mean_of(bad_ni)                      # no error yet ...
+        assert bool(torch.isnan(torch.as_tensor(out)[0]).all()) and bool(torch.isfinite(torch.as_tensor(out)[1]).all())
+        with pytest.raises(np.linalg.LinAlgError, match="one call late"):
+            mean_of(good_ni)                       # ... the next checked call reports it
+        _lib.flush_spd_checks()                    # (the good call's own counter: clean)
+        mean_of(bad_ni)
+        with pytest.raises(np.linalg.LinAlgError):
+            _lib.flush_spd_checks()
+        _lib.flush_spd_checks()                    # nothing pending: no error
+    finally:
+        config.state.check_spd = before
+        _lib._SPD_PENDING.clear()
+
+
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 @pytest.mark.parametrize("materialize", [False, True])
 def test_free_smoothness_model_matches_reference(dtype, materialize):
