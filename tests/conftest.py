@@ -17,6 +17,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _process_wide_state_is_put_back():
+    """config.state survives a test (the library is one process-wide backend): a test that changes the
+    not-positive-definite check mode or the lazy-tensor switch must not decide what the tests after it see."""
+    from muygpys_amd.config import config as mconfig
+
+    spd, lazy = mconfig.state.check_spd, mconfig.state.lazy_tensors
+    yield
+    mconfig.state.check_spd, mconfig.state.lazy_tensors = spd, lazy
+    from muygpys_amd import _lib
+
+    _lib._SPD_PENDING.clear()
+
+
 def _npz_names():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
 
