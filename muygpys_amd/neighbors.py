@@ -144,22 +144,29 @@ class NN_Wrapper:
         m, k = q.shape[0], int(nn_count)
         if m == 0:
             return None
-        # exact k-best over the first rows of the table (Gram-form distances, like the scan's)
-        head = self.train[:SCAN_INIT_ROWS]
+        # exact k-best over the first rows of the table (Gram-form distances, like the scan's).  How many rows: a query
+        # collects ~ k / rows-seen candidates per row and its queue (16 entries) is emptied once per tile at the
+        # earliest, so the first tile -- 128 rows for the short packed rows, 64 otherwise -- should bring two at most
+        # (P(Poisson(2) >= 17) ~ 5e-11): tile * k / 2 rows, in steps of 1 024, SCAN_INIT_ROWS at most.  torch's topk
+        # over these rows was a fifth of the search's time at 1 M x 1 M, k = 30 (round 5)
+        tile_rows = 128 if (self.scan_kind == "bf16x3" and self.feature_count + 2 <= 16) else 64
+        init_rows = min(SCAN_INIT_ROWS, max(1024, -(-(tile_rows * k // 2) // 1024) * 1024))
+        head = self.train[:init_rows]
         best_d = torch.empty((m, k), device=q.device, dtype=torch.float32)
         best_i = torch.empty((m, k), device=q.device, dtype=torch.int32)
         qn = (q * q).sum(1)
-        for s in range(0, m, self.chunk):
-            qq = q[s:s + self.chunk]
-            d2 = self._sq[None, :SCAN_INIT_ROWS] - 2.0 * (qq @ head.T) + qn[s:s + self.chunk, None]
+        init_chunk = max(self.chunk, 16384)  # (a 16 384 x 4 096 distance block is 268 MB; fewer, larger launches)
+        for s in range(0, m, init_chunk):
+            qq = q[s:s + init_chunk]
+            d2 = self._sq[None, :init_rows] - 2.0 * (qq @ head.T) + qn[s:s + init_chunk, None]
             if exclude is not None:
-                ex = exclude[s:s + self.chunk]
-                inside = ex < SCAN_INIT_ROWS
+                ex = exclude[s:s + init_chunk]
+                inside = ex < init_rows
                 rows = torch.arange(qq.shape[0], device=q.device)[inside]
                 d2[rows, ex[inside]] = float("inf")
             bd, bi = d2.topk(k, dim=1, largest=False)
-            best_d[s:s + self.chunk] = bd
-            best_i[s:s + self.chunk] = bi.to(torch.int32)
+            best_d[s:s + init_chunk] = bd
+            best_i[s:s + init_chunk] = bi.to(torch.int32)
         overflow = torch.zeros((m,), device=q.device, dtype=torch.int32)
         ex64 = None if exclude is None else exclude.to(torch.int64).contiguous()
         if self.scan_kind == "bf16x3":
@@ -186,12 +193,12 @@ class NN_Wrapper:
             rc = scan(
                 _lib.ptr(self.train), _lib.ptr(self._packed_train), _lib.ptr(self._sq_scan), self.train_count,
                 self.feature_count, _lib.ptr(q), _lib.ptr(packed_q), _lib.ptr(qn), _lib.ptr(ex64), m, k,
-                SCAN_INIT_ROWS, _lib.ptr(best_d), _lib.ptr(best_i), _lib.ptr(overflow), _lib.stream_ptr(),
+                init_rows, _lib.ptr(best_d), _lib.ptr(best_i), _lib.ptr(overflow), _lib.stream_ptr(),
             )
         else:
             rc = _lib.load().mgp_knn_scan_f32(
                 _lib.ptr(self.train), _lib.ptr(self._sq_scan), self.train_count, self.feature_count,
-                _lib.ptr(q), _lib.ptr(qn), _lib.ptr(ex64), m, k, SCAN_INIT_ROWS,
+                _lib.ptr(q), _lib.ptr(qn), _lib.ptr(ex64), m, k, init_rows,
                 _lib.ptr(best_d), _lib.ptr(best_i), _lib.ptr(overflow), _lib.stream_ptr(),
             )
         if rc == -2:  # MGP_EUNSUPPORTED (alignment)
