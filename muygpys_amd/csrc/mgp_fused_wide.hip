@@ -38,6 +38,9 @@
 #ifndef MGP_WIDE_GC
 #define MGP_WIDE_GC 2
 #endif
+#ifndef MGP_WIDE_SPLIT
+#define MGP_WIDE_SPLIT 1  // the first wave stops at its last lower-triangle group (0: both waves run every group)
+#endif
 
 namespace mgp {
 
@@ -45,6 +48,13 @@ struct WideGeom {
   int q, dst, xs, vec_ok;
 };
 
+// NG (round 5): the 16-byte column groups of the system, 4 NG >= k + 1 + R slots -- query and responses sit in the last
+// 1 + R of THEM (q = 4 NG - 1 - R, the launcher's choice), the row registers and every elimination step's trailing
+// update end there (k = 100: 26 groups instead of 32; the lanes past 4 NG carry rows nobody reads).  And the first
+// wave -- rows 0 .. 63 -- stops at group 15 and at block 15: its rows have no lower-triangle entry beyond, it only
+// keeps the workgroup's barriers from there on (two copies of the elimination, one per wave, compile-time limits:
+// a uniform run-time test inside the unrolled trailing update costs more than it saves, see below).
+template <int NG>
 __global__ __launch_bounds__(128, 2) void fused_wide_kernel(FusedArgs a, WideGeom g) {
   using T = float;
   constexpr int NP = 128;
@@ -198,7 +208,7 @@ __global__ __launch_bounds__(128, 2) void fused_wide_kernel(FusedArgs a, WideGeo
 #endif
     const T mydiag = i < k ? T(1) + myeps : (i <= q ? T(1) : T(0));
     auto tri = [](int r) { const int a = r >> 2; return (a + 1) * (8 * a + 4 * (r & 3)); };
-    V A[NP / E];
+    V A[NG];
     __syncthreads();  // every lane is done reading the feature tile (the exchange matrix aliases it)
     {
       int i3 = i;
@@ -218,7 +228,7 @@ __global__ __launch_bounds__(128, 2) void fused_wide_kernel(FusedArgs a, WideGeo
         if (i3 <= q + 1 + r) tile[tri(q + 1 + r) + i3] = i3 < k ? targets[mytg * (int64_t)R + r] : T(0);
       __syncthreads();
 #pragma unroll
-      for (int c4 = 0; c4 < NP / E; ++c4) A[c4] = *reinterpret_cast<const V*>(tile + myrow + c4 * E);
+      for (int c4 = 0; c4 < NG; ++c4) A[c4] = *reinterpret_cast<const V*>(tile + myrow + c4 * E);
     }
 
 #if MGP_WIDE_PRIO
@@ -239,10 +249,17 @@ __global__ __launch_bounds__(128, 2) void fused_wide_kernel(FusedArgs a, WideGeo
     bool bad = false;
     T* rawbuf = colbuf;            // 128 x 4 raw block entries (row-major: lane i at rawbuf + 4 i)
     T* ubuf = colbuf + NP * E;     // 4 x 128 eliminated entries, transposed: ubuf[m * 128 + i]
-    static_for<NP / E>([&](auto jbc) {
+    auto eliminate = [&](auto glc) {
+    constexpr int GL = decltype(glc)::value;  // this wave's rows have lower-triangle entries in groups 0 .. GL - 1
+    static_for<NG>([&](auto jbc) {
       constexpr int jb = decltype(jbc)::value;
       constexpr int J0 = jb * E;
-      if (J0 < k) {  // uniform
+      if constexpr (jb >= GL) {
+        if (J0 < k) {  // (uniform) the other wave's block: keep its two barriers
+          __syncthreads();
+          __syncthreads();
+        }
+      } else if (J0 < k) {  // uniform
         V pg = A[jb];
         const int mlim = min(E, k - J0);  // columns of this block that are eliminated (the last block may be short)
         *reinterpret_cast<V*>(rawbuf + i * E) = pg;
@@ -287,31 +304,34 @@ __global__ __launch_bounds__(128, 2) void fused_wide_kernel(FusedArgs a, WideGeo
         // followed at once by its two FMAs pays a full LDS round trip per 16 bytes)
         constexpr int GC = MGP_WIDE_GC;
 #pragma unroll
-        for (int c0 = jb; c0 < NP / E; c0 += GC) {
+        for (int c0 = jb; c0 < GL; c0 += GC) {
           V cv[GC][E];
 #pragma unroll
           for (int g2 = 0; g2 < GC; ++g2)
 #pragma unroll
             for (int m = 0; m < E; ++m)
-              if (c0 + g2 < NP / E) cv[g2][m] = *reinterpret_cast<const V*>(ubuf + m * NP + (c0 + g2) * E);
+              if (c0 + g2 < GL) cv[g2][m] = *reinterpret_cast<const V*>(ubuf + m * NP + (c0 + g2) * E);
 #pragma unroll
           for (int g2 = 0; g2 < GC; ++g2)
 #pragma unroll
             for (int m = 0; m < E; ++m)
-              if (c0 + g2 < NP / E) A[c0 + g2] = cv[g2][m] * V(nt[m]) + A[c0 + g2];
+              if (c0 + g2 < GL) A[c0 + g2] = cv[g2][m] * V(nt[m]) + A[c0 + g2];
         }
       }
     });
+    };
+    if (MGP_WIDE_SPLIT && i < 64) eliminate(ic<(NG < 16 ? NG : 16)>{});  // (wave-uniform: the workgroup's first wave)
+    else eliminate(ic<NG>{});
 
 #if MGP_WIDE_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
     // ---- phase 5: Schur block -> outputs --------------------------------------------------------
     // lane q holds S[q][q]; lane q+1+r holds S[q+1+r][q] and S[q+1+r][q+1+r]: picked out of the
-    // registers by a compare-select sweep over the last 32 columns (q >= 111 as R <= 16)
+    // registers by a compare-select sweep over the last 32 columns (q >= 4 NG - 17 as R <= 16)
     T aq = T(0), aii = T(0);
 #pragma unroll
-    for (int c = NP - 32; c < NP; ++c) {
+    for (int c = NG * E - 32; c < NG * E; ++c) {
       const T v = A[c / E][c % E];
       aq = c == q ? v : aq;
       aii = c == i ? v : aii;
@@ -322,7 +342,7 @@ __global__ __launch_bounds__(128, 2) void fused_wide_kernel(FusedArgs a, WideGeo
     if (i == q) {
       var[nb] = bad ? num<T>::nan() : aq;
       if (bad && a.info) atomicAdd(a.info, 1);
-    } else if (i > q) {
+    } else if (i > q && i <= q + R) {  // (the lanes past q + R hold no row of the system when 4 NG < 128)
       const int r = i - q - 1;
       mean[nb * R + r] = bad ? num<T>::nan() : -aq;
       if (yk) yk[nb * R + r] = bad ? num<T>::nan() : -aii;
@@ -342,8 +362,15 @@ int launch_fused_wide(const FusedArgs& a, hipStream_t stream) {
     // k = 100: 17.6 vs 4.7, k = 126: 15.6 vs 1.7 M neighbourhoods/s) although it pays for all 128 slots
     if (rows < MGP_WIDE_MIN_ROWS || rows > NP || a.R > 16 || a.d > 64 || a.packed_nn != nullptr || a.coeffs != nullptr)
       return MGP_EUNSUPPORTED;  // more slots / responses / feature stages: the LDS workgroup kernel
+    // column groups: the smallest instantiation that holds the rows (17 .. 32 in steps of 2 or 3)
+#ifdef MGP_WIDE_FORCE_NG32  // (A/B builds: the 128-slot form of rounds 2-4)
+    const int ng = 32;
+#else
+    const int ng = rows <= 68 ? 17 : rows <= 80 ? 20 : rows <= 88 ? 22 : rows <= 96 ? 24 : rows <= 104 ? 26
+                   : rows <= 112 ? 28 : rows <= 120 ? 30 : 32;
+#endif
     WideGeom g;
-    g.q = NP - 1 - a.R;
+    g.q = ng * E - 1 - a.R;
     const int dpad = (a.d + CH - 1) / CH * CH;
     g.dst = dpad < 64 ? dpad : 64;
     g.xs = g.dst + E;
@@ -352,9 +379,18 @@ int launch_fused_wide(const FusedArgs& a, hipStream_t stream) {
     const size_t tile_elems = (size_t)NP * g.xs > TRI ? (size_t)NP * g.xs : TRI;
     size_t lds = (tile_elems + 2 * NP * E + g.dst + 2 * 17 + ((g.dst + 2 * 17) & 1)) * sizeof(float) + NP * sizeof(int64_t);
     lds = (lds + 15) & ~(size_t)15;
-    static Residency res;
+    const void* fn = nullptr;
+    static Residency res[8];
+    int ri = 0;
+    switch (ng) {
+#define MGP_WIDE_CASE(N, I) case N: fn = reinterpret_cast<const void*>(&fused_wide_kernel<N>); ri = I; break;
+      MGP_WIDE_CASE(17, 0) MGP_WIDE_CASE(20, 1) MGP_WIDE_CASE(22, 2) MGP_WIDE_CASE(24, 3)
+      MGP_WIDE_CASE(26, 4) MGP_WIDE_CASE(28, 5) MGP_WIDE_CASE(30, 6)
+      default: fn = reinterpret_cast<const void*>(&fused_wide_kernel<32>); ri = 7; break;
+#undef MGP_WIDE_CASE
+    }
     int per_cu = 0, cus = 0;
-    const int rc = res.lookup(reinterpret_cast<const void*>(&fused_wide_kernel), NP, lds, &per_cu, &cus);
+    const int rc = res[ri].lookup(fn, NP, lds, &per_cu, &cus);
     if (rc != MGP_OK) return rc;
     int64_t grid = (int64_t)cus * per_cu;
     if (grid > a.b) grid = a.b;
@@ -362,9 +398,14 @@ int launch_fused_wide(const FusedArgs& a, hipStream_t stream) {
     if (trace)
       fprintf(stderr, "mgp: fused_wide_kernel b=%lld k=%d d=%d R=%d grid=%lld lds=%zu per_cu=%d\n", (long long)a.b, a.k, a.d,
               a.R, (long long)grid, lds, per_cu);
-    hipLaunchKernelGGL(fused_wide_kernel, dim3((unsigned)grid), dim3(NP), lds, stream, a, g);
+    void* kargs[] = {const_cast<FusedArgs*>(&a), &g};
+    {
+      const hipError_t le = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(NP), kargs, lds, stream);
+      if (le != hipSuccess) return -(1000 + (int)le);
+    }
     MGP_HIP_CHECK_LAUNCH();
-    note_launch("mgp::fused_wide_kernel");
+    note_launch("mgp::fused_wide_kernel<%d>", ng);
+    note_launch_geometry(grid, lds);
     return MGP_OK;
   }
 }
