@@ -28,12 +28,20 @@
 #define MGP_WIDE64_PRIO 2
 #endif
 
+#ifndef MGP_WIDE64_SPLIT
+#define MGP_WIDE64_SPLIT 1  // the waves of rows 0 .. 63 stop at their last lower-triangle block
+#endif
+
 namespace mgp {
 
 struct Wide64Geom {
   int q, dst, xs, vec_ok;
 };
 
+// NB (round 5, as NG of mgp_fused_wide.hip): the 4-column blocks of the system, even, 4 NB >= k + 1 + R -- query and
+// responses in the last 1 + R of those slots, rows and trailing updates end there; and the waves that hold rows
+// 0 .. 63 stop at block 15 (their rows have no lower-triangle entry beyond) and only keep the barriers after it.
+template <int NB>
 __global__ __launch_bounds__(256, 2) void fused_wide64_kernel(FusedArgs a, Wide64Geom g) {
   using T = double;
   constexpr int NP = 128;        // slots
@@ -42,7 +50,7 @@ __global__ __launch_bounds__(256, 2) void fused_wide64_kernel(FusedArgs a, Wide6
   constexpr int BA = 4, BP = NS / BA, BPH = BP / 2;  // own rows, partner rows per slot / per lane
   auto own_offset = [](int j) { return j == 0 ? 0 : (j + 1) * BP + 1; };
   constexpr int E = 2, CH = 4;
-  constexpr int NB = NP / 4;     // 4-column blocks of a row
+  static_assert(NB % 2 == 0 && NB >= 18 && NB <= NP / 4, "4-column blocks of a row, shared by two lanes");
   constexpr int LB = NB / 2;     // ... owned by one lane
   constexpr int TRI = 2 * 64 * 65 + 2 * NP;  // packed lower-triangular exchange matrix + over-read pad
   using V = v16<T>::type;
@@ -216,12 +224,19 @@ __global__ __launch_bounds__(256, 2) void fused_wide64_kernel(FusedArgs a, Wide6
     __builtin_amdgcn_s_setprio(MGP_WIDE64_PRIO);
 #endif
     bool bad = false;
+    auto eliminate = [&](auto llc) {
+    constexpr int LBL = decltype(llc)::value;  // this wave's rows have lower-triangle entries in local blocks 0 .. LBL - 1
     static_for<NB>([&](auto bc) {
       constexpr int b = decltype(bc)::value;
       constexpr int J0 = 4 * b;
       constexpr int lb = b >> 1;      // the owner's local block
       constexpr int ho = b & 1;       // the owner half
-      if (J0 < k) {  // uniform
+      if constexpr (b >= 2 * LBL) {
+        if (J0 < k) {  // (uniform) a block of the lower rows only: keep its two barriers
+          __syncthreads();
+          __syncthreads();
+        }
+      } else if (J0 < k) {  // uniform
         const int mlim = min(4, k - J0);
         T pg[4];
         if (h == ho) {  // wave-uniform: the owner posts its raw block entries
@@ -281,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void fused_wide64_kernel(FusedArgs a, Wide6
         constexpr int first_other = (b + 1) >> 1;             // other lane (h != ho): global block 2 lb' + h >= b
         const int lb0 = h == ho ? first_owner : first_other;  // wave-uniform
 #pragma unroll
-        for (int lbb = 0; lbb < LB; ++lbb) {
+        for (int lbb = 0; lbb < LBL; ++lbb) {
           if (lbb >= (first_owner < first_other ? first_owner : first_other) && lbb >= lb0) {
             const int gb = 2 * lbb + h;  // global block
             V cv[2][4];
@@ -297,14 +312,17 @@ __global__ __launch_bounds__(256, 2) void fused_wide64_kernel(FusedArgs a, Wide6
         }
       }
     });
+    };
+    if (MGP_WIDE64_SPLIT && i < 64) eliminate(ic<(LB < 8 ? LB : 8)>{});  // (wave-uniform: waves 0 and 2 hold rows 0 .. 63)
+    else eliminate(ic<LB>{});
 
     // ---- phase 5: Schur block -> outputs --------------------------------------------------------
 #if MGP_WIDE64_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
     // column c of row i is held by lane (i, (c >> 2) & 1) in local group 2 (c >> 3) + ((c >> 1) & 1),
-    // element c & 1; q >= 111, so a compare-select sweep over the lane's last four blocks (columns
-    // 96 .. 127) finds column q and the diagonal
+    // element c & 1; q >= 4 NB - 17, so a compare-select sweep over the lane's last four blocks (the
+    // last 32 columns) finds column q and the diagonal
     T aq = T(0), aii = T(0);
     bool has_q = false, has_i = false;
 #pragma unroll
@@ -324,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void fused_wide64_kernel(FusedArgs a, Wide6
     if (i == q && has_q) {
       var[nb] = bad ? num<T>::nan() : aq;
       if (bad && a.info) atomicAdd(a.info, 1);
-    } else if (i > q) {
+    } else if (i > q && i <= q + R) {  // (lanes past q + R hold no row of the system when 4 NB < 128)
       const int r = i - q - 1;
       if (has_q) mean[nb * R + r] = bad ? num<T>::nan() : -aq;
       if (has_i && yk) yk[nb * R + r] = bad ? num<T>::nan() : -aii;
@@ -337,8 +355,14 @@ int launch_fused_wide64(const FusedArgs& a, hipStream_t stream) {
   const int rows = a.k + 1 + a.R;
   if (rows < 65 || rows > NP || a.k <= 64 || a.R > 16 || a.d > 64 || a.packed_nn != nullptr || a.coeffs != nullptr)
     return MGP_EUNSUPPORTED;
+#ifdef MGP_WIDE_FORCE_NG32
+  const int nb = 32;
+#else
+  const int nb = rows <= 72 ? 18 : rows <= 80 ? 20 : rows <= 88 ? 22 : rows <= 96 ? 24 : rows <= 104 ? 26
+                 : rows <= 112 ? 28 : rows <= 120 ? 30 : 32;
+#endif
   Wide64Geom g;
-  g.q = NP - 1 - a.R;
+  g.q = 4 * nb - 1 - a.R;
   const int dpad = (a.d + CH - 1) / CH * CH;
   g.dst = dpad < 64 ? dpad : 64;
   g.xs = g.dst + E;
@@ -347,9 +371,18 @@ int launch_fused_wide64(const FusedArgs& a, hipStream_t stream) {
   const size_t tile_elems = (size_t)NP * g.xs > TRI ? (size_t)NP * g.xs : TRI;
   size_t lds = (tile_elems + 2 * NP * 4 + g.dst) * sizeof(double) + NP * sizeof(int64_t);
   lds = (lds + 15) & ~(size_t)15;
-  static Residency res;
+  const void* fn = nullptr;
+  static Residency res[8];
+  int ri = 0;
+  switch (nb) {
+#define MGP_WIDE64_CASE(N, I) case N: fn = reinterpret_cast<const void*>(&fused_wide64_kernel<N>); ri = I; break;
+    MGP_WIDE64_CASE(18, 0) MGP_WIDE64_CASE(20, 1) MGP_WIDE64_CASE(22, 2) MGP_WIDE64_CASE(24, 3)
+    MGP_WIDE64_CASE(26, 4) MGP_WIDE64_CASE(28, 5) MGP_WIDE64_CASE(30, 6)
+    default: fn = reinterpret_cast<const void*>(&fused_wide64_kernel<32>); ri = 7; break;
+#undef MGP_WIDE64_CASE
+  }
   int per_cu = 0, cus = 0;
-  const int rc = res.lookup(reinterpret_cast<const void*>(&fused_wide64_kernel), 256, lds, &per_cu, &cus);
+  const int rc = res[ri].lookup(fn, 256, lds, &per_cu, &cus);
   if (rc != MGP_OK) return rc;
   int64_t grid = (int64_t)cus * per_cu;
   if (grid > a.b) grid = a.b;
@@ -357,9 +390,14 @@ int launch_fused_wide64(const FusedArgs& a, hipStream_t stream) {
   if (trace)
     fprintf(stderr, "mgp: fused_wide64_kernel b=%lld k=%d d=%d R=%d grid=%lld lds=%zu per_cu=%d\n", (long long)a.b, a.k, a.d,
             a.R, (long long)grid, lds, per_cu);
-  hipLaunchKernelGGL(fused_wide64_kernel, dim3((unsigned)grid), dim3(256), lds, stream, a, g);
+  {
+    void* kargs[] = {const_cast<FusedArgs*>(&a), &g};
+    const hipError_t le = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(256), kargs, lds, stream);
+    if (le != hipSuccess) return -(1000 + (int)le);
+  }
   MGP_HIP_CHECK_LAUNCH();
-  note_launch("mgp::fused_wide64_kernel");
+  note_launch("mgp::fused_wide64_kernel<%d>", nb);
+  note_launch_geometry(grid, lds);
   return MGP_OK;
 }
 
