@@ -58,8 +58,13 @@ template <int NG>
 __global__ __launch_bounds__(128, 2) void fused_wide_kernel(FusedArgs a, WideGeom g) {
   using T = float;
   constexpr int NP = 128;
-  constexpr int NS = NP / 2;  // pairs per lane
-  constexpr int BA = 4, BP = NS / BA;
+  // Pair scheme on a ring of M = k + 1 rows (the neighbours and the query; round 5 -- the ring used to be all 128
+  // slots): lane i < M takes the pairs {i + o_j, i + s} mod M, o = 0, 2 BP + 1, 3 BP + 1, 4 BP + 1, s = 1 .. BP --
+  // cyclic distances 1 .. 4 BP, each pair of rows at least once as 4 BP >= (M - 1) / 2 (a distance past that meets a
+  // pair from its other end: the same value to the same place).  4 BP = 2 NG + (0 .. 2) covers every M that NG serves;
+  // k = 68: 36 pairs per lane instead of 64.  Lanes past M repeat lane i - M.
+  constexpr int BA = 4, BP = (NG + 1) / 2;
+  constexpr int NS = BA * BP;  // pairs per lane
   auto own_offset = [](int j) { return j == 0 ? 0 : (j + 1) * BP + 1; };
   constexpr int E = 4, CH = 8;
   constexpr int TRI = 8 * 32 * 33 + 2 * NP + 2 * E;  // packed lower-triangular exchange matrix (+ over-read pad)
@@ -111,18 +116,18 @@ __global__ __launch_bounds__(128, 2) void fused_wide_kernel(FusedArgs a, WideGeo
     if (g.vec_ok) {
       // consecutive lanes walk a row in 16-byte pieces; slots without features are zero rows
       const int c16 = w / E, c16p = wp / E;
-      for (int t = i; t < NP * c16p; t += NP) {
+      // (tile row r = ring position r: the neighbours, then the query at row k)
+      for (int t = i; t < (k + 1) * c16p; t += NP) {
         const int row = t / c16p, c = t - row * c16p;
         V v = V(0);
-        if (c < c16 && (row < k || row == q))
-          v = *reinterpret_cast<const V*>((row < k ? feat_nn : feat_q) + idxbuf[row] + c * E);
+        if (c < c16) v = *reinterpret_cast<const V*>((row < k ? feat_nn + idxbuf[row] : feat_q + idxbuf[q]) + c * E);
         *reinterpret_cast<V*>(tile + row * xs + c * E) = v;
       }
     } else {
-      for (int t = i; t < NP * wp; t += NP) {
+      for (int t = i; t < (k + 1) * wp; t += NP) {
         const int row = t / wp, c = t - row * wp;
         T v = T(0);
-        if (c < w && (row < k || row == q)) v = ((row < k ? feat_nn : feat_q) + idxbuf[row])[c];
+        if (c < w) v = (row < k ? feat_nn + idxbuf[row] : feat_q + idxbuf[q])[c];
         tile[row * xs + c] = v;
       }
     }
@@ -136,6 +141,9 @@ __global__ __launch_bounds__(128, 2) void fused_wide_kernel(FusedArgs a, WideGeo
     // ---- phase 2: squared distances, then covariances; two halves of the own rows so that the
     //      64 packed accumulators of a lane never coexist (register budget: 256 with the 128-entry row)
     T kv[NS];
+    const int M = k + 1;
+    const int ir = i < M ? i : i - M;  // ring position of the lane (M >= 65: one wrap)
+    auto wrap = [&](int x) { return x >= M ? x - M : x; };
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       constexpr int HB = BA / 2;
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(128, 2) void fused_wide_kernel(FusedArgs a, WideGeo
           V own0[HB], own1[HB];
 #pragma unroll
           for (int j = 0; j < HB; ++j) {
-            const T* xj = tile + ((i + own_offset(half * HB + j)) & (NP - 1)) * xs + c0;
+            const T* xj = tile + wrap(ir + own_offset(half * HB + j)) * xs + c0;
             own0[j] = *reinterpret_cast<const V*>(xj);
             own1[j] = *reinterpret_cast<const V*>(xj + E);
           }
@@ -165,7 +173,8 @@ __global__ __launch_bounds__(128, 2) void fused_wide_kernel(FusedArgs a, WideGeo
             V o0[PB], o1[PB];
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
-              const T* xo = tile + ((i + s0 + u) & (NP - 1)) * xs + c0;
+              if (s0 + u > BP) continue;  // (compile-time: BP need not be a multiple of PB)
+              const T* xo = tile + wrap(ir + s0 + u) * xs + c0;
               o0[u] = *reinterpret_cast<const V*>(xo);
               o1[u] = *reinterpret_cast<const V*>(xo + E);
             }
@@ -173,6 +182,7 @@ __global__ __launch_bounds__(128, 2) void fused_wide_kernel(FusedArgs a, WideGeo
             for (int u = 0; u < PB; ++u)
 #pragma unroll
               for (int j = 0; j < HB; ++j) {
+                if (s0 + u > BP) continue;
                 if constexpr (ANISO) {
                   accum(acc[j * BP + s0 + u - 1], vsub(own0[j], o0[u]) * il0);
                   accum(acc[j * BP + s0 + u - 1], vsub(own1[j], o1[u]) * il1);
@@ -214,13 +224,19 @@ __global__ __launch_bounds__(128, 2) void fused_wide_kernel(FusedArgs a, WideGeo
       int i3 = i;
       asm volatile("" : "+v"(i3));
       const int dump = tri(NP - 1) + NP + E;  // behind the last row
+      const int ir3 = i3 < M ? i3 : i3 - M;
 #pragma unroll
       for (int s = 1; s <= NS; ++s) {
-        const int r1 = (i3 + own_offset((s - 1) / BP)) & (NP - 1);
-        const int c = (i3 + (s - 1) % BP + 1) & (NP - 1);
-        const int hi = max(r1, c), lo = min(r1, c);
-        const T v = (lo < k && (hi < k || hi == q)) ? kv[s - 1] : T(0);
-        tile[hi <= q ? tri(hi) + lo : dump] = v;
+        // ring positions -> slots: the query (position k) is slot q; every pair of ring rows is an entry of the system
+        const int r1 = wrap(ir3 + own_offset((s - 1) / BP)), c = wrap(ir3 + (s - 1) % BP + 1);
+        const int s1 = r1 < k ? r1 : q, sc = c < k ? c : q;
+        const int hi = max(s1, sc), lo = min(s1, sc);
+        tile[hi != lo ? tri(hi) + lo : dump] = kv[s - 1];
+      }
+      // what no pair writes: the padding slots k .. q - 1 (rows of zeros) and their columns in the query's row
+      if (i3 >= k && i3 <= q) {
+        const int rowz = tri(i3);
+        for (int cz = i3 == q ? k : 0; cz < i3; ++cz) tile[rowz + cz] = T(0);
       }
       const int myrow = tri(i3);
       tile[myrow + i3] = mydiag;
