@@ -325,7 +325,7 @@ def make_step(cfg, w, route: str, path: str, use_packed: bool):
     return step
 
 
-def time_steps(step, warmup: int, steps: int, dist, backend: str, dev):
+def time_steps(step, warmup: int, steps: int, dist, backend: str, dev, settle_steps: int = 0):
     """W untimed steps, then K steps bracketed by barrier + synchronize; MAX over ranks.  Per-step HIP
     events on the launch stream (torch's current stream is the one every library call is given)."""
     import torch
@@ -341,7 +341,9 @@ def time_steps(step, warmup: int, steps: int, dist, backend: str, dev):
     gc.disable()
     last = None
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
-    for _ in range(warmup):
+    # (settle_steps: untimed steps that bring the clocks up -- HERE, behind the collection above: run before it, its
+    # 75 ms of idle GPU put a short loop, --steps 20 --warmup 5, back on the ramp: 0.422 instead of 0.434)
+    for _ in range(settle_steps + warmup):
         last = step()
     torch.cuda.synchronize()
     try:
@@ -471,11 +473,18 @@ def secondary_line(name: str, cfg_id: int, route: str, args, dev, steps: int = 5
     step = make_step(cfg, w, route, "auto", use_packed if route == "fused" else "auto")
     # the first launches after a pause run on ramping clocks (the headline kernel: 2.1 ms falling to 1.5 over ~20
     # launches): warm for >= 60 ms of this config's steps, then time >= 150 ms of them
-    t0 = time.perf_counter()
-    step()
+    # (the estimate of a step: the FASTEST of three after an untimed first one -- one-time costs of the first call, or a
+    # cyclic garbage collection falling into a timed pair, made a 0.22 ms step look like 30 ms and the line was then
+    # measured over 5 steps on the clock ramp: 498 instead of 570 M/s in one run of round 5)
     step()
     torch.cuda.synchronize()
-    est = max((time.perf_counter() - t0) / 2, 1e-4)
+    est = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        est = min(est, time.perf_counter() - t0)
+    est = max(est, 1e-5)
     # (caps of 60 / 40 steps until round 4: a 0.23 ms step was then warmed for 10 ms and timed for 14 -- on the ramp)
     steps = int(min(1000, max(steps, np.ceil(0.15 / est))))
     elapsed, kern_ms, _, last = time_steps(step, int(min(400, max(2, np.ceil(0.06 / est)))), steps, None, "", dev)
@@ -616,7 +625,7 @@ def main():
     # `value`; with the driver's short loops (--steps 20 --warmup 5 = 40 ms) it lies inside the clock ramp (the kernel's
     # launches read 2.1, 2.0, 1.85 ... 1.5 ms over the first ~25).  `value`: the same W + K steps after the GPU has run
     # the step for --settle-ms (150 ms: what the secondary lines have always done) -- steady state.
-    ramp = None
+    ramp, settle_steps = None, 0
     if args.settle_ms > 0:
         r_elapsed, r_kern, _, _ = time_steps(step, args.warmup, args.steps, dist, args.backend, dev)
         ramp = {"value": total_b * args.steps / r_elapsed, "ms_per_step": r_elapsed / args.steps * 1e3,
@@ -624,10 +633,9 @@ def main():
                 "what": f"{args.warmup} + {args.steps} steps from an idle GPU (the convention of rounds 1-4)"}
         # (a step count, the same on every rank -- r_elapsed is the maximum over the ranks --, not a clock: a step of an
         # objective config ends in a collective)
-        for _ in range(int(min(2000, np.ceil(args.settle_ms * 1e-3 / max(r_elapsed / args.steps, 1e-5))))):
-            step()
-        torch.cuda.synchronize()
-    elapsed, kern_ms, ranks_seen, last = time_steps(step, args.warmup, args.steps, dist, args.backend, dev)
+        settle_steps = int(min(2000, np.ceil(args.settle_ms * 1e-3 / max(r_elapsed / args.steps, 1e-5))))
+    elapsed, kern_ms, ranks_seen, last = time_steps(step, args.warmup, args.steps, dist, args.backend, dev,
+                                                    settle_steps=settle_steps)
     non_spd = int(w["info"].item())
     kernel_name = _lib.last_kernel()  # the instantiation the timed steps actually launched (this thread's last call)
     if cfg["objective"]:
@@ -700,9 +708,13 @@ def main():
             # knn: config 2 on exact k-NN neighbourhoods (real gather locality instead of uniform-random rows);
             # points8M: config 2 on an 8 M-row table (1.5 GB prepared: far beyond the 256 MB Infinity Cache);
             # c3_shard8: one LOOCV evaluation of 125 k neighbourhoods = what each of 8 ranks runs under --scaling strong
+            # (c3_shard8 right behind c3, the line it is divided by: as the last line, behind the 1.5 GB table of points8M
+            # and its empty_cache(), it read 0.219 ms per step in some runs and 0.26 in others -- tools/c3bench.py in a
+            # fresh process is stable at 0.222-0.227 --, i.e. it measured where the allocator had put its table)
             plan = [("dropin", 2, "dropin", {}), ("dropin_plain", 2, "dropin_plain", {}), ("c3", 3, "fused", {}),
+                    ("c3_shard8", 3, "fused", {"batch": 125_000}),
                     ("c4", 4, "fused", {}), ("c5", 5, "fused", {}), ("knn", 2, "fused", {"knn": True}),
-                    ("points8M", 2, "fused", {"points": 8_000_000}), ("c3_shard8", 3, "fused", {"batch": 125_000})]
+                    ("points8M", 2, "fused", {"points": 8_000_000})]
             for name, cid, route, over in plan:
                 if cid == args.config and route == args.route and not over:
                     continue
