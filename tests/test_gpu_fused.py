@@ -569,6 +569,18 @@ WIDE_CASES = [
     ("matern15", 65, 12, 1, False),   # 67 rows, k > 64: the first shape of the 128-slot kernel
     ("matern15", 75, 24, 1, False),
     ("matern15", 90, 37, 3, False),   # unaligned rows, several responses
+    # round 5 -- fused_wide_kernel<NG> / fused_wide64_kernel<NB>: one shape per column-group count, most of them at
+    # the last row count the instantiation serves (no padding slot between the neighbours and the query)
+    ("matern15", 66, 8, 1, False),    # 68 rows  -> 17 groups (fp64: 18 blocks)
+    ("rbf", 67, 20, 1, True),         # 69 rows  -> 20
+    ("matern25", 78, 12, 1, False),   # 80 rows  -> 20, full
+    ("matern15", 84, 16, 3, False),   # 88 rows  -> 22, full
+    ("matern15", 94, 8, 1, True),     # 96 rows  -> 24, full
+    ("matern15", 101, 12, 2, False),  # 104 rows -> 26, full
+    ("rbf", 95, 8, 16, False),        # 112 rows -> 28, full, sixteen responses
+    ("matern15", 110, 8, 9, False),   # 120 rows -> 30, full
+    ("matern25", 111, 8, 16, False),  # 128 rows -> 32, full, sixteen responses
+    ("matern15", 65, 8, 16, False),   # 82 rows, a pair ring of 66 rows under 22 column groups
 ]
 
 
@@ -614,6 +626,7 @@ STALE_LDS_CASES = [
     # k, R, dtype -- the 128-slot kernel (partial / full last block), the packed 64-slot exchange matrix,
     # the square exchange matrices of the 32-slot and the rhs-column kernels
     (126, 1, "float32"), (125, 1, "float32"), (122, 3, "float32"), (99, 2, "float32"),
+    (65, 1, "float32"), (77, 1, "float32"), (83, 3, "float32"), (90, 16, "float32"),     # ... with padding slots under 17 / 20 / 22 / 28 groups
     (50, 1, "float32"), (50, 1, "float64"), (61, 1, "float32"), (30, 1, "float32"), (29, 2, "float64"),
     (64, 16, "float32"), (63, 4, "float64"),
     (126, 1, "float64"), (125, 1, "float64"), (99, 2, "float64"), (65, 1, "float64"),   # two lanes per row
