@@ -325,7 +325,7 @@ def make_step(cfg, w, route: str, path: str, use_packed: bool):
     return step
 
 
-def time_steps(step, warmup: int, steps: int, dist, backend: str, dev, settle_steps: int = 0):
+def time_steps(step, warmup: int, steps: int, dist, backend: str, dev, settle_steps: int = 0, event_stride: int = 1):
     """W untimed steps, then K steps bracketed by barrier + synchronize; MAX over ranks.  Per-step HIP
     events on the launch stream (torch's current stream is the one every library call is given)."""
     import torch
@@ -340,7 +340,10 @@ def time_steps(step, warmup: int, steps: int, dist, backend: str, dev, settle_st
     gc_was = gc.isenabled()
     gc.disable()
     last = None
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    # (event_stride: an event every so many steps -- recording one costs ~2 us of host time, 1 % of a 0.2 ms
+    # synchronous step; kern_ms then holds the per-step average of each stride)
+    event_stride = max(1, min(int(event_stride), steps))
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps // event_stride + 1)]
     # (settle_steps: untimed steps that bring the clocks up -- HERE, behind the collection above: run before it, its
     # 75 ms of idle GPU put a short loop, --steps 20 --warmup 5, back on the ramp: 0.422 instead of 0.434)
     for _ in range(settle_steps + warmup):
@@ -354,7 +357,8 @@ def time_steps(step, warmup: int, steps: int, dist, backend: str, dev, settle_st
         ev[0].record()
         for i in range(steps):
             last = step()
-            ev[i + 1].record()
+            if (i + 1) % event_stride == 0:
+                ev[(i + 1) // event_stride].record()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -363,7 +367,7 @@ def time_steps(step, warmup: int, steps: int, dist, backend: str, dev, settle_st
     finally:
         if gc_was:
             gc.enable()
-    kern_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+    kern_ms = [ev[i].elapsed_time(ev[i + 1]) / event_stride for i in range(steps // event_stride)]
     from muygpys_amd import _lib
 
     _lib.flush_spd_checks()  # (drop-in routes: the last step's not-positive-definite counter, see make_step)
@@ -487,7 +491,8 @@ def secondary_line(name: str, cfg_id: int, route: str, args, dev, steps: int = 5
     est = max(est, 1e-5)
     # (caps of 60 / 40 steps until round 4: a 0.23 ms step was then warmed for 10 ms and timed for 14 -- on the ramp)
     steps = int(min(1000, max(steps, np.ceil(0.15 / est))))
-    elapsed, kern_ms, _, last = time_steps(step, int(min(400, max(2, np.ceil(0.06 / est)))), steps, None, "", dev)
+    elapsed, kern_ms, _, last = time_steps(step, int(min(400, max(2, np.ceil(0.06 / est)))), steps, None, "", dev,
+                                           event_stride=int(max(1, 0.002 / est)))  # (events >= 2 ms apart)
     if route == "fused" and cfg["objective"]:
         assert np.isfinite(last["lool"]) and np.isfinite(last["sigma_sq"]), f"{name}: non-finite objective"
     avg_ms = float(np.mean(kern_ms))

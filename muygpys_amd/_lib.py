@@ -160,8 +160,17 @@ def ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def raw_stream() -> int:
+    """The current HIP stream of the current device as an integer (torch.cuda.current_stream().cuda_stream without the
+    Stream object: 0.2 instead of 1.5 us -- it sits in front of every launch of an optimiser's loop)."""
+    try:
+        return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+    except AttributeError:  # (a torch without the private accessor)
+        return torch.cuda.current_stream().cuda_stream
+
+
 def stream_ptr():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(raw_stream())
 
 
 def served_by(d: int, k: int, R: int, dtype, packed: bool = False, path: str = "auto") -> str:

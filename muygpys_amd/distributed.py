@@ -57,11 +57,24 @@ def shard_rows(x, rank: int, size: int):
 
 
 def _world(group=None):
-    import torch.distributed as dist
-
-    if dist.is_available() and dist.is_initialized():
+    dist = _dist()
+    if dist is not None and dist.is_initialized():
         return dist.get_rank(group), dist.get_world_size(group)
     return 0, 1
+
+
+_DIST = False
+
+
+def _dist():
+    """torch.distributed, or None when this torch has none (imported once: the functions below sit in front of every
+    objective evaluation)."""
+    global _DIST
+    if _DIST is False:
+        import torch.distributed as dist
+
+        _DIST = dist if dist.is_available() else None
+    return _DIST
 
 
 def _collectives_on(group=None) -> bool:
@@ -70,9 +83,8 @@ def _collectives_on(group=None) -> bool:
     (tests/test_gpu_distributed.py), instead of short-circuiting them."""
     import os
 
-    import torch.distributed as dist
-
-    if not (dist.is_available() and dist.is_initialized()):
+    dist = _dist()
+    if dist is None or not dist.is_initialized():
         return False
     return dist.get_world_size(group) > 1 or os.environ.get("MUYGPYS_HIP_FORCE_COLLECTIVES") == "1"
 
@@ -216,11 +228,11 @@ def _loocv_plan(spec, features, targets, batch_indices, nn_indices, packed, hube
     lp = _LAST_PLAN
     if (lp is not None and lp[0] is features and lp[1] is targets and lp[2] is batch_indices and lp[3] is nn_indices
             and lp[4] == (spec.kernel, spec.metric, aniso, packed, huber_delta, host_result) and lp[5] is noise_t
-            and lp[6] == (features._version, targets._version) and lp[7] == torch.cuda.current_stream().cuda_stream):
+            and lp[6] == (features._version, targets._version) and lp[7] == _lib_raw_stream()):
         return lp[8]
     key = (spec.kernel, spec.metric, aniso, id(features), features._version, id(targets), targets._version,
            id(batch_indices), id(nn_indices), None if noise_t is None else id(noise_t), str(packed), float(huber_delta),
-           bool(host_result), int(torch.cuda.current_stream().cuda_stream))
+           bool(host_result), int(_lib_raw_stream()))
     plan = _PLANS.get(key)
     if plan is None:
         if len(_PLANS) >= _PLANS_MAX:
@@ -229,11 +241,17 @@ def _loocv_plan(spec, features, targets, batch_indices, nn_indices, packed, hube
                          noise_tensor=noise_t, huber_delta=huber_delta, packed=packed, host_result=host_result)
         _PLANS[key] = plan
     _LAST_PLAN = (features, targets, batch_indices, nn_indices, (spec.kernel, spec.metric, aniso, packed, huber_delta, host_result),
-                  noise_t, (features._version, targets._version), torch.cuda.current_stream().cuda_stream, plan)
+                  noise_t, (features._version, targets._version), _lib_raw_stream(), plan)
     return plan
 
 
 _LAST_PLAN = None
+
+
+def _lib_raw_stream() -> int:
+    from muygpys_amd import _lib
+
+    return _lib.raw_stream()
 
 
 def clear_plans() -> None:
