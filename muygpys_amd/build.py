@@ -19,7 +19,11 @@ LIB = os.path.join(LIBDIR, "libmuygpys_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          # explicit vector types carry the packed-f32 math; the SLP vectoriser only shuffles registers
-         "-fno-slp-vectorize"]
+         "-fno-slp-vectorize",
+         # every `#pragma unroll` of the kernels is meant: loops over a lane's register groups index registers at
+         # compile time or not at all (for every file since round 5 -- tools/mkvariant.sh and the run-time compiler
+         # always had it, and the regular build of the fp64 128-slot kernel ran 12-14 % behind its own A/B copy)
+         "-mllvm", "-pragma-unroll-threshold=1000000", "-Wno-pass-failed"]
 # the k-NN scans test the MFMA results right away: keep them in VGPRs (no v_accvgpr_read per value)
 PER_FILE_FLAGS = {
     "mgp_knn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
@@ -34,6 +38,8 @@ PER_FILE_FLAGS = {
     **{f"mgp_fused_wave_inst_{n}.hip": ["-mllvm", "-pragma-unroll-threshold=1000000", "-Rpass-analysis=kernel-resource-usage"]
        for n in ("f32", "f64")},
     "mgp_solve_wave.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
+    "mgp_fused_wide.hip": ["-Rpass-analysis=kernel-resource-usage"],
+    "mgp_fused_wide64.hip": ["-Rpass-analysis=kernel-resource-usage"],
     "mgp_backward.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
     "mgp_backward_wave.hip": ["-mllvm", "-pragma-unroll-threshold=1000000", "-Rpass-analysis=kernel-resource-usage"],
 }
@@ -54,7 +60,8 @@ def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    # (this file too: its per-file compiler flags are part of what the library is)
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h")) + [__file__]
     return any(os.path.getmtime(p) > t for p in deps)
 
 

@@ -46,8 +46,14 @@ __global__ __launch_bounds__(256, 2) void fused_wide64_kernel(FusedArgs a, Wide6
   using T = double;
   constexpr int NP = 128;        // slots
   constexpr int NT = 256;        // threads
-  constexpr int NS = NP / 2;     // pairs per slot
-  constexpr int BA = 4, BP = NS / BA, BPH = BP / 2;  // own rows, partner rows per slot / per lane
+  // NB <= 24 (k <= 94): the pair ring of mgp_fused_wide.hip -- the k + 1 real rows instead of all 128 slots, BP partners
+  // per own row (even: the two lanes of a slot take half each; 4 BP >= 2 NB >= (k + 1) / 2): k = 70 13.0 -> 15.0 M/s.
+  // Larger systems keep the 128-slot ring, as a SEPARATE copy of the three places it touches: there the ring saves an
+  // eighth of the pairs at most and its addressing (a compare and a select per row address where the 128-slot ring
+  // has a mask) costs more -- k = 100 equal, k = 126 8.3 -> 7.7 -- and a version that folded both forms into one body
+  // ran 10-15 % slower than either (round 5, measured).
+  constexpr bool RING = NB <= 24;
+  constexpr int BA = 4, BP = RING ? 2 * ((NB + 3) / 4) : NP / 8, BPH = BP / 2;  // own rows, partner rows per slot / per lane
   auto own_offset = [](int j) { return j == 0 ? 0 : (j + 1) * BP + 1; };
   constexpr int E = 2, CH = 4;
   static_assert(NB % 2 == 0 && NB >= 18 && NB <= NP / 4, "4-column blocks of a row, shared by two lanes");
@@ -100,7 +106,25 @@ __global__ __launch_bounds__(256, 2) void fused_wide64_kernel(FusedArgs a, Wide6
     // ---- phase 1: stage the features (one stage: d <= 64) -----------------------------------------
     const int w = d, wp = (d + CH - 1) / CH * CH;
     __syncthreads();
-    if (g.vec_ok) {
+    if constexpr (RING) {
+      // tile row r = ring position r: the neighbours, then the query at row k
+      if (g.vec_ok) {
+        const int c16 = w / E, c16p = wp / E;
+        for (int t = tid; t < (k + 1) * c16p; t += NT) {
+          const int row = t / c16p, c = t - row * c16p;
+          V v = V(0);
+          if (c < c16) v = *reinterpret_cast<const V*>((row < k ? feat_nn + idxbuf[row] : feat_q + idxbuf[q]) + c * E);
+          *reinterpret_cast<V*>(tile + row * xs + c * E) = v;
+        }
+      } else {
+        for (int t = tid; t < (k + 1) * wp; t += NT) {
+          const int row = t / wp, c = t - row * wp;
+          T v = T(0);
+          if (c < w) v = (row < k ? feat_nn + idxbuf[row] : feat_q + idxbuf[q])[c];
+          tile[row * xs + c] = v;
+        }
+      }
+    } else if (g.vec_ok) {
       const int c16 = w / E, c16p = wp / E;
       for (int t = tid; t < NP * c16p; t += NT) {
         const int row = t / c16p, c = t - row * c16p;
@@ -127,6 +151,12 @@ __global__ __launch_bounds__(256, 2) void fused_wide64_kernel(FusedArgs a, Wide6
     __builtin_amdgcn_s_setprio(1);
 #endif
     T kv[BA * BPH];
+    const int M = k + 1;                                  // (RING) rows of the pair ring
+    const int ir = RING ? (i < M ? i : i - M) : i;         // ring position of the slot (M >= 66: one wrap)
+    auto ringrow = [&](int x) {                            // row of the tile at ring position x (< 2 M)
+      if constexpr (RING) return x >= M ? x - M : x;
+      else return x & (NP - 1);
+    };
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       constexpr int HB = BA / 2;
@@ -135,12 +165,15 @@ __global__ __launch_bounds__(256, 2) void fused_wide64_kernel(FusedArgs a, Wide6
       for (int s = 0; s < HB * BPH; ++s) acc[s] = T(0);
       auto chunks = [&](auto anis) {
         constexpr bool ANISO = decltype(anis)::value != 0;
-        constexpr int PB = 4;
+        // partner rows requested together: four, or -- RING, where a lane's 5 or 6 partners are no multiple of four --
+        // all of them (a guard inside the unrolled loops instead cost the 128-slot shapes 10-15 %: measured)
+        constexpr int PB = RING ? BPH : 4;
+        static_assert(BPH % PB == 0, "whole partner batches");
         for (int c0 = 0; c0 < wp; c0 += CH) {
           V own0[HB], own1[HB];
 #pragma unroll
           for (int j = 0; j < HB; ++j) {
-            const T* xj = tile + ((i + own_offset(half * HB + j)) & (NP - 1)) * xs + c0;
+            const T* xj = tile + ringrow(ir + own_offset(half * HB + j)) * xs + c0;
             own0[j] = *reinterpret_cast<const V*>(xj);
             own1[j] = *reinterpret_cast<const V*>(xj + E);
           }
@@ -154,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void fused_wide64_kernel(FusedArgs a, Wide6
             V o0[PB], o1[PB];
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
-              const T* xo = tile + ((i + h * BPH + s0 + u + 1) & (NP - 1)) * xs + c0;
+              const T* xo = tile + ringrow(ir + h * BPH + s0 + u + 1) * xs + c0;
               o0[u] = *reinterpret_cast<const V*>(xo);
               o1[u] = *reinterpret_cast<const V*>(xo + E);
             }
@@ -195,6 +228,22 @@ __global__ __launch_bounds__(256, 2) void fused_wide64_kernel(FusedArgs a, Wide6
       int i3 = i;
       asm volatile("" : "+v"(i3));
       const int dump = tri(NP - 1) + NP;  // behind the last row
+      if constexpr (RING) {
+        const int ir3 = i3 < M ? i3 : i3 - M;
+        static_for<BA * BPH>([&](auto sc) {
+          constexpr int s = decltype(sc)::value;  // pair (own row j = s / BPH, partner BPH h + s % BPH + 1)
+          // ring positions -> slots: the query (position k) is slot q; a pair met from both ends writes the same value twice
+          const int r1 = ringrow(ir3 + own_offset(s / BPH)), c = ringrow(ir3 + h * BPH + s % BPH + 1);
+          const int s1 = r1 < k ? r1 : q, sc2 = c < k ? c : q;
+          const int hi = max(s1, sc2), lo = min(s1, sc2);
+          tile[hi != lo ? tri(hi) + lo : dump] = kv[s];
+        });
+        // what no pair writes: the padding slots k .. q - 1 (rows of zeros) and their columns in the query's row
+        if (h == 1 && i3 >= k && i3 <= q) {
+          const int rowz = tri(i3);
+          for (int cz = i3 == q ? k : 0; cz < i3; ++cz) tile[rowz + cz] = T(0);
+        }
+      } else {
       static_for<BA * BPH>([&](auto sc) {
         constexpr int s = decltype(sc)::value;  // pair (own row j = s / BPH, partner 8 h + s % BPH + 1)
         const int r1 = (i3 + own_offset(s / BPH)) & (NP - 1);
@@ -204,6 +253,7 @@ __global__ __launch_bounds__(256, 2) void fused_wide64_kernel(FusedArgs a, Wide6
         // cyclic distance 64 is met from both ends (own row 3, partner 16 <-> own row 0 ...): both write the same value
         tile[hi <= q ? tri(hi) + lo : dump] = v;
       });
+      }
       const int myrow = tri(i3);
       if (h == 0) {
         tile[myrow + i3] = mydiag;
