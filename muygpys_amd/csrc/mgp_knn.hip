@@ -334,7 +334,7 @@ constexpr int KB_CAP = 16;    // queue entries per query
 #define MGP_KNN_SWIZZLE 1
 #endif
 #ifndef MGP_KNN_PIPE_KP
-#define MGP_KNN_PIPE_KP 16     // packed row lengths up to this run the survivor test one column block behind the matrix instructions
+#define MGP_KNN_PIPE_KP 32     // packed row lengths up to this run the survivor test one column block behind the matrix instructions (32: +2-3 % at d = 16 / 24; 48 spills 38 registers)
 #endif
 #ifndef MGP_KNN_CADENCE_MAX
 #define MGP_KNN_CADENCE_MAX 16384
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(64 * NW, (RBN > 2 ? 3 : KP <= 16 ? 4 : KP <= 48 ? 3
     } else if constexpr (KP <= MGP_KNN_PIPE_KP) {
       // short rows (one matrix instruction per chain): the vector work on a column block's accumulators -- the max over
       // 16 registers, the survivor branch -- sits behind the NEXT block's matrix instructions instead of waiting for its
-      // own (a second pair of accumulators: the registers are there at KP <= 16)
+      // own (a second pair of accumulators: the registers are there up to KP = 32)
       f16x accp[2][2];
       blocks(0, 0, accp[0]);
 #pragma unroll

@@ -90,7 +90,8 @@ def test_end_to_end_with_true_neighbours():
 
 
 @pytest.mark.parametrize("scan_kind", ["bf16x3", "f32"])
-@pytest.mark.parametrize("d,k,n,m", [(40, 30, 30000, 3000), (8, 50, 50000, 2500), (36, 10, 20000, 1000), (64, 64, 12000, 777)])
+@pytest.mark.parametrize("d,k,n,m", [(40, 30, 30000, 3000), (8, 50, 50000, 2500), (36, 10, 20000, 1000), (64, 64, 12000, 777),
+                                     (24, 30, 40000, 2000), (16, 20, 30000, 1500)])  # (32-slot packed rows)
 def test_mfma_scan_matches_dense_path(d, k, n, m, scan_kind):
     """The fused MFMA scan (mgp_knn_scan_f32) and the dense matmul+topk path return the same
     neighbour distances (index sets may differ only where distances tie to fp32 rounding)."""
