@@ -744,6 +744,9 @@ __global__ __launch_bounds__(64 * NW, (RBN > 2 ? 3 : KP <= 16 ? 4 : KP <= 48 ? 3
 #ifndef MGP_KNN_TN16
 #define MGP_KNN_TN16 128
 #endif
+#ifndef MGP_KNN_TNL
+#define MGP_KNN_TNL KNN_TN  // rows per staged tile of the longer packed rows (128 = two workgroups per CU at KP = 48: 586 against 318 ms at d = 40, 290 against 241 at d = 24)
+#endif
 #ifndef MGP_KNN_NW16
 #define MGP_KNN_NW16 4
 #endif
@@ -755,7 +758,7 @@ __global__ __launch_bounds__(64 * NW, (RBN > 2 ? 3 : KP <= 16 ? 4 : KP <= 48 ? 3
 #endif
 template <int KP, int RBN = 2>
 static int launch_knn_packed_kp(const KnnPackedArgs& a, hipStream_t stream) {
-  constexpr int TN = KP <= 16 ? MGP_KNN_TN16 : KNN_TN;
+  constexpr int TN = KP <= 16 ? MGP_KNN_TN16 : MGP_KNN_TNL;
   constexpr int NW = KP <= 16 ? MGP_KNN_NW16 : 4, NBUF = KP <= 16 ? MGP_KNN_NBUF16 : 2;
   constexpr int KB_QB = KB_RB * RBN * NW;
   const int64_t grid = (a.m + KB_QB - 1) / KB_QB;
