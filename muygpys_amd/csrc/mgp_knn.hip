@@ -747,6 +747,9 @@ __global__ __launch_bounds__(64 * NW, (RBN > 2 ? 3 : KP <= 16 ? 4 : KP <= 48 ? 3
 #ifndef MGP_KNN_TNL
 #define MGP_KNN_TNL KNN_TN  // rows per staged tile of the longer packed rows (128 = two workgroups per CU at KP = 48: 586 against 318 ms at d = 40, 290 against 241 at d = 24)
 #endif
+#ifndef MGP_KNN_NWL
+#define MGP_KNN_NWL 4  // waves per workgroup, longer packed rows (6 = two workgroups per CU: 452 against 329 ms at d = 40)
+#endif
 #ifndef MGP_KNN_NW16
 #define MGP_KNN_NW16 4
 #endif
@@ -759,7 +762,7 @@ __global__ __launch_bounds__(64 * NW, (RBN > 2 ? 3 : KP <= 16 ? 4 : KP <= 48 ? 3
 template <int KP, int RBN = 2>
 static int launch_knn_packed_kp(const KnnPackedArgs& a, hipStream_t stream) {
   constexpr int TN = KP <= 16 ? MGP_KNN_TN16 : MGP_KNN_TNL;
-  constexpr int NW = KP <= 16 ? MGP_KNN_NW16 : 4, NBUF = KP <= 16 ? MGP_KNN_NBUF16 : 2;
+  constexpr int NW = KP <= 16 ? MGP_KNN_NW16 : MGP_KNN_NWL, NBUF = KP <= 16 ? MGP_KNN_NBUF16 : 2;
   constexpr int KB_QB = KB_RB * RBN * NW;
   const int64_t grid = (a.m + KB_QB - 1) / KB_QB;
   constexpr int XSB = KP == 8 ? 48 : 4 * KP + (MGP_KNN_SWIZZLE && KP == 16 ? 0 : 16);  // staged row (see the kernel)
