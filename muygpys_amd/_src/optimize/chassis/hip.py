@@ -77,7 +77,12 @@ def _analytic_value_and_grad(muygps, obj_fn, x0_names):
     with homoscedastic noise -- anything else raises (there is no silent fall-back to finite differences: the caller
     asked for an analytic gradient).  A free ``noise`` is refused too: inside the reference's objective sigma^2 is
     computed with the STORED noise while mean and variance take the trial value (gp/hyperparameter/scale.py:206,214
-    against gp/noise/homoscedastic.py:112-113), which is not the function the gradient kernel differentiates."""
+    against gp/noise/homoscedastic.py:112-113), which is not the function the gradient kernel differentiates.
+
+    The sigma^2 inside ``lool`` is whatever the objective was built with, and the gradient follows it: the closed
+    form of ``AnalyticScale`` (any ``iteration_count``: the fixed-point passes are scalar algebra on the first value
+    and are differentiated as such) or the constant of ``FixedScale`` / a plain ``ScaleFn`` (no cotangent through
+    ``y^T K^-1 y``).  A ``scale_fn`` that is neither of the two closures ``ScaleFn.get_opt_fn`` returns is refused."""
     from muygpys_amd import distributed as D
     from muygpys_amd import lazy, lazy_eval
     from muygpys_amd.fused import loocv_value_and_grad
@@ -89,6 +94,7 @@ def _analytic_value_and_grad(muygps, obj_fn, x0_names):
     loss = "lool" if ctx["loss_fn"] is lool_fn else ("mse" if ctx["loss_fn"] is mse_fn else None)
     if loss is None or ctx["target_mask"] is not None:
         raise ValueError("analytic_gradient=True: the gradient is written out for lool_fn and mse_fn (no target mask)")
+    scale_mode = _scale_mode(muygps, ctx.get("scale_fn")) if loss == "lool" else ("analytic", 1)
     pair, cross, nn_t = ctx["pairwise_diffs"], ctx["crosswise_diffs"], ctx["batch_nn_targets"]
     if not (isinstance(pair, lazy.LazyDiffs) and isinstance(cross, lazy.LazyDiffs) and isinstance(nn_t, lazy.LazyTargets)):
         raise ValueError("analytic_gradient=True: needs the lazy training tensors (MuyGPS.make_train_tensors under "
@@ -114,10 +120,31 @@ def _analytic_value_and_grad(muygps, obj_fn, x0_names):
         spec = lazy_eval._spec(Kin)
         spec.noise = noise
         value, g_ls, _ = loocv_value_and_grad(spec, pair.nn_data, nn_t.targets, cross.data_indices, pair.nn_indices,
-                                              loss=loss, reduce_fn=reduce_fn)
+                                              loss=loss, reduce_fn=reduce_fn, scale=scale_mode)
         return value, np.array([g_ls[index[j]] for j in range(len(x0_names))], dtype=np.float64)
 
     return value_and_grad
+
+
+def _scale_mode(muygps, scale_fn):
+    """Which sigma^2 the objective's ``lool`` divides by: ``("analytic", iteration_count)`` or ``("fixed", value)``.
+    Read from the closure the objective was BUILT with (gp/hyperparameter/scale.py:60-63,172-219 of the reference:
+    ``noop_scale_opt_fn`` returns ``muygps.scale()``, ``analytic_scale_opt_fn`` the closed form), cross-checked
+    against the model's scale object; anything else cannot be differentiated here and raises."""
+    from muygpys_amd.gp.hyperparameter.scale import AnalyticScale
+
+    name = getattr(scale_fn, "__name__", None)
+    scale = getattr(muygps, "scale", None)
+    if name == "analytic_scale_opt_fn" and isinstance(scale, AnalyticScale):
+        if np.asarray(scale.val).size != 1:
+            raise ValueError("analytic_gradient=True: the analytic scale of a vector-valued sigma^2 is not written out")
+        return ("analytic", max(int(scale.iteration_count), 1))
+    if name == "noop_scale_opt_fn" and scale is not None and not isinstance(scale, AnalyticScale):
+        return ("fixed", _as_float(scale()))
+    raise ValueError(
+        "analytic_gradient=True: lool_fn's gradient is written out for the sigma^2 of AnalyticScale.get_opt_fn "
+        f"or a fixed ScaleFn value; the objective was built with scale_fn={name!r} on a {type(scale).__name__} model"
+    )
 
 
 def _scipy_optimize(muygps, obj_fn: Callable, verbose: bool = False, analytic_gradient: bool = False, **kwargs):

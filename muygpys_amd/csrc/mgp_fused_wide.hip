@@ -376,7 +376,10 @@ int launch_fused_wide(const FusedArgs& a, hipStream_t stream) {
     // every shape past the 64 slots of a wave that the rhs-column kernel (k <= 64) did not take: faster
     // than the LDS workgroup kernel from the first row on (k = 68: 19.8 vs 15.1, k = 75: 18.8 vs 13.0,
     // k = 100: 17.6 vs 4.7, k = 126: 15.6 vs 1.7 M neighbourhoods/s) although it pays for all 128 slots
-    if (rows < MGP_WIDE_MIN_ROWS || rows > NP || a.R > 16 || a.d > 64 || a.packed_nn != nullptr || a.coeffs != nullptr)
+    // (a.k < 64: the pair ring of k + 1 rows wraps ONCE -- `ir`, wrap() -- which needs 2 (k + 1) >= 128 slots; the
+    // rhs-column kernel takes every k <= 64 before this launcher is asked, and must: k = 48 .. 55 with 16 responses
+    // would read tile rows the gather no longer loads)
+    if (rows < MGP_WIDE_MIN_ROWS || a.k < 64 || rows > NP || a.R > 16 || a.d > 64 || a.packed_nn != nullptr || a.coeffs != nullptr)
       return MGP_EUNSUPPORTED;  // more slots / responses / feature stages: the LDS workgroup kernel
     // column groups: the smallest instantiation that holds the rows (17 .. 32 in steps of 2 or 3)
 #ifdef MGP_WIDE_FORCE_NG32  // (A/B builds: the 128-slot form of rounds 2-4)

@@ -228,11 +228,14 @@ def _loocv_plan(spec, features, targets, batch_indices, nn_indices, packed, hube
     lp = _LAST_PLAN
     if (lp is not None and lp[0] is features and lp[1] is targets and lp[2] is batch_indices and lp[3] is nn_indices
             and lp[4] == (spec.kernel, spec.metric, aniso, packed, huber_delta, host_result) and lp[5] is noise_t
-            and lp[6] == (features._version, targets._version) and lp[7] == _lib_raw_stream()):
+            and lp[6] == _versions(features, targets, batch_indices, nn_indices, noise_t) and lp[7] == _lib_raw_stream()):
         return lp[8]
-    key = (spec.kernel, spec.metric, aniso, id(features), features._version, id(targets), targets._version,
-           id(batch_indices), id(nn_indices), None if noise_t is None else id(noise_t), str(packed), float(huber_delta),
-           bool(host_result), int(_lib_raw_stream()))
+    # (the plan holds converted copies of indices / noise whenever dtype or layout differ: an in-place update of the
+    # caller's tensors must make a new plan, like one of the tables)
+    versions = _versions(features, targets, batch_indices, nn_indices, noise_t)
+    key = (spec.kernel, spec.metric, aniso, id(features), id(targets), id(batch_indices), id(nn_indices),
+           None if noise_t is None else id(noise_t), versions, str(packed), float(huber_delta), bool(host_result),
+           int(_lib_raw_stream()))
     plan = _PLANS.get(key)
     if plan is None:
         if len(_PLANS) >= _PLANS_MAX:
@@ -241,8 +244,12 @@ def _loocv_plan(spec, features, targets, batch_indices, nn_indices, packed, hube
                          noise_tensor=noise_t, huber_delta=huber_delta, packed=packed, host_result=host_result)
         _PLANS[key] = plan
     _LAST_PLAN = (features, targets, batch_indices, nn_indices, (spec.kernel, spec.metric, aniso, packed, huber_delta, host_result),
-                  noise_t, (features._version, targets._version), _lib_raw_stream(), plan)
+                  noise_t, versions, _lib_raw_stream(), plan)
     return plan
+
+
+def _versions(*tensors) -> tuple:
+    return tuple(-1 if t is None else t._version for t in tensors)
 
 
 _LAST_PLAN = None
@@ -261,25 +268,36 @@ def clear_plans() -> None:
 
 
 def hip_local_partials(spec, features, targets, batch_indices, nn_indices, packed="auto", huber_delta: float = 1.5,
-                       host_result: bool = False):
+                       host_result: bool = False, own_outputs: bool = True):
     """The local shard's partial sums on the GPU: ONE launch (``mgp_loocv_*``: the fused kernel walks the fixed-order
     fp64 reduction tree itself) through a prepared evaluation (:class:`muygpys_amd.fused.LoocvPlan`: tables, buffers
     and the argument list are set up once per search, an evaluation costs one ctypes call).
 
     Returns ``(partials float64 [6], mean, var)``: ``partials`` a device tensor, or -- ``host_result``: a single
-    process needs no all-reduce -- a numpy array read from the pinned host memory the kernel wrote it to."""
+    process needs no all-reduce -- a numpy array read from the pinned host memory the kernel wrote it to.
+
+    The plan is cached and its buffers are rewritten by the next evaluation on the same tables.  ``own_outputs``
+    (default) hands back copies: ``mean`` / ``var`` (and a device ``partials``) stay what this call computed whatever
+    is evaluated afterwards.  ``own_outputs=False`` returns ``mean = var = None`` and the plan's own ``partials``
+    buffer (to be consumed before the next evaluation) -- what an optimiser's objective, which only needs the scalar,
+    asks for."""
     general = spec.kernel == "matern_gen"
     if general:  # (the general-smoothness model is not on the prepared-evaluation path)
         from muygpys_amd.fused import loocv_partials
 
-        return loocv_partials(spec, features, targets, batch_indices, nn_indices, huber_delta=huber_delta, packed=packed)
+        res = loocv_partials(spec, features, targets, batch_indices, nn_indices, huber_delta=huber_delta, packed=packed)
+        return res if own_outputs else (res[0], None, None)
     plan = _loocv_plan(spec, features, targets, batch_indices, nn_indices, packed, huber_delta, host_result)
     ls = spec.length_scale
     if isinstance(ls, torch.Tensor):
         ls = ls.detach().cpu().tolist() if ls.numel() > 1 else float(ls)
     noise = 0.0 if isinstance(spec.noise, torch.Tensor) and spec.noise.ndim >= 1 else float(spec.noise)
     plan.launch(ls, noise)
-    return (plan.wait() if host_result else plan.partials), plan.mean, plan.var
+    if not own_outputs:
+        return (plan.wait() if host_result else plan.partials), None, None
+    # (clones are ordered behind the launch on the same stream; wait() returns a fresh numpy array)
+    mean, var = plan.mean.clone(), plan.var.clone()
+    return (plan.wait() if host_result else plan.partials.clone()), mean, var
 
 
 def hip_local_looph(mean, targets_b, var, sigma_sq: float, looph_delta: float = 3.0) -> torch.Tensor:
@@ -319,6 +337,7 @@ def sharded_loocv(
     looph_fn: Callable = hip_local_looph,
     packed="auto",
     loss_kwargs: Optional[Dict] = None,
+    return_outputs: bool = True,
 ) -> Dict:
     """One LOOCV objective evaluation over all ranks (objective.py:101-103 semantics: the value
     under ``"objective"`` is MINUS the loss).
@@ -328,7 +347,9 @@ def sharded_loocv(
     ``pseudo_huber``); ``looph`` is not separable in sigma^2 and takes a second, one-scalar
     all-reduce after sigma^2 is known (reference: three all-reduces, loss/mpi.py:57-104 +
     scale/mpi.py:35-36).  Returns the global scalars plus this rank's ``mean`` / ``var`` (which stay
-    sharded, like the reference's results)."""
+    sharded, like the reference's results): tensors of their own -- a later evaluation does not change them.
+    ``return_outputs=False`` leaves them out (``None``), which saves the two copies; ``looph`` needs them and
+    keeps them whatever the flag."""
     if loss not in LOSSES:
         raise ValueError(f"sharded_loocv supports {LOSSES}, not {loss!r}")
     loss_kwargs = dict(loss_kwargs or {})
@@ -339,7 +360,8 @@ def sharded_loocv(
     kw = {}
     if local_fn is hip_local_partials:
         # (one process: the kernel writes the sums to pinned host memory and nothing is all-reduced)
-        kw = dict(packed=packed, huber_delta=float(loss_kwargs.get("boundary_scale", 1.5)), host_result=not _collectives_on(group))
+        kw = dict(packed=packed, huber_delta=float(loss_kwargs.get("boundary_scale", 1.5)), host_result=not _collectives_on(group),
+                  own_outputs=return_outputs or loss == "looph")
     partials, mean, var = local_fn(spec, features, targets, batch_indices, nn_indices, **kw)
     if isinstance(partials, torch.Tensor):
         allreduce_sum_(partials, group)
@@ -367,7 +389,7 @@ def spec_objective(spec_fn: Callable, features, targets, batch_indices, nn_indic
 
     def obj_fn(**hyper):
         return sharded_loocv(spec_fn(**hyper), features, targets, batch_indices, nn_indices, loss=loss, group=group,
-                             presharded=True, **kwargs)["objective"]
+                             presharded=True, return_outputs=False, **kwargs)["objective"]
 
     return obj_fn
 

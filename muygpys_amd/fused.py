@@ -447,7 +447,13 @@ class LoocvPlan:
 
     ``length_scale`` per evaluation: a float (Isotropy) or a sequence of d floats (Anisotropy: copied to the device by
     one asynchronous transfer); ``noise``: a float (HomoscedasticNoise), or fixed per plan as a tensor (heteroscedastic
-    table ``(n,)`` / batch ``(b, k)``).  One response."""
+    table ``(n,)`` / batch ``(b, k)``).  One response.
+
+    The length scale of Isotropy and the result slot are single words of pinned host memory the kernel reads /
+    writes while it runs, so ONE evaluation is in flight per plan: :meth:`launch` waits for the previous one if the
+    caller did not (``wait()``, or -- device-side partials -- whatever consumed them), and it must be called under the
+    stream the plan was made on.  ``info`` (the kernels' count of non-positive pivots) is looked at when a sum comes
+    back NaN: ``numpy.linalg.LinAlgError`` as everywhere else (``config.state.check_spd``)."""
 
     def __init__(self, kernel: str, metric: str, train_features: torch.Tensor, train_targets: torch.Tensor,
                  batch_indices: torch.Tensor, nn_indices: torch.Tensor, anisotropic: bool = False,
@@ -512,13 +518,24 @@ class LoocvPlan:
         # (every argument converted once: an evaluation is one foreign call on ready-made objects; the stream is the
         # one current when the plan was made -- the plan's scratch must not serve two streams anyway)
         self._stream = _lib.stream_ptr()
+        self._raw_stream = _lib.raw_stream()
+        self._in_flight = None  # an event behind the last launch whose completion nobody has observed yet
         sig = self._fn.argtypes
         self._args = tuple(a if isinstance(a, _lib.C._SimpleCData) or a is None else t(a) for a, t in zip(head + tail + [self._stream], sig))
         self._np = np
         self._launched = False
 
     def launch(self, length_scale, noise: float = 0.0) -> None:
-        """Put one evaluation on the current stream (nothing waits)."""
+        """Put one evaluation on the plan's stream (nothing waits, unless the previous evaluation is still running)."""
+        if _lib.raw_stream() != self._raw_stream:
+            raise RuntimeError("LoocvPlan.launch(): the current stream is not the one the plan was prepared on")
+        if self._in_flight is not None:
+            # the kernel in flight reads the length-scale word and writes the result slot this call is about to reset
+            if self.host_result:
+                self.wait()
+            else:
+                self._in_flight.synchronize()
+            self._in_flight = None
         if self.anisotropic:
             ls = self._np.asarray(length_scale, dtype=self._ls_np.dtype).reshape(-1)
             if ls.size != self.d:
@@ -535,6 +552,20 @@ class LoocvPlan:
             self.scratch.zero_()
         _lib.check(rc, "mgp_loocv")
         self._launched = True
+        if self.host_result:
+            self._in_flight = True
+        elif self.b > 0:
+            self._in_flight = torch.cuda.Event()
+            self._in_flight.record()
+
+    def _check_spd(self, sums) -> None:
+        if sums[0] != sums[0] or sums[1] != sums[1] or sums[5] != sums[5]:  # NaN: some neighbourhood did not factorise
+            from muygpys_amd.config import config
+
+            bad = int(self.info.item())
+            self.info.zero_()
+            if bad and config.state.check_spd:
+                _lib._raise_not_spd(bad, "LOOCV evaluation")
 
     def wait(self, spin_seconds: float = 2.0):
         """The six partial sums of the evaluation last launched, as host floats (numpy float64 array)."""
@@ -543,7 +574,10 @@ class LoocvPlan:
         if self.b == 0:
             return self._np.zeros(6)
         if not self.host_result:
-            return self.partials.cpu().numpy()
+            sums = self.partials.cpu().numpy()
+            self._in_flight = None
+            self._check_spd(sums)
+            return sums
         import time
 
         res, want = self._res, float(self.b)
@@ -555,7 +589,10 @@ class LoocvPlan:
                 torch.cuda.current_stream().synchronize()
                 if res[3] != want:
                     raise _lib.HipLibraryError("mgp_loocv: the kernel finished without publishing its sums")
-        return res[:6].copy()
+        self._in_flight = None
+        sums = res[:6].copy()
+        self._check_spd(sums)
+        return sums
 
     def evaluate(self, length_scale, noise: float = 0.0):
         self.launch(length_scale, noise)
@@ -564,7 +601,7 @@ class LoocvPlan:
 
 def loocv_value_and_grad(spec: KernelSpec, train_features: torch.Tensor, train_targets: torch.Tensor,
                          batch_indices: torch.Tensor, nn_indices: torch.Tensor, loss: str = "lool",
-                         packed: Union[str, bool] = "auto", reduce_fn=None):
+                         packed: Union[str, bool] = "auto", reduce_fn=None, scale=("analytic", 1)):
     """A LOOCV loss and its ANALYTIC gradient with respect to the length scale(s) and a homoscedastic noise: one
     forward evaluation (``mgp_loocv_*``) and one backward launch (``mgp_loocv_backward_*``) instead of the ``p + 1``
     forward evaluations per iteration scipy's finite differences cost the reference's L-BFGS-B driver
@@ -579,6 +616,11 @@ def loocv_value_and_grad(spec: KernelSpec, train_features: torch.Tensor, train_t
     and the backward kernel turns the three cotangents into per-neighbourhood partials of d / d length_scale and
     d / d noise.  ``reduce_fn`` (sharded batches): sums a float64 device vector over the ranks in place -- applied to
     the six partial sums (so that s, A, n are global before the cotangents are formed) and to the gradient.
+
+    ``scale`` names the sigma^2 of ``lool``: ``("analytic", iteration_count)`` -- the closed form above, followed by
+    ``iteration_count - 1`` passes of ``s <- (s + f0 / s) / 2`` on the first value ``f0`` (gp/hyperparameter/scale.py:
+    205-217 of the reference; ``ds / df0`` by the same recurrence) -- or ``("fixed", value)``: a constant, nothing
+    flows through ``y^T K^-1 y`` (``FixedScale``, the reference's ``noop_scale_opt_fn``).
 
     Returns ``(value, grad_length_scale (numpy, ls_count), grad_noise (float))`` of the LOSS (the objective the
     drivers maximise is its negative)."""
@@ -605,13 +647,22 @@ def loocv_value_and_grad(spec: KernelSpec, train_features: torch.Tensor, train_t
     if reduce_fn is not None:
         reduce_fn(partials)
     A, B, r2sum, n, _, cy = (float(v) for v in partials.tolist())
-    s = cy / (n * k)
+    mode, arg = scale
+    if mode == "analytic":
+        s = f0 = cy / (n * k)
+        ds = 1.0                                  # d s / d f0 through the fixed-point passes
+        for _ in range(1, int(arg)):
+            s, ds = 0.5 * (s + f0 / s), 0.5 * (ds + 1.0 / s - f0 * ds / (s * s))
+    elif mode == "fixed":
+        s, ds = float(arg), 0.0
+    else:
+        raise ValueError(f"scale = {scale!r}: ('analytic', iteration_count) or ('fixed', value)")
     r = mean - tg[:, 0][bi]
     if loss == "lool":
         value = A / s + B + n * math.log(s)
         gm = (2.0 / s) * r / var
         gv = 1.0 / var - (r * r) / (s * var * var)
-        gyk = torch.full_like(var, (n / s - A / (s * s)) / (n * k))
+        gyk = torch.full_like(var, (n / s - A / (s * s)) * ds / (n * k))
     else:
         value = r2sum / n
         gm = (2.0 / n) * r

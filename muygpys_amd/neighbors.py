@@ -68,7 +68,7 @@ class NN_Wrapper:
         # measured (1 M x 1 M, end to end): split-bf16 pre-filter 0.47 s (d = 40) / 0.36 s (d = 8),
         # plain fp32 scan 0.90 s / 0.43 s
         self.scan_kind = "bf16x3" if scan_kind == "auto" else scan_kind
-        self._packed_train, self._packed_qmax = None, None
+        self._packed_train, self._packed_qmax, self._packed_layout = None, None, None
         self.last_overflow = None  # per-query overflow flags of the most recent scan (device int32)
         self._sq = (self.train.double() ** 2).sum(1).to(self.train.dtype)
         # the scan kernel reads |x|^2 in whole 64-row tiles: +inf past the end (never a neighbour)
@@ -184,7 +184,9 @@ class NN_Wrapper:
             d8 = self.feature_count <= 8 and os.environ.get("MUYGPYS_HIP_KNN_D8", "1") != "0"  # (0: A/B against the three-chain kernel)
             pack = self._pack_bf16_d8 if d8 else self._pack_bf16
             scan = _lib.load().mgp_knn_scan_bf16x2_d8 if d8 else _lib.load().mgp_knn_scan_bf16x3
-            if self._packed_train is None or qmax > self._packed_qmax:
+            # (the cache remembers WHICH layout it holds: the A/B switch may be flipped on a live object)
+            if self._packed_train is None or self._packed_layout != d8 or qmax > self._packed_qmax:
+                self._packed_layout = d8
                 self._packed_qmax = 1.25 * qmax
                 c = -0.5 * self._sq + (2.0**-14 * self._packed_qmax) * self._sq.sqrt()
                 c = c + 2.0**-15 * c.abs()

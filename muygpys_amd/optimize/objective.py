@@ -37,7 +37,7 @@ def make_loo_crossval_fn(
 
     # what the objective was built from, for a driver that differentiates it analytically instead of by finite
     # differences (_src/optimize/chassis/hip.py: _scipy_optimize(..., analytic_gradient=True))
-    obj_fn.loocv_context = dict(loss_fn=loss_fn, kernel_fn=kernel_fn, pairwise_diffs=pairwise_diffs,
+    obj_fn.loocv_context = dict(loss_fn=loss_fn, kernel_fn=kernel_fn, scale_fn=scale_fn, pairwise_diffs=pairwise_diffs,
                                 crosswise_diffs=crosswise_diffs, batch_nn_targets=batch_nn_targets,
                                 batch_targets=batch_targets, target_mask=target_mask, loss_kwargs=dict(loss_kwargs))
     return obj_fn
