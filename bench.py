@@ -58,7 +58,7 @@ CONFIGS = {
     3: dict(points=1_000_000, batch=1_000_000, k=30, d=40, R=1, dtype="f32", kernel="matern15", metric="l2",
             aniso=False, noise=1e-3, objective=True,
             what="one LOOCV objective evaluation (mean, variance, y^T K^-1 y -> sigma^2, lool; one all-reduce)"),
-    4: dict(points=10_000_000, batch=2_000_000, k=50, d=8, R=1, dtype="f64", kernel="matern15", metric="l2",
+    4: dict(points=10_000_000, batch=10_000_000, k=50, d=8, R=1, dtype="f64", kernel="matern15", metric="l2",
             aniso=True, noise=1e-5, objective=True,
             what="one LOOCV objective evaluation of the anisotropic fp64 model (the unit of the Bayes-opt loop)"),
     5: dict(points=2_000_000, batch=500_000, k=64, d=40, R=16, dtype="f32", kernel="rbf", metric="F2",
@@ -126,13 +126,14 @@ def knn_neighbors(Xd, bi, k: int, chunk: int = 2048):
 
 
 def _cpu_worker(args):
-    """One host process of the P-process CPU baseline (the reference's `mpirun -n P` layout:
-    contiguous row blocks, README.md:99-109)."""
-    k, d, lo, hi, seed, fp32, chunk = args
+    """One host process of the CPU baseline: rows [lo, hi) of a batch of `hi` neighbourhoods on an n-row table
+    (P processes: the reference's `mpirun -n P` layout, contiguous row blocks, README.md:99-109).  Returns
+    (seconds of the evaluation itself, seconds since this function was entered)."""
+    k, d, lo, hi, seed, fp32, chunk, n = args
+    t_in = time.perf_counter()
     os.environ.setdefault("OMP_NUM_THREADS", "1")
     from oracle import muygps_oracle as orc  # checker/baseline only -- never on the product path
 
-    n = 65536
     X, y = synth(n, d, seed)
     ft = np.float32 if fp32 else np.float64
     X, y = X.astype(ft), y.astype(ft)
@@ -143,14 +144,20 @@ def _cpu_worker(args):
     spec = orc.Spec("matern15", "l2", 5.0, 1e-3)
     t0 = time.perf_counter()
     orc.posterior_mean_var_chunked(spec, X, X, bi[lo:hi], ni[lo:hi], y, chunk=chunk)
-    return time.perf_counter() - t0
+    t1 = time.perf_counter()
+    return t1 - t0, t1 - t_in
 
 
-def cpu_baseline(k: int, d: int, sample: int, seed: int):
-    """The oracle (numpy restatement of the reference's numpy backend, same op sequence)
-    timed on this box's host cores on a bounded sample of the same workload: fp64 and fp32, one
-    process and P = os.cpu_count() processes (BASELINE.md sec. 2 / SURVEY.md sec. 8d).  `value`
-    is the fp64 single-process figure (the reference's default configuration)."""
+CPU_BATCH, CPU_CHUNK, CPU_RUNS = 65536, 4096, 3
+
+
+def cpu_baseline(k: int, d: int, sample: int, seed: int, points: int = 1_000_000):
+    """BASELINE.md sec. 2, as stated there: the oracle (numpy restatement of the reference's numpy backend, same op
+    sequence) on this box's host cores -- b = 65 536 neighbourhoods of the config-2 shape on the 1 M-row table in
+    chunks of 4 096, fp64 and fp32, one process: MEDIAN OF 3 runs each; and P = os.cpu_count() worker processes over
+    contiguous row blocks (one run each, the compute time of the slowest worker AND the wall clock of the whole pool
+    with process start-up and table set-up).  `value` is the fp64 single-process median (the reference's default
+    configuration).  `sample` < 65 536 (--cpu-sample) shrinks the batch for self-tests and says so."""
     import multiprocessing as mp
     import platform
 
@@ -164,30 +171,42 @@ def cpu_baseline(k: int, d: int, sample: int, seed: int):
     except OSError:
         pass
     P = os.cpu_count() or 1
+    b1 = min(sample, CPU_BATCH)
+    chunk1 = min(CPU_CHUNK, b1)
     variants = {}
-    _cpu_worker((k, d, 0, 256, seed, False, 256))  # warm (imports, page-ins)
-    for name, fp32, procs in (("fp64_1proc", False, 1), ("fp32_1proc", True, 1), ("fp64_Pproc", False, P),
-                              ("fp32_Pproc", True, P)):
-        n_s = sample if procs == 1 else sample * min(procs, 16)
-        if procs == 1:
-            dt = _cpu_worker((k, d, 0, n_s, seed, fp32, 1024))
-        else:
-            # every process computes its block concurrently; the slowest one's compute time counts
-            # (process start-up and the synthetic-data set-up are not part of the reference's timing either)
-            bounds = np.linspace(0, n_s, procs + 1).astype(int)
-            # one BLAS / OpenMP thread per worker process (set before the children import numpy)
-            for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
-                os.environ[var] = "1"
-            with mp.get_context("spawn").Pool(procs) as pool:
-                # small chunks: P processes x the (chunk, k, k, d) difference tensor must fit the host
-                dt = max(pool.map(_cpu_worker, [(k, d, int(bounds[i]), int(bounds[i + 1]), seed, fp32, 128)
-                                                for i in range(procs)]))
-        variants[name] = {"neighborhoods_per_s": n_s / dt, "processes": procs, "sample": n_s, "seconds": dt}
+    _cpu_worker((k, d, 0, 256, seed, False, 256, 4096))  # warm (imports, page-ins)
+    for name, fp32 in (("fp64_1proc", False), ("fp32_1proc", True)):
+        runs = sorted(_cpu_worker((k, d, 0, b1, seed, fp32, chunk1, points))[0] for _ in range(CPU_RUNS))
+        dt = runs[len(runs) // 2]
+        variants[name] = {"neighborhoods_per_s": b1 / dt, "processes": 1, "sample": b1, "chunk": chunk1, "table_rows": points,
+                          "seconds_median": dt, "seconds_runs": runs}
+    if P > 1:
+        # every worker: its block of 65 536 x min(P, 16) neighbourhoods; the (chunk, k, k, d) difference tensors of all
+        # workers together are held to ~64 GB of host memory (P = 256: chunks of 512 instead of 4 096), and each worker
+        # builds its own copy of a 131 072-row table (1 M rows x 256 processes would be 80 GB of tables)
+        n_s = b1 * min(P, 16)
+        per = -(-n_s // P)
+        cap = int(64e9 // (P * k * k * d * 8))
+        chunkP = int(max(128, min(CPU_CHUNK, per, 1 << max(cap, 1).bit_length() - 1)))
+        bounds = np.linspace(0, n_s, P + 1).astype(int)
+        for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):  # (before the children import numpy)
+            os.environ[var] = "1"
+        for name, fp32 in (("fp64_Pproc", False), ("fp32_Pproc", True)):
+            t0 = time.perf_counter()
+            with mp.get_context("spawn").Pool(P) as pool:
+                res = pool.map(_cpu_worker, [(k, d, int(bounds[i]), int(bounds[i + 1]), seed, fp32, chunkP, 131072)
+                                             for i in range(P)])
+            wall = time.perf_counter() - t0
+            dt = max(r[0] for r in res)
+            variants[name] = {"neighborhoods_per_s": n_s / dt, "neighborhoods_per_s_with_startup": n_s / wall,
+                              "processes": P, "sample": n_s, "chunk": chunkP, "table_rows": 131072,
+                              "seconds": dt, "seconds_with_startup": wall}
     v = variants["fp64_1proc"]
     return {
         "value": v["neighborhoods_per_s"], "unit": "neighborhoods/s", "cores": 1, "kind": "port",
-        "sample": f"{v['sample']} neighbourhoods (k={k}, d={d}, fp64 numpy oracle = the reference's numpy-backend "
-                  f"op sequence, chunks of 1024, {v['seconds']:.1f} s)",
+        "sample": f"{v['sample']} neighbourhoods (k={k}, d={d}) on a {points}-row table in chunks of {v['chunk']}, fp64 numpy "
+                  f"oracle = the reference's numpy-backend op sequence, median of {CPU_RUNS} runs ({v['seconds_median']:.1f} s each; "
+                  f"BASELINE.md sec. 2)",
         "cpu_model": cpu, "host_cores": P, "numpy": np.__version__,
         "variants": variants,
     }
@@ -215,14 +234,41 @@ def launch_ranks(n: int, argv) -> int:
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    return supervise_ranks(procs, float(os.environ.get("BENCH_RANKS_TIMEOUT_S", "1800")))
+
+
+def supervise_ranks(procs, timeout_s: float, poll_s: float = 0.05, grace_s: float = 5.0) -> int:
+    """Wait for the ranks TOGETHER: the first one to exit non-zero takes its siblings down at once (a rank that dies
+    before its first collective would otherwise leave the others blocked in RCCL until the watchdog, ten minutes),
+    and so does the overall timeout.  Returns 0 only if every rank returned 0; the first failing rank's code
+    otherwise (124 for the timeout, as coreutils' timeout does).  Children are terminated, then killed after a grace
+    period -- by handle, never by pattern."""
+    deadline = time.monotonic() + timeout_s
     rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:
+            rc = bad[0] if bad[0] > 0 else 128 - bad[0]  # (a signal's negative code -> the shell's 128 + signal)
+            print(f"bench.py: a rank exited with {bad[0]}; stopping the other ranks", file=sys.stderr)
+            break
+        if all(c == 0 for c in codes):
+            return 0
+        if time.monotonic() > deadline:
+            rc = 124
+            print(f"bench.py: ranks still running after {timeout_s:.0f} s; stopping them", file=sys.stderr)
+            break
+        time.sleep(poll_s)
     for p in procs:
-        p.wait()
-        rc = rc or p.returncode
-    if rc:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
+        if p.poll() is None:
+            p.terminate()
+    t_end = time.monotonic() + grace_s
+    for p in procs:
+        try:
+            p.wait(timeout=max(0.0, t_end - time.monotonic()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
     return rc
 
 
@@ -247,6 +293,14 @@ def build_workload(cfg, dev, rank: int, knn: bool, world: int = 1, strong: bool 
         bi_np = np.random.default_rng(seed).permutation(n)[:b].astype(np.int64)[lo:hi]
         bi = torch.from_numpy(bi_np).to(dev)
         ni = knn_neighbors(Xd.float(), bi, k)
+    elif b * k >= 100_000_000 and dev.type == "cuda":
+        # (config 4 at b = N = 10 M: 4 GB of int64 neighbour rows -- drawn on the device, same distribution as
+        # random_neighbors: uniform rows of the table excluding the point itself)
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        bi = (torch.randperm(n, generator=g, device=dev)[:b] if b < n else torch.arange(n, device=dev))[lo:hi].contiguous()
+        ni = torch.randint(0, n - 1, (hi - lo, k), generator=g, device=dev)
+        ni += ni >= bi[:, None]
     else:
         bi_np, ni_np = random_neighbors(n, b, k, seed)
         bi, ni = torch.from_numpy(bi_np[lo:hi].copy()).to(dev), torch.from_numpy(ni_np[lo:hi].copy()).to(dev)
@@ -279,8 +333,10 @@ def make_step(cfg, w, route: str, path: str, use_packed: bool):
     spec = KernelSpec(cfg["kernel"], cfg["metric"], w["ls"], cfg["noise"])
     if route == "fused":
         if cfg["objective"]:
+            # (what an optimiser's objective asks for: the scalars; mean / var stay in the prepared evaluation's buffers,
+            # where _outputs_of reads them for the spot check)
             return lambda: D.sharded_loocv(spec, w["X"], w["y"], w["bi"], w["ni"], loss="lool", presharded=True,
-                                           packed=use_packed)
+                                           packed=use_packed, return_outputs=False)
         return lambda: posterior_mean_var(spec, w["X"], w["X"], w["bi"], w["ni"], w["y"], out_mean=w["mean"],
                                           out_var=w["var"], info=w["info"], path=path, packed=use_packed)
     import torch
@@ -421,7 +477,11 @@ def spot_check(cfg, w, mean, var, rows: int = 256):
 def _outputs_of(cfg, w, route: str, last):
     """(mean, var) device tensors of the last timed step."""
     if route == "fused" and cfg["objective"]:
-        return last["mean"], last["var"]
+        from muygpys_amd import distributed as D
+
+        plan = D.last_plan()  # the prepared evaluation the timed steps ran: its buffers hold the last step's outputs
+        assert plan is not None and plan.b == w["b"]
+        return plan.mean, plan.var
     if route == "fused":
         return w["mean"], w["var"]
     return last[0], last[1]
@@ -475,6 +535,29 @@ def secondary_line(name: str, cfg_id: int, route: str, args, dev, steps: int = 5
     if use_packed and route == "fused":
         pack_table(w["X"], w["y"])
     step = make_step(cfg, w, route, "auto", use_packed if route == "fused" else "auto")
+    acquire = None
+    if cfg.get("acquire"):
+        # one trial of the Bayes loop = one evaluation + one acquisition step (surrogate fit on the trials so far,
+        # 10 000 candidates on the device, polish; _src/optimize/chassis/hip.py) -- 16 recorded trials of this model's
+        # d length scales, the middle of the reference's default budget of 26
+        from muygpys_amd._src.optimize.chassis.hip import _UCBBayesOpt
+
+        evaluate = step
+        rng = np.random.RandomState(5)
+        opt = _UCBBayesOpt(lambda **kw: 0.0, [f"length_scale{i}" for i in range(w["d"])],
+                           np.array([[0.1, 10.0]] * w["d"]), random_state=7)
+        for x in opt._sample(16):
+            opt.X.append(x)
+            opt.y.append(-float(((np.log(x) - 0.3) ** 2).sum()) + 0.01 * rng.randn())
+        acquire = {"seconds": 0.0, "n": 0}
+
+        def step():  # noqa: F811
+            out = evaluate()
+            t0 = time.perf_counter()
+            opt._suggest(2.576)
+            acquire["seconds"] += time.perf_counter() - t0
+            acquire["n"] += 1
+            return out
     # the first launches after a pause run on ramping clocks (the headline kernel: 2.1 ms falling to 1.5 over ~20
     # launches): warm for >= 60 ms of this config's steps, then time >= 150 ms of them
     # (the estimate of a step: the FASTEST of three after an untimed first one -- one-time costs of the first call, or a
@@ -512,6 +595,10 @@ def secondary_line(name: str, cfg_id: int, route: str, args, dev, steps: int = 5
         "valu": {"frac": roof["valu"]["frac"], "achieved": roof["valu"]["achieved"], "unit": "TFLOP/s"},
         "kernel": roof["kernel"], "check": check,
     }
+    if acquire is not None:
+        out["acquisition_ms"] = acquire["seconds"] / max(acquire["n"], 1) * 1e3
+        out["note"] = ("one trial of the Bayes loop: the LOOCV evaluation of this shard plus one acquisition step "
+                       "(host clock around _UCBBayesOpt._suggest, 16 recorded trials)")
     if override or knn:
         out["override"] = dict(override, **({"neighbours": "exact kNN (GPU brute force)"} if knn else {}))
     if gathered_route:
@@ -546,7 +633,8 @@ def main():
     ap.add_argument("--objective", action="store_true",
                     help="time one LOOCV objective evaluation (fused launch + loss sums + the all-reduce)")
     ap.add_argument("--knn", action="store_true", help="exact GPU kNN neighbourhoods instead of random rows")
-    ap.add_argument("--cpu-sample", type=int, default=32768, help="0 disables the CPU baseline leg")
+    ap.add_argument("--cpu-sample", type=int, default=CPU_BATCH,
+                    help="neighbourhoods of the CPU baseline leg (default: BASELINE.md sec. 2's 65 536); 0 disables it")
     ap.add_argument("--path", default="auto", choices=["auto", "generic", "rhs"], help="kernel family to time")
     ap.add_argument("--no-prepared-tables", action="store_true", help="read the plain feature / target tables")
     ap.add_argument("--no-secondary", action="store_true",
@@ -655,6 +743,9 @@ def main():
         roof = roofline_of(cfg, w, avg_ms, kernel_name, cfg["objective"])
         check = spot_check(cfg, w, *_outputs_of(cfg, w, args.route, last))
         assert check is None or check["ok"], f"timed outputs differ from the fp64 workgroup kernel: {check}"
+        if ramp is not None:  # (inside `roofline`: the driver's record keeps it; the top-level `ramp` it drops)
+            roof["ramp_value"], roof["ramp_ms_per_step"] = ramp["value"], ramp["ms_per_step"]
+            roof["settle_ms"] = args.settle_ms
         if pack_ms is not None:
             roof["prepared_table_pack_kernel_ms"] = pack_ms
             roof["prepared_table_pack_cold_ms"] = pack_cold_ms
@@ -718,7 +809,8 @@ def main():
             # fresh process is stable at 0.222-0.227 --, i.e. it measured where the allocator had put its table)
             plan = [("dropin", 2, "dropin", {}), ("dropin_plain", 2, "dropin_plain", {}), ("c3", 3, "fused", {}),
                     ("c3_shard8", 3, "fused", {"batch": 125_000}),
-                    ("c4", 4, "fused", {}), ("c5", 5, "fused", {}), ("knn", 2, "fused", {"knn": True}),
+                    ("c4", 4, "fused", {}), ("c4_shard8", 4, "fused", {"batch": 1_250_000, "acquire": True}),
+                    ("c5", 5, "fused", {}), ("knn", 2, "fused", {"knn": True}),
                     ("points8M", 2, "fused", {"points": 8_000_000})]
             for name, cid, route, over in plan:
                 if cid == args.config and route == args.route and not over:
@@ -731,9 +823,21 @@ def main():
                 # what strong scaling over 8 GPUs can reach at best: the 125 k-neighbourhood launch's rate relative to
                 # the 1 M-neighbourhood launch's (grid fill, clock ramp and the fixed cost of an evaluation)
                 sec["c3_shard8"]["rate_vs_full_batch"] = sec["c3_shard8"]["value"] / sec["c3"]["value"]
+            if "value" in sec.get("c4_shard8", {}) and "value" in sec.get("c4", {}):
+                sec["c4_shard8"]["rate_vs_full_batch"] = sec["c4_shard8"]["value"] / sec["c4"]["value"]
             out["secondary"] = sec
+            # the same, compact, inside `roofline` (the driver's record keeps `roofline` and `config` whole and drops
+            # unknown top-level keys): value [neighbourhoods/s], ms per step, fraction of the HBM roofline / of the
+            # vector peak, kernel
+            out["roofline"]["secondaries"] = {
+                name: ({"error": v["error"]} if "error" in v else dict(
+                    {"value": v["value"], "ms_per_step": v["ms_per_step"], "frac": v["roofline"]["frac"],
+                     "valu_frac": v["valu"]["frac"], "kernel": v["kernel"], "batch": v["batch"],
+                     "check_ok": None if v["check"] is None else v["check"]["ok"]},
+                    **{key: v[key] for key in ("rate_vs_full_batch", "acquisition_ms") if key in v}))
+                for name, v in sec.items()}
         if args.cpu_sample > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(k, d, args.cpu_sample, 20241008)
+            out["cpu_baseline"] = cpu_baseline(k, d, args.cpu_sample, 20241008, points=min(n, 1_000_000))
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -261,6 +261,12 @@ def _lib_raw_stream() -> int:
     return _lib.raw_stream()
 
 
+def last_plan():
+    """The prepared evaluation the most recent :func:`hip_local_partials` call ran (None before the first): its
+    ``mean`` / ``var`` buffers hold that call's outputs until the next evaluation on the same tables."""
+    return None if _LAST_PLAN is None else _LAST_PLAN[8]
+
+
 def clear_plans() -> None:
     global _LAST_PLAN
     _PLANS.clear()
