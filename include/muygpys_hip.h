@@ -312,6 +312,17 @@ int64_t mgp_loocv_scratch_zero_bytes(void);
  * (persistent workgroups, neighbourhoods per task); grid = 0: it walked none (the three-launch walk on the
  * canonical leaves served it) */
 int mgp_last_loocv_geometry(int* grid, int* nh);
+/* How the one-launch evaluation hands sums from workgroup to workgroup (process-wide; initial value from the
+ * environment variable MUYGPYS_HIP_LOOCV_TREE = tickets | fenced | three_launch, default tickets):
+ *   0 tickets       write-through stores, drained vmcnt, relaxed agent-scope ticket, sc1 loads (no fence)
+ *   1 fenced        release fence / ACQ_REL ticket / acquire fence: what the memory model guarantees anywhere
+ *   2 three_launch  the fused kernel does not walk; three kernels walk the SAME leaves behind it
+ * All three give the same sums bit for bit (same values, same order).  The Python host runs a start-up self-check
+ * of the default form against three_launch and falls back to it, for the rest of the process, if they ever differ
+ * (muygpys_amd/_lib.py: loocv_tree_selfcheck).  Replaces the host-side reductions of the reference's
+ * _src/optimize/loss/mpi.py:57. */
+int mgp_loocv_tree_mode_get(void);
+int mgp_loocv_tree_mode_set(int mode);
 /* launch geometry of the calling thread's most recent wave-kernel / matrix-core-layout launch: workgroups (the
  * persistent grid) and dynamic LDS bytes per workgroup -- what profiles/ quote next to the compiler's register
  * record (lib/kernel_resources.json); diagnostic */

@@ -124,6 +124,10 @@ def load():
     lib.mgp_last_launch_geometry.restype = _i
     lib.mgp_last_loocv_geometry.argtypes = [C.POINTER(_i), C.POINTER(_i)]
     lib.mgp_last_loocv_geometry.restype = _i
+    lib.mgp_loocv_tree_mode_get.argtypes = []
+    lib.mgp_loocv_tree_mode_get.restype = _i
+    lib.mgp_loocv_tree_mode_set.argtypes = [_i]
+    lib.mgp_loocv_tree_mode_set.restype = _i
     lib.mgp_matern_gen_constants.argtypes = [_d, C.POINTER(C.c_double)]
     lib.mgp_matern_gen_constants.restype = _i
     lib.mgp_jit_prepare.argtypes = [_i, _i, _i, _i, _i, _i]
@@ -223,6 +227,67 @@ def last_loocv_geometry():
     g, n = C.c_int(0), C.c_int(0)
     check(load().mgp_last_loocv_geometry(C.byref(g), C.byref(n)), "mgp_last_loocv_geometry")
     return g.value, n.value
+
+
+TREE_MODES = ("tickets", "fenced", "three_launch")
+_TREE_CHECKED = {"done": False, "fell_back": False}
+
+
+def loocv_tree_mode() -> str:
+    return TREE_MODES[load().mgp_loocv_tree_mode_get()]
+
+
+def set_loocv_tree_mode(mode: str) -> None:
+    """``tickets`` | ``fenced`` | ``three_launch`` (include/muygpys_hip.h: mgp_loocv_tree_mode_set); process-wide."""
+    check(load().mgp_loocv_tree_mode_set(TREE_MODES.index(mode)), "mgp_loocv_tree_mode_set")
+
+
+def loocv_tree_selfcheck(device=None, rounds: int = 6, force: bool = False) -> bool:
+    """Once per process, before the first prepared LOOCV evaluation: the in-kernel walk of the reduction tree (whose
+    hand-off between workgroups relies on write-through stores and a relaxed ticket, csrc/mgp_loocv_tree.h) against the
+    walk by three kernels over the same leaves, on a small synthetic shard, ``rounds`` evaluations at three grid
+    sizes -- the sums must agree BIT FOR BIT.  If they ever differ (a driver / compiler that reorders what this GPU
+    model and ROCm release do not), the process switches to ``three_launch`` for good and says so; nothing else
+    changes for the caller (same sums, two small launches more per evaluation).  Skipped when the form was chosen
+    explicitly (MUYGPYS_HIP_LOOCV_TREE) or is not the in-kernel default.  Returns True when the in-kernel walk stays."""
+    import os
+    import warnings
+
+    if _TREE_CHECKED["done"] and not force:
+        return not _TREE_CHECKED["fell_back"]
+    _TREE_CHECKED["done"] = True
+    if (os.environ.get("MUYGPYS_HIP_LOOCV_TREE") and not force) or loocv_tree_mode() == "three_launch":
+        return loocv_tree_mode() != "three_launch"
+    import numpy as np
+
+    from muygpys_amd import fused
+
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    mode = loocv_tree_mode()
+    rng = np.random.default_rng(20251004)
+    n, k, d = 6000, 30, 40
+    X = torch.from_numpy(rng.standard_normal((n, d), dtype=np.float32)).to(dev)
+    y = torch.from_numpy(rng.standard_normal(n, dtype=np.float32)).to(dev)
+    ok = True
+    for b in (64, 4097, 30000):  # one level-2 block / a ragged grid / the full persistent grid
+        bi = torch.from_numpy(rng.integers(0, n, size=b)).to(dev)
+        ni = torch.from_numpy(rng.integers(0, n, size=(b, k))).to(dev)
+        spec = fused.KernelSpec("matern15", "l2", 5.0, 1e-2)
+        try:
+            set_loocv_tree_mode("three_launch")
+            ref = fused.loocv_partials(spec, X, y, bi, ni, packed=False)[0].cpu().numpy()
+        finally:
+            set_loocv_tree_mode(mode)
+        for _ in range(rounds):
+            got = fused.loocv_partials(spec, X, y, bi, ni, packed=False)[0].cpu().numpy()
+            ok = ok and got.tobytes() == ref.tobytes()
+    if not ok:
+        _TREE_CHECKED["fell_back"] = True
+        set_loocv_tree_mode("three_launch")
+        warnings.warn("muygpys_amd: the one-launch LOOCV reduction tree disagreed with its three-launch walk on this "
+                      "device / driver; using MUYGPYS_HIP_LOOCV_TREE=three_launch for the rest of the process",
+                      RuntimeWarning, stacklevel=2)
+    return ok
 
 
 def last_launch_geometry():

@@ -6,11 +6,22 @@
 #include "mgp_args.h"
 
 #include <cstdarg>
+#include <cstring>
 
 namespace mgp {
 
 static thread_local char g_last_kernel[256] = "";
 static thread_local int g_tree_grid = 0, g_tree_nh = 0;
+// how the one-launch LOOCV evaluation hands sums between workgroups (mgp_loocv_tree.h); process-wide
+static int tree_mode_from_env() {
+  const char* e = getenv("MUYGPYS_HIP_LOOCV_TREE");
+  if (!e || !*e || !strcmp(e, "tickets")) return kTreeTickets;
+  if (!strcmp(e, "fenced")) return kTreeFenced;
+  if (!strcmp(e, "three_launch")) return kTreeThreeLaunch;
+  fprintf(stderr, "mgp: MUYGPYS_HIP_LOOCV_TREE=%s is none of tickets / fenced / three_launch; using three_launch\n", e);
+  return kTreeThreeLaunch;  // (an unknown word must not select the least conservative form)
+}
+static int g_tree_mode = tree_mode_from_env();
 void note_tree_geometry(int grid, int nh) { g_tree_grid = grid, g_tree_nh = nh; }
 static thread_local int64_t g_launch_grid = 0;
 static thread_local int g_launch_lds = 0;
@@ -161,6 +172,16 @@ int solve(const T* Kin, const T* Kc, const T* Y, int64_t b, int k, int R, double
   if (rc != MGP_EUNSUPPORTED) return rc;
   return launch_solve_generic<T>(a, static_cast<hipStream_t>(stream));
 }
+// behind the fused launch of a LOOCV evaluation: nothing when a wave kernel walked the tree itself; the walk by kernels
+// over the SAME leaves when it was launched without (three_launch); over the canonical leaves behind another family
+template <typename T>
+int loocv_finish(int rc, bool served, const LoocvTree& tr, const T* mean, const T* var, const T* yk, const int64_t* bi,
+                 int64_t b, hipStream_t s) {
+  if (rc != MGP_OK) return rc;
+  if (served && tr.mode != kTreeThreeLaunch) return MGP_OK;
+  const int grid = served ? g_tree_grid : 0, nh = served ? g_tree_nh : 0;
+  return launch_loocv_tree<T>(tr, grid, nh, mean, var, yk, bi, b, s);
+}
 }  // namespace mgp
 
 using namespace mgp;
@@ -209,6 +230,12 @@ int64_t mgp_loocv_scratch_zero_bytes(void) { return tree_zero_bytes(); }
 int mgp_last_launch_geometry(int64_t* workgroups, int* lds_bytes) {
   if (!workgroups || !lds_bytes) return MGP_EINVAL;
   *workgroups = g_launch_grid, *lds_bytes = g_launch_lds;
+  return MGP_OK;
+}
+int mgp_loocv_tree_mode_get(void) { return g_tree_mode; }
+int mgp_loocv_tree_mode_set(int mode) {
+  if (mode != kTreeTickets && mode != kTreeFenced && mode != kTreeThreeLaunch) return MGP_EINVAL;
+  g_tree_mode = mode;
   return MGP_OK;
 }
 int mgp_last_loocv_geometry(int* grid, int* nh) {
@@ -332,12 +359,12 @@ int mgp_posterior_f64(const double* fq, const double* fn, int d, const int64_t* 
                       T* yk, int* info, double huber_delta, double* partials, void* scratch, void* st) {             \
     if ((b > 0 && (!mean || !var || !yk)) || !partials || !scratch || !(huber_delta > 0)) return MGP_EINVAL;         \
     LoocvTree tr = loocv_tree_layout(scratch, partials, tg, (int64_t)sizeof(T), huber_delta);                        \
+    tr.mode = g_tree_mode;                                                                                           \
     bool served = false;                                                                                             \
     note_tree_geometry(0, 0);                                                                                        \
     const int rc = posterior<T>(feat, feat, d, bi, ni, b, k, tg, 1, nm, eps, nd, kid, mid, ls, lsc, mean, var, yk,  \
                                 info, st, PATH_AUTO, nullptr, 0, nullptr, 0, 0, &tr, &served);                       \
-    if (rc != MGP_OK || served) return rc;                                                                           \
-    return launch_loocv_tree<T>(tr, 0, 0, mean, var, yk, bi, b, S_(st));                                             \
+    return loocv_finish<T>(rc, served, tr, mean, var, yk, bi, b, S_(st));                                            \
   }                                                                                                                  \
   int mgp_loocv_tree_##SUF(const T* mean, const T* var, const T* yk, const void* resp, int64_t resp_stride,          \
                            const int64_t* bi, int64_t b, double huber_delta, int grid, int nh, double* partials,     \
@@ -354,12 +381,12 @@ int mgp_posterior_f64(const double* fq, const double* fn, int d, const int64_t* 
     if ((b > 0 && (!mean || !var || !yk)) || !partials || !scratch || !(huber_delta > 0)) return MGP_EINVAL;         \
     LoocvTree tr = loocv_tree_layout(scratch, partials, static_cast<const char*>(packed) + (size_t)d * sizeof(T),    \
                                      stride, huber_delta);                                                           \
+    tr.mode = g_tree_mode;                                                                                           \
     bool served = false;                                                                                             \
     note_tree_geometry(0, 0);                                                                                        \
     const int rc = posterior<T>(nullptr, nullptr, d, bi, ni, b, k, nullptr, 1, nm, eps, nd, kid, mid, ls, lsc, mean, \
                                 var, yk, info, st, PATH_AUTO, packed, stride, packed, stride, 0, &tr, &served);      \
-    if (rc != MGP_OK || served) return rc;                                                                           \
-    return launch_loocv_tree<T>(tr, 0, 0, mean, var, yk, bi, b, S_(st));                                             \
+    return loocv_finish<T>(rc, served, tr, mean, var, yk, bi, b, S_(st));                                            \
   }
 MGP_DEFINE_PATHS(f32, float)
 MGP_DEFINE_PATHS(f64, double)

@@ -106,6 +106,7 @@ static int launch_jit(const FusedArgs& a, hipStream_t stream) {
   FusedArgs args = a;
   args.tree.grid = (int)grid;  // (the leaves of the reduction tree are this launch's workgroups)
   args.tree.nh = WD.NH;
+  if (a.tree.mode == kTreeThreeLaunch) args.tree.out = nullptr;  // (as launch_np_impl)
   void* params[] = {&args, &g};
   const hipError_t err = hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 64, 1, 1, (unsigned)lds, stream, params, nullptr);
   if (err != hipSuccess) return -(1000 + (int)err);

@@ -106,6 +106,7 @@ int launch_np_impl(const FusedArgs& a, hipStream_t stream) {
   FusedArgs al = a;
   al.tree.grid = (int)grid;
   al.tree.nh = NH;
+  if (a.tree.mode == kTreeThreeLaunch) al.tree.out = nullptr;  // (the caller walks these leaves by kernels behind the launch)
   static const bool trace = getenv("MGP_TRACE") != nullptr;  // which instantiation served a call
   if (trace)
     fprintf(stderr, "mgp: fused_wave_kernel<%s,%d,%d,%d,%d,%s%s%s> b=%lld k=%d d=%d R=%d grid=%lld lds=%zu\n",

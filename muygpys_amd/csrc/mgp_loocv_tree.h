@@ -48,7 +48,17 @@ struct LoocvTree {
   int64_t resp_stride = 0;
   double huber_delta = 1.5;
   int grid = 0, nh = 0;         // the leaves: persistent workgroups of the launch, neighbourhoods per task
+  int mode = 0;                 // kTreeTickets / kTreeFenced (how the in-kernel walk hands sums over) / kTreeThreeLaunch
 };
+
+// How one workgroup's sums reach the workgroup that adds them up (MUYGPYS_HIP_LOOCV_TREE, mgp_loocv_tree_mode_set):
+//   tickets       write-through stores, a drained vmcnt, a RELAXED agent-scope ticket, sc1 loads -- no fence (the default:
+//                 the form the microarchitecture guide gives for "the adder whose add came last reads")
+//   fenced        the textbook form: release fence, ACQ_REL ticket, acquire fence -- what the memory model guarantees on
+//                 any driver / compiler; the same sums bit for bit, a few hundred cycles more per workgroup
+//   three_launch  the fused kernel does not walk the tree at all; three small kernels do, behind it, over the SAME
+//                 leaves (grid, nh) -- kernel boundaries are the only synchronisation; again the same bits
+constexpr int kTreeTickets = 0, kTreeFenced = 1, kTreeThreeLaunch = 2;
 
 constexpr int kTreeCtrlBytes = 128;
 constexpr int kTreeWordL3 = 0;
@@ -186,29 +196,48 @@ __device__ __forceinline__ void tree_result(double* out, const double (&t)[6], i
 
 // In the fused kernel, when workgroup w has run out of tasks (its output stores drained): its leaf, and up the tree as far
 // as this wave's tickets are the last ones.  One wave per workgroup; uniform control flow.
+template <bool FENCED>
+__device__ __forceinline__ void tree_handoff() {  // this wave's published sums are visible before its ticket is
+  if constexpr (FENCED) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  else drain_stores();
+}
+template <bool FENCED>
+__device__ __forceinline__ unsigned tree_ticket(unsigned* counter, int lane) {
+  unsigned old = 0;
+  if (lane == 0)
+    old = FENCED ? __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
+                 : __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __builtin_amdgcn_readfirstlane(old);
+}
+template <typename T, bool FENCED>
+__device__ __forceinline__ void tree_climb(const LoocvTree& tr, int w, int lane, double (&t)[6]) {
+  tree_publish(tr.part1 + 6 * w, t, lane);
+  tree_handoff<FENCED>();
+  const int j2 = w >> 6, left2 = tr.grid - (j2 << 6);
+  const unsigned old2 = tree_ticket<FENCED>(tr.cnt2 + j2, lane);
+  if (old2 + 1u != (unsigned)(left2 < 64 ? left2 : 64)) return;
+  if constexpr (FENCED) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  tree_level2<true>(tr, j2, lane, t);
+  tree_publish(tr.part2 + 6 * j2, t, lane);
+  if (lane == 0) st_agent(tr.cnt2 + j2, 0u);  // (the counter is this call's no longer: left zero for the next)
+  tree_handoff<FENCED>();
+  const unsigned old3 = tree_ticket<FENCED>(tr.ctrl + kTreeWordL3, lane);
+  if ((int64_t)old3 + 1 != tree_nb2(tr.grid)) return;
+  if constexpr (FENCED) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  tree_level3<true>(tr, lane, t);  // the last level-2 block of the launch: the shard's sums
+  tree_result(tr.out, t, lane);
+  if (lane == 0) st_agent(tr.ctrl + kTreeWordL3, 0u);
+}
+
+// In the fused kernel, when workgroup w has run out of tasks (its output stores drained): its leaf, and up the tree as far
+// as this wave's tickets are the last ones.  One wave per workgroup; uniform control flow.
 template <typename T>
 __device__ __forceinline__ void tree_leaf_done(const LoocvTree& tr, const T* mean, const T* var, const T* yk,
                                                const int64_t* batch_idx, int64_t b, int w, int lane) {
   double t[6];
   tree_level1<T>(tr, mean, var, yk, batch_idx, b, w, lane, t);
-  tree_publish(tr.part1 + 6 * w, t, lane);
-  drain_stores();
-  const int j2 = w >> 6, left2 = tr.grid - (j2 << 6);
-  unsigned old2 = 0;
-  if (lane == 0) old2 = __hip_atomic_fetch_add(tr.cnt2 + j2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  old2 = __builtin_amdgcn_readfirstlane(old2);
-  if (old2 + 1u != (unsigned)(left2 < 64 ? left2 : 64)) return;
-  tree_level2<true>(tr, j2, lane, t);
-  tree_publish(tr.part2 + 6 * j2, t, lane);
-  if (lane == 0) st_agent(tr.cnt2 + j2, 0u);  // (the counter is this call's no longer: left zero for the next)
-  drain_stores();
-  unsigned old3 = 0;
-  if (lane == 0) old3 = __hip_atomic_fetch_add(tr.ctrl + kTreeWordL3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  old3 = __builtin_amdgcn_readfirstlane(old3);
-  if ((int64_t)old3 + 1 != tree_nb2(tr.grid)) return;
-  tree_level3<true>(tr, lane, t);  // the last level-2 block of the launch: the shard's sums
-  tree_result(tr.out, t, lane);
-  if (lane == 0) st_agent(tr.ctrl + kTreeWordL3, 0u);
+  if (tr.mode == kTreeFenced) tree_climb<T, true>(tr, w, lane, t);
+  else tree_climb<T, false>(tr, w, lane, t);
 }
 
 }  // namespace mgp

@@ -462,6 +462,7 @@ class LoocvPlan:
         import numpy as np
 
         _lib.require_cuda(train_features, train_targets, batch_indices, nn_indices, noise_tensor)
+        _lib.loocv_tree_selfcheck(train_features.device)  # (once per process: in-kernel walk vs the walk by kernels)
         self.spec = KernelSpec(kernel, metric, 1.0, 0.0)
         dtype = train_features.dtype
         if train_targets.dtype != dtype:

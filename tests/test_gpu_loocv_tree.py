@@ -188,3 +188,93 @@ def test_sharded_loocv_uses_the_prepared_evaluation_and_matches_the_oracle_losse
     D.sharded_loocv(KernelSpec("rbf", "F2", 3.0, 1e-2), Xd, yd, bid, nid, loss="mse", presharded=True)
     assert len(D._PLANS) == 2
     D.clear_plans()
+
+
+@pytest.fixture
+def tree_mode():
+    """Set the hand-off form for one test and put the process's own back."""
+    from muygpys_amd import _lib
+
+    before = _lib.loocv_tree_mode()
+    yield _lib.set_loocv_tree_mode
+    _lib.set_loocv_tree_mode(before)
+
+
+@pytest.mark.parametrize("dtype,k,d,packed,b", [("float32", 30, 40, True, 70_001), ("float64", 50, 8, True, 4_100),
+                                                ("float32", 10, 8, True, 5_003), ("float32", 64, 40, False, 1_030)],
+                         ids=lambda v: str(v))
+def test_the_three_hand_off_forms_give_the_same_bits(dtype, k, d, packed, b, tree_mode):
+    """MUYGPYS_HIP_LOOCV_TREE = tickets | fenced | three_launch (csrc/mgp_loocv_tree.h): the same leaves, the same order,
+    the same sums bit for bit -- and the same outputs; ``three_launch`` reports the fused launch's leaves although the
+    kernel did not walk them."""
+    from muygpys_amd import _lib
+    from muygpys_amd.fused import KernelSpec, loocv_partials
+
+    X, y, bi, ni, Xd, yd, bid, nid = _problem(5 + k, 5_000, b, k, d, dtype)
+    spec = KernelSpec("matern15", "l2", 3.0 if d >= 16 else 1.5, 1e-2)
+    got = {}
+    for mode in _lib.TREE_MODES:
+        tree_mode(mode)
+        assert _lib.loocv_tree_mode() == mode
+        p, mean, var = loocv_partials(spec, Xd, yd, bid, nid, packed=packed)
+        got[mode] = (p.cpu().numpy().tobytes(), mean.cpu().numpy().tobytes(), var.cpu().numpy().tobytes(),
+                     _lib.last_loocv_geometry(), _lib.last_kernel())
+    assert got["tickets"][:4] == got["fenced"][:4] == got["three_launch"][:4], {m: (v[3], v[4]) for m, v in got.items()}
+
+
+@pytest.mark.parametrize("mode", ["tickets", "fenced"])
+def test_ten_thousand_back_to_back_evaluations_equal_the_three_launch_walk(mode, tree_mode):
+    """The in-kernel walk under load: 10 000 evaluations back to back on one stream (no synchronisation in between, one
+    scratch buffer), at three grid sizes -- one level-2 block, a ragged grid, the full persistent grid --, every one of
+    them compared with the sums of the three-launch walk of the same leaves, bit for bit.  A hand-off that a driver
+    or compiler update reorders shows up here as a differing sum (or a sum that never arrives), not as a silently
+    wrong loss (reference: the host reductions of _src/optimize/loss/mpi.py:57 this replaces)."""
+    from muygpys_amd.fused import KernelSpec, LoocvPlan
+
+    n, k, d = 6_000, 30, 40
+    for b, evaluations in ((64, 4_000), (4_097, 3_000), (40_000, 3_000)):
+        X, y, bi, ni, Xd, yd, bid, nid = _problem(3 + b, n, b, k, d, "float32")
+        tree_mode("three_launch")
+        ref = LoocvPlan("matern15", "l2", Xd, yd, bid, nid, host_result=False)
+        want = {}
+        for nz in (1e-2, 2e-2, 5e-2):   # (the noise travels by value with each launch; the length scale is one host word)
+            ref.launch(3.0, nz)
+            want[nz] = ref.wait().tobytes()
+        tree_mode(mode)
+        plan = LoocvPlan("matern15", "l2", Xd, yd, bid, nid, host_result=False)
+        # device-side results, collected without a host round trip: evaluation e's six sums are copied behind it
+        out = torch.zeros((evaluations, 6), device=Xd.device, dtype=torch.float64)
+        noises = [(1e-2, 2e-2, 5e-2)[e % 3] for e in range(evaluations)]
+        for e, nz in enumerate(noises):
+            plan._in_flight = None      # (the stream orders them: same plan, same buffers, no host wait)
+            plan.launch(3.0, nz)
+            out[e].copy_(plan.partials, non_blocking=True)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        bad = [e for e, nz in enumerate(noises) if got[e].tobytes() != want[nz]]
+        assert not bad, f"{mode}, b = {b}: {len(bad)} of {evaluations} evaluations differ from the three-launch walk (first: {bad[:5]})"
+        assert int(plan.scratch[: 4096].to(torch.int64).sum()) == 0  # (counters left zero)
+
+
+def test_startup_selfcheck_keeps_the_in_kernel_walk_and_falls_back_when_it_disagrees(monkeypatch, tree_mode):
+    from muygpys_amd import _lib, fused
+
+    tree_mode("tickets")
+    monkeypatch.delenv("MUYGPYS_HIP_LOOCV_TREE", raising=False)
+    assert _lib.loocv_tree_selfcheck(force=True) is True and _lib.loocv_tree_mode() == "tickets"
+    # a walk that returns other bits than the three-launch one (simulated: the in-kernel result perturbed in its last
+    # place) must switch the process over -- and the evaluation behind it is then served by the three launches
+    real = fused.loocv_partials
+
+    def flaky(*a, **kw):
+        res = real(*a, **kw)
+        if _lib.loocv_tree_mode() != "three_launch":
+            res[0][0] = torch.nextafter(res[0][0], res[0][0] + 1)
+        return res
+
+    monkeypatch.setattr(fused, "loocv_partials", flaky)
+    with pytest.warns(RuntimeWarning, match="three_launch"):
+        assert _lib.loocv_tree_selfcheck(force=True) is False
+    assert _lib.loocv_tree_mode() == "three_launch"
+    monkeypatch.setattr(fused, "loocv_partials", real)
+    _lib._TREE_CHECKED.update(done=True, fell_back=False)
