@@ -181,10 +181,10 @@ def cpu_baseline(k: int, d: int, sample: int, seed: int, points: int = 1_000_000
         variants[name] = {"neighborhoods_per_s": b1 / dt, "processes": 1, "sample": b1, "chunk": chunk1, "table_rows": points,
                           "seconds_median": dt, "seconds_runs": runs}
     if P > 1:
-        # every worker: its block of 65 536 x min(P, 16) neighbourhoods; the (chunk, k, k, d) difference tensors of all
+        # every worker: its block of 65 536 x min(P, 8) neighbourhoods; the (chunk, k, k, d) difference tensors of all
         # workers together are held to ~64 GB of host memory (P = 256: chunks of 512 instead of 4 096), and each worker
         # builds its own copy of a 131 072-row table (1 M rows x 256 processes would be 80 GB of tables)
-        n_s = b1 * min(P, 16)
+        n_s = b1 * min(P, 8)
         per = -(-n_s // P)
         cap = int(64e9 // (P * k * k * d * 8))
         chunkP = int(max(128, min(CPU_CHUNK, per, 1 << max(cap, 1).bit_length() - 1)))
@@ -549,14 +549,13 @@ def secondary_line(name: str, cfg_id: int, route: str, args, dev, steps: int = 5
         for x in opt._sample(16):
             opt.X.append(x)
             opt.y.append(-float(((np.log(x) - 0.3) ** 2).sum()) + 0.01 * rng.randn())
-        acquire = {"seconds": 0.0, "n": 0}
+        acquire = []  # host seconds of every acquisition step (the first ones pay one-time library initialisation)
 
         def step():  # noqa: F811
             out = evaluate()
             t0 = time.perf_counter()
             opt._suggest(2.576)
-            acquire["seconds"] += time.perf_counter() - t0
-            acquire["n"] += 1
+            acquire.append(time.perf_counter() - t0)
             return out
     # the first launches after a pause run on ramping clocks (the headline kernel: 2.1 ms falling to 1.5 over ~20
     # launches): warm for >= 60 ms of this config's steps, then time >= 150 ms of them
@@ -596,9 +595,11 @@ def secondary_line(name: str, cfg_id: int, route: str, args, dev, steps: int = 5
         "kernel": roof["kernel"], "check": check,
     }
     if acquire is not None:
-        out["acquisition_ms"] = acquire["seconds"] / max(acquire["n"], 1) * 1e3
+        timed = acquire[-steps:]  # (the timed steps' acquisitions: warm-up ones carry one-time library initialisation)
+        out["acquisition_ms"] = float(np.median(timed)) * 1e3
+        out["acquisition_ms_mean"] = float(np.mean(timed)) * 1e3
         out["note"] = ("one trial of the Bayes loop: the LOOCV evaluation of this shard plus one acquisition step "
-                       "(host clock around _UCBBayesOpt._suggest, 16 recorded trials)")
+                       "(host clock around _UCBBayesOpt._suggest, 16 recorded trials; median / mean over the timed steps)")
     if override or knn:
         out["override"] = dict(override, **({"neighbours": "exact kNN (GPU brute force)"} if knn else {}))
     if gathered_route:
@@ -834,7 +835,7 @@ def main():
                     {"value": v["value"], "ms_per_step": v["ms_per_step"], "frac": v["roofline"]["frac"],
                      "valu_frac": v["valu"]["frac"], "kernel": v["kernel"], "batch": v["batch"],
                      "check_ok": None if v["check"] is None else v["check"]["ok"]},
-                    **{key: v[key] for key in ("rate_vs_full_batch", "acquisition_ms") if key in v}))
+                    **{key: v[key] for key in ("rate_vs_full_batch", "acquisition_ms", "acquisition_ms_mean") if key in v}))
                 for name, v in sec.items()}
         if args.cpu_sample > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(k, d, args.cpu_sample, 20241008, points=min(n, 1_000_000))

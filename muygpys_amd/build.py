@@ -42,6 +42,7 @@ PER_FILE_FLAGS = {
     "mgp_fused_wide64.hip": ["-Rpass-analysis=kernel-resource-usage"],
     "mgp_backward.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
     "mgp_backward_wave.hip": ["-mllvm", "-pragma-unroll-threshold=1000000", "-Rpass-analysis=kernel-resource-usage"],
+    "mgp_backward_dlt.hip": ["-mllvm", "-pragma-unroll-threshold=1000000", "-Rpass-analysis=kernel-resource-usage"],
 }
 
 

@@ -36,6 +36,16 @@ struct FusedArgs {
   // ones (mgp_loocv_tree.h).  Only launch_fused_wave serves it (and fills in tree.grid / tree.nh); behind every other
   // kernel family the caller walks the same tree with launch_loocv_tree (mgp_tensor_ops.hip).
   LoocvTree tree;
+  // Backward of one response's outputs on the dealt-triangle kernels (BWD instantiations of fused_wave_kernel,
+  // mgp_backward_dlt.hip; nullptr everywhere else): upstream cotangents of mean / variance / y^T K^-1 y, (b) each (any
+  // may be null = zero), and the per-neighbourhood partials they produce -- d/d length scale(s) (b, ls_count), the
+  // diagonal (noise) cotangent (b, k), and the cotangent of the neighbours' responses (n, 1; atomic adds)
+  const void* bwd_gmean = nullptr;
+  const void* bwd_gvar = nullptr;
+  const void* bwd_gyk = nullptr;
+  void* bwd_gls = nullptr;
+  void* bwd_gnz = nullptr;
+  void* bwd_gtg = nullptr;
 };
 
 #ifndef __HIPCC_RTC__  // the rest is host side: other argument blocks and the launcher declarations
@@ -71,6 +81,10 @@ struct BackwardArgs {
 };
 template <typename T> int launch_backward(const BackwardArgs&, hipStream_t);
 template <typename T> int launch_backward_wave(const BackwardArgs&, hipStream_t);  // Isotropy, k + 2 <= 64: on the wave kernel's phases
+// fp64, hyper-parameter gradients of one response (no feature cotangents) for the static shapes of the dealt-triangle
+// forward kernels (BASELINE config 4: k = 50, d = 8): the forward kernel's own phases + the saved factor
+// (mgp_backward_dlt.hip); MGP_EUNSUPPORTED for everything else
+int launch_backward_dlt(const BackwardArgs&, hipStream_t);
 int max_nn_count_backward(int elem_size);
 
 // Exact k-NN scan on the matrix cores (mgp_knn.hip)

@@ -1,0 +1,92 @@
+// Backward (vector-Jacobian product) of one response's posterior mean / variance / y^T K^-1 y with respect to the
+// HYPER-PARAMETERS -- length scale(s), the noise diagonal, the neighbours' responses; no feature cotangents -- for the
+// fp64 static shapes of the dealt-triangle forward kernels (BASELINE config 4: anisotropic Matern, k = 50, d = 8: the
+// gradient of the LOOCV objective that L-BFGS-B and the torch layer ask for; round 6).
+//
+// Reference: torch autograd over src/MuyGPyS/torch/muygps_layer.py:129-164 (the reference's way to these gradients);
+// the numpy chassis has only finite differences (src/MuyGPyS/_src/optimize/chassis/numpy.py:57-81).  The maths is
+// mgp_backward.hip's:  a = K^-1 c, u = K^-1 y,  K-bar_ij = 2 gv a_i a_j - gm (a_i u_j + a_j u_i) - 2 gy u_i u_j,
+// c-bar_j = gm u_j - 2 gv a_j,  q_ij = K-bar_ij dk/dacc_ij,  dL/dl_f = -(2 / l_f) sum_pairs q_ij (z_if - z_jf)^2.
+//
+// The kernel IS the forward kernel (mgp_fused_wave_kernel.h, BWD instantiation): gather, pair distances (kept in
+// registers), covariances, the dealt lower triangle and its elimination -- 434 FMAs per neighbourhood instead of the
+// 1 400 of a row per lane -- with every finished column written back into the dealt image, which so becomes the
+// factor; then back-substitution for the two vectors on that image, the pair cotangents in the pair scheme's own
+// layout, and the length-scale partials from the tile.  Two waves per SIMD; round 5's row-per-lane kernel
+// (mgp_backward_wave.hip: a 64-double row, 32 kept distances, the multipliers in a 34 KB LDS matrix) ran at one:
+// 117.7 ms per 2 M neighbourhoods against a 12.9 ms forward.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#include "mgp_fused_wave_launch.h"
+
+namespace mgp {
+
+template <int KFIX, int DFIX>
+static int launch_bwd_dlt_impl(const BackwardArgs& b, hipStream_t stream) {
+  using T = double;
+  constexpr int NP = 64, RFIX = 1;
+  constexpr WaveDims WD = wave_dims(sizeof(T), NP, KFIX, RFIX, DFIX, false, false);
+  static_assert(WD.DLT && WD.NH == 1, "the dealt-triangle shapes");
+  constexpr int E = WD.E, CH = WD.CH, KMAT = WD.KMAT;
+  FusedArgs a = b.f;
+  a.mean = a.var = a.ykinvy = nullptr;
+  a.coeffs = nullptr;
+  a.tree = LoocvTree{};
+  a.packed_q = a.packed_nn = nullptr;
+  a.bwd_gmean = b.grad_mean;
+  a.bwd_gvar = b.grad_var;
+  a.bwd_gyk = b.grad_yk;
+  a.bwd_gls = b.grad_ls;
+  a.bwd_gnz = b.grad_noise;
+  a.bwd_gtg = b.grad_targets;
+  WaveGeom g;
+  g.mask = 0xF;
+  g.q = KFIX;
+  const int dpad = (a.d + CH - 1) / CH * CH;
+  g.dst = dpad;
+  g.xs = g.dst + E;
+  g.vec_ok = 1;
+  g.ntasks = a.b;
+  size_t lds_unused = 0;
+  gen_geometry(a, &g, &lds_unused, (int)sizeof(T));
+  const size_t tile_feat = (size_t)wave_tile_rows(WD, NP, KFIX, g.xs) * g.xs + wave_stage_elems(WD);
+  size_t lds = (tile_feat + KMAT) * sizeof(T) + wave_colbuf_bytes(sizeof(T), NP, false);
+  lds = (lds + 15) & ~(size_t)15;
+  static Residency res;
+  int per_cu = 0, cus = 0;
+  const void* fn = reinterpret_cast<const void*>(&fused_wave_kernel<T, NP, KFIX, RFIX, DFIX, true, false, false, false, false, true>);
+  const int rrc = res.lookup(fn, 64, lds, &per_cu, &cus);
+  if (rrc != MGP_OK) return rrc;
+  static const int env_per_cu = getenv("MGP_BWD_DLT_PER_CU") ? atoi(getenv("MGP_BWD_DLT_PER_CU")) : 0;  // occupancy experiments
+  if (env_per_cu > 0 && env_per_cu < per_cu) per_cu = env_per_cu;
+  int64_t grid = (int64_t)cus * per_cu / 8 * 8;
+  if (grid < 8) grid = 8;
+  if (grid > g.ntasks) grid = (g.ntasks + 7) / 8 * 8;
+  static const bool trace = getenv("MGP_TRACE") != nullptr;
+  if (trace)
+    fprintf(stderr, "mgp: backward on the dealt triangle, k = %d, d = %d: b = %lld, grid %lld, lds %zu B, %d workgroups per CU\n", KFIX,
+            DFIX, (long long)a.b, (long long)grid, lds, per_cu);
+  hipLaunchKernelGGL((fused_wave_kernel<T, NP, KFIX, RFIX, DFIX, true, false, false, false, false, true>), dim3((unsigned)grid), dim3(64),
+                     lds, stream, a, g);
+  MGP_HIP_CHECK_LAUNCH();
+  note_launch("mgp::fused_wave_kernel<double,%d,%d,%d,%d,true,false,false,false,false,backward>", NP, KFIX, RFIX, DFIX);
+  note_launch_geometry(grid, lds);
+  return MGP_OK;
+}
+
+// hyper-parameter gradients of one response; plain tables, 16-byte aligned rows; the shapes instantiated below
+int launch_backward_dlt(const BackwardArgs& b, hipStream_t stream) {
+  const FusedArgs& f = b.f;
+  if (f.R != 1 || b.grad_feat_q || b.grad_feat_nn || f.targets_batch || f.kernel_id == MGP_KERNEL_MATERN_GEN) return MGP_EUNSUPPORTED;
+  if (f.ls_count != 1 && f.ls_count != f.d) return MGP_EUNSUPPORTED;
+  const uintptr_t align = (uintptr_t)f.feat_q | (uintptr_t)f.feat_nn;
+  if (align % 16 != 0 || f.b >= ((int64_t)1 << 31)) return MGP_EUNSUPPORTED;
+  static const bool off = getenv("MGP_BACKWARD_DLT") != nullptr && atoi(getenv("MGP_BACKWARD_DLT")) == 0;  // A/B switch (timing only)
+  if (off) return MGP_EUNSUPPORTED;
+  if (f.k == 50 && f.d == 8) return launch_bwd_dlt_impl<50, 8>(b, stream);
+  return MGP_EUNSUPPORTED;
+}
+
+}  // namespace mgp

@@ -150,6 +150,13 @@ int posterior_backward(const T* fq, const T* fn, int d, const int64_t* bi, const
                  gmean, gvar, gfq, gfn, gtg, gls, gnz};
   g.grad_yk = gyk;
   static const bool lds_only = getenv("MGP_BACKWARD_LDS") != nullptr;  // A/B switch (timing only)
+  if constexpr (sizeof(T) == 8) {
+    // hyper-parameter gradients on the dealt-triangle forward kernel (round 6: BASELINE config 4's shape)
+    if (!lds_only) {
+      const int rc = launch_backward_dlt(g, static_cast<hipStream_t>(stream));
+      if (rc != MGP_EUNSUPPORTED) return rc;
+    }
+  }
   if (!lds_only) {
     const int rc = launch_backward_wave<T>(g, static_cast<hipStream_t>(stream));
     if (rc != MGP_EUNSUPPORTED) return rc;

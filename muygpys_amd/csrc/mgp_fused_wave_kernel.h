@@ -127,6 +127,18 @@
 #define MGP_F64_DIST_HALF 0
 #endif
 
+// (BWD keeps all NS squared distances through the covariance phase, where the forward retires them batch by batch:
+// five interleaved exp chains on top of that spill 26 registers at two waves per SIMD)
+#ifndef MGP_BWD_COV_BATCH
+#define MGP_BWD_COV_BATCH 3
+#endif
+#ifndef MGP_BWD_SWEEP_PAIRS
+#define MGP_BWD_SWEEP_PAIRS 2
+#endif
+#ifndef MGP_BWD_EXP
+#define MGP_BWD_EXP 0  // (experiments: bits switch parts of the BWD instantiation off -- 1 length-scale partials, 2 pair cotangents, 4 back-substitution, 8 factor write-back)
+#endif
+
 namespace mgp {
 
 struct WaveGeom {
@@ -207,6 +219,35 @@ constexpr WaveDims wave_dims(int es, int NP, int KFIX, int RFIX, int DFIX, bool 
   }
   w.NS = w.BA * w.BP;
   return w;
+}
+// (BWD) pair s = j * BP + (p - 1) of a lane joins rows i + o_j and i + p (cyclic, modulo M): cyclic distance
+// delta = (o_j - p) mod M.  Sums over unordered pairs must meet every pair ONCE: a pair is counted by the first s whose
+// distance class {delta, M - delta} it is (the surplus of the blocking, and t / M - t of the modulo scheme, repeat
+// classes); the half-way class 2 delta = M is met from both ends by the same s -- the kernel keeps the end with r1 < c.
+constexpr int wave_pair_delta(int s, int BP, int M) {
+  const int j = s / BP, p = s % BP + 1, o = j == 0 ? 0 : (j + 1) * BP + 1;
+  return ((o - p) % M + M) % M;
+}
+constexpr bool wave_pair_first(int s, int BP, int M) {
+  const int d = wave_pair_delta(s, BP, M);
+  if (d == 0) return false;
+  for (int t = 0; t < s; ++t) {
+    const int e = wave_pair_delta(t, BP, M);
+    if (e == d || e == M - d) return false;
+  }
+  return true;
+}
+constexpr unsigned long long wave_pair_first_mask(int NS, int BP, int M) {  // bit s: pair s counts
+  unsigned long long m = 0;
+  for (int s = 0; s < NS; ++s)
+    if (wave_pair_first(s, BP, M)) m |= 1ull << s;
+  return m;
+}
+constexpr unsigned long long wave_pair_half_mask(int NS, int BP, int M) {  // bit s: pair s is of the half-way class
+  unsigned long long m = 0;
+  for (int s = 0; s < NS; ++s)
+    if (2 * wave_pair_delta(s, BP, M) == M) m |= 1ull << s;
+  return m;
 }
 // rows of the feature tile: all NP slots of every neighbourhood of the wave, or -- one static
 // neighbourhood per wave -- the live slots only (the direct-to-LDS gather stops after the query row;
@@ -317,9 +358,14 @@ __device__ unsigned long long g_wave_timing[8];
 #else
 #define MGP_WAVE_T(slot)
 #endif
+// BWD: (dealt-triangle instantiations, one response) the BACKWARD of the instantiation's outputs with respect to the
+//        hyper-parameters -- the forward phases, with the squared distances kept, the feature tile and the dealt image of
+//        the system in separate LDS regions (the image becomes the factor: every column is written back when it is
+//        posted), then back-substitution, pair cotangents and length-scale partials.  See "phase 6B" below and
+//        mgp_backward_dlt.hip.  Two waves per SIMD.
 template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF = false, bool PACKED = false,
-          bool GRAM = false, bool GEN64 = false>
-__global__ __launch_bounds__(64, wave_min_waves(sizeof(T), NP, KFIX, RFIX, DFIX))
+          bool GRAM = false, bool GEN64 = false, bool BWD = false>
+__global__ __launch_bounds__(64, BWD ? 2 : wave_min_waves(sizeof(T), NP, KFIX, RFIX, DFIX))
 void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   static_assert(!GEN64 || sizeof(T) == 8, "GEN64 is the fp64 general-smoothness instantiation");
   static_assert(!PACKED || PIPED, "prepared tables are gathered by the direct-to-LDS pipeline");
@@ -365,6 +411,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   // pairs 64 s + l, s = 0 .. NSL-1.  The exchange matrix is stored in exactly that order, so the read-back is NSL
   // lane-linear ds_read_b128.
   constexpr bool DLT = WD.DLT;
+  static_assert(!BWD || (DLT && RFIX == 1 && PIPED && !PACKED && !GRAM && !GEN64), "BWD: the dealt-triangle kernels on plain tables, one response");
   constexpr int NR2 = WD.NR2, NPAIR = WD.NPAIR, NSL = WD.NSL;
   auto cs2 = [](int c) { return dlt_col_start(c, NR2); };
   auto eoff = [&](int hi, int lo) {  // element offset of entry (hi, lo) of a neighbourhood's exchange matrix, hi >= lo
@@ -389,7 +436,9 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   const int xs = DFIX > 0 ? DSTFIX + E : g.xs;
   const int tile_rows = wave_tile_rows(WD, NP, KFIX, xs);
   const int tile_feat = tile_rows * xs + wave_stage_elems(WD);  // (DLT: the staging area lies behind the rows the gather fills)
-  const int tile_elems = tile_feat > NH * KMAT ? tile_feat : NH * KMAT;
+  // (BWD: the dealt image of the system lies BEHIND the feature tile, which the last phase still reads)
+  const int kmat_base = BWD ? tile_feat : 0;
+  const int tile_elems = BWD ? tile_feat + NH * KMAT : (tile_feat > NH * KMAT ? tile_feat : NH * KMAT);
   T* tile = reinterpret_cast<T*>(smem);               // feature tile, later the exchange matrix
   // Plain kernels: [tile][colbuf 64][ilbuf dst][idxbuf 64 x int64].  Pipelined kernels keep LDS
   // at tile + 256 bytes (9 allocation granules of 1280 B -> 14 workgroups per CU): the 32-bit row
@@ -563,12 +612,12 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 #define MGP_FOLD_DPRE 0
 #endif
   constexpr bool XPK = XPRE && (NS > 16 || (FOLD && (MGP_FOLD_XPK || sizeof(T) == 8)));  // (FOLD, fp64: the parked rows need the registers)
-  static_assert(!XPK || NH * KMAT < 65536, "packed exchange offsets are 16-bit");
+  static_assert(!XPK || NH * KMAT + (BWD ? 4096 : 0) < 65536, "packed exchange offsets are 16-bit");
   int xoff[XPRE ? (XPK ? (NS + 1) / 2 : NS) : 1];
   unsigned xkeep = 0;
   if constexpr (XPRE) {
     const int i0 = threadIdx.x & (NP - 1);
-    const int hbase = (NH == 1 ? 0 : (int)threadIdx.x / NP) * KMAT;
+    const int hbase = (NH == 1 ? 0 : (int)threadIdx.x / NP) * KMAT + kmat_base;
     const int dump0 = DLT ? KMAT - 2 : (TRI ? KMAT - E : (NP - 1) * KS + NP);
 #pragma unroll
     for (int s = 1; s <= NS; ++s) {
@@ -615,7 +664,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     const int h = NH == 1 ? 0 : lane / NP;
     const int i = lane & (NP - 1);
     T* Xh = tile + h * NP * xs;
-    T* Kh = tile + h * KMAT;
+    T* Kh = tile + kmat_base + h * KMAT;
     T* colh = colbuf + h * NP;
     int64_t* idxh = idxbuf + h * NP;
     const int64_t nb0 = (int64_t)task * NH;
@@ -997,7 +1046,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       // are computed now and not kept alive (or spilled) across the distance loop
       int i3 = i;
       asm volatile("" : "+v"(i3));
-      T* Kh3 = tile + (NH == 1 ? 0 : (lane / NP) * KMAT);
+      T* Kh3 = tile + kmat_base + (NH == 1 ? 0 : (lane / NP) * KMAT);
       if (MGP_PHASE(g, 4)) {
         // fp32: all NS covariances first (independent chains the scheduler can interleave), then the
         // stores -- unconditional: an entry whose row is a response slot (hi > q) goes to the
@@ -1086,7 +1135,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 #pragma unroll
             for (int s = 1; s <= NS; ++s) put(s, kv[s - 1]);
           } else {
-            constexpr int CB = MGP_F64_COV_BATCH;
+            constexpr int CB = BWD ? MGP_BWD_COV_BATCH : MGP_F64_COV_BATCH;
 #pragma unroll
             for (int s0 = 0; s0 < NS; s0 += CB) {
               T kv[CB];
@@ -1168,7 +1217,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     // the next task's rows are requested now: their latency hides behind the factorisation, and
     // the registers they land in are not live during the (register-hungry) distance phase
     t2 = seq_gen();  // the task after the next: its index row is requested now
-    if (PIPE && t1 >= 0) {
+    if (PIPE && !BWD && t1 >= 0) {
       pipe_issue(t1, fix_index(next_idx, t1, h, i), lane);
       if (t2 >= 0) next_idx = load_index(t2, h, i);
     }
@@ -1359,6 +1408,17 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
           const int s0 = ep >> 6, s1 = (cs2(j + 1) - 1) >> 6;  // the slot(s) that hold column j
 #pragma unroll
           for (int s = s0; s <= s1; ++s) *reinterpret_cast<V*>(stg + 2 * (64 * (s - s0)) + 2 * lane) = Dp[s];
+          if constexpr (BWD && !(MGP_BWD_EXP & 8)) {
+            // the column is final: back into the dealt image (its own pairs only -- earlier columns' pairs of the same
+            // slot have taken junk updates since they were saved, later ones are not finished)
+            // Branch-free (a predicated store makes every step a basic block of its own: 544 spilled registers): the
+            // lanes that hold other columns' pairs repeat their staging-area write instead.
+#pragma unroll
+            for (int s = s0; s <= s1; ++s) {
+              T* dstp = wcol[s] == j ? Kh + 2 * (64 * s) + 2 * lane : stg + 2 * (64 * (s - s0)) + 2 * lane;
+              *reinterpret_cast<V*>(dstp) = Dp[s];
+            }
+          }
           const long long pb = __double_as_longlong(Dp[s0][j & 1]);
           const unsigned plo = __builtin_amdgcn_readlane((int)(pb & 0xFFFFFFFFll), ep & 63);
           const unsigned phi = __builtin_amdgcn_readlane((int)(pb >> 32), ep & 63);
@@ -1414,6 +1474,172 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       __builtin_amdgcn_s_setprio(0);
 #endif
       MGP_WAVE_T(4)
+      if constexpr (BWD) {
+#ifndef __HIPCC_RTC__  // (BWD instantiations are built into the library only: mgp_backward_dlt.hip)
+        // ---- phase 5B: a = K^-1 c and u = K^-1 y by back-substitution on the saved factor -------------------------
+        // K = L D L^T (unit L, D = the pivots): the dealt image now holds, raw, a_m,j = l_m,j p_j for m >= j -- the
+        // diagonal is p_j, rows q and q + 1 are (D L^-1 c)^T and (D L^-1 y)^T.  Lane i owns column i: entry (m, i) lies
+        // at lbase + m.  L^T x = D^-1 L^-1 rhs from the last row up: x_m is final when the rows above it are done; it is
+        // handed down by v_readlane and lane i < m takes l_m,i x_m off (mgp_backward_wave.hip, phase 5).
+        __syncthreads();
+        const T* Lh = Kh;
+        const int ic = i < KFIX ? i : KFIX - 1;  // (lanes without a neighbour row: any valid column)
+        const int lbase = 2 * (cs2(ic) - (ic >> 1));
+        const T rp = pivot_rcp(Lh[lbase + ic]);
+        T xa = i < KFIX ? Lh[lbase + KFIX] * rp : T(0);
+        T xu = i < KFIX ? Lh[lbase + KFIX + 1] * rp : T(0);
+        if (!(MGP_BWD_EXP & 4)) {
+          constexpr int BB = 8;
+#pragma unroll
+          for (int mb = (KFIX - 1) / BB * BB; mb >= 0; mb -= BB) {
+            T lm[BB];
+#pragma unroll
+            for (int e = 0; e < BB; ++e)
+              if (mb + e >= 1 && mb + e < KFIX) lm[e] = Lh[lbase + mb + e];  // (junk for m <= i: masked below)
+#pragma unroll
+            for (int e = BB - 1; e >= 0; --e) {
+              const int m = mb + e;
+              if (m >= 1 && m < KFIX) {
+                const T am = lane_value(xa, m), um = lane_value(xu, m);
+                const T t = i < m ? lm[e] * rp : T(0);
+                xa = fma_t(-t, am, xa);
+                xu = fma_t(-t, um, xu);
+              }
+            }
+          }
+        }
+        // the two vectors where the pair phase picks them up by row.  The query row enters as a = -1, u = 0: with
+        //   gK_rc = a_r P_c - u_r Q_c,  P_c = 2 gv a_c - gm u_c,  Q_c = gm a_c + 2 gy u_c
+        // (= 2 gv a_r a_c - gm (a_r u_c + a_c u_r) - 2 gy u_r u_c, symmetric) a pair with the query row gives
+        // gm u_c - 2 gv a_c, the cotangent of the cross-covariance, with no case distinction.
+        T* avec = tile + tile_rows * xs;  // (the staging area of the posted columns: dead)
+        T* uvec = avec + 64;
+        __syncthreads();
+        avec[lane] = i < KFIX ? xa : (i == KFIX ? T(-1) : T(0));
+        uvec[lane] = i < KFIX ? xu : T(0);
+        __syncthreads();
+        const T gmv = (live && a.bwd_gmean) ? static_cast<const T*>(a.bwd_gmean)[nb0] : T(0);
+        const T gvv = (live && a.bwd_gvar) ? static_cast<const T*>(a.bwd_gvar)[nb0] : T(0);
+        const T gyv = (live && a.bwd_gyk) ? static_cast<const T*>(a.bwd_gyk)[nb0] : T(0);
+        const bool skip = bad || !live;  // (cotangents of a neighbourhood that did not factorise are left untouched)
+
+        // ---- phase 6B: pair cotangents q_rc = gK_rc dk/dacc_rc, in the pair scheme's own layout (the kept squared
+        // distances acc[s] are replaced by q) -- each unordered pair once ------------------------------------------
+        T liso = T(0);
+        {
+          T ar[BA], ur[BA], Pc[BP], Qc[BP];
+#pragma unroll
+          for (int j = 0; j < BA; ++j) {
+            const int r = wrap(i + own_offset(j));
+            ar[j] = avec[r];
+            ur[j] = uvec[r];
+          }
+#pragma unroll
+          for (int p = 0; p < BP; ++p) {
+            const int c = wrap(i + p + 1);
+            const T ac = avec[c], uc = uvec[c];
+            Pc[p] = T(2) * gvv * ac - gmv * uc;
+            Qc[p] = gmv * ac + T(2) * gyv * uc;
+          }
+          const bool lane_on = i < M;  // (modulo scheme: the idle lanes repeat live ones)
+          constexpr unsigned long long FIRSTM = wave_pair_first_mask(NS, BP, M), HALFM = wave_pair_half_mask(NS, BP, M);
+          if (!(MGP_BWD_EXP & 2))
+          kernel_dispatch(a.kernel_id, a.metric_id, [&](auto kid, auto mid) {
+            constexpr int KID = decltype(kid)::value, MID = decltype(mid)::value;
+            constexpr int CB = MGP_BWD_COV_BATCH;
+#pragma unroll
+            for (int s0 = 0; s0 < NS; s0 += CB) {
+              T dv[CB];
+#pragma unroll
+              for (int u = 0; u < CB; ++u) dv[u] = acc[s0 + u < NS ? s0 + u : NS - 1];
+              dcov_batch64<CB, KID, MID>(dv, post_scale);
+#pragma unroll
+              for (int u = 0; u < CB; ++u) {
+                if (s0 + u < NS) {
+                  const int sidx = s0 + u;
+                  const int jj = sidx / BP, pp = sidx % BP;
+                  bool on = lane_on && ((xkeep >> sidx) & 1u) != 0 && ((FIRSTM >> sidx) & 1ull) != 0;
+                  if ((HALFM >> sidx) & 1ull)  // (the half-way class: the end with r1 < c)
+                    on = on && wrap(i + own_offset(jj)) < wrap(i + pp + 1);
+                  const T gK = ar[jj] * Pc[pp] - ur[jj] * Qc[pp];
+                  const T qv = on ? gK * dv[u] : T(0);
+                  liso = fma_t(qv, acc[sidx], liso);
+                  acc[sidx] = qv;
+                }
+              }
+              __builtin_amdgcn_sched_barrier(0);  // keep the batches apart
+            }
+          });
+        }
+        // per-neighbourhood outputs that need a and u only
+        if (!skip && i < KFIX) {
+          if (a.bwd_gnz) static_cast<T*>(a.bwd_gnz)[nb0 * KFIX + i] = gvv * xa * xa - gmv * xa * xu - gyv * xu * xu;
+          if (a.bwd_gtg) unsafeAtomicAdd(static_cast<T*>(a.bwd_gtg) + myidx, gmv * xa + T(2) * gyv * xu);
+        }
+        // ---- phase 7B: length-scale partials ------------------------------------------------------------------
+        if (a.bwd_gls && !(MGP_BWD_EXP & 1)) {  // (uniform)
+          T* gls = static_cast<T*>(a.bwd_gls);
+          if (!aniso) {
+            // Isotropy: dL/dl = -(1 | 2) / l sum gK k'(x) x, and k'(x) x = dk/dacc acc (2 | 1) for (l2 | F2)
+            T sum = liso;
+            for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+            if (!skip && lane == 0) gls[nb0] = T(-2) / ls[0] * sum;  // (-(1 | 2) / l times the (2 | 1) above)
+          } else {
+            // Anisotropy: dL/dl_f = -(2 / l_f) sum_pairs q_rc (z_rf - z_cf)^2 on the scaled rows the tile still holds
+            constexpr int DGF = DSTFIX / E;
+            V s2h[DGF];
+#pragma unroll
+            for (int c4 = 0; c4 < DGF; ++c4) s2h[c4] = V(0);
+#pragma unroll
+            for (int j = 0; j < BA; ++j) {
+              const T* xa_ = Xh + wrap(i + own_offset(j)) * xs;
+              V own[DGF];
+#pragma unroll
+              for (int c4 = 0; c4 < DGF; ++c4) own[c4] = *reinterpret_cast<const V*>(xa_ + c4 * E);
+#pragma unroll
+              for (int p = 0; p < BP; ++p) {
+                const T* xb_ = Xh + wrap(i + p + 1) * xs;
+                const V qv = V(acc[j * BP + p]);
+#pragma unroll
+                for (int c4 = 0; c4 < DGF; ++c4) {
+                  const V dz = own[c4] - *reinterpret_cast<const V*>(xb_ + c4 * E);
+                  s2h[c4] = (dz * qv) * dz + s2h[c4];
+                }
+                // (two partner rows' reads in flight at a time: hoisted together, the 25 x DGF reads of the unrolled
+                // sweep spill)
+                if (MGP_BWD_SWEEP_PAIRS == 1 || (p & (MGP_BWD_SWEEP_PAIRS - 1)) == MGP_BWD_SWEEP_PAIRS - 1 || p == BP - 1) __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+            // sum over the lanes through the (dead) dealt image: lane i writes its DSTFIX sums, lane (g, f) adds rows
+            // 64 / G g .. of feature f, a butterfly over g finishes
+            constexpr int FP = DSTFIX <= 2 ? 2 : DSTFIX <= 4 ? 4 : DSTFIX <= 8 ? 8 : DSTFIX <= 16 ? 16 : DSTFIX <= 32 ? 32 : 64;
+            constexpr int G = 64 / FP, RPG = 64 / G;
+            T* red = Kh;
+            __syncthreads();
+#pragma unroll
+            for (int c4 = 0; c4 < DGF; ++c4) *reinterpret_cast<V*>(red + lane * DSTFIX + c4 * E) = s2h[c4];
+            __syncthreads();
+            const int f = lane & (FP - 1), gq = lane / FP;
+            T tot = T(0);
+            if (f < DSTFIX) {
+#pragma unroll
+              for (int r = 0; r < RPG; ++r) tot += red[(gq * RPG + r) * DSTFIX + f];
+            }
+            for (int off = FP; off < 64; off <<= 1) tot += __shfl_xor(tot, off, 64);
+            if (!skip && lane < d) gls[nb0 * (int64_t)d + lane] = T(-2) * ilbuf[lane] * tot;
+          }
+        }
+        if (bad && live && lane == 0 && a.info) atomicAdd(a.info, 1);
+        // the next task's rows: only now is the tile free
+        __syncthreads();
+        if (PIPE && t1 >= 0) {
+          pipe_issue(t1, fix_index(next_idx, t1, h, i), lane);
+          if (t2 >= 0) next_idx = load_index(t2, h, i);
+        }
+        MGP_WAVE_T(5)
+#endif  // !__HIPCC_RTC__
+        continue;
+      }
       {
         // the Schur block sits in compile-time lanes: (q, q) = variance, (q + 1 + r, q) = -mean_r, (q + 1 + r, q + 1 + r) = -y_r^T K^-1 y_r
         constexpr int QF = KFIX;

@@ -443,6 +443,116 @@ __device__ __forceinline__ void cov_batch64(double (&v)[CB], double post_scale) 
   }
 }
 
+// d covariance / d (squared distance accumulator) of CB pairs, fp64, stage by stage like cov_batch64() (the backward of
+// the dealt-triangle kernels, mgp_backward_dlt.hip).  in: v[u] = acc (the squared distance of the rows as the kernel
+// holds them: scaled by the inverse length scales under Anisotropy, raw under Isotropy); out: v[u] = dk / d acc, with
+// x = metric(acc) * post_scale the kernel's argument:
+//   dk/dacc = k'(x) dx/dacc,  dx/dacc = post_scale (F2)  |  post_scale / (2 sqrt(acc)) (l2)
+//   k'(x):  RBF -1/2 e^(-x/2) | Matern-1/2 -e^(-x) | 3/2 -3 x e^(-sqrt3 x) | 5/2 -5/3 x (1 + t) e^(-t), t = sqrt5 x |
+//           inf -x e^(-x^2/2)
+// Under l2 the factor x of the last three cancels 1 / sqrt(acc): no division and no singularity at acc = 0; the first
+// two keep h ~ 1 / (2 sqrt(acc)) from the square-root iteration and return 0 at acc = 0 (mgp_backward.hip does too).
+// (The chain-rule term of the isotropic length scale, gK k'(x) x, is dk/dacc * acc * (l2 ? 2 : 1): the caller's.)
+template <int CB, int KID, int MID>
+__device__ __forceinline__ void dcov_batch64(double (&v)[CB], double post_scale) {
+  constexpr auto C = [](unsigned long long bits) { return __builtin_bit_cast(double, bits); };
+  double t[CB], w[CB];
+  constexpr bool L2 = MID == MGP_METRIC_L2;
+  constexpr bool XCANCELS = KID == MGP_KERNEL_MATERN_15 || KID == MGP_KERNEL_MATERN_25 || KID == MGP_KERNEL_MATERN_INF;
+  const double ps2 = post_scale * post_scale;
+  if constexpr (L2) {
+    double y[CB], h[CB], a0[CB];
+#pragma unroll
+    for (int u = 0; u < CB; ++u) a0[u] = v[u];
+#pragma unroll
+    for (int u = 0; u < CB; ++u) v[u] = v[u] + 1e-280;
+#pragma unroll
+    for (int u = 0; u < CB; ++u) y[u] = __builtin_amdgcn_rsq(v[u]);
+#pragma unroll
+    for (int u = 0; u < CB; ++u) t[u] = v[u] * y[u];
+#pragma unroll
+    for (int u = 0; u < CB; ++u) h[u] = y[u] * 0.5;
+#pragma unroll
+    for (int u = 0; u < CB; ++u) y[u] = __builtin_fma(-h[u], t[u], 0.5);
+#pragma unroll
+    for (int u = 0; u < CB; ++u) t[u] = __builtin_fma(t[u], y[u], t[u]);
+#pragma unroll
+    for (int u = 0; u < CB; ++u) h[u] = __builtin_fma(h[u], y[u], h[u]);
+#pragma unroll
+    for (int u = 0; u < CB; ++u) y[u] = __builtin_fma(-t[u], t[u], v[u]);
+#pragma unroll
+    for (int u = 0; u < CB; ++u) v[u] = __builtin_fma(y[u], h[u], t[u]);  // sqrt(acc)
+    // w = k'(x) dx/dacc without its exponential
+#pragma unroll
+    for (int u = 0; u < CB; ++u) {
+      const double x = v[u] * post_scale;
+      if constexpr (KID == MGP_KERNEL_RBF) {
+        t[u] = x * 0.5;
+        w[u] = a0[u] > 0.0 ? -0.5 * post_scale * h[u] : 0.0;
+      } else if constexpr (KID == MGP_KERNEL_MATERN_05) {
+        t[u] = x;
+        w[u] = a0[u] > 0.0 ? -post_scale * h[u] : 0.0;
+      } else if constexpr (KID == MGP_KERNEL_MATERN_15) {
+        t[u] = x * 1.7320508075688772935;
+        w[u] = -1.5 * ps2;
+      } else if constexpr (KID == MGP_KERNEL_MATERN_25) {
+        t[u] = x * 2.2360679774997896964;
+        w[u] = (-5.0 / 6.0) * ps2 * (1.0 + t[u]);
+      } else {
+        t[u] = x * x * 0.5;
+        w[u] = -0.5 * ps2;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < CB; ++u) {
+      const double x = v[u] * post_scale;
+      if constexpr (KID == MGP_KERNEL_RBF) {
+        t[u] = x * 0.5;
+        w[u] = -0.5 * post_scale;
+      } else if constexpr (KID == MGP_KERNEL_MATERN_05) {
+        t[u] = x;
+        w[u] = -post_scale;
+      } else if constexpr (KID == MGP_KERNEL_MATERN_15) {
+        t[u] = x * 1.7320508075688772935;
+        w[u] = -3.0 * x * post_scale;
+      } else if constexpr (KID == MGP_KERNEL_MATERN_25) {
+        t[u] = x * 2.2360679774997896964;
+        w[u] = (-5.0 / 3.0) * x * (1.0 + t[u]) * post_scale;
+      } else {
+        t[u] = x * x * 0.5;
+        w[u] = -x * post_scale;
+      }
+    }
+  }
+  (void)XCANCELS;
+  double n[CB], r[CB], q[CB];
+#pragma unroll
+  for (int u = 0; u < CB; ++u) t[u] = __builtin_fmin(t[u], 800.0);
+#pragma unroll
+  for (int u = 0; u < CB; ++u) n[u] = __builtin_rint(t[u] * -1.4426950408889634074);
+#pragma unroll
+  for (int u = 0; u < CB; ++u) r[u] = __builtin_fma(n[u], -6.93147180369123816490e-01, -t[u]);
+#pragma unroll
+  for (int u = 0; u < CB; ++u) r[u] = __builtin_fma(n[u], -1.90821492927058770002e-10, r[u]);
+#pragma unroll
+  for (int u = 0; u < CB; ++u) q[u] = fma_sc(r[u], C(0x3e5ae64567f544e4ull), C(0x3e928af3fca7ab0cull));
+  constexpr unsigned long long coef[8] = {0x3ec71dee623fde64ull, 0x3efa01997c89e6b0ull, 0x3f2a01a014761f6eull, 0x3f56c16c1852b7b0ull,
+                                          0x3f81111111122322ull, 0x3fa55555555502a1ull, 0x3fc5555555555511ull, 0x3fe000000000000bull};
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int u = 0; u < CB; ++u) q[u] = fma_sc(q[u], r[u], C(coef[c]));
+#pragma unroll
+  for (int u = 0; u < CB; ++u) q[u] = __builtin_fma(q[u], r[u], 1.0);
+#pragma unroll
+  for (int u = 0; u < CB; ++u) q[u] = __builtin_fma(q[u], r[u], 1.0);
+#pragma unroll
+  for (int u = 0; u < CB; ++u) q[u] = __builtin_amdgcn_ldexp(q[u], cvt_i32_sat(n[u]));
+#pragma unroll
+  for (int u = 0; u < CB; ++u) v[u] = w[u] * q[u];
+}
+
 // Two covariances at once (fp32): the polynomial / scaling arithmetic runs as packed ops
 // (v_pk_mul_f32 / v_pk_fma_f32), only v_sqrt_f32 and v_exp_f32 stay scalar.  Same formulas and
 // the same two-term log2(e) as the scalar form above.

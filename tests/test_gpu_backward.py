@@ -423,3 +423,108 @@ def test_differentiable_losses_match_torch_expression():
         assert_close(gp.cpu().numpy(), p.grad.cpu().numpy(), 1e-10, "d/dpred")
         if gv is not None:
             assert_close(gv.cpu().numpy(), v.grad.cpu().numpy(), 1e-10, "d/dvar")
+
+
+DLT_CASES = [
+    # kernel, metric, aniso, b   (k = 50, d = 8, one response: BASELINE config 4's shape)
+    ("matern15", "l2", True, 700), ("matern25", "l2", True, 300), ("maternInf", "l2", True, 130), ("matern05", "l2", True, 257),
+    ("matern15", "l2", False, 300), ("rbf", "F2", False, 200), ("rbf", "F2", True, 64), ("matern05", "l2", False, 65),
+]
+
+
+@pytest.mark.parametrize("case", DLT_CASES, ids=[f"{c[0]}-{c[1]}-{'aniso' if c[2] else 'iso'}-b{c[3]}" for c in DLT_CASES])
+@pytest.mark.parametrize("which", ["mean+var", "mean", "var"])
+def test_hyper_parameter_backward_on_the_dealt_triangle(case, which):
+    """Round 6: with no feature cotangent asked for, the fp64 k = 50, d = 8 backward runs on the dealt-triangle FORWARD
+    kernel (csrc/mgp_backward_dlt.hip: saved factor, back-substitution, pair cotangents in the pair scheme's layout)
+    instead of the row-per-lane kernel at one wave per SIMD.  Every hyper-parameter gradient -- length scale(s), noise,
+    responses -- against the oracle's vector-Jacobian product (reference: torch autograd over
+    torch/muygps_layer.py:129-164), and the launch must be the new kernel's."""
+    from muygpys_amd import _lib
+    from muygpys_amd.autograd import posterior
+    from muygpys_amd.fused import KernelSpec
+
+    kernel, metric, aniso, b = case
+    d, k = 8, 50
+    rng = np.random.default_rng(900 + DLT_CASES.index(case))
+    n = 2500
+    X = rng.normal(size=(n, d))
+    Y = np.sin(X @ rng.normal(size=(d, 1)) / np.sqrt(d)) + 0.1 * rng.normal(size=(n, 1))
+    bi = rng.choice(n, size=b, replace=False)
+    ni = np.stack([rng.choice(np.setdiff1d(np.arange(n), [i]), size=k, replace=False) for i in bi])
+    ls = np.sqrt(d) * rng.uniform(0.6, 1.6, size=d) if aniso else float(np.sqrt(d)) * 1.1
+    spec_o = orc.Spec(kernel, metric, ls, 3e-2)
+    gm = rng.normal(size=(b, 1)) if "mean" in which else np.zeros((b, 1))
+    gv = rng.normal(size=b) if "var" in which else np.zeros(b)
+    ref = orc.posterior_vjp(spec_o, X, X, bi, ni, Y, gm, gv)
+    td = torch.float64
+    x = to_dev(X, td)  # (no gradient: the hyper-parameter form)
+    y = to_dev(Y, td).requires_grad_(True)
+    lst = to_dev(np.atleast_1d(ls), td).requires_grad_(True)
+    nz = torch.tensor(3e-2, device="cuda", dtype=td, requires_grad=True)
+    mean, var = posterior(KernelSpec(kernel=kernel, metric=metric, length_scale=lst, noise=nz), x, x, to_dev(bi), to_dev(ni), y)
+    loss = 0.0
+    if "mean" in which:
+        loss = loss + (mean * to_dev(gm.reshape(mean.shape), td)).sum()
+    if "var" in which:
+        loss = loss + (var * to_dev(gv, td)).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert "backward" in _lib.last_kernel() and "double,64,50,1,8" in _lib.last_kernel(), _lib.last_kernel()
+    assert_close(y.grad.cpu().numpy(), ref["targets"], 1e-5, "g_targets")
+    assert_close(lst.grad.cpu().numpy(), np.atleast_1d(ref["length_scale"]), 1e-5, "g_length_scale")
+    assert_close(nz.grad.cpu().numpy().reshape(()), ref["noise"], 1e-5, "g_noise")
+
+
+def test_dealt_triangle_backward_loocv_form_and_table_noise():
+    """The LOOCV form (cotangent of y^T K^-1 y chained in, mgp_loocv_backward_*) and a per-point noise table through
+    the same kernel: against the row-per-lane / workgroup kernels' results on a shape they share (the same C entry with
+    feature cotangents requested, which the new launcher declines)."""
+    from muygpys_amd import _lib
+
+    rng = np.random.default_rng(31)
+    n, d, k, b = 3000, 8, 50, 900
+    td = torch.float64
+    X = to_dev(rng.normal(size=(n, d)), td)
+    y = to_dev(rng.normal(size=(n, 1)), td)
+    bi = to_dev(rng.choice(n, size=b, replace=False))
+    ni = to_dev(rng.integers(0, n, size=(b, k)))
+    ni = torch.where(ni == bi[:, None], (ni + 1) % n, ni)
+    ls = to_dev(np.sqrt(d) * rng.uniform(0.7, 1.4, size=d), td)
+    gm, gv, gy = (to_dev(rng.normal(size=b), td) for _ in range(3))
+    noise_tab = to_dev(rng.uniform(1e-2, 5e-2, size=n), td)
+
+    def run(mode, nz_t, with_features, loocv):
+        g_l = torch.zeros((b, d), device="cuda", dtype=td)
+        g_n = torch.zeros((b, k), device="cuda", dtype=td)
+        g_t = torch.zeros_like(y)
+        g_x = torch.zeros_like(X) if with_features else None
+        info = torch.zeros(1, device="cuda", dtype=torch.int32)
+        if loocv:
+            rc = _lib.fn("loocv_backward", td)(_lib.ptr(X), d, _lib.ptr(bi), _lib.ptr(ni), b, k, _lib.ptr(y), mode, 2e-2, _lib.ptr(nz_t),
+                                               2, 0, _lib.ptr(ls), d, _lib.ptr(gm), _lib.ptr(gv), _lib.ptr(gy), _lib.ptr(g_l), _lib.ptr(g_n),
+                                               _lib.ptr(info), _lib.stream_ptr())
+        else:
+            rc = _lib.fn("posterior_backward", td)(_lib.ptr(X), _lib.ptr(X), d, _lib.ptr(bi), _lib.ptr(ni), b, k, _lib.ptr(y), 1, mode, 2e-2,
+                                                   _lib.ptr(nz_t), 2, 0, _lib.ptr(ls), d, _lib.ptr(gm), _lib.ptr(gv), _lib.ptr(g_x), _lib.ptr(g_x),
+                                                   _lib.ptr(g_t), _lib.ptr(g_l), _lib.ptr(g_n), _lib.ptr(info), _lib.stream_ptr())
+        assert rc == 0 and int(info.item()) == 0
+        torch.cuda.synchronize()
+        return g_l.cpu().numpy(), g_n.cpu().numpy(), g_t.cpu().numpy(), _lib.last_kernel()
+
+    for mode, nz_t in ((_lib.NOISE_SCALAR, None), (_lib.NOISE_TABLE, noise_tab)):
+        new = run(mode, nz_t, False, False)
+        old = run(mode, nz_t, True, False)
+        assert "backward" in new[3], new[3]
+        for a_, b_, what in zip(new[:3], old[:3], ("g_ls", "g_noise", "g_targets")):
+            assert_close(a_, b_, 1e-9, f"{what} (noise mode {mode})")
+    # the LOOCV form: the new kernel against the same launch with the dealt-triangle path switched off is a process-wide
+    # switch, so compare with the chain rule instead: gy = 0 must reproduce the plain form's length-scale partials
+    gy0 = gy
+    gy = torch.zeros_like(gy0)
+    lo0 = run(_lib.NOISE_SCALAR, None, False, True)
+    pl0 = run(_lib.NOISE_SCALAR, None, False, False)
+    assert_close(lo0[0], pl0[0], 1e-12, "LOOCV form at zero y^T K^-1 y cotangent")
+    gy = gy0
+    lo1 = run(_lib.NOISE_SCALAR, None, False, True)
+    assert np.abs(lo1[0] - lo0[0]).max() > 1e-6  # (the third cotangent does flow)

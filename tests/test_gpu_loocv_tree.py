@@ -253,7 +253,10 @@ def test_ten_thousand_back_to_back_evaluations_equal_the_three_launch_walk(mode,
         got = out.cpu().numpy()
         bad = [e for e, nz in enumerate(noises) if got[e].tobytes() != want[nz]]
         assert not bad, f"{mode}, b = {b}: {len(bad)} of {evaluations} evaluations differ from the three-launch walk (first: {bad[:5]})"
-        assert int(plan.scratch[: 4096].to(torch.int64).sum()) == 0  # (counters left zero)
+        from muygpys_amd import _lib
+
+        zero = int(_lib.load().mgp_loocv_scratch_zero_bytes())
+        assert int(plan.scratch[:zero].to(torch.int64).sum()) == 0  # (control block and counters left zero)
 
 
 def test_startup_selfcheck_keeps_the_in_kernel_walk_and_falls_back_when_it_disagrees(monkeypatch, tree_mode):
