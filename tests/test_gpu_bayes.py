@@ -27,13 +27,14 @@ def test_bayes_optimize_recovers_planted_length_scales_on_the_gpu(capsys):
     from examples.anisotropic_bayes_pipeline import run
     from muygpys_amd._src.optimize.chassis import hip as chassis
 
-    spent = {"suggest": 0.0, "n": 0}
+    spent = {"suggest": 0.0, "n": 0, "each": []}
     original = chassis._UCBBayesOpt._suggest
 
     def timed(self, kappa):
         t0 = time.perf_counter()
         out = original(self, kappa)
-        spent["suggest"] += time.perf_counter() - t0
+        spent["each"].append(time.perf_counter() - t0)
+        spent["suggest"] += spent["each"][-1]
         spent["n"] += 1
         return out
 
@@ -48,10 +49,13 @@ def test_bayes_optimize_recovers_planted_length_scales_on_the_gpu(capsys):
     assert out["objective_evaluations"] == 1 + 5 + 20
     err = _sq_rel_err(out["true_length_scale"], out["length_scale"])
     opt_s = out["seconds"]["bayes optimisation over 8 length scales"]
-    per_suggest_ms = spent["suggest"] / max(spent["n"], 1) * 1e3
+    # (the first acquisition of a process pays one-time library initialisation -- the BLAS behind torch's fp64 matmul,
+    # the topk kernel: ~100 ms --, which is not a cost per trial: the median is what a trial costs)
+    per_suggest_ms = float(np.median(spent["each"])) * 1e3
     with capsys.disabled():
         print(f"\n[bayes/gpu] {out['objective_evaluations']} trials in {opt_s:.2f} s = {out['objective_evaluations'] / opt_s:.1f} "
-              f"trials/s; acquisition step {per_suggest_ms:.1f} ms (x{spent['n']}); length scales {out['length_scale']} vs "
+              f"trials/s; acquisition step {per_suggest_ms:.2f} ms median (x{spent['n']}; first {spent['each'][0] * 1e3:.0f} ms, "
+              f"mean of the rest {np.mean(spent['each'][1:]) * 1e3:.2f} ms); length scales {out['length_scale']} vs "
               f"planted {out['true_length_scale']}; median sq rel err {np.median(err):.3f}; rmse {out['rmse']:.4f} "
               f"(target std {out['target_std']:.3f}); 95% coverage {out['coverage_95']:.3f}")
     err0 = _sq_rel_err(out["true_length_scale"], 2.0)
@@ -60,7 +64,7 @@ def test_bayes_optimize_recovers_planted_length_scales_on_the_gpu(capsys):
     # (40 k points in eight dimensions are sparse: what counts is that the fitted model beats the mean)
     assert out["rmse"] < 0.95 * out["target_std"], "the fitted model must predict better than the mean"
     assert 0.80 <= out["coverage_95"] <= 1.0
-    assert per_suggest_ms <= 60.0, f"acquisition step {per_suggest_ms:.1f} ms: the driver is host-bound again"
+    assert per_suggest_ms <= 5.0, f"acquisition step {per_suggest_ms:.1f} ms: the driver is host-bound again"
 
 
 def test_surrogate_matches_scikit_learn():
