@@ -375,7 +375,7 @@ def _bayes_opt_optimize(muygps, obj_fn: Callable, verbose: bool = False, **kwarg
     scale-like parameters whose bounds span decades (length scales in (0.1, 10)) the uniform initial points and the
     stationary surrogate then see every decade alike, where the linear box puts nine samples in ten above 1.  With the
     reference's defaults on BASELINE config 4 (eight length scales, 25 trials) the linear search never improved on its
-    start point; see DESIGN.md sec. 4.5."""
+    start point; see docs/HISTORY.md sec. 4.5."""
     x0_names, x0, bounds = _get_opt_lists(muygps, verbose=verbose)
     if kwargs.get("random_state") is None:
         from muygpys_amd import distributed as _D

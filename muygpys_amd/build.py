@@ -66,8 +66,34 @@ def _stale() -> bool:
     return any(os.path.getmtime(p) > t for p in deps)
 
 
+def _headers_of(path: str, seen=None) -> set:
+    """The project headers a source file includes, transitively (`#include "..."` under csrc/ and include/)."""
+    import re
+
+    seen = set() if seen is None else seen
+    try:
+        text = open(path).read()
+    except OSError:
+        return seen
+    for name in re.findall(r'^\s*#\s*include\s+"([^"]+)"', text, flags=re.M):
+        for base in (CSRC, os.path.join(HERE, "..", "include")):
+            h = os.path.normpath(os.path.join(base, name))
+            if os.path.exists(h) and h not in seen:
+                seen.add(h)
+                _headers_of(h, seen)
+    return seen
+
+
+def _object_stale(src: str, obj: str) -> bool:
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(p) > t for p in [src, __file__, *_headers_of(src)])
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every .hip under csrc/ (one object per file, in parallel) and link the .so."""
+    """Compile the .hip files under csrc/ whose object is older than the source or a header it includes (one object
+    per file, in parallel; `force`: all of them) and link the .so."""
     if not force and not _stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
@@ -76,15 +102,23 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(objdir, exist_ok=True)
     procs = []
     objs = []
+    resources = {}
+    res_path = os.path.join(LIBDIR, "kernel_resources.json")
+    if not force and os.path.exists(res_path):  # (the records of the objects that are kept)
+        import json
+
+        with open(res_path) as f:
+            resources = json.load(f)
+    extra = os.environ.get("MGP_EXTRA_HIPCC_FLAGS", "").split()
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        cmd = [hipcc, *FLAGS, *PER_FILE_FLAGS.get(os.path.basename(src), []),
-               *os.environ.get("MGP_EXTRA_HIPCC_FLAGS", "").split(), "-c", src, "-o", obj]
+        if not force and not extra and not _object_stale(src, obj):
+            continue
+        cmd = [hipcc, *FLAGS, *PER_FILE_FLAGS.get(os.path.basename(src), []), *extra, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-    resources = {}
     for cmd, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
@@ -129,6 +163,8 @@ def _parse_resource_remarks(text: str) -> dict:
 # tables in fp32, prepared tables in fp64.  Any other shape is compiled on first use (~1 s).
 PREWARM_K = (10, 20, 25, 30, 40, 50)
 PREWARM_D = (8, 16, 32, 40, 64)
+# ... and the fp64 hyper-parameter backward of a few shapes next to BASELINE config 4's built-in (50, 8) (round 6)
+PREWARM_BWD = ((40, 8), (40, 16), (50, 16), (32, 8))
 
 
 def _prewarm_one(job):
@@ -136,6 +172,10 @@ def _prewarm_one(job):
 
     es, k, d, packed = job
     lib = ctypes.CDLL(LIB)
+    if packed == "bwd":
+        lib.mgp_jit_prepare_backward.argtypes = [ctypes.c_int] * 2
+        lib.mgp_jit_prepare_backward.restype = ctypes.c_int
+        return job, lib.mgp_jit_prepare_backward(k, d)
     lib.mgp_jit_prepare.argtypes = [ctypes.c_int] * 6
     lib.mgp_jit_prepare.restype = ctypes.c_int
     return job, lib.mgp_jit_prepare(es, k, 1, d, packed, 2)  # kernel id 2 = Matern-3/2 (any Gram-form kernel)
@@ -148,6 +188,7 @@ def prewarm(verbose: bool = False) -> int:
 
     jobs = [(4, k, d, p) for k in PREWARM_K for d in PREWARM_D for p in (1, 0)]
     jobs += [(8, k, d, 1) for k in PREWARM_K for d in PREWARM_D if d <= 32]
+    jobs += [(8, k, d, "bwd") for k, d in PREWARM_BWD]
     with mp.get_context("spawn").Pool(min(8, os.cpu_count() or 1)) as pool:
         done = pool.map(_prewarm_one, jobs)
     ok = sum(1 for _, rc in done if rc == 0)

@@ -127,8 +127,9 @@ template <typename T> int launch_solve_wave(const SolveArgs&, hipStream_t);  // 
 template <typename T> int launch_fused_wave(const FusedArgs&, hipStream_t);
 // run-time specialisation of the wave kernel (mgp_jit.hip)
 int jit_wave_function(int es, int np, int k, int R, int d, bool packed, bool gram, hipFunction_t* fn, bool allow_compile = true,
-                      bool gen64 = false);
-int jit_wave_prepare(int es, int np, int k, int R, int d, bool packed, bool gram, bool gen64 = false);
+                      bool gen64 = false, bool bwd = false);
+int jit_wave_prepare(int es, int np, int k, int R, int d, bool packed, bool gram, bool gen64 = false, bool bwd = false);
+int prepare_backward_dlt(int k, int d);  // compile the backward instantiation of a shape into the disk cache (mgp_backward_dlt.hip)
 // one instantiation of the wave kernel (mgp_fused_wave_launch.h; instantiated in mgp_fused_wave_inst_*.hip)
 template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF, bool PACKED, bool GRAM, bool GEN64>
 int launch_np_impl(const FusedArgs& a, hipStream_t stream);

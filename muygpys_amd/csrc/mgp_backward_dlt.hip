@@ -23,6 +23,8 @@
 
 namespace mgp {
 
+static void bwd_args(const BackwardArgs& b, FusedArgs* a);
+
 template <int KFIX, int DFIX>
 static int launch_bwd_dlt_impl(const BackwardArgs& b, hipStream_t stream) {
   using T = double;
@@ -30,17 +32,8 @@ static int launch_bwd_dlt_impl(const BackwardArgs& b, hipStream_t stream) {
   constexpr WaveDims WD = wave_dims(sizeof(T), NP, KFIX, RFIX, DFIX, false, false);
   static_assert(WD.DLT && WD.NH == 1, "the dealt-triangle shapes");
   constexpr int E = WD.E, CH = WD.CH, KMAT = WD.KMAT;
-  FusedArgs a = b.f;
-  a.mean = a.var = a.ykinvy = nullptr;
-  a.coeffs = nullptr;
-  a.tree = LoocvTree{};
-  a.packed_q = a.packed_nn = nullptr;
-  a.bwd_gmean = b.grad_mean;
-  a.bwd_gvar = b.grad_var;
-  a.bwd_gyk = b.grad_yk;
-  a.bwd_gls = b.grad_ls;
-  a.bwd_gnz = b.grad_noise;
-  a.bwd_gtg = b.grad_targets;
+  FusedArgs a;
+  bwd_args(b, &a);
   WaveGeom g;
   g.mask = 0xF;
   g.q = KFIX;
@@ -76,7 +69,70 @@ static int launch_bwd_dlt_impl(const BackwardArgs& b, hipStream_t stream) {
   return MGP_OK;
 }
 
-// hyper-parameter gradients of one response; plain tables, 16-byte aligned rows; the shapes instantiated below
+// The same for a static shape the library was not built with: the BWD instantiation compiled at run time (mgp_jit.hip:
+// one second per shape, cached on disk), geometry from wave_dims() evaluated at run time -- as launch_jit of
+// mgp_fused_wave.hip does for the forward kernels.
+static bool dlt_shape(int k, int d) {  // fp64, one response: 33 .. 64 slots, rows of whole 16-byte groups, one feature stage
+  return k + 2 >= 33 && k + 2 <= 64 && d >= 2 && d % 2 == 0 && (d + 3) / 4 * 4 <= 64;
+}
+static void bwd_args(const BackwardArgs& b, FusedArgs* a) {
+  *a = b.f;
+  a->mean = a->var = a->ykinvy = nullptr;
+  a->coeffs = nullptr;
+  a->tree = LoocvTree{};
+  a->packed_q = a->packed_nn = nullptr;
+  a->bwd_gmean = b.grad_mean;
+  a->bwd_gvar = b.grad_var;
+  a->bwd_gyk = b.grad_yk;
+  a->bwd_gls = b.grad_ls;
+  a->bwd_gnz = b.grad_noise;
+  a->bwd_gtg = b.grad_targets;
+}
+static int launch_bwd_dlt_jit(const BackwardArgs& b, hipStream_t stream) {
+  using T = double;
+  constexpr int NP = 64;
+  FusedArgs a;
+  bwd_args(b, &a);
+  if (!dlt_shape(a.k, a.d) || jit_mode() == 0) return MGP_EUNSUPPORTED;
+  const WaveDims WD = wave_dims(sizeof(T), NP, a.k, 1, a.d, false, false);
+  if (!WD.DLT) return MGP_EUNSUPPORTED;
+  hipFunction_t fn = nullptr;
+  const int jrc = jit_wave_function(sizeof(T), NP, a.k, 1, a.d, false, false, &fn, jit_mode() == 2 || a.b >= jit_min_batch(), false, true);
+  if (jrc != MGP_OK) return jrc;
+  WaveGeom g;
+  g.mask = 0xF;
+  g.q = a.k;
+  g.dst = (a.d + WD.CH - 1) / WD.CH * WD.CH;
+  g.xs = g.dst + WD.E;
+  g.vec_ok = 1;
+  g.ntasks = a.b;
+  size_t lds_unused = 0;
+  gen_geometry(a, &g, &lds_unused, (int)sizeof(T));
+  const size_t tile_feat = (size_t)wave_tile_rows(WD, NP, a.k, g.xs) * g.xs + wave_stage_elems(WD);
+  size_t lds = (tile_feat + WD.KMAT) * sizeof(T) + wave_colbuf_bytes(sizeof(T), NP, false);
+  lds = (lds + 15) & ~(size_t)15;
+  static Residency res;
+  int per_cu = 0, cus = 0;
+  const int rrc = res.lookup(fn, 64, lds, &per_cu, &cus);
+  if (rrc != MGP_OK) return rrc;
+  int64_t grid = (int64_t)cus * per_cu / 8 * 8;
+  if (grid < 8) grid = 8;
+  if (grid > g.ntasks) grid = (g.ntasks + 7) / 8 * 8;
+  void* params[] = {&a, &g};
+  const hipError_t err = hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 64, 1, 1, (unsigned)lds, stream, params, nullptr);
+  if (err != hipSuccess) return -(1000 + (int)err);
+  note_launch("mgp::fused_wave_kernel<double,%d,%d,1,%d,true,false,false,false,false,backward> [run-time compiled]", NP, a.k, a.d);
+  note_launch_geometry(grid, lds);
+  return MGP_OK;
+}
+
+int prepare_backward_dlt(int k, int d) {
+  if (k == 50 && d == 8) return MGP_OK;  // built into the library
+  if (!dlt_shape(k, d) || !wave_dims(8, 64, k, 1, d, false, false).DLT) return MGP_EUNSUPPORTED;
+  return jit_wave_prepare(8, 64, k, 1, d, false, false, false, true);
+}
+
+// hyper-parameter gradients of one response; plain tables, 16-byte aligned rows
 int launch_backward_dlt(const BackwardArgs& b, hipStream_t stream) {
   const FusedArgs& f = b.f;
   if (f.R != 1 || b.grad_feat_q || b.grad_feat_nn || f.targets_batch || f.kernel_id == MGP_KERNEL_MATERN_GEN) return MGP_EUNSUPPORTED;
@@ -86,7 +142,7 @@ int launch_backward_dlt(const BackwardArgs& b, hipStream_t stream) {
   static const bool off = getenv("MGP_BACKWARD_DLT") != nullptr && atoi(getenv("MGP_BACKWARD_DLT")) == 0;  // A/B switch (timing only)
   if (off) return MGP_EUNSUPPORTED;
   if (f.k == 50 && f.d == 8) return launch_bwd_dlt_impl<50, 8>(b, stream);
-  return MGP_EUNSUPPORTED;
+  return launch_bwd_dlt_jit(b, stream);
 }
 
 }  // namespace mgp

@@ -281,6 +281,10 @@ int mgp_jit_prepare(int elem_size, int k, int R, int d, int packed, int kernel_i
     return MGP_EINVAL;
   return prepare_fused_wave(elem_size, d, k, R, packed, kernel_id);
 }
+int mgp_jit_prepare_backward(int k, int d) {
+  if (k < 1 || d < 1) return MGP_EINVAL;
+  return prepare_backward_dlt(k, d);
+}
 int mgp_jit_mode(void) { return jit_mode(); }
 int mgp_jit_loaded_count(void) { return jit_loaded_count(); }
 int mgp_jit_source_hash(char* buf, int len) {

@@ -1475,7 +1475,6 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 #endif
       MGP_WAVE_T(4)
       if constexpr (BWD) {
-#ifndef __HIPCC_RTC__  // (BWD instantiations are built into the library only: mgp_backward_dlt.hip)
         // ---- phase 5B: a = K^-1 c and u = K^-1 y by back-substitution on the saved factor -------------------------
         // K = L D L^T (unit L, D = the pivots): the dealt image now holds, raw, a_m,j = l_m,j p_j for m >= j -- the
         // diagonal is p_j, rows q and q + 1 are (D L^-1 c)^T and (D L^-1 y)^T.  Lane i owns column i: entry (m, i) lies
@@ -1574,7 +1573,8 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         // per-neighbourhood outputs that need a and u only
         if (!skip && i < KFIX) {
           if (a.bwd_gnz) static_cast<T*>(a.bwd_gnz)[nb0 * KFIX + i] = gvv * xa * xa - gmv * xa * xu - gyv * xu * xu;
-          if (a.bwd_gtg) unsafeAtomicAdd(static_cast<T*>(a.bwd_gtg) + myidx, gmv * xa + T(2) * gyv * xu);
+          if (a.bwd_gtg)
+            __hip_atomic_fetch_add(static_cast<T*>(a.bwd_gtg) + myidx, gmv * xa + T(2) * gyv * xu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // ---- phase 7B: length-scale partials ------------------------------------------------------------------
         if (a.bwd_gls && !(MGP_BWD_EXP & 1)) {  // (uniform)
@@ -1610,23 +1610,28 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
                 if (MGP_BWD_SWEEP_PAIRS == 1 || (p & (MGP_BWD_SWEEP_PAIRS - 1)) == MGP_BWD_SWEEP_PAIRS - 1 || p == BP - 1) __builtin_amdgcn_sched_barrier(0);
               }
             }
-            // sum over the lanes through the (dead) dealt image: lane i writes its DSTFIX sums, lane (g, f) adds rows
-            // 64 / G g .. of feature f, a butterfly over g finishes
+            // sum over the lanes through the tile (every lane is done reading it): lane i writes its DSTFIX sums over its
+            // own row, lane (g, f) adds rows 64 / G g .. of feature f, a butterfly over g finishes.  (Rows >= M hold no
+            // sums -- idle lanes, zero -- and the last slot's row holds the inverse length scales: read first.)
             constexpr int FP = DSTFIX <= 2 ? 2 : DSTFIX <= 4 ? 4 : DSTFIX <= 8 ? 8 : DSTFIX <= 16 ? 16 : DSTFIX <= 32 ? 32 : 64;
             constexpr int G = 64 / FP, RPG = 64 / G;
-            T* red = Kh;
+            constexpr int RROWS = M < NPL ? M : NPL;  // rows that carry sums (all of them exist in the tile)
+            const T il = ilbuf[lane < d ? lane : 0];
             __syncthreads();
+            if (i < RROWS) {
 #pragma unroll
-            for (int c4 = 0; c4 < DGF; ++c4) *reinterpret_cast<V*>(red + lane * DSTFIX + c4 * E) = s2h[c4];
+              for (int c4 = 0; c4 < DGF; ++c4) *reinterpret_cast<V*>(Xh + i * xs + c4 * E) = s2h[c4];
+            }
             __syncthreads();
             const int f = lane & (FP - 1), gq = lane / FP;
             T tot = T(0);
             if (f < DSTFIX) {
 #pragma unroll
-              for (int r = 0; r < RPG; ++r) tot += red[(gq * RPG + r) * DSTFIX + f];
+              for (int r = 0; r < RPG; ++r)
+                if (gq * RPG + r < RROWS) tot += Xh[(gq * RPG + r) * xs + f];
             }
             for (int off = FP; off < 64; off <<= 1) tot += __shfl_xor(tot, off, 64);
-            if (!skip && lane < d) gls[nb0 * (int64_t)d + lane] = T(-2) * ilbuf[lane] * tot;
+            if (!skip && lane < d) gls[nb0 * (int64_t)d + lane] = T(-2) * il * tot;
           }
         }
         if (bad && live && lane == 0 && a.info) atomicAdd(a.info, 1);
@@ -1637,7 +1642,6 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
           if (t2 >= 0) next_idx = load_index(t2, h, i);
         }
         MGP_WAVE_T(5)
-#endif  // !__HIPCC_RTC__
         continue;
       }
       {

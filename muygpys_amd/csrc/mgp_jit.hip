@@ -131,21 +131,22 @@ Env& env() {
   return e;
 }
 
-using Key = std::tuple<int, int, int, int, int, int, int, int>;  // es, np, k, R, d, packed, gram, gen64
+using Key = std::tuple<int, int, int, int, int, int, int, int>;  // es, np, k, R, d, packed, gram, flags (1: gen64, 2: backward)
 
 std::string instantiation(const Key& key) {
-  char buf[160];
-  snprintf(buf, sizeof buf, "mgp::fused_wave_kernel<%s, %d, %d, %d, %d, true, false, %s, %s, %s>",
+  char buf[176];
+  snprintf(buf, sizeof buf, "mgp::fused_wave_kernel<%s, %d, %d, %d, %d, true, false, %s, %s, %s, %s>",
            std::get<0>(key) == 4 ? "float" : "double", std::get<1>(key), std::get<2>(key), std::get<3>(key), std::get<4>(key),
-           std::get<5>(key) ? "true" : "false", std::get<6>(key) ? "true" : "false", std::get<7>(key) ? "true" : "false");
+           std::get<5>(key) ? "true" : "false", std::get<6>(key) ? "true" : "false", (std::get<7>(key) & 1) ? "true" : "false",
+           (std::get<7>(key) & 2) ? "true" : "false");
   return buf;
 }
 
 std::string cache_path(const Key& key) {
   char buf[128];
-  snprintf(buf, sizeof buf, "/wave_f%d_np%d_k%d_r%d_d%d_p%d_g%d%s_%016llx.hsaco", std::get<0>(key) * 8, std::get<1>(key),
-           std::get<2>(key), std::get<3>(key), std::get<4>(key), std::get<5>(key), std::get<6>(key), std::get<7>(key) ? "_n1" : "",
-           (unsigned long long)env().src_hash);
+  snprintf(buf, sizeof buf, "/wave_f%d_np%d_k%d_r%d_d%d_p%d_g%d%s%s_%016llx.hsaco", std::get<0>(key) * 8, std::get<1>(key),
+           std::get<2>(key), std::get<3>(key), std::get<4>(key), std::get<5>(key), std::get<6>(key), (std::get<7>(key) & 1) ? "_n1" : "",
+           (std::get<7>(key) & 2) ? "_b1" : "", (unsigned long long)env().src_hash);
   return env().cache_dir + buf;
 }
 
@@ -193,7 +194,8 @@ int compile_once(const Key& key, const char* extra_option, std::string* name, st
 int ensure_code(const Key& key, std::string* name, std::string* code) {
   if (load_cached(key, name, code)) return MGP_OK;
   int rc = compile_once(key, nullptr, name, code);
-  if (rc == MGP_OK && spilled_vgprs(*code) > 0) {
+  // (the backward instantiations run at two waves per SIMD and may keep a handful of loop invariants in scratch: as built)
+  if (rc == MGP_OK && spilled_vgprs(*code) > 0 && !(std::get<7>(key) & 2)) {
     // register-hungry options an instantiation may not afford: the folded elimination (fp32), three waves per SIMD
     // for the dealt-lower-triangle kernels (fp64) -- the first build without spills is what gets cached
     for (const char* opt : {"-DMGP_FOLD=0", "-DMGP_C4_W3=0"}) {
@@ -260,10 +262,11 @@ std::map<std::pair<int, Key>, Loaded> g_loaded;
 // MGP_OK and the kernel of one static instantiation on the current device, or MGP_EUNSUPPORTED.
 // allow_compile = false: only what is loaded already or lies in the disk cache (the shapes compiled at build time,
 // or by an earlier run) -- a call too short to pay for a compile still gets its specialised kernel then.
-int jit_wave_function(int es, int np, int k, int R, int d, bool packed, bool gram, hipFunction_t* fn, bool allow_compile, bool gen64) {
+int jit_wave_function(int es, int np, int k, int R, int d, bool packed, bool gram, hipFunction_t* fn, bool allow_compile, bool gen64,
+                      bool bwd) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return MGP_EHIP;
-  const Key key{es, np, k, R, d, packed ? 1 : 0, gram ? 1 : 0, gen64 ? 1 : 0};
+  const Key key{es, np, k, R, d, packed ? 1 : 0, gram ? 1 : 0, (gen64 ? 1 : 0) | (bwd ? 2 : 0)};
   std::lock_guard<std::mutex> lock(g_mu);
   Loaded& l = g_loaded[{dev, key}];
   if (l.fn == nullptr && l.module == nullptr && (l.status == MGP_EUNSUPPORTED || (l.status == -4 && allow_compile))) {
@@ -299,9 +302,9 @@ int jit_loaded_count() {
 }
 
 // compile into the disk cache only (build time; no GPU): MGP_OK / MGP_EUNSUPPORTED
-int jit_wave_prepare(int es, int np, int k, int R, int d, bool packed, bool gram, bool gen64) {
+int jit_wave_prepare(int es, int np, int k, int R, int d, bool packed, bool gram, bool gen64, bool bwd) {
   std::string name, code;
-  return ensure_code(Key{es, np, k, R, d, packed ? 1 : 0, gram ? 1 : 0, gen64 ? 1 : 0}, &name, &code);
+  return ensure_code(Key{es, np, k, R, d, packed ? 1 : 0, gram ? 1 : 0, (gen64 ? 1 : 0) | (bwd ? 2 : 0)}, &name, &code);
 }
 
 // MUYGPYS_HIP_JIT: "0" never; "force" every eligible shape; otherwise (default) eligible shapes from

@@ -1,5 +1,5 @@
 """CPU: the dealt-lower-triangle elimination of the fp64 64-slot kernels (csrc/mgp_fused_wave_kernel.h, phase 4D;
-DESIGN.md sec. 4.1e), restated in numpy with the kernel's own index maps -- `dlt_col_start`, pair -> (slot, lane),
+docs/HISTORY.md sec. 4.1e), restated in numpy with the kernel's own index maps -- `dlt_col_start`, pair -> (slot, lane),
 which slots a step touches, where the pivot and the Schur block sit -- and compared with a direct solve.  The GPU
 parity tests (tests/test_gpu_jit.py, tests/test_gpu_fused.py) check the kernel; this pins the scheme itself: posting the
 raw column in lane order, junk in finished columns and in the odd upper-triangle elements never reaching a live entry,
@@ -78,4 +78,4 @@ def test_dealt_elimination_matches_a_direct_solve(k, R):
     np.testing.assert_allclose(mean, w @ Y, rtol=1e-8, atol=1e-11)
     np.testing.assert_allclose(yk, np.einsum("kr,kr->r", Y, np.linalg.solve(K, Y)), rtol=1e-8)
     if (k, R) == (50, 1):
-        assert steps == 217  # 217 slot updates = 434 FMAs against 688 group updates of the row form
+        assert steps == 217  # docs/HISTORY.md sec. 4.1e: 217 slot updates = 434 FMAs against 688 group updates of the row form

@@ -528,3 +528,44 @@ def test_dealt_triangle_backward_loocv_form_and_table_noise():
     gy = gy0
     lo1 = run(_lib.NOISE_SCALAR, None, False, True)
     assert np.abs(lo1[0] - lo0[0]).max() > 1e-6  # (the third cotangent does flow)
+
+
+@pytest.mark.parametrize("kernel,aniso,k,d,b", [("matern25", True, 40, 6, 300), ("matern15", False, 62, 16, 129), ("rbf", True, 31, 2, 500)])
+def test_dealt_triangle_backward_of_run_time_compiled_shapes(kernel, aniso, k, d, b):
+    """Any fp64 shape of the dealt-triangle kernels (33 <= nn_count + 2 <= 64, even feature count): the backward
+    instantiation compiled at run time (mgp_jit_prepare_backward, cached on disk), the same oracle comparison, and the
+    launch reports it."""
+    from muygpys_amd import _lib
+
+    metric = "F2" if kernel == "rbf" else "l2"
+    rc = _lib.load().mgp_jit_prepare_backward(k, d)
+    if rc == -2:
+        pytest.skip("no hiprtc on this machine: the row-per-lane kernels serve the shape")
+    assert rc == 0
+    rng = np.random.default_rng(1200 + k)
+    n = 2000
+    X = rng.normal(size=(n, d))
+    Y = np.sin(X @ rng.normal(size=(d, 1)) / np.sqrt(d)) + 0.1 * rng.normal(size=(n, 1))
+    bi = rng.choice(n, size=b, replace=False)
+    ni = np.stack([rng.choice(np.setdiff1d(np.arange(n), [i]), size=k, replace=False) for i in bi])
+    ls = np.sqrt(d) * rng.uniform(0.7, 1.5, size=d) if aniso else float(np.sqrt(d))
+    spec_o = orc.Spec(kernel, metric, ls, 2e-2)
+    gm, gv = rng.normal(size=(b, 1)), rng.normal(size=b)
+    ref = orc.posterior_vjp(spec_o, X, X, bi, ni, Y, gm, gv)
+    td = torch.float64
+    Xd, yd, lsd = to_dev(X, td), to_dev(Y, td), to_dev(np.atleast_1d(ls), td)
+    g_l = torch.zeros((b, lsd.numel()), device="cuda", dtype=td)
+    g_n = torch.zeros((b, k), device="cuda", dtype=td)
+    g_t = torch.zeros_like(yd)
+    info = torch.zeros(1, device="cuda", dtype=torch.int32)
+    bid, nid, gmd, gvd = to_dev(bi), to_dev(ni), to_dev(gm, td), to_dev(gv, td)
+    kid = {"rbf": 0, "matern05": 1, "matern15": 2, "matern25": 3, "maternInf": 4}[kernel]
+    rc = _lib.fn("posterior_backward", td)(_lib.ptr(Xd), _lib.ptr(Xd), d, _lib.ptr(bid), _lib.ptr(nid), b, k, _lib.ptr(yd), 1, 0, 2e-2, None,
+                                           kid, 0 if metric == "l2" else 1, _lib.ptr(lsd), lsd.numel(), _lib.ptr(gmd), _lib.ptr(gvd), None, None,
+                                           _lib.ptr(g_t), _lib.ptr(g_l), _lib.ptr(g_n), _lib.ptr(info), _lib.stream_ptr())
+    assert rc == 0 and int(info.item()) == 0
+    name = _lib.last_kernel()
+    assert "backward" in name and "run-time compiled" in name and f"double,64,{k},1,{d}" in name, name
+    assert_close(g_l.sum(0).cpu().numpy(), np.atleast_1d(ref["length_scale"]), 1e-5, "g_length_scale")
+    assert_close(g_n.sum().cpu().numpy().reshape(()), ref["noise"], 1e-5, "g_noise")
+    assert_close(g_t.cpu().numpy(), ref["targets"], 1e-5, "g_targets")
