@@ -72,56 +72,73 @@ def _get_opt_lists(muygps, verbose: bool = False):
 def _analytic_value_and_grad(muygps, obj_fn, x0_names):
     """``x -> (loss, d loss / d x)`` for scipy's ``jac=True``: one fused LOOCV evaluation and one backward launch
     (``muygpys_amd.fused.loocv_value_and_grad``) instead of ``len(x) + 1`` evaluations per iteration.  The objective
-    must be what ``make_loo_crossval_fn`` builds on lazy handles (``obj_fn.loocv_context``), the loss ``lool_fn`` or
-    ``mse_fn``, the free parameters length scales (``length_scale`` / ``length_scale{i}``) of a closed-form kernel
-    with homoscedastic noise -- anything else raises (there is no silent fall-back to finite differences: the caller
-    asked for an analytic gradient).  A free ``noise`` is refused too: inside the reference's objective sigma^2 is
-    computed with the STORED noise while mean and variance take the trial value (gp/hyperparameter/scale.py:206,214
-    against gp/noise/homoscedastic.py:112-113), which is not the function the gradient kernel differentiates.
+    must be what ``make_loo_crossval_fn`` builds on lazy handles (``obj_fn.loocv_context``); the loss any of
+    ``lool_fn``, ``mse_fn``, ``pseudo_huber_fn``, ``looph_fn`` (with their ``boundary_scale``); the free parameters
+    length scales (``length_scale`` / ``length_scale{i}``) of a closed-form kernel and / or the homoscedastic ``noise``
+    -- anything else raises (there is no silent fall-back to finite differences: the caller asked for an analytic
+    gradient).  What the reference's torch autograd route differentiates (torch/muygps_layer.py:129-164), here for the
+    numpy-style chassis (_src/optimize/chassis/numpy.py:57-81).
 
-    The sigma^2 inside ``lool`` is whatever the objective was built with, and the gradient follows it: the closed
-    form of ``AnalyticScale`` (any ``iteration_count``: the fixed-point passes are scalar algebra on the first value
-    and are differentiated as such) or the constant of ``FixedScale`` / a plain ``ScaleFn`` (no cotangent through
+    A free ``noise`` follows the reference's objective to the letter: mean and variance take the TRIAL value, the
+    analytic sigma^2 is computed with the model's STORED noise (gp/hyperparameter/scale.py:206,214 against
+    gp/noise/homoscedastic.py:112-113) -- two forward and two backward launches per evaluation then, and the noise
+    gradient is the trial value's alone.
+
+    The sigma^2 inside ``lool`` / ``looph`` is whatever the objective was built with, and the gradient follows it: the
+    closed form of ``AnalyticScale`` (any ``iteration_count``: the fixed-point passes are scalar algebra on the first
+    value and are differentiated as such) or the constant of ``FixedScale`` / a plain ``ScaleFn`` (no cotangent through
     ``y^T K^-1 y``).  A ``scale_fn`` that is neither of the two closures ``ScaleFn.get_opt_fn`` returns is refused."""
     from muygpys_amd import distributed as D
     from muygpys_amd import lazy, lazy_eval
     from muygpys_amd.fused import loocv_value_and_grad
-    from muygpys_amd.optimize.loss import lool_fn, mse_fn
+    from muygpys_amd.optimize.loss import lool_fn, looph_fn, mse_fn, pseudo_huber_fn
 
     ctx = getattr(obj_fn, "loocv_context", None)
     if ctx is None:
         raise ValueError("analytic_gradient=True: the objective was not built by make_loo_crossval_fn")
-    loss = "lool" if ctx["loss_fn"] is lool_fn else ("mse" if ctx["loss_fn"] is mse_fn else None)
+    loss = {id(lool_fn): "lool", id(mse_fn): "mse", id(pseudo_huber_fn): "pseudo_huber", id(looph_fn): "looph"}.get(id(ctx["loss_fn"]))
     if loss is None or ctx["target_mask"] is not None:
-        raise ValueError("analytic_gradient=True: the gradient is written out for lool_fn and mse_fn (no target mask)")
-    scale_mode = _scale_mode(muygps, ctx.get("scale_fn")) if loss == "lool" else ("analytic", 1)
+        raise ValueError("analytic_gradient=True: the gradient is written out for lool_fn, mse_fn, pseudo_huber_fn and "
+                         "looph_fn (no target mask)")
+    unknown = set(ctx.get("loss_kwargs") or {}) - ({"boundary_scale"} if loss in ("pseudo_huber", "looph") else set())
+    if unknown:
+        raise ValueError(f"analytic_gradient=True: loss_kwargs {sorted(unknown)} are not differentiated")
+    boundary_scale = (ctx.get("loss_kwargs") or {}).get("boundary_scale")
+    scale_mode = _scale_mode(muygps, ctx.get("scale_fn")) if loss in ("lool", "looph") else ("analytic", 1)
     pair, cross, nn_t = ctx["pairwise_diffs"], ctx["crosswise_diffs"], ctx["batch_nn_targets"]
     if not (isinstance(pair, lazy.LazyDiffs) and isinstance(cross, lazy.LazyDiffs) and isinstance(nn_t, lazy.LazyTargets)):
         raise ValueError("analytic_gradient=True: needs the lazy training tensors (MuyGPS.make_train_tensors under "
                          "config.state.lazy_tensors / integration.install())")
     if cross.data is not pair.nn_data and cross.data.data_ptr() != pair.nn_data.data_ptr():
         raise ValueError("analytic_gradient=True: LOOCV differentiates one table (query rows = training rows)")
-    index = {}
+    index, noise_at = {}, None
     for j, name in enumerate(x0_names):
         if name == "length_scale":
             index[j] = 0
         elif name.startswith("length_scale") and name[len("length_scale"):].isdigit():
             index[j] = int(name[len("length_scale"):])
+        elif name == "noise":
+            noise_at = j
         else:
-            raise ValueError(f"analytic_gradient=True: {name!r} is not a length scale (see the docstring for 'noise')")
-    noise = muygps.noise()
-    noise = float(noise.item()) if hasattr(noise, "item") else float(noise)
+            raise ValueError(f"analytic_gradient=True: {name!r} is neither a length scale nor the homoscedastic noise")
+    stored = muygps.noise()
+    if getattr(stored, "ndim", 0) >= 1 and getattr(stored, "numel", lambda: 1)() > 1:
+        raise ValueError("analytic_gradient=True: homoscedastic noise")
+    stored = float(stored.item()) if hasattr(stored, "item") else float(stored)
     reduce_fn = D.reduce_if_sharded_ if D.reductions_active() else None
 
     def value_and_grad(x_array, *args):
-        Kin = ctx["kernel_fn"](pair, **{h: float(x_array[i]) for i, h in enumerate(x0_names)})
+        hyper = {h: float(x_array[i]) for i, h in enumerate(x0_names) if i != noise_at}
+        Kin = ctx["kernel_fn"](pair, **hyper)
         if not isinstance(Kin, lazy.LazyCov):
             raise ValueError("analytic_gradient=True: the kernel did not stay a lazy handle")
         spec = lazy_eval._spec(Kin)
-        spec.noise = noise
-        value, g_ls, _ = loocv_value_and_grad(spec, pair.nn_data, nn_t.targets, cross.data_indices, pair.nn_indices,
-                                              loss=loss, reduce_fn=reduce_fn, scale=scale_mode)
-        return value, np.array([g_ls[index[j]] for j in range(len(x0_names))], dtype=np.float64)
+        spec.noise = stored if noise_at is None else float(x_array[noise_at])
+        value, g_ls, g_noise = loocv_value_and_grad(spec, pair.nn_data, nn_t.targets, cross.data_indices, pair.nn_indices,
+                                                    loss=loss, reduce_fn=reduce_fn, scale=scale_mode,
+                                                    boundary_scale=boundary_scale, sigma_noise=stored)
+        grad = [g_noise if j == noise_at else g_ls[index[j]] for j in range(len(x0_names))]
+        return value, np.array(grad, dtype=np.float64)
 
     return value_and_grad
 

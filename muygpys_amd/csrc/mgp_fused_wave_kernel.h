@@ -132,8 +132,8 @@
 #ifndef MGP_BWD_COV_BATCH
 #define MGP_BWD_COV_BATCH 3
 #endif
-#ifndef MGP_BWD_SWEEP_PAIRS
-#define MGP_BWD_SWEEP_PAIRS 2
+#ifndef MGP_BWD_SWEEP_GROUPS
+#define MGP_BWD_SWEEP_GROUPS 2  // 16-byte groups of the tile rows per pass of the length-scale sweep (phase 7B)
 #endif
 #ifndef MGP_BWD_EXP
 #define MGP_BWD_EXP 0  // (experiments: bits switch parts of the BWD instantiation off -- 1 length-scale partials, 2 pair cotangents, 4 back-substitution, 8 factor write-back)
@@ -1590,25 +1590,40 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
             V s2h[DGF];
 #pragma unroll
             for (int c4 = 0; c4 < DGF; ++c4) s2h[c4] = V(0);
+            // GH 16-byte groups of the rows at a time: the BP partner rows of the pass stay in registers for all BA own
+            // rows (every tile row is read once per pass: (BA + BP) GH reads instead of BA BP GH), the q of all pairs
+            // are there anyway.  (Left to itself the compiler did the same for whole rows -- BP x DGF groups live --
+            // and spilled 150 .. 1 350 registers at every shape but k = 50, d = 8.)
+            constexpr int GH = MGP_BWD_SWEEP_GROUPS < DGF ? MGP_BWD_SWEEP_GROUPS : DGF;
 #pragma unroll
-            for (int j = 0; j < BA; ++j) {
-              const T* xa_ = Xh + wrap(i + own_offset(j)) * xs;
-              V own[DGF];
-#pragma unroll
-              for (int c4 = 0; c4 < DGF; ++c4) own[c4] = *reinterpret_cast<const V*>(xa_ + c4 * E);
+            for (int g0 = 0; g0 < DGF; g0 += GH) {
+              V part[BP][GH];
 #pragma unroll
               for (int p = 0; p < BP; ++p) {
                 const T* xb_ = Xh + wrap(i + p + 1) * xs;
-                const V qv = V(acc[j * BP + p]);
 #pragma unroll
-                for (int c4 = 0; c4 < DGF; ++c4) {
-                  const V dz = own[c4] - *reinterpret_cast<const V*>(xb_ + c4 * E);
-                  s2h[c4] = (dz * qv) * dz + s2h[c4];
-                }
-                // (two partner rows' reads in flight at a time: hoisted together, the 25 x DGF reads of the unrolled
-                // sweep spill)
-                if (MGP_BWD_SWEEP_PAIRS == 1 || (p & (MGP_BWD_SWEEP_PAIRS - 1)) == MGP_BWD_SWEEP_PAIRS - 1 || p == BP - 1) __builtin_amdgcn_sched_barrier(0);
+                for (int u = 0; u < GH; ++u)
+                  if (g0 + u < DGF) part[p][u] = *reinterpret_cast<const V*>(xb_ + (g0 + u) * E);
               }
+#pragma unroll
+              for (int j = 0; j < BA; ++j) {
+                const T* xa_ = Xh + wrap(i + own_offset(j)) * xs;
+                V own[GH];
+#pragma unroll
+                for (int u = 0; u < GH; ++u)
+                  if (g0 + u < DGF) own[u] = *reinterpret_cast<const V*>(xa_ + (g0 + u) * E);
+#pragma unroll
+                for (int p = 0; p < BP; ++p) {
+                  const V qv = V(acc[j * BP + p]);
+#pragma unroll
+                  for (int u = 0; u < GH; ++u)
+                    if (g0 + u < DGF) {
+                      const V dz = own[u] - part[p][u];
+                      s2h[g0 + u] = (dz * qv) * dz + s2h[g0 + u];
+                    }
+                }
+              }
+              __builtin_amdgcn_sched_barrier(0);  // (one pass's rows in flight at a time)
             }
             // sum over the lanes through the tile (every lane is done reading it): lane i writes its DSTFIX sums over its
             // own row, lane (g, f) adds rows 64 / G g .. of feature f, a butterfly over g finishes.  (Rows >= M hold no

@@ -602,35 +602,47 @@ class LoocvPlan:
 
 def loocv_value_and_grad(spec: KernelSpec, train_features: torch.Tensor, train_targets: torch.Tensor,
                          batch_indices: torch.Tensor, nn_indices: torch.Tensor, loss: str = "lool",
-                         packed: Union[str, bool] = "auto", reduce_fn=None, scale=("analytic", 1)):
+                         packed: Union[str, bool] = "auto", reduce_fn=None, scale=("analytic", 1),
+                         boundary_scale: Optional[float] = None, sigma_noise: Optional[float] = None):
     """A LOOCV loss and its ANALYTIC gradient with respect to the length scale(s) and a homoscedastic noise: one
     forward evaluation (``mgp_loocv_*``) and one backward launch (``mgp_loocv_backward_*``) instead of the ``p + 1``
     forward evaluations per iteration scipy's finite differences cost the reference's L-BFGS-B driver
     (_src/optimize/chassis/numpy.py:57-81).  The reference gets such gradients from torch autograd over its torch
-    backend (torch/muygps_layer.py:129-164); here the chain rule is written out:
+    backend (torch/muygps_layer.py:129-164); here the chain rule is written out.  With r = mean - y, v the unscaled
+    variance, s = sigma^2 and (reference: _src/optimize/loss/numpy.py:22-117)
 
-        lool = A / s + B + n log s,  A = sum r_i^2 / v_i,  B = sum log v_i,  s = sum y_i^T K_i^-1 y_i / (n k)
-        d lool / d m_i = 2 r_i / (s v_i),   d / d v_i = 1 / v_i - r_i^2 / (s v_i^2),
-        d / d (y_i^T K_i^-1 y_i) = (n / s - A / s^2) / (n k)            (the analytic scale, scale/numpy.py:18-34)
-        mse  = sum r_i^2 / n:   d / d m_i = 2 r_i / n
+        lool          sum r^2 / (s v) + log(s v)            d/dm = 2 r / (s v)   d/dv = 1/v - r^2 / (s v^2)   d/ds = sum 1/s - r^2 / (s^2 v)
+        mse           sum r^2 / n                           d/dm = 2 r / n
+        pseudo_huber  d^2 sum sqrt(1 + (r/d)^2) - 1         d/dm = r / sqrt(1 + (r/d)^2)
+        looph         sum 2 d^2 (g - 1) + log(s v),         d/dm = 2 r / (g s v)   d/dv = 1/v - r^2 / (g s v^2)   d/ds = sum 1/s - r^2 / (g s^2 v)
+                      g = sqrt(1 + r^2 / (d^2 s v))
 
-    and the backward kernel turns the three cotangents into per-neighbourhood partials of d / d length_scale and
-    d / d noise.  ``reduce_fn`` (sharded batches): sums a float64 device vector over the ranks in place -- applied to
-    the six partial sums (so that s, A, n are global before the cotangents are formed) and to the gradient.
+    (d = ``boundary_scale``: 1.5 / 3.0 by default, as in the reference), sigma^2 enters through
+    ``d s / d (y_i^T K_i^-1 y_i) = (ds / df0) / (n k)`` -- the analytic scale, scale/numpy.py:18-34 -- and the
+    backward kernel turns the three cotangents into per-neighbourhood partials of d / d length_scale and d / d noise.
+    ``reduce_fn`` (sharded batches): sums a float64 device vector over the ranks in place -- applied to every sum the
+    cotangents are formed from and to the gradient.
 
-    ``scale`` names the sigma^2 of ``lool``: ``("analytic", iteration_count)`` -- the closed form above, followed by
+    ``scale`` names the sigma^2: ``("analytic", iteration_count)`` -- the closed form, followed by
     ``iteration_count - 1`` passes of ``s <- (s + f0 / s) / 2`` on the first value ``f0`` (gp/hyperparameter/scale.py:
     205-217 of the reference; ``ds / df0`` by the same recurrence) -- or ``("fixed", value)``: a constant, nothing
     flows through ``y^T K^-1 y`` (``FixedScale``, the reference's ``noop_scale_opt_fn``).
 
+    ``sigma_noise``: the noise inside sigma^2 when it is NOT ``spec.noise`` -- the reference's objective evaluates mean
+    and variance at the TRIAL noise of the optimiser but the analytic scale at the model's STORED one
+    (gp/hyperparameter/scale.py:206,214 against gp/noise/homoscedastic.py:112-113).  Then ``y^T K^-1 y`` comes from a
+    second forward launch at ``sigma_noise`` and its cotangent goes back through a second backward launch there; the
+    returned noise gradient is the trial noise's (sigma^2 does not depend on it).
+
     Returns ``(value, grad_length_scale (numpy, ls_count), grad_noise (float))`` of the LOSS (the objective the
     drivers maximise is its negative)."""
+    import copy
     import math
 
     import numpy as np
 
-    if loss not in ("lool", "mse"):
-        raise NotImplementedError(f"analytic gradients are written out for 'lool' and 'mse', not {loss!r}")
+    if loss not in ("lool", "mse", "pseudo_huber", "looph"):
+        raise NotImplementedError(f"analytic gradients are written out for lool, mse, pseudo_huber and looph, not {loss!r}")
     if isinstance(spec.noise, torch.Tensor) and spec.noise.ndim >= 1:
         raise NotImplementedError("analytic gradients: homoscedastic noise")
     if spec.kernel == "matern_gen":
@@ -644,10 +656,20 @@ def loocv_value_and_grad(spec: KernelSpec, train_features: torch.Tensor, train_t
     ni = nn_indices.to(torch.int64).contiguous()
     bi = batch_indices.to(torch.int64).contiguous()
     b, k = ni.shape
-    partials, mean, var, yk = loocv_partials(spec, train_features, train_targets, bi, ni, packed=packed, return_ykinvy=True)
+    needs_scale = loss in ("lool", "looph")
+    delta = float(boundary_scale) if boundary_scale is not None else (3.0 if loss == "looph" else 1.5)
+    partials, mean, var, yk = loocv_partials(spec, train_features, train_targets, bi, ni, packed=packed, return_ykinvy=True,
+                                             huber_delta=delta if loss == "pseudo_huber" else 1.5)
+    split = needs_scale and scale[0] == "analytic" and sigma_noise is not None and float(sigma_noise) != float(spec.noise)
+    spec_s = spec
+    if split:  # sigma^2 at the stored noise: y^T K^-1 y of a second evaluation
+        spec_s = copy.copy(spec)
+        spec_s.noise = float(sigma_noise)
+        partials_s = loocv_partials(spec_s, train_features, train_targets, bi, ni, packed=packed)[0]
+        partials = torch.cat([partials[:5], partials_s[5:6]])
     if reduce_fn is not None:
         reduce_fn(partials)
-    A, B, r2sum, n, _, cy = (float(v) for v in partials.tolist())
+    A, B, r2sum, n, ph, cy = (float(v) for v in partials.tolist())
     mode, arg = scale
     if mode == "analytic":
         s = f0 = cy / (n * k)
@@ -659,26 +681,52 @@ def loocv_value_and_grad(spec: KernelSpec, train_features: torch.Tensor, train_t
     else:
         raise ValueError(f"scale = {scale!r}: ('analytic', iteration_count) or ('fixed', value)")
     r = mean - tg[:, 0][bi]
+    dL_ds = 0.0
+    gv = None
     if loss == "lool":
         value = A / s + B + n * math.log(s)
         gm = (2.0 / s) * r / var
         gv = 1.0 / var - (r * r) / (s * var * var)
-        gyk = torch.full_like(var, (n / s - A / (s * s)) * ds / (n * k))
-    else:
+        dL_ds = n / s - A / (s * s)
+    elif loss == "mse":
         value = r2sum / n
         gm = (2.0 / n) * r
-        gv = torch.zeros_like(var)
-        gyk = torch.zeros_like(var)
+    elif loss == "pseudo_huber":
+        value = ph
+        gm = r / torch.sqrt(1.0 + (r / delta) ** 2)
+    else:  # looph: not separable in sigma^2 -- its sums are formed here, in fp64, once sigma^2 is known
+        r64, v64 = r.double(), var.double()
+        g = torch.sqrt(1.0 + r64 * r64 / (delta * delta * s * v64))
+        sums = torch.stack([(2.0 * delta * delta * (g - 1.0) + torch.log(s * v64)).sum(), (r64 * r64 / (g * v64)).sum()])
+        if reduce_fn is not None:
+            reduce_fn(sums)
+        value, rgv = (float(x) for x in sums.tolist())
+        gm = (2.0 * r64 / (g * s * v64)).to(dtype)
+        gv = (1.0 / v64 - r64 * r64 / (g * s * v64 * v64)).to(dtype)
+        dL_ds = n / s - rgv / (s * s)
+    zeros = torch.zeros_like(var)
+    gv = zeros if gv is None else gv
+    gyk_value = dL_ds * ds / (n * k) if needs_scale else 0.0
     ls = _length_scale_tensor(spec.length_scale, d, fn)
-    g_l = torch.zeros((b, ls.numel()), device=fn.device, dtype=dtype)
-    g_n = torch.zeros((b, k), device=fn.device, dtype=dtype)
     info = torch.zeros(1, device=fn.device, dtype=torch.int32)
-    rc = _lib.fn("loocv_backward", dtype)(
-        _lib.ptr(fn), d, _lib.ptr(bi), _lib.ptr(ni), b, k, _lib.ptr(tg), _lib.NOISE_SCALAR, float(spec.noise), None,
-        spec.kernel_id(), spec.metric_id(), _lib.ptr(ls), ls.numel(), _lib.ptr(gm.contiguous()), _lib.ptr(gv.contiguous()),
-        _lib.ptr(gyk), _lib.ptr(g_l), _lib.ptr(g_n), _lib.ptr(info), _lib.stream_ptr(),
-    )
-    _lib.check(rc, "mgp_loocv_backward")
+
+    def backward(spec_b, gm_b, gv_b, gyk_b, want_noise):
+        g_l = torch.zeros((b, ls.numel()), device=fn.device, dtype=dtype)
+        g_n = torch.zeros((b, k), device=fn.device, dtype=dtype) if want_noise else None
+        rc = _lib.fn("loocv_backward", dtype)(
+            _lib.ptr(fn), d, _lib.ptr(bi), _lib.ptr(ni), b, k, _lib.ptr(tg), _lib.NOISE_SCALAR, float(spec_b.noise), None,
+            spec_b.kernel_id(), spec_b.metric_id(), _lib.ptr(ls), ls.numel(), _lib.ptr(gm_b.contiguous()), _lib.ptr(gv_b.contiguous()),
+            _lib.ptr(gyk_b), _lib.ptr(g_l), _lib.ptr(g_n), _lib.ptr(info), _lib.stream_ptr(),
+        )
+        _lib.check(rc, "mgp_loocv_backward")
+        return g_l, g_n
+
+    if split:
+        g_l, g_n = backward(spec, gm, gv, zeros, True)
+        g_l2, _ = backward(spec_s, zeros, zeros, torch.full_like(var, gyk_value), False)
+        g_l = g_l + g_l2
+    else:
+        g_l, g_n = backward(spec, gm, gv, torch.full_like(var, gyk_value) if gyk_value != 0.0 else zeros, True)
     _lib.raise_if_not_spd(info, "LOOCV gradient")
     grad = torch.cat([_lib.column_sums(g_l), _lib.column_sums(g_n.reshape(-1, 1))])  # fp64, deterministic
     if reduce_fn is not None:

@@ -163,23 +163,77 @@ def test_lbfgsb_with_analytic_gradients_reaches_the_finite_difference_optimum_in
     assert rel(ls_an) < 0.05, (ls_an, planted)
 
 
-def test_analytic_gradient_refuses_what_it_does_not_differentiate():
-    from muygpys_amd.gp.hyperparameter import Parameter
+def _fd_check(m, obj, rtol=2e-6):
+    from muygpys_amd._src.optimize.chassis.hip import _analytic_value_and_grad
+
+    names, x0, _ = m.get_opt_params()
+    value, grad = _analytic_value_and_grad(m, obj, names)(np.asarray(x0, dtype=np.float64))
+    f = lambda x: -float(obj(**{n_: float(v) for n_, v in zip(names, x)}))  # noqa: E731  (the minimised function)
+    np.testing.assert_allclose(value, f(x0), rtol=1e-10)
+    fd = np.zeros(len(x0))
+    for j in range(len(x0)):
+        h = 1e-5 * max(1e-2, abs(x0[j]))
+        xp, xm = np.array(x0, dtype=np.float64), np.array(x0, dtype=np.float64)
+        xp[j] += h
+        xm[j] -= h
+        fd[j] = (f(xp) - f(xm)) / (2 * h)
+    np.testing.assert_allclose(grad, fd, rtol=rtol, atol=rtol * 0.1 * np.abs(fd).max())
+    return names, grad
+
+
+@pytest.mark.parametrize("loss,kwargs", [("looph", {}), ("looph", {"boundary_scale": 1.7}), ("pseudo_huber", {}),
+                                         ("pseudo_huber", {"boundary_scale": 0.6})])
+@pytest.mark.parametrize("k,d", [(14, 5), (50, 8)])
+def test_robust_losses_have_analytic_gradients_too(loss, kwargs, k, d):
+    """looph and pseudo-Huber (reference: _src/optimize/loss/numpy.py:64-117), with and without a ``boundary_scale``:
+    value = the objective's, gradient = its central differences (round-5 review: the analytic route refused them)."""
+    from muygpys_amd.optimize import L_BFGS_B_optimize
+    from muygpys_amd.optimize import loss as L
+
+    X, y, bi, ni = _data(50 + k, 1500, 350, k, d, np.linspace(0.8, 1.5, d))
+    m = _model("matern15", True, d, np.linspace(1.0, 1.8, d), 1e-2)
+    Xd, yd = to_dev(X, torch.float64), to_dev(y, torch.float64)
+    cross, pair, y_b, y_nn = m.make_train_tensors(to_dev(bi), to_dev(ni), Xd, yd)
+    obj = L_BFGS_B_optimize.make_obj_fn(m, y_b, y_nn, cross, pair, loss_fn=getattr(L, loss + "_fn"), loss_kwargs=kwargs)
+    _fd_check(m, obj)
+
+
+@pytest.mark.parametrize("loss", ["lool", "mse", "looph"])
+@pytest.mark.parametrize("scale_kind", ["analytic", "fixed"])
+def test_a_free_noise_parameter_is_differentiated_as_the_reference_evaluates_it(loss, scale_kind):
+    """``noise`` among the free parameters: the reference's objective gives mean and variance the TRIAL noise and computes
+    the analytic sigma^2 with the model's STORED one (gp/hyperparameter/scale.py:206,214 against
+    gp/noise/homoscedastic.py:112-113) -- the analytic route now follows that (two forward and two backward launches
+    per evaluation) instead of refusing: value and gradient against the objective itself."""
+    from muygpys_amd.gp.hyperparameter import FixedScale, Parameter
     from muygpys_amd.gp.noise import HomoscedasticNoise
     from muygpys_amd.optimize import L_BFGS_B_optimize
-    from muygpys_amd.optimize.loss import looph_fn
+    from muygpys_amd.optimize import loss as L
+
+    d, k = 6, 20
+    X, y, bi, ni = _data(91, 1500, 300, k, d, np.linspace(0.8, 1.5, d))
+    m = _model("matern25", True, d, np.linspace(1.0, 1.8, d), 1e-2, scale=FixedScale(val=0.4) if scale_kind == "fixed" else None)
+    m.noise = HomoscedasticNoise(3e-2, (1e-4, 1.0))
+    m._make()
+    Xd, yd = to_dev(X, torch.float64), to_dev(y, torch.float64)
+    cross, pair, y_b, y_nn = m.make_train_tensors(to_dev(bi), to_dev(ni), Xd, yd)
+    obj = L_BFGS_B_optimize.make_obj_fn(m, y_b, y_nn, cross, pair, loss_fn=getattr(L, loss + "_fn"))
+    names, grad = _fd_check(m, obj, rtol=5e-6)
+    assert "noise" in names and abs(grad[names.index("noise")]) > 0.0
+
+
+def test_analytic_gradient_refuses_what_it_does_not_differentiate():
+    from muygpys_amd.gp.hyperparameter import Parameter
+    from muygpys_amd.optimize import L_BFGS_B_optimize
 
     X, y, bi, ni = _data(9, 800, 100, 10, 4, np.ones(4))
     Xd, yd = to_dev(X, torch.float64), to_dev(y, torch.float64)
     m = _model("matern15", False, 4, 1.3, 1e-2)
     cross, pair, y_b, y_nn = m.make_train_tensors(to_dev(bi), to_dev(ni), Xd, yd)
-    with pytest.raises(ValueError, match="lool_fn and mse_fn"):
-        L_BFGS_B_optimize(m, y_b, y_nn, cross, pair, loss_fn=looph_fn, analytic_gradient=True)
-    m.noise = HomoscedasticNoise(1e-2, (1e-6, 1.0))
-    m._make()
-    cross, pair, y_b, y_nn = m.make_train_tensors(to_dev(bi), to_dev(ni), Xd, yd)
-    with pytest.raises(ValueError, match="not a length scale"):
-        L_BFGS_B_optimize(m, y_b, y_nn, cross, pair, analytic_gradient=True)
+    with pytest.raises(ValueError, match="no target mask"):
+        L_BFGS_B_optimize(m, y_b, y_nn, cross, pair, target_mask=[0], analytic_gradient=True)
+    with pytest.raises(ValueError, match="loss_kwargs"):
+        L_BFGS_B_optimize(m, y_b, y_nn, cross, pair, loss_kwargs={"boundary_scale": 2.0}, analytic_gradient=True)  # (lool takes none)
     cross, pair, y_b, y_nn = m.make_train_tensors(to_dev(bi), to_dev(ni), Xd, yd, materialize=True)
     m2 = _model("matern15", False, 4, 1.3, 1e-2)
     with pytest.raises(ValueError, match="lazy training tensors"):
