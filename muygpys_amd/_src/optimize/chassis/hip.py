@@ -136,7 +136,8 @@ def _analytic_value_and_grad(muygps, obj_fn, x0_names):
         spec.noise = stored if noise_at is None else float(x_array[noise_at])
         value, g_ls, g_noise = loocv_value_and_grad(spec, pair.nn_data, nn_t.targets, cross.data_indices, pair.nn_indices,
                                                     loss=loss, reduce_fn=reduce_fn, scale=scale_mode,
-                                                    boundary_scale=boundary_scale, sigma_noise=stored)
+                                                    boundary_scale=boundary_scale,
+                                                    sigma_noise=stored if noise_at is not None else None)
         grad = [g_noise if j == noise_at else g_ls[index[j]] for j in range(len(x0_names))]
         return value, np.array(grad, dtype=np.float64)
 

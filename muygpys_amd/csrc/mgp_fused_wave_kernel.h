@@ -132,8 +132,8 @@
 #ifndef MGP_BWD_COV_BATCH
 #define MGP_BWD_COV_BATCH 3
 #endif
-#ifndef MGP_BWD_SWEEP_GROUPS
-#define MGP_BWD_SWEEP_GROUPS 2  // 16-byte groups of the tile rows per pass of the length-scale sweep (phase 7B)
+#ifndef MGP_BWD_SWEEP_LATE
+#define MGP_BWD_SWEEP_LATE -1  // length-scale sweep behind the pair phase (1), inside it (0), by shape (-1)
 #endif
 #ifndef MGP_BWD_EXP
 #define MGP_BWD_EXP 0  // (experiments: bits switch parts of the BWD instantiation off -- 1 length-scale partials, 2 pair cotangents, 4 back-substitution, 8 factor write-back)
@@ -1525,6 +1525,20 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         // ---- phase 6B: pair cotangents q_rc = gK_rc dk/dacc_rc, in the pair scheme's own layout (the kept squared
         // distances acc[s] are replaced by q) -- each unordered pair once ------------------------------------------
         T liso = T(0);
+        // (Anisotropy) per-feature sums of q_rc (z_rf - z_cf)^2 over the lane's pairs, taken on the scaled rows the tile
+        // still holds RIGHT WHERE q_rc is formed: kept for a separate sweep, the NS q values cost 2 NS registers
+        // through the covariance-derivative batches -- 128 spill slots and 30.4 instead of 27.0 ms at k = 50, d = 8
+        constexpr int DGF = DSTFIX / E;
+        V s2h[DGF];  // (unused under SWEEP_LATE)
+        const bool sweep_any = a.bwd_gls != nullptr && aniso && !(MGP_BWD_EXP & 1);  // (uniform)
+        // ... except at BASELINE config 4's own shape, where keeping the q values and sweeping afterwards -- the partner
+        // rows of a lane read once for all its own rows -- fits with 8 spill slots: 27.0 against 30.8 ms per 2 M
+        constexpr bool SWEEP_LATE = MGP_BWD_SWEEP_LATE < 0 ? (KFIX == 50 && DFIX == 8) : MGP_BWD_SWEEP_LATE != 0;
+        const bool sweep = sweep_any && !SWEEP_LATE;
+        if constexpr (!SWEEP_LATE) {
+#pragma unroll
+          for (int c4 = 0; c4 < DGF; ++c4) s2h[c4] = V(0);
+        }
         {
           T ar[BA], ur[BA], Pc[BP], Qc[BP];
 #pragma unroll
@@ -1563,7 +1577,18 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
                   const T gK = ar[jj] * Pc[pp] - ur[jj] * Qc[pp];
                   const T qv = on ? gK * dv[u] : T(0);
                   liso = fma_t(qv, acc[sidx], liso);
-                  acc[sidx] = qv;
+                  if constexpr (SWEEP_LATE) acc[sidx] = qv;
+                  if constexpr (!SWEEP_LATE)
+                  if (sweep) {
+                    const T* xa_ = Xh + wrap(i + own_offset(jj)) * xs;
+                    const T* xb_ = Xh + wrap(i + pp + 1) * xs;
+                    const V qq = V(qv);
+#pragma unroll
+                    for (int c4 = 0; c4 < DGF; ++c4) {
+                      const V dz = *reinterpret_cast<const V*>(xa_ + c4 * E) - *reinterpret_cast<const V*>(xb_ + c4 * E);
+                      s2h[c4] = (dz * qq) * dz + s2h[c4];
+                    }
+                  }
                 }
               }
               __builtin_amdgcn_sched_barrier(0);  // keep the batches apart
@@ -1585,45 +1610,29 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
             for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
             if (!skip && lane == 0) gls[nb0] = T(-2) / ls[0] * sum;  // (-(1 | 2) / l times the (2 | 1) above)
           } else {
-            // Anisotropy: dL/dl_f = -(2 / l_f) sum_pairs q_rc (z_rf - z_cf)^2 on the scaled rows the tile still holds
-            constexpr int DGF = DSTFIX / E;
-            V s2h[DGF];
+            // Anisotropy: dL/dl_f = -(2 / l_f) sum_pairs q_rc (z_rf - z_cf)^2 (the lane's share: s2h, phase 6B)
+            V s2r[DGF];  // (the sums the reduction below takes: a local of this phase under SWEEP_LATE)
 #pragma unroll
-            for (int c4 = 0; c4 < DGF; ++c4) s2h[c4] = V(0);
-            // GH 16-byte groups of the rows at a time: the BP partner rows of the pass stay in registers for all BA own
-            // rows (every tile row is read once per pass: (BA + BP) GH reads instead of BA BP GH), the q of all pairs
-            // are there anyway.  (Left to itself the compiler did the same for whole rows -- BP x DGF groups live --
-            // and spilled 150 .. 1 350 registers at every shape but k = 50, d = 8.)
-            constexpr int GH = MGP_BWD_SWEEP_GROUPS < DGF ? MGP_BWD_SWEEP_GROUPS : DGF;
-#pragma unroll
-            for (int g0 = 0; g0 < DGF; g0 += GH) {
-              V part[BP][GH];
-#pragma unroll
-              for (int p = 0; p < BP; ++p) {
-                const T* xb_ = Xh + wrap(i + p + 1) * xs;
-#pragma unroll
-                for (int u = 0; u < GH; ++u)
-                  if (g0 + u < DGF) part[p][u] = *reinterpret_cast<const V*>(xb_ + (g0 + u) * E);
-              }
+            for (int c4 = 0; c4 < DGF; ++c4) s2r[c4] = SWEEP_LATE ? V(0) : s2h[SWEEP_LATE ? 0 : c4];
+            if constexpr (SWEEP_LATE) {
 #pragma unroll
               for (int j = 0; j < BA; ++j) {
                 const T* xa_ = Xh + wrap(i + own_offset(j)) * xs;
-                V own[GH];
+                V own[DGF];
 #pragma unroll
-                for (int u = 0; u < GH; ++u)
-                  if (g0 + u < DGF) own[u] = *reinterpret_cast<const V*>(xa_ + (g0 + u) * E);
+                for (int c4 = 0; c4 < DGF; ++c4) own[c4] = *reinterpret_cast<const V*>(xa_ + c4 * E);
 #pragma unroll
                 for (int p = 0; p < BP; ++p) {
+                  const T* xb_ = Xh + wrap(i + p + 1) * xs;
                   const V qv = V(acc[j * BP + p]);
 #pragma unroll
-                  for (int u = 0; u < GH; ++u)
-                    if (g0 + u < DGF) {
-                      const V dz = own[u] - part[p][u];
-                      s2h[g0 + u] = (dz * qv) * dz + s2h[g0 + u];
-                    }
+                  for (int c4 = 0; c4 < DGF; ++c4) {
+                    const V dz = own[c4] - *reinterpret_cast<const V*>(xb_ + c4 * E);
+                    s2r[c4] = (dz * qv) * dz + s2r[c4];
+                  }
+                  if ((p & 1) == 1 || p == BP - 1) __builtin_amdgcn_sched_barrier(0);
                 }
               }
-              __builtin_amdgcn_sched_barrier(0);  // (one pass's rows in flight at a time)
             }
             // sum over the lanes through the tile (every lane is done reading it): lane i writes its DSTFIX sums over its
             // own row, lane (g, f) adds rows 64 / G g .. of feature f, a butterfly over g finishes.  (Rows >= M hold no
@@ -1633,9 +1642,14 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
             constexpr int RROWS = M < NPL ? M : NPL;  // rows that carry sums (all of them exist in the tile)
             const T il = ilbuf[lane < d ? lane : 0];
             __syncthreads();
-            if (i < RROWS) {
+            // (through the dead dealt image where it is large enough: the built-in shape -- through the tile the same
+            // kernel spills 476 registers instead of 8)
+            constexpr bool RED_IMG = 64 * DSTFIX <= KMAT;
+            T* redb = RED_IMG ? Kh : Xh;
+            const int rstride = RED_IMG ? DSTFIX : xs;
+            if (RED_IMG || i < RROWS) {
 #pragma unroll
-              for (int c4 = 0; c4 < DGF; ++c4) *reinterpret_cast<V*>(Xh + i * xs + c4 * E) = s2h[c4];
+              for (int c4 = 0; c4 < DGF; ++c4) *reinterpret_cast<V*>(redb + i * rstride + c4 * E) = s2r[c4];
             }
             __syncthreads();
             const int f = lane & (FP - 1), gq = lane / FP;
@@ -1643,7 +1657,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
             if (f < DSTFIX) {
 #pragma unroll
               for (int r = 0; r < RPG; ++r)
-                if (gq * RPG + r < RROWS) tot += Xh[(gq * RPG + r) * xs + f];
+                if (RED_IMG || gq * RPG + r < RROWS) tot += redb[(gq * RPG + r) * rstride + f];
             }
             for (int off = FP; off < 64; off <<= 1) tot += __shfl_xor(tot, off, 64);
             if (!skip && lane < d) gls[nb0 * (int64_t)d + lane] = T(-2) * il * tot;

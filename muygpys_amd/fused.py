@@ -660,7 +660,10 @@ def loocv_value_and_grad(spec: KernelSpec, train_features: torch.Tensor, train_t
     delta = float(boundary_scale) if boundary_scale is not None else (3.0 if loss == "looph" else 1.5)
     partials, mean, var, yk = loocv_partials(spec, train_features, train_targets, bi, ni, packed=packed, return_ykinvy=True,
                                              huber_delta=delta if loss == "pseudo_huber" else 1.5)
-    split = needs_scale and scale[0] == "analytic" and sigma_noise is not None and float(sigma_noise) != float(spec.noise)
+    # (sigma_noise given = the noise is a VARIABLE of the caller's function while sigma^2 holds its own, constant one:
+    # the cotangent of y^T K^-1 y must not reach the noise gradient even where the two values coincide)
+    split_bwd = needs_scale and scale[0] == "analytic" and sigma_noise is not None
+    split = split_bwd and float(sigma_noise) != float(spec.noise)
     spec_s = spec
     if split:  # sigma^2 at the stored noise: y^T K^-1 y of a second evaluation
         spec_s = copy.copy(spec)
@@ -721,7 +724,7 @@ def loocv_value_and_grad(spec: KernelSpec, train_features: torch.Tensor, train_t
         _lib.check(rc, "mgp_loocv_backward")
         return g_l, g_n
 
-    if split:
+    if split_bwd:
         g_l, g_n = backward(spec, gm, gv, zeros, True)
         g_l2, _ = backward(spec_s, zeros, zeros, torch.full_like(var, gyk_value), False)
         g_l = g_l + g_l2
