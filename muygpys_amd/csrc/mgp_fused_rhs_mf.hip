@@ -235,18 +235,20 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
     // squared distances |a'|^2 + |b'|^2 - 2 a'.b' with the cancellation guard (mgp_wave_common.h); the two diagonal
     // entries a lane may hold (distance zero against twice the norm) stay out of the guard
     const int rdiag = ((c >> 2) & 1) == h ? 4 * (c >> 3) + (c & 3) : -1;  // the register with row == column (tiles 00, 11)
-    f2 D2[24];
+    // (round 6: the 24 pairs of squared distances are NOT kept between the guard and the covariances -- 48 registers on
+    // top of the three accumulators were what spilled at three waves per SIMD (13 registers, 0.68 GB of scratch writes
+    // per launch).  The guard pass keeps its minimum only; the covariance pass forms each pair again from the
+    // accumulators and the norms: one packed FMA.)
+    bool diff_form = false;  // (wave-uniform) the guard tripped: the accumulators hold difference-form distances
     {
       const T nc0 = normb[c], nc1 = normb[HALF + c];
       T guard = T(1);
-      // (the norms of the columns one 16-byte group at a time, right where they are used: all eight groups up front are
-      // 32 registers on top of the three accumulators and the distances -- that was what spilled at three waves per SIMD)
       static_for<4>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         const V nra = *reinterpret_cast<const V*>(normb + 8 * q + 4 * h);
         const V nrb = *reinterpret_cast<const V*>(normb + HALF + 8 * q + 4 * h);
         static_for<6>([&](auto pc) {
-          constexpr int tl = decltype(pc)::value / 2, r = 4 * q + 2 * (decltype(pc)::value % 2), pr = 8 * tl + r / 2;
+          constexpr int tl = decltype(pc)::value / 2, r = 4 * q + 2 * (decltype(pc)::value % 2);
           const F16& gg = tl == 0 ? g00 : (tl == 1 ? g01 : g11);
           const V& nr = tl == 2 ? nrb : nra;
           const T nc = tl == 0 ? nc0 : nc1;
@@ -258,11 +260,12 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
             tt.y = rdiag == r + 1 ? T(1) : tt.y;
           }
           guard = __builtin_fminf(__builtin_fminf(guard, tt.x), tt.y);
-          D2[pr] = f2{__builtin_fmaxf(dd.x, 0.0f), __builtin_fmaxf(dd.y, 0.0f)};
         });
       });
       if (gram_guard_tripped(guard)) {
-        // this neighbourhood's distances again in the difference form, entry by entry (rare: registers before speed)
+        // this neighbourhood's distances again in the difference form, entry by entry (rare: registers before speed),
+        // INTO the accumulators
+        diff_form = true;
         static_for<48>([&](auto ec) {
           constexpr int en = decltype(ec)::value, tl = en / 16, r = en % 16;
           const T* xa = tile + ((tl == 2 ? HALF : 0) + 8 * (r / 4) + 4 * h + r % 4) * xs;
@@ -271,8 +274,8 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
 #pragma nounroll
           for (int c0 = 0; c0 < wp; c0 += E)
             accum(sum, vsub(*reinterpret_cast<const V*>(xa + c0), *reinterpret_cast<const V*>(xb + c0)));
-          if (en % 2 == 0) D2[en / 2].x = acc_total(sum);
-          else D2[en / 2].y = acc_total(sum);
+          F16& gg = tl == 0 ? g00 : (tl == 1 ? g01 : g11);
+          gg[r] = acc_total(sum);
         });
       }
     }
@@ -290,18 +293,31 @@ __global__ __launch_bounds__(64, MGP_RHS_MF_WAVES) void fused_rhs_mf_kernel(Fuse
     {
       const T cscale = post_scale;  // (1 under Anisotropy: the rows are scaled)
       T kq = T(0);
+      const T nc0 = normb[c], nc1 = normb[HALF + c];
       kernel_dispatch(a.kernel_id, a.metric_id, [&](auto kid, auto mid) {
         constexpr int KID = decltype(kid)::value, MID = decltype(mid)::value;
-        static_for<24>([&](auto pc) {
-          constexpr int pr = decltype(pc)::value, tl = pr / 8, r = 2 * (pr % 8);
-          const f2 kk = cov_from_sqdist2(D2[pr], KID, MID, cscale);
-          if constexpr (tl == 0) {
-            KS[r / 4][r % 4] = kk.x;
-            KS[r / 4][r % 4 + 1] = kk.y;
-          } else {
-            KL[(tl == 2 ? 4 : 0) + r / 4][r % 4] = kk.x;
-            KL[(tl == 2 ? 4 : 0) + r / 4][r % 4 + 1] = kk.y;
-          }
+        static_for<4>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          const V nra = *reinterpret_cast<const V*>(normb + 8 * q + 4 * h);
+          const V nrb = *reinterpret_cast<const V*>(normb + HALF + 8 * q + 4 * h);
+          static_for<6>([&](auto pc) {
+            constexpr int tl = decltype(pc)::value / 2, r = 4 * q + 2 * (decltype(pc)::value % 2);
+            const F16& gg = tl == 0 ? g00 : (tl == 1 ? g01 : g11);
+            const V& nr = tl == 2 ? nrb : nra;
+            const T nc = tl == 0 ? nc0 : nc1;
+            const f2 ns = f2{nr[r % 4] + nc, nr[r % 4 + 1] + nc};
+            f2 dd = f2{gg[r], gg[r + 1]} * f2{-2.0f, -2.0f} + ns;
+            dd = f2{__builtin_fmaxf(dd.x, 0.0f), __builtin_fmaxf(dd.y, 0.0f)};
+            if (diff_form) dd = f2{gg[r], gg[r + 1]};
+            const f2 kk = cov_from_sqdist2(dd, KID, MID, cscale);
+            if constexpr (tl == 0) {
+              KS[r / 4][r % 4] = kk.x;
+              KS[r / 4][r % 4 + 1] = kk.y;
+            } else {
+              KL[(tl == 2 ? 4 : 0) + r / 4][r % 4] = kk.x;
+              KL[(tl == 2 ? 4 : 0) + r / 4][r % 4 + 1] = kk.y;
+            }
+          });
         });
         kq = cov_from_sqdist<T>(nrm, KID, MID, cscale);
       });

@@ -67,6 +67,13 @@ def test_headline_kernels_hold_their_register_budget():
     # (the count is the union over the ten covariance-function variants of the pair phase; few per executed path --
     # bounded here, timed on the GPU by tools/gradbench.py)
     assert res[c4b[0]]["Occupancy [waves/SIMD]"] >= 2 and res[c4b[0]]["VGPRs Spill"] <= 200, res[c4b[0]]
+    # BASELINE config 5 (fused_rhs_mf_kernel<16>: Gram matrix on the matrix cores' layout): three waves per SIMD and --
+    # round 6 -- no spilled register (13 until the pair distances stopped being kept between guard and covariances:
+    # 0.68 GB of scratch writes per launch)
+    c5 = [k for k in res if "fused_rhs_mf_kernelILi16EE" in k]
+    assert len(c5) == 1, sorted(res)
+    assert res[c5[0]]["VGPRs Spill"] == 0 and res[c5[0]]["ScratchSize [bytes/lane]"] == 0, res[c5[0]]
+    assert res[c5[0]]["Occupancy [waves/SIMD]"] >= 3, res[c5[0]]
     # run-time-shape wave kernels: no accumulator live range around the persistent loop (round 4: zeroing the distance
     # accumulators under `d0 == 0` inside the feature-stage loop kept 64 registers live through the whole task: 219
     # instead of 156..176 VGPRs for the fp32 64-slot kernels, 20 spilled in the fp64 one)
