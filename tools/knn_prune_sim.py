@@ -10,9 +10,10 @@ could use (round 6; the reference hands `algorithm=` to scikit-learn's kd / ball
 
 Prints the fraction of tiles that survive, with the exact k-th distances and with the estimate a first pass over the
 2 048 rows around the block would give.  Result (profiles/r06_knn_prune_sim.txt): 96-100 % of the tiles survive at
-1 M points and ~all at 10 M -- in eight dimensions 13-17 tree levels split each coordinate about twice, a tile's box
-spans a quarter to a half of the data's range in every coordinate, and the block's worst query (a tail point of the
-Gaussian) sets the radius.  The quadratic scan stays.
+1 M points; at 10 M, 60 % with the exact radii and 91 % with the first-pass estimate -- in eight dimensions 13-17 tree
+levels split each coordinate about twice, a tile's box spans a quarter to a half of the data's range in every
+coordinate, and the block's worst query (a tail point of the Gaussian) sets the radius.  A 10-40 % saving does not pay
+for the ordering, the first pass and the culling; the quadratic scan stays.
 
     python tools/knn_prune_sim.py [N] [QB]
 """
