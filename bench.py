@@ -47,7 +47,7 @@ FP32_VECTOR_TFLOPS = 157.3  # same guide: peak FP32 (vector)
 FP64_VECTOR_TFLOPS = 78.6   # half the fp32 vector rate (v_fma_f64 at the v_pk_fma_f32 issue cost, tools/ubench)
 # committed PMC passes, newest first (each names the shape(s) it was taken on)
 TRAFFIC_FILES = [(os.path.join(ROOT, "profiles", f), f) for f in (
-    "r05_wave_pmc_traffic.json", "r05_c45_pmc_traffic.json", "r04_wave_pmc_traffic.json", "r04_c45_pmc_traffic.json", "r03_wave_pmc_traffic.json", "r03_c45_pmc_traffic.json",
+    "r06_wave_pmc_traffic.json", "r06_c45_pmc_traffic.json", "r05_wave_pmc_traffic.json", "r05_c45_pmc_traffic.json", "r04_wave_pmc_traffic.json", "r04_c45_pmc_traffic.json", "r03_wave_pmc_traffic.json", "r03_c45_pmc_traffic.json",
     "r02_wave_pmc_traffic.json", "r02_c45_pmc_traffic.json")]
 
 # BASELINE.json configs: shape, model and what one step does

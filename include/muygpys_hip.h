@@ -385,6 +385,20 @@ int mgp_fast_coefficients_f64(const double* feat, int d, const int64_t* nn_idx, 
                               int kernel_id, int metric_id, const double* length_scale, int ls_count,
                               double* coeffs, int* info, void* stream);
 
+/* The selection steps around the scans (round 6; torch's topk / argsort did them until then: a quarter of a search's time).
+ * Reference: scikit-learn's brute-force kneighbors behind NN_Wrapper.get_nns / get_batch_nns
+ * (src/MuyGPyS/neighbors.py:129-211): exact neighbours in ascending order of distance.
+ *   mgp_topk_rows_f32   the k smallest entries of every row of x (rows, cols <= 4096; row_stride elements apart):
+ *                       values and column numbers, UNORDERED (the scans' initial lists); ties at the k-th value: any of them.
+ *   mgp_knn_finish_f32  candidates (m, k) int32 rows of `train`: squared distances to the queries re-measured in the
+ *                       difference form, each query's k candidates put in ascending order (ties: position in the
+ *                       list), row numbers through row_map (int64, or NULL) -> out_idx (m, k) int64, out_dist (m, k).
+ *                       d % 4 == 0, 16-byte aligned rows, k <= 64; MGP_EUNSUPPORTED otherwise. */
+int mgp_topk_rows_f32(const float* x, int64_t rows, int cols, int64_t row_stride, int k, float* out_values,
+                      int32_t* out_cols, void* stream);
+int mgp_knn_finish_f32(const float* queries, const float* train, int d, const int32_t* candidates, int64_t m, int k,
+                       const int64_t* row_map, int64_t* out_idx, float* out_dist, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Exact k-nearest-neighbour scan (the step upstream of the hot path).  Replaces
  * the exact search behind NN_Wrapper (src/MuyGPyS/neighbors.py:106-107 builds a

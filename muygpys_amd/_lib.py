@@ -110,6 +110,10 @@ def load():
     lib.mgp_knn_scan_bf16x3.restype = _i
     lib.mgp_knn_scan_bf16x2_d8.argtypes = lib.mgp_knn_scan_bf16x3.argtypes
     lib.mgp_knn_scan_bf16x2_d8.restype = _i
+    lib.mgp_topk_rows_f32.argtypes = [_p, _l, _i, _l, _i, _p, _p, _p]
+    lib.mgp_topk_rows_f32.restype = _i
+    lib.mgp_knn_finish_f32.argtypes = [_p, _p, _i, _p, _l, _i, _p, _p, _p, _p]
+    lib.mgp_knn_finish_f32.restype = _i
     lib.mgp_posterior_kernel_name.argtypes = [_i, _i, _i, _i, _i, _i, C.c_char_p, _i]
     lib.mgp_posterior_kernel_name.restype = _i
     lib.mgp_allreduce_partials.argtypes = [_p, _i, _p, _p]

@@ -119,6 +119,11 @@ struct KnnPackedArgs {
   int layout = 0;               // 0: rows [hi(KP) | lo(KP)], KP = 16 ceil((d + 2) / 16); 1: d <= 8, rows [hi(8) | lo(8) | T(8)]
 };
 int launch_knn_scan_packed(const KnnPackedArgs&, hipStream_t);
+// the selection steps around the scan (mgp_knn_select.hip): k smallest of every row, unordered; exact re-measurement +
+// stable order + row-number mapping of the scan's winners
+int launch_topk_rows(const float* x, int64_t rows, int cols, int64_t stride, int k, float* out_v, int* out_i, hipStream_t);
+int launch_knn_finish(const float* queries, const float* train, int d, const int* cand, int64_t m, int k, const int64_t* perm,
+                      int64_t* out_idx, float* out_dist, hipStream_t);
 
 template <typename T> int launch_fused_generic(const FusedArgs&, hipStream_t);
 template <typename T> int launch_solve_generic(const SolveArgs&, hipStream_t);

@@ -402,6 +402,21 @@ int mgp_posterior_f64(const double* fq, const double* fn, int d, const int64_t* 
 MGP_DEFINE_PATHS(f32, float)
 MGP_DEFINE_PATHS(f64, double)
 
+int mgp_topk_rows_f32(const float* x, int64_t rows, int cols, int64_t row_stride, int k, float* out_values, int32_t* out_cols,
+                      void* st) {
+  if (rows < 0 || cols < 1 || k < 1 || row_stride < cols) return MGP_EINVAL;
+  if (rows == 0) return MGP_OK;
+  if (!x || !out_values || !out_cols) return MGP_EINVAL;
+  return launch_topk_rows(x, rows, cols, row_stride, k, out_values, out_cols, S_(st));
+}
+int mgp_knn_finish_f32(const float* queries, const float* train, int d, const int32_t* candidates, int64_t m, int k,
+                       const int64_t* row_map, int64_t* out_idx, float* out_dist, void* st) {
+  if (m < 0 || d < 1 || k < 1) return MGP_EINVAL;
+  if (m == 0) return MGP_OK;
+  if (!queries || !train || !candidates || !out_idx || !out_dist) return MGP_EINVAL;
+  return launch_knn_finish(queries, train, d, candidates, m, k, row_map, out_idx, out_dist, S_(st));
+}
+
 int mgp_knn_scan_f32(const float* train, const float* train_sqn, int64_t n, int d, const float* queries,
                      const float* query_sqn, const int64_t* self_idx, int64_t m, int k, int64_t start, float* best_d,
                      int32_t* best_i, int32_t* overflow, void* st) {

@@ -164,9 +164,17 @@ class NN_Wrapper:
                 inside = ex < init_rows
                 rows = torch.arange(qq.shape[0], device=q.device)[inside]
                 d2[rows, ex[inside]] = float("inf")
-            bd, bi = d2.topk(k, dim=1, largest=False)
-            best_d[s:s + init_chunk] = bd
-            best_i[s:s + init_chunk] = bi.to(torch.int32)
+            # the k smallest per row, unordered (csrc/mgp_knn_select.hip: one wave per row, bisection on the key bits);
+            # torch.topk's multi-block radix select on a million short rows was a sixth of the search (round 5)
+            rc_sel = _lib.load().mgp_topk_rows_f32(_lib.ptr(d2), d2.shape[0], d2.shape[1], d2.stride(0), k,
+                                                   _lib.ptr(best_d[s:s + init_chunk]), _lib.ptr(best_i[s:s + init_chunk]),
+                                                   _lib.stream_ptr())
+            if rc_sel == -2:  # (more than 4 096 columns: not this path's sizes)
+                bd, bi = d2.topk(k, dim=1, largest=False)
+                best_d[s:s + init_chunk] = bd
+                best_i[s:s + init_chunk] = bi.to(torch.int32)
+            else:
+                _lib.check(rc_sel, "mgp_topk_rows_f32")
         overflow = torch.zeros((m,), device=q.device, dtype=torch.int32)
         ex64 = None if exclude is None else exclude.to(torch.int64).contiguous()
         if self.scan_kind == "bf16x3":
@@ -206,16 +214,23 @@ class NN_Wrapper:
         if rc == -2:  # MGP_EUNSUPPORTED (alignment)
             return None
         _lib.check(rc, "mgp_knn_scan_f32")
-        cand = best_i.to(torch.int64)
+        # the winners re-measured in difference form, put in order and mapped to the caller's row numbers in one launch
+        # (csrc/mgp_knn_select.hip) -- was gather (m, k, d) / subtract / square / sum / argsort / gather / gather
         idx = torch.empty((m, k), dtype=torch.int64, device=q.device)
         dist = torch.empty((m, k), dtype=q.dtype, device=q.device)
-        for s in range(0, m, 65536):
-            c = cand[s:s + 65536]
-            diff = q[s:s + 65536, None, :] - self.train[c]
-            dd = (diff * diff).sum(-1)
-            order = dd.argsort(dim=1, stable=True)
-            idx[s:s + 65536] = c.gather(1, order)
-            dist[s:s + 65536] = dd.gather(1, order)
+        rc_fin = _lib.load().mgp_knn_finish_f32(_lib.ptr(q), _lib.ptr(self.train), self.feature_count, _lib.ptr(best_i), m, k,
+                                                None, _lib.ptr(idx), _lib.ptr(dist), _lib.stream_ptr())
+        if rc_fin == -2:
+            cand = best_i.to(torch.int64)
+            for s in range(0, m, 65536):
+                c = cand[s:s + 65536]
+                diff = q[s:s + 65536, None, :] - self.train[c]
+                dd = (diff * diff).sum(-1)
+                order = dd.argsort(dim=1, stable=True)
+                idx[s:s + 65536] = c.gather(1, order)
+                dist[s:s + 65536] = dd.gather(1, order)
+        else:
+            _lib.check(rc_fin, "mgp_knn_finish_f32")
         self.last_overflow = overflow
         redo = overflow.nonzero().reshape(-1)
         if redo.numel():  # queues overflowed (adversarial row order): those queries go dense
