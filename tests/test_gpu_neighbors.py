@@ -215,3 +215,57 @@ def test_four_row_block_scan_returns_the_same_lists(monkeypatch):
     assert torch.equal(d4, d2) and float((i4 == i2).float().mean()) > 0.9999
     ref = torch.cdist(Q[:300].double(), X.double()) ** 2
     torch.testing.assert_close(d4[:300].double(), ref.topk(50, dim=1, largest=False)[0], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("rows,cols,k", [(1, 64, 1), (257, 1000, 30), (1000, 1920, 50), (33, 4096, 64), (5, 70, 70), (64, 129, 7)])
+def test_topk_rows_kernel_selects_the_k_smallest(rows, cols, k):
+    """mgp_topk_rows_f32 (round 6: the scans' initial lists, off torch.topk): per row the same SET of values as
+    torch.topk(largest=False), the reported columns hold those values, no column twice -- with ties, infinities
+    (the excluded self-match) and a padded last lane group."""
+    from muygpys_amd import _lib
+
+    g = torch.Generator(device="cuda").manual_seed(rows * 7 + cols)
+    x = torch.randn((rows, cols), device="cuda", generator=g)
+    x[:, ::5] = x[:, ::5].round(decimals=1)           # ties
+    x[torch.arange(rows, device="cuda"), torch.randint(0, cols, (rows,), device="cuda", generator=g)] = float("inf")
+    vals = torch.empty((rows, k), device="cuda")
+    idx = torch.empty((rows, k), device="cuda", dtype=torch.int32)
+    rc = _lib.load().mgp_topk_rows_f32(_lib.ptr(x), rows, cols, x.stride(0), k, _lib.ptr(vals), _lib.ptr(idx), _lib.stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref = x.topk(k, dim=1, largest=False).values.sort(dim=1).values
+    assert torch.equal(vals.sort(dim=1).values, ref)
+    assert torch.equal(x.gather(1, idx.long()), vals)
+    assert all(len(set(r.tolist())) == k for r in idx.cpu())
+
+
+@pytest.mark.parametrize("m,k,d", [(1, 1, 4), (1000, 30, 40), (777, 50, 8), (130, 64, 16), (65, 17, 12)])
+def test_knn_finish_kernel_orders_and_maps(m, k, d):
+    """mgp_knn_finish_f32: exact difference-form distances of the candidates, ascending, ties by position in the list,
+    indices through the row map -- against the torch expression it replaced."""
+    from muygpys_amd import _lib
+
+    g = torch.Generator(device="cuda").manual_seed(m + k)
+    n = 5000
+    train = torch.randn((n, d), device="cuda", generator=g)
+    q = torch.randn((m, d), device="cuda", generator=g)
+    cand = torch.stack([torch.randperm(n, device="cuda", generator=g)[:k] for _ in range(m)]).to(torch.int32)
+    if k > 2:
+        train[cand[:, 1].long()] = train[cand[:, 0].long()]  # an exact tie per query
+    perm = torch.randperm(n, device="cuda", generator=g)
+    idx = torch.empty((m, k), device="cuda", dtype=torch.int64)
+    dist = torch.empty((m, k), device="cuda")
+    for row_map in (None, perm):
+        rc = _lib.load().mgp_knn_finish_f32(_lib.ptr(q), _lib.ptr(train), d, _lib.ptr(cand), m, k, _lib.ptr(row_map),
+                                            _lib.ptr(idx), _lib.ptr(dist), _lib.stream_ptr())
+        assert rc == 0
+        torch.cuda.synchronize()
+        dd = ((q[:, None, :] - train[cand.long()]) ** 2).sum(-1)
+        torch.testing.assert_close(dist, dd.sort(dim=1).values, rtol=2e-6, atol=1e-6)
+        assert bool((dist[:, 1:] >= dist[:, :-1]).all())
+        # the same multiset of rows per query; where distances differ clearly, the same order
+        want = cand.long() if row_map is None else perm[cand.long()]
+        assert torch.equal(idx.sort(dim=1).values, want.sort(dim=1).values)
+        order = dd.argsort(dim=1, stable=True)
+        clear = (dd.gather(1, order)[:, 1:] - dd.gather(1, order)[:, :-1]).abs().min(dim=1).values > 1e-4
+        assert torch.equal(idx[clear], want.gather(1, order)[clear])
