@@ -269,3 +269,7 @@ def test_knn_finish_kernel_orders_and_maps(m, k, d):
         order = dd.argsort(dim=1, stable=True)
         clear = (dd.gather(1, order)[:, 1:] - dd.gather(1, order)[:, :-1]).abs().min(dim=1).values > 1e-4
         assert torch.equal(idx[clear], want.gather(1, order)[clear])
+        if k > 2:  # the planted tie: list positions 0 and 1 carry the same row -> position 0 first (a stable order)
+            p0 = (idx == want[:, :1]).float().argmax(dim=1)
+            p1 = (idx == want[:, 1:2]).float().argmax(dim=1)
+            assert bool((p0 < p1).all())
