@@ -535,6 +535,19 @@ def secondary_line(name: str, cfg_id: int, route: str, args, dev, steps: int = 5
     if use_packed and route == "fused":
         pack_table(w["X"], w["y"])
     step = make_step(cfg, w, route, "auto", use_packed if route == "fused" else "auto")
+    grad = None
+    if cfg.get("grad"):
+        # one evaluation of the LOOCV objective AND its analytic gradient with respect to the length scales (what
+        # L_BFGS_B_optimize(..., analytic_gradient=True) runs per iteration: fused.loocv_value_and_grad = the forward
+        # launch, the backward launch on the same kernel family, two column sums)
+        from muygpys_amd.fused import KernelSpec, loocv_value_and_grad
+
+        gspec = KernelSpec(cfg["kernel"], cfg["metric"], w["ls"], cfg["noise"])
+        grad = {}
+
+        def step():  # noqa: F811
+            grad["value"], grad["g_ls"], grad["g_noise"] = loocv_value_and_grad(gspec, w["X"], w["y"], w["bi"], w["ni"], loss="lool")
+            return {"lool": grad["value"], "sigma_sq": 1.0}
     acquire = None
     if cfg.get("acquire"):
         # one trial of the Bayes loop = one evaluation + one acquisition step (surrogate fit on the trials so far,
@@ -584,7 +597,25 @@ def secondary_line(name: str, cfg_id: int, route: str, args, dev, steps: int = 5
         print(f"[debug] {name}: est {est * 1e3:.3f} ms, steps {steps}, plans {[(p.b, p.host_result) for p in D_._PLANS.values()]}, "
               f"mean {np.mean(kern_ms):.3f} kern_ms {[round(v, 3) for v in kern_ms][:12]}", file=sys.stderr)
     roof = roofline_of(cfg, w, avg_ms, _lib.last_kernel(), cfg["objective"])  # the instantiation actually launched
-    check = spot_check(cfg, w, *_outputs_of(cfg, w, route, last))
+    if grad is not None:
+        # the gradient against central differences of the objective itself along the first length scale
+        from muygpys_amd import distributed as D_
+        from muygpys_amd.fused import KernelSpec as KS_
+
+        def lool_at(delta):
+            ls = list(w["ls"]) if isinstance(w["ls"], (list, tuple)) else [w["ls"]]
+            ls[0] = ls[0] + delta
+            sp = KS_(cfg["kernel"], cfg["metric"], ls if len(ls) > 1 else ls[0], cfg["noise"])
+            return D_.sharded_loocv(sp, w["X"], w["y"], w["bi"], w["ni"], loss="lool", presharded=True, return_outputs=False)["lool"]
+
+        h = 1e-5 * float(w["ls"][0] if isinstance(w["ls"], (list, tuple)) else w["ls"])
+        fd = (lool_at(h) - lool_at(-h)) / (2 * h)
+        err = abs(float(grad["g_ls"][0]) - fd) / max(abs(fd), 1e-300)
+        tol = 1e-4 if cfg["dtype"] == "f64" else 5e-2
+        check = {"rows": int(w["b"]), "max_rel_err": err, "tol": tol, "ok": bool(err <= tol),
+                 "against": "central differences of the LOOCV objective along the first length scale"}
+    else:
+        check = spot_check(cfg, w, *_outputs_of(cfg, w, route, last))
     out = {
         "baseline_config": cfg_id, "route": route, "what": cfg["what"], "dtype": cfg["dtype"],
         "value": w["b"] * steps / elapsed, "unit": "neighborhoods/s", "steps": steps, "ms_per_step": elapsed / steps * 1e3,
@@ -594,6 +625,9 @@ def secondary_line(name: str, cfg_id: int, route: str, args, dev, steps: int = 5
         "valu": {"frac": roof["valu"]["frac"], "achieved": roof["valu"]["achieved"], "unit": "TFLOP/s"},
         "kernel": roof["kernel"], "check": check,
     }
+    if grad is not None:
+        out["note"] = ("one LOOCV objective evaluation AND its analytic gradient with respect to the length scales "
+                       "(fused.loocv_value_and_grad); `kernel` names the backward launch")
     if acquire is not None:
         timed = acquire[-steps:]  # (the timed steps' acquisitions: warm-up ones carry one-time library initialisation)
         out["acquisition_ms"] = float(np.median(timed)) * 1e3
@@ -811,6 +845,7 @@ def main():
             plan = [("dropin", 2, "dropin", {}), ("dropin_plain", 2, "dropin_plain", {}), ("c3", 3, "fused", {}),
                     ("c3_shard8", 3, "fused", {"batch": 125_000}),
                     ("c4", 4, "fused", {}), ("c4_shard8", 4, "fused", {"batch": 1_250_000, "acquire": True}),
+                    ("c4_grad", 4, "fused", {"batch": 2_000_000, "grad": True}),
                     ("c5", 5, "fused", {}), ("knn", 2, "fused", {"knn": True}),
                     ("points8M", 2, "fused", {"points": 8_000_000})]
             for name, cid, route, over in plan:
