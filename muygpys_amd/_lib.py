@@ -136,7 +136,7 @@ def load():
     lib.mgp_matern_gen_constants.restype = _i
     lib.mgp_jit_prepare.argtypes = [_i, _i, _i, _i, _i, _i]
     lib.mgp_jit_prepare.restype = _i
-    lib.mgp_jit_prepare_backward.argtypes = [_i, _i]
+    lib.mgp_jit_prepare_backward.argtypes = [_i, _i, _i, _i]
     lib.mgp_jit_prepare_backward.restype = _i
     lib.mgp_jit_mode.argtypes = []
     lib.mgp_jit_mode.restype = _i

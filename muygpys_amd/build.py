@@ -164,7 +164,7 @@ def _parse_resource_remarks(text: str) -> dict:
 PREWARM_K = (10, 20, 25, 30, 40, 50)
 PREWARM_D = (8, 16, 32, 40, 64)
 # ... and the fp64 hyper-parameter backward of a few shapes next to BASELINE config 4's built-in (50, 8) (round 6)
-PREWARM_BWD = ((40, 8), (40, 16), (50, 16), (32, 8))
+PREWARM_BWD = ((8, 40, 8), (8, 40, 16), (8, 50, 16), (8, 32, 8), (4, 30, 16), (4, 20, 40), (4, 25, 8), (8, 30, 40))
 
 
 def _prewarm_one(job):
@@ -173,9 +173,9 @@ def _prewarm_one(job):
     es, k, d, packed = job
     lib = ctypes.CDLL(LIB)
     if packed == "bwd":
-        lib.mgp_jit_prepare_backward.argtypes = [ctypes.c_int] * 2
+        lib.mgp_jit_prepare_backward.argtypes = [ctypes.c_int] * 4
         lib.mgp_jit_prepare_backward.restype = ctypes.c_int
-        return job, lib.mgp_jit_prepare_backward(k, d)
+        return job, lib.mgp_jit_prepare_backward(es, k, d, 2)
     lib.mgp_jit_prepare.argtypes = [ctypes.c_int] * 6
     lib.mgp_jit_prepare.restype = ctypes.c_int
     return job, lib.mgp_jit_prepare(es, k, 1, d, packed, 2)  # kernel id 2 = Matern-3/2 (any Gram-form kernel)
@@ -188,7 +188,7 @@ def prewarm(verbose: bool = False) -> int:
 
     jobs = [(4, k, d, p) for k in PREWARM_K for d in PREWARM_D for p in (1, 0)]
     jobs += [(8, k, d, 1) for k in PREWARM_K for d in PREWARM_D if d <= 32]
-    jobs += [(8, k, d, "bwd") for k, d in PREWARM_BWD]
+    jobs += [(es, k, d, "bwd") for es, k, d in PREWARM_BWD]
     with mp.get_context("spawn").Pool(min(8, os.cpu_count() or 1)) as pool:
         done = pool.map(_prewarm_one, jobs)
     ok = sum(1 for _, rc in done if rc == 0)

@@ -81,10 +81,10 @@ struct BackwardArgs {
 };
 template <typename T> int launch_backward(const BackwardArgs&, hipStream_t);
 template <typename T> int launch_backward_wave(const BackwardArgs&, hipStream_t);  // Isotropy, k + 2 <= 64: on the wave kernel's phases
-// fp64, hyper-parameter gradients of one response (no feature cotangents) for the static shapes of the dealt-triangle
-// forward kernels (BASELINE config 4: k = 50, d = 8): the forward kernel's own phases + the saved factor
-// (mgp_backward_dlt.hip); MGP_EUNSUPPORTED for everything else
-int launch_backward_dlt(const BackwardArgs&, hipStream_t);
+// hyper-parameter gradients of one response (no feature cotangents) on the forward kernel's own phases + the saved
+// factor (mgp_backward_dlt.hip): fp64 dealt-triangle shapes (BASELINE config 4: k = 50, d = 8) and the 32-slot static
+// shapes of either type (config 3: k = 30, d = 40); MGP_EUNSUPPORTED for everything else
+template <typename T> int launch_backward_fwd(const BackwardArgs&, hipStream_t);
 int max_nn_count_backward(int elem_size);
 
 // Exact k-NN scan on the matrix cores (mgp_knn.hip)
@@ -134,7 +134,7 @@ template <typename T> int launch_fused_wave(const FusedArgs&, hipStream_t);
 int jit_wave_function(int es, int np, int k, int R, int d, bool packed, bool gram, hipFunction_t* fn, bool allow_compile = true,
                       bool gen64 = false, bool bwd = false);
 int jit_wave_prepare(int es, int np, int k, int R, int d, bool packed, bool gram, bool gen64 = false, bool bwd = false);
-int prepare_backward_dlt(int k, int d);  // compile the backward instantiation of a shape into the disk cache (mgp_backward_dlt.hip)
+int prepare_backward_fwd(int elem_size, int k, int d, int kernel_id);  // compile the backward instantiation of a shape into the disk cache (mgp_backward_dlt.hip)
 // one instantiation of the wave kernel (mgp_fused_wave_launch.h; instantiated in mgp_fused_wave_inst_*.hip)
 template <typename T, int NP, int KFIX, int RFIX, int DFIX, bool PIPED, bool COEFF, bool PACKED, bool GRAM, bool GEN64>
 int launch_np_impl(const FusedArgs& a, hipStream_t stream);

@@ -126,14 +126,106 @@ static int launch_bwd_dlt_jit(const BackwardArgs& b, hipStream_t stream) {
   return MGP_OK;
 }
 
-int prepare_backward_dlt(int k, int d) {
-  if (k == 50 && d == 8) return MGP_OK;  // built into the library
-  if (!dlt_shape(k, d) || !wave_dims(8, 64, k, 1, d, false, false).DLT) return MGP_EUNSUPPORTED;
-  return jit_wave_prepare(8, 64, k, 1, d, false, false, false, true);
+// ---- row-per-lane form: 32-slot static shapes of either element type (BASELINE config 3's k = 30, d = 40 built in) ----
+template <typename T>
+static bool row_shape(int k, int d) {  // 17 .. 32 slots, rows of whole 16-byte groups, one feature stage
+  constexpr int E = 16 / (int)sizeof(T), CH = 2 * E;
+  return k + 2 >= 17 && k + 2 <= 32 && d >= E && d % E == 0 && (d + CH - 1) / CH * CH <= 64;
+}
+template <typename T>
+static bool row_gram(const FusedArgs& f) {  // (the forward kernels' rule: fp32, not the Matern-1/2 kernel)
+  return sizeof(T) == 4 && MGP_GRAM && f.kernel_id != MGP_KERNEL_MATERN_05;
+}
+template <typename T>
+static void row_geometry(const FusedArgs& a, const WaveDims& WD, int NP, WaveGeom* g, size_t* lds) {
+  g->mask = 0xF;
+  g->q = a.k;
+  g->dst = (a.d + WD.CH - 1) / WD.CH * WD.CH;
+  g->xs = g->dst + WD.E;
+  g->vec_ok = 1;
+  g->ntasks = (a.b + WD.NH - 1) / WD.NH;
+  size_t unused = 0;
+  gen_geometry(a, g, &unused, (int)sizeof(T));
+  const size_t tile_feat = (size_t)wave_tile_rows(WD, NP, a.k, g->xs) * g->xs + wave_stage_elems(WD);
+  // (behind tile and exchange images: the column buffers / norm array / row addresses, and -- BWD -- the two solved
+  // vectors of both neighbourhoods: 128 entries)
+  const size_t tail = wave_colbuf_bytes(sizeof(T), NP, false) > 128 * sizeof(T) ? wave_colbuf_bytes(sizeof(T), NP, false) : 128 * sizeof(T);
+  *lds = ((tile_feat + (size_t)WD.NH * WD.KMAT) * sizeof(T) + tail + 15) & ~(size_t)15;
+}
+static int64_t row_grid(int cus, int per_cu, int64_t ntasks) {
+  int64_t grid = (int64_t)cus * per_cu / 8 * 8;
+  if (grid < 8) grid = 8;
+  if (grid > ntasks) grid = (ntasks + 7) / 8 * 8;
+  return grid;
+}
+template <typename T, int KFIX, int DFIX, bool GRAM>
+static int launch_bwd_row_impl(const BackwardArgs& b, hipStream_t stream) {
+  constexpr int NP = 32;
+  constexpr WaveDims WD = wave_dims(sizeof(T), NP, KFIX, 1, DFIX, false, GRAM);
+  static_assert(!WD.DLT && WD.STAT, "a 32-slot static shape");
+  FusedArgs a;
+  bwd_args(b, &a);
+  WaveGeom g;
+  size_t lds = 0;
+  row_geometry<T>(a, WD, NP, &g, &lds);
+  static Residency res;
+  int per_cu = 0, cus = 0;
+  const void* fn = reinterpret_cast<const void*>(&fused_wave_kernel<T, NP, KFIX, 1, DFIX, true, false, false, GRAM, false, true>);
+  const int rrc = res.lookup(fn, 64, lds, &per_cu, &cus);
+  if (rrc != MGP_OK) return rrc;
+  const int64_t grid = row_grid(cus, per_cu, g.ntasks);
+  hipLaunchKernelGGL((fused_wave_kernel<T, NP, KFIX, 1, DFIX, true, false, false, GRAM, false, true>), dim3((unsigned)grid), dim3(64), lds,
+                     stream, a, g);
+  MGP_HIP_CHECK_LAUNCH();
+  note_launch("mgp::fused_wave_kernel<%s,%d,%d,1,%d,true,false,false,%s,false,backward>", sizeof(T) == 4 ? "float" : "double", NP, KFIX,
+              DFIX, GRAM ? "true" : "false");
+  note_launch_geometry(grid, lds);
+  return MGP_OK;
+}
+template <typename T>
+static int launch_bwd_row_jit(const BackwardArgs& b, hipStream_t stream) {
+  constexpr int NP = 32;
+  FusedArgs a;
+  bwd_args(b, &a);
+  if (!row_shape<T>(a.k, a.d) || jit_mode() == 0) return MGP_EUNSUPPORTED;
+  const bool gram = row_gram<T>(a);
+  const WaveDims WD = wave_dims(sizeof(T), NP, a.k, 1, a.d, false, gram);
+  if (WD.DLT || !WD.STAT) return MGP_EUNSUPPORTED;
+  hipFunction_t fn = nullptr;
+  const int jrc = jit_wave_function(sizeof(T), NP, a.k, 1, a.d, false, gram, &fn, jit_mode() == 2 || a.b >= jit_min_batch(), false, true);
+  if (jrc != MGP_OK) return jrc;
+  WaveGeom g;
+  size_t lds = 0;
+  row_geometry<T>(a, WD, NP, &g, &lds);
+  static Residency res;
+  int per_cu = 0, cus = 0;
+  const int rrc = res.lookup(fn, 64, lds, &per_cu, &cus);
+  if (rrc != MGP_OK) return rrc;
+  const int64_t grid = row_grid(cus, per_cu, g.ntasks);
+  void* params[] = {&a, &g};
+  const hipError_t err = hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 64, 1, 1, (unsigned)lds, stream, params, nullptr);
+  if (err != hipSuccess) return -(1000 + (int)err);
+  note_launch("mgp::fused_wave_kernel<%s,%d,%d,1,%d,true,false,false,%s,false,backward> [run-time compiled]", sizeof(T) == 4 ? "float" : "double",
+              NP, a.k, a.d, gram ? "true" : "false");
+  note_launch_geometry(grid, lds);
+  return MGP_OK;
+}
+
+int prepare_backward_fwd(int elem_size, int k, int d, int kernel_id) {
+  if (elem_size == 8 && dlt_shape(k, d) && wave_dims(8, 64, k, 1, d, false, false).DLT) {
+    if (k == 50 && d == 8) return MGP_OK;  // built into the library
+    return jit_wave_prepare(8, 64, k, 1, d, false, false, false, true);
+  }
+  const bool ok = elem_size == 4 ? row_shape<float>(k, d) : (elem_size == 8 && row_shape<double>(k, d));
+  if (!ok) return MGP_EUNSUPPORTED;
+  const bool gram = elem_size == 4 && MGP_GRAM && kernel_id != MGP_KERNEL_MATERN_05;
+  if (elem_size == 4 && k == 30 && d == 40 && gram) return MGP_OK;  // built in
+  return jit_wave_prepare(elem_size, 32, k, 1, d, false, gram, false, true);
 }
 
 // hyper-parameter gradients of one response; plain tables, 16-byte aligned rows
-int launch_backward_dlt(const BackwardArgs& b, hipStream_t stream) {
+template <typename T>
+int launch_backward_fwd(const BackwardArgs& b, hipStream_t stream) {
   const FusedArgs& f = b.f;
   if (f.R != 1 || b.grad_feat_q || b.grad_feat_nn || f.targets_batch || f.kernel_id == MGP_KERNEL_MATERN_GEN) return MGP_EUNSUPPORTED;
   if (f.ls_count != 1 && f.ls_count != f.d) return MGP_EUNSUPPORTED;
@@ -141,8 +233,15 @@ int launch_backward_dlt(const BackwardArgs& b, hipStream_t stream) {
   if (align % 16 != 0 || f.b >= ((int64_t)1 << 31)) return MGP_EUNSUPPORTED;
   static const bool off = getenv("MGP_BACKWARD_DLT") != nullptr && atoi(getenv("MGP_BACKWARD_DLT")) == 0;  // A/B switch (timing only)
   if (off) return MGP_EUNSUPPORTED;
-  if (f.k == 50 && f.d == 8) return launch_bwd_dlt_impl<50, 8>(b, stream);
-  return launch_bwd_dlt_jit(b, stream);
+  if constexpr (sizeof(T) == 8) {
+    if (f.k == 50 && f.d == 8) return launch_bwd_dlt_impl<50, 8>(b, stream);
+    if (dlt_shape(f.k, f.d)) return launch_bwd_dlt_jit(b, stream);
+  } else {
+    if (f.k == 30 && f.d == 40 && row_gram<T>(f)) return launch_bwd_row_impl<float, 30, 40, true>(b, stream);
+  }
+  return launch_bwd_row_jit<T>(b, stream);
 }
+template int launch_backward_fwd<float>(const BackwardArgs&, hipStream_t);
+template int launch_backward_fwd<double>(const BackwardArgs&, hipStream_t);
 
 }  // namespace mgp

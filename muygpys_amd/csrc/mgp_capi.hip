@@ -150,12 +150,11 @@ int posterior_backward(const T* fq, const T* fn, int d, const int64_t* bi, const
                  gmean, gvar, gfq, gfn, gtg, gls, gnz};
   g.grad_yk = gyk;
   static const bool lds_only = getenv("MGP_BACKWARD_LDS") != nullptr;  // A/B switch (timing only)
-  if constexpr (sizeof(T) == 8) {
-    // hyper-parameter gradients on the dealt-triangle forward kernel (round 6: BASELINE config 4's shape)
-    if (!lds_only) {
-      const int rc = launch_backward_dlt(g, static_cast<hipStream_t>(stream));
-      if (rc != MGP_EUNSUPPORTED) return rc;
-    }
+  // hyper-parameter gradients on the forward kernel itself (round 6: the dealt-triangle shapes of BASELINE config 4 and
+  // the 32-slot shapes of config 3)
+  if (!lds_only) {
+    const int rc = launch_backward_fwd<T>(g, static_cast<hipStream_t>(stream));
+    if (rc != MGP_EUNSUPPORTED) return rc;
   }
   if (!lds_only) {
     const int rc = launch_backward_wave<T>(g, static_cast<hipStream_t>(stream));
@@ -281,9 +280,9 @@ int mgp_jit_prepare(int elem_size, int k, int R, int d, int packed, int kernel_i
     return MGP_EINVAL;
   return prepare_fused_wave(elem_size, d, k, R, packed, kernel_id);
 }
-int mgp_jit_prepare_backward(int k, int d) {
-  if (k < 1 || d < 1) return MGP_EINVAL;
-  return prepare_backward_dlt(k, d);
+int mgp_jit_prepare_backward(int elem_size, int k, int d, int kernel_id) {
+  if ((elem_size != 4 && elem_size != 8) || k < 1 || d < 1 || !valid_kernel(kernel_id)) return MGP_EINVAL;
+  return prepare_backward_fwd(elem_size, k, d, kernel_id);
 }
 int mgp_jit_mode(void) { return jit_mode(); }
 int mgp_jit_loaded_count(void) { return jit_loaded_count(); }

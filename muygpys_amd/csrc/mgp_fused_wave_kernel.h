@@ -380,7 +380,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   constexpr int NS = WD.NS;       // pairs per lane
   // (32 slots, fp32, Gram form; or -- MGP_FOLD64 -- 64 slots: one neighbourhood per half-wave.  The query and
   // response rows must be among the long rows: k >= NP / 2)
-  constexpr bool FOLD = wave_fold(sizeof(T), NP, KFIX, RFIX, DFIX, PIPED, COEFF, GRAM);
+  constexpr bool FOLD = !BWD && wave_fold(sizeof(T), NP, KFIX, RFIX, DFIX, PIPED, COEFF, GRAM);  // (BWD keeps the factor: row per lane)
   constexpr int HALF = NP / 2;    // (FOLD) lanes per neighbourhood; lane l owns rows l and HALF + l
   constexpr int NGS = HALF / WD.E;  // (FOLD) 16-byte groups of a short row
   constexpr int LOGH = NP == 64 ? 5 : (NP == 32 ? 4 : 3);
@@ -411,7 +411,13 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   // pairs 64 s + l, s = 0 .. NSL-1.  The exchange matrix is stored in exactly that order, so the read-back is NSL
   // lane-linear ds_read_b128.
   constexpr bool DLT = WD.DLT;
-  static_assert(!BWD || (DLT && RFIX == 1 && PIPED && !PACKED && !GRAM && !GEN64), "BWD: the dealt-triangle kernels on plain tables, one response");
+  // BWD comes in two layouts: on the dealt triangle (fp64, 64 slots) and -- round 6, second half -- row per lane for the
+  // 32-slot static shapes of either element type (BASELINE config 3's shape: the multipliers kept in the exchange image
+  // as the COEFF variant keeps them, two neighbourhoods per wave)
+  constexpr bool BWD_ROW = BWD && !DLT;
+  static_assert(!BWD || (RFIX == 1 && PIPED && !PACKED && !GEN64 && !COEFF && WD.STAT), "BWD: static shapes on plain tables, one response");
+  static_assert(!BWD || DLT || NP == 32, "BWD: the dealt-triangle shapes or the 32-slot ones");
+  static_assert(!(BWD && DLT && GRAM), "BWD on the dealt triangle: difference form");
   constexpr int NR2 = WD.NR2, NPAIR = WD.NPAIR, NSL = WD.NSL;
   auto cs2 = [](int c) { return dlt_col_start(c, NR2); };
   auto eoff = [&](int hi, int lo) {  // element offset of entry (hi, lo) of a neighbourhood's exchange matrix, hi >= lo
@@ -1739,7 +1745,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
           const T p = cp[j % E];
           bad = bad || !(p > T(0));
           const V nt = V(-ajj * pivot_rcp(p));
-          if constexpr (COEFF) Kh[i * KS + j] = -nt[0];
+          if constexpr (COEFF || BWD_ROW) Kh[i * KS + j] = -nt[0];
           A[j / E] = cp * nt + A[j / E];
           // trailing groups GC at a time: the GC loads are in flight together, then the 2 GC FMAs (a
           // single wave needs ~8 outstanding 16-byte reads to cover the LDS latency with FMAs)
@@ -1762,7 +1768,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
           const T p = piv[j % E];
           bad = bad || !(p > T(0));
           const V nt = V(-ajj * pivot_rcp(p));
-          if constexpr (COEFF) Kh[i * KS + j] = -nt[0];  // multiplier l_ij, kept for the back-substitution
+          if constexpr (COEFF || BWD_ROW) Kh[i * KS + j] = -nt[0];  // multiplier l_ij, kept for the back-substitution
           constexpr int JL = (STAT ? KFIX : NP - 2) - 1;    // last step of the loop
           const int g1 = (j < JL ? j + 1 : j) / E;         // compile-time after unrolling
           A[g1] = col[g1] * nt + A[g1];
@@ -1790,6 +1796,154 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 #if MGP_CHOL_PRIO && !MGP_PRIO_LATE_DROP
     __builtin_amdgcn_s_setprio(0);
 #endif
+    if constexpr (BWD_ROW) {
+      // ---- phases 5B-7B, row-per-lane form (32-slot static shapes, NH neighbourhoods per wave): the multipliers
+      // l_m,j sit in the exchange image (Kh[m * KS + j], written step by step above); see the dealt-triangle form of
+      // these phases for the algebra.  Reference: torch autograd over torch/muygps_layer.py:129-164. ----------------
+      __syncthreads();
+      const int hoff = NH == 1 ? 0 : h * NP;
+      T xa = i < KFIX ? Kh[KFIX * KS + i] : T(0);        // l_q,i = (D^-1 L^-1 c)_i
+      T xu = i < KFIX ? Kh[(KFIX + 1) * KS + i] : T(0);  // l_y,i
+      {
+        constexpr int BB = 8;
+#pragma unroll
+        for (int mb = (KFIX - 1) / BB * BB; mb >= 0; mb -= BB) {
+          T lm[BB];
+#pragma unroll
+          for (int e = 0; e < BB; ++e)
+            if (mb + e >= 1 && mb + e < KFIX) lm[e] = Kh[(mb + e) * KS + i];  // (junk for m <= i: masked below)
+#pragma unroll
+          for (int e = BB - 1; e >= 0; --e) {
+            const int m = mb + e;
+            if (m >= 1 && m < KFIX) {
+              T am = lane_value(xa, m), um = lane_value(xu, m);
+              if constexpr (NH == 2) {
+                const T am1 = lane_value(xa, m + NP), um1 = lane_value(xu, m + NP);
+                am = h == 0 ? am : am1;
+                um = h == 0 ? um : um1;
+              }
+              const T t = i < m ? lm[e] : T(0);
+              xa = fma_t(-t, am, xa);
+              xu = fma_t(-t, um, xu);
+            }
+          }
+        }
+      }
+      T* avec = colbuf;       // 64 + 64 entries: the norm array's space (dead since the distance phase)
+      T* uvec = colbuf + 64;
+      __syncthreads();
+      avec[lane] = i < KFIX ? xa : (i == KFIX ? T(-1) : T(0));
+      uvec[lane] = i < KFIX ? xu : T(0);
+      __syncthreads();
+      const int64_t nbw = nb0 + h;
+      const T gmv = (live && a.bwd_gmean) ? static_cast<const T*>(a.bwd_gmean)[nbw] : T(0);
+      const T gvv = (live && a.bwd_gvar) ? static_cast<const T*>(a.bwd_gvar)[nbw] : T(0);
+      const T gyv = (live && a.bwd_gyk) ? static_cast<const T*>(a.bwd_gyk)[nbw] : T(0);
+      const bool skip = bad || !live;
+      T liso = T(0);
+      constexpr int DGF = DSTFIX / E;
+      V s2h[DGF];
+#pragma unroll
+      for (int c4 = 0; c4 < DGF; ++c4) s2h[c4] = V(0);
+      const bool sweep = a.bwd_gls != nullptr && aniso;  // (uniform)
+      {
+        T ar[BA], ur[BA], Pc[BP], Qc[BP];
+#pragma unroll
+        for (int j = 0; j < BA; ++j) {
+          const int r = wrap(i + own_offset(j));
+          ar[j] = avec[hoff + r];
+          ur[j] = uvec[hoff + r];
+        }
+#pragma unroll
+        for (int p = 0; p < BP; ++p) {
+          const int c = wrap(i + p + 1);
+          const T ac = avec[hoff + c], uc = uvec[hoff + c];
+          Pc[p] = T(2) * gvv * ac - gmv * uc;
+          Qc[p] = gmv * ac + T(2) * gyv * uc;
+        }
+        const bool lane_on = i < M;
+        constexpr unsigned long long FIRSTM = wave_pair_first_mask(NS, BP, M), HALFM = wave_pair_half_mask(NS, BP, M);
+        kernel_dispatch(a.kernel_id, a.metric_id, [&](auto kid, auto mid) {
+          constexpr int KID = decltype(kid)::value, MID = decltype(mid)::value;
+#pragma unroll
+          for (int sidx = 0; sidx < NS; ++sidx) {
+            const int jj = sidx / BP, pp = sidx % BP;
+            T sq;
+            if constexpr (GRAM) sq = gram_sq(acc[sidx]);
+            else sq = acc_total(acc[sidx]);
+            const T dk = dcov_dacc<T, KID, MID>(sq, post_scale);
+            bool on = lane_on && ((xkeep >> sidx) & 1u) != 0 && ((FIRSTM >> sidx) & 1ull) != 0;
+            if ((HALFM >> sidx) & 1ull) on = on && wrap(i + own_offset(jj)) < wrap(i + pp + 1);
+            const T gK = ar[jj] * Pc[pp] - ur[jj] * Qc[pp];
+            const T qv = on ? gK * dk : T(0);
+            liso = fma_t(qv, sq, liso);
+            if (sweep) {
+              const T* xa_ = Xh + wrap(i + own_offset(jj)) * xs;
+              const T* xb_ = Xh + wrap(i + pp + 1) * xs;
+              const V qq = V(qv);
+#pragma unroll
+              for (int c4 = 0; c4 < DGF; ++c4) {
+                const V dz = vsub(*reinterpret_cast<const V*>(xa_ + c4 * E), *reinterpret_cast<const V*>(xb_ + c4 * E));
+                s2h[c4] = (dz * qq) * dz + s2h[c4];
+              }
+            }
+          }
+        });
+      }
+      if (!skip && i < KFIX) {
+        if (a.bwd_gnz) static_cast<T*>(a.bwd_gnz)[nbw * KFIX + i] = gvv * xa * xa - gmv * xa * xu - gyv * xu * xu;
+        if (a.bwd_gtg)
+          __hip_atomic_fetch_add(static_cast<T*>(a.bwd_gtg) + myidx, gmv * xa + T(2) * gyv * xu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (a.bwd_gls) {  // (uniform)
+        T* gls = static_cast<T*>(a.bwd_gls);
+        if (!aniso) {
+          T sum = liso;
+          for (int off = NP / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+          if (!skip && i == 0) gls[nbw] = T(-2) / ls[0] * sum;
+        } else {
+          // per-feature sums over the neighbourhood's lanes, through its (dead) exchange image, FPP features per pass:
+          // lane i writes its sums of the pass, lane f adds the NP rows of feature f
+          constexpr int FPP = (KMAT / NP) / E * E;  // features of a pass (whole 16-byte groups)
+          static_assert(FPP >= E, "exchange image too small for the length-scale reduction");
+#pragma unroll
+          for (int f0 = 0; f0 < DSTFIX; f0 += FPP) {
+            const int nf = DSTFIX - f0 < FPP ? DSTFIX - f0 : FPP;  // (compile-time after unrolling)
+            __syncthreads();
+#pragma unroll
+            for (int c4 = 0; c4 < FPP / E; ++c4)
+              if (f0 / E + c4 < DGF) *reinterpret_cast<V*>(Kh + i * FPP + c4 * E) = s2h[f0 / E + c4];
+            __syncthreads();
+#pragma unroll
+            for (int ff = 0; ff < (FPP + NP - 1) / NP; ++ff) {
+              const int f = ff * NP + i;  // feature of the pass this lane sums
+              if (ff * NP < nf) {
+                T t0 = T(0), t1 = T(0), t2 = T(0), t3 = T(0);
+                if (f < nf) {
+#pragma unroll
+                  for (int r = 0; r < NP; r += 4) {
+                    t0 += Kh[(r + 0) * FPP + f];
+                    t1 += Kh[(r + 1) * FPP + f];
+                    t2 += Kh[(r + 2) * FPP + f];
+                    t3 += Kh[(r + 3) * FPP + f];
+                  }
+                  const int fg = f0 + f;  // the feature
+                  if (!skip && fg < d) gls[nbw * (int64_t)d + fg] = T(-2) * ilbuf[fg] * ((t0 + t1) + (t2 + t3));
+                }
+              }
+            }
+          }
+        }
+      }
+      if (bad && live && i == 0 && a.info) atomicAdd(a.info, 1);
+      // the next task's rows: only now is the tile free
+      __syncthreads();
+      if (PIPE && t1 >= 0) {
+        pipe_issue(t1, fix_index(next_idx, t1, h, i), lane);
+        if (t2 >= 0) next_idx = load_index(t2, h, i);
+      }
+      continue;
+    }
     // ---- phase 4b (COEFF): x = K^-1 y by back-substitution -------------------------------
     // K = L D L^T with unit lower L; the forward sweep formed l_ij (j < i) in lane i, and the
     // response row's multipliers are w_j = (D^-1 L^-1 y)_j.  Solve L^T x = w: the multipliers are

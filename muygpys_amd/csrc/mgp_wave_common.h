@@ -443,6 +443,43 @@ __device__ __forceinline__ void cov_batch64(double (&v)[CB], double post_scale) 
   }
 }
 
+// d covariance / d (squared distance accumulator), one pair, any element type (the fp32 backward instantiations of the
+// wave kernel: hardware exp / rsq; fp64 callers use the staged dcov_batch64 below).  Same formulas.
+template <typename T, int KID, int MID>
+__device__ __forceinline__ T dcov_dacc(T acc, T post_scale) {
+  if constexpr (MID == MGP_METRIC_L2) {
+    const T ps2 = post_scale * post_scale;
+    const T x = sqrt_fast(acc) * post_scale;
+    if constexpr (KID == MGP_KERNEL_MATERN_15) {
+      return T(-1.5) * ps2 * exp_neg(x * T(1.7320508075688772935));
+    } else if constexpr (KID == MGP_KERNEL_MATERN_25) {
+      const T t = x * T(2.2360679774997896964);
+      return T(-5.0 / 6.0) * ps2 * (T(1) + t) * exp_neg(t);
+    } else if constexpr (KID == MGP_KERNEL_MATERN_INF) {
+      return T(-0.5) * ps2 * exp_neg(x * x * T(0.5));
+    } else {
+      // k'(x) / (2 sqrt(acc)): singular at acc = 0, where the forward's kink leaves no derivative either -> 0
+      const T h = acc > T(0) ? T(0.5) * post_scale / sqrt_fast(acc) : T(0);
+      if constexpr (KID == MGP_KERNEL_RBF) return T(-0.5) * exp_neg(x * T(0.5)) * h;
+      else return -exp_neg(x) * h;
+    }
+  } else {
+    const T x = acc * post_scale;
+    if constexpr (KID == MGP_KERNEL_RBF) {
+      return T(-0.5) * post_scale * exp_neg(x * T(0.5));
+    } else if constexpr (KID == MGP_KERNEL_MATERN_05) {
+      return -post_scale * exp_neg(x);
+    } else if constexpr (KID == MGP_KERNEL_MATERN_15) {
+      return T(-3) * x * post_scale * exp_neg(x * T(1.7320508075688772935));
+    } else if constexpr (KID == MGP_KERNEL_MATERN_25) {
+      const T t = x * T(2.2360679774997896964);
+      return T(-5.0 / 3.0) * x * (T(1) + t) * post_scale * exp_neg(t);
+    } else {
+      return -x * post_scale * exp_neg(x * x * T(0.5));
+    }
+  }
+}
+
 // d covariance / d (squared distance accumulator) of CB pairs, fp64, stage by stage like cov_batch64() (the backward of
 // the dealt-triangle kernels, mgp_backward_dlt.hip).  in: v[u] = acc (the squared distance of the rows as the kernel
 // holds them: scaled by the inverse length scales under Anisotropy, raw under Isotropy); out: v[u] = dk / d acc, with

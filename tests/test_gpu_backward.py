@@ -537,7 +537,8 @@ def test_dealt_triangle_backward_of_run_time_compiled_shapes(kernel, aniso, k, d
     from muygpys_amd import _lib
 
     metric = "F2" if kernel == "rbf" else "l2"
-    rc = _lib.load().mgp_jit_prepare_backward(k, d)
+    kid = {"rbf": 0, "matern05": 1, "matern15": 2, "matern25": 3, "maternInf": 4}[kernel]
+    rc = _lib.load().mgp_jit_prepare_backward(8, k, d, kid)
     if rc == -2:
         pytest.skip("no hiprtc on this machine: the row-per-lane kernels serve the shape")
     assert rc == 0
@@ -568,3 +569,56 @@ def test_dealt_triangle_backward_of_run_time_compiled_shapes(kernel, aniso, k, d
     assert_close(g_l.sum(0).cpu().numpy(), np.atleast_1d(ref["length_scale"]), 1e-5, "g_length_scale")
     assert_close(g_n.sum().cpu().numpy().reshape(()), ref["noise"], 1e-5, "g_noise")
     assert_close(g_t.cpu().numpy(), ref["targets"], 1e-5, "g_targets")
+
+
+ROW_CASES = [
+    # dtype, kernel, metric, aniso, k, d, b      (17 <= k + 2 <= 32: the row-per-lane form; BASELINE config 3's shape first)
+    ("float32", "matern15", "l2", False, 30, 40, 1001), ("float32", "matern15", "l2", True, 30, 40, 600),
+    ("float32", "matern25", "l2", True, 30, 40, 257), ("float32", "rbf", "F2", False, 30, 40, 300),
+    ("float32", "matern05", "l2", True, 30, 40, 200),    # (difference form: no Gram for the Matern-1/2 kernel)
+    ("float32", "maternInf", "l2", True, 20, 16, 333), ("float32", "matern15", "l2", False, 25, 8, 129),
+    ("float64", "matern15", "l2", True, 30, 40, 400), ("float64", "matern25", "l2", False, 16, 6, 90),
+]
+
+
+@pytest.mark.parametrize("case", ROW_CASES, ids=[f"{c[0]}-{c[1]}-{c[2]}-{'aniso' if c[3] else 'iso'}-k{c[4]}-d{c[5]}" for c in ROW_CASES])
+def test_hyper_parameter_backward_row_per_lane_form(case):
+    """Round 6, second half: the 32-slot static shapes (BASELINE config 3: k = 30, d = 40, fp32) take their
+    hyper-parameter gradients from the forward kernel too -- row per lane, the multipliers kept in the exchange image,
+    Gram form, pipelined gather (csrc/mgp_backward_dlt.hip, BWD_ROW).  Every gradient against the oracle's
+    vector-Jacobian product (reference: torch autograd over torch/muygps_layer.py:129-164)."""
+    from muygpys_amd import _lib
+
+    dtype, kernel, metric, aniso, k, d, b = case
+    kid = {"rbf": 0, "matern05": 1, "matern15": 2, "matern25": 3, "maternInf": 4}[kernel]
+    es = 4 if dtype == "float32" else 8
+    rc = _lib.load().mgp_jit_prepare_backward(es, k, d, kid)
+    if rc == -2 and not (es == 4 and k == 30 and d == 40):
+        pytest.skip("no hiprtc on this machine: the older kernels serve the shape")
+    rng = np.random.default_rng(1500 + ROW_CASES.index(case))
+    n = 3000
+    X = rng.normal(size=(n, d))
+    Y = np.sin(X @ rng.normal(size=(d, 1)) / np.sqrt(d)) + 0.1 * rng.normal(size=(n, 1))
+    bi = rng.choice(n, size=b, replace=False)
+    ni = np.stack([rng.choice(np.setdiff1d(np.arange(n), [i]), size=k, replace=False) for i in bi])
+    ls = np.sqrt(d) * rng.uniform(0.7, 1.5, size=d) if aniso else float(np.sqrt(d))
+    spec_o = orc.Spec(kernel, metric, ls, 2e-2)
+    gm, gv = rng.normal(size=(b, 1)), rng.normal(size=b)
+    ref = orc.posterior_vjp(spec_o, X, X, bi, ni, Y, gm, gv)
+    td = getattr(torch, dtype)
+    Xd, yd, lsd = to_dev(X, td), to_dev(Y, td), to_dev(np.atleast_1d(ls), td)
+    g_l = torch.zeros((b, lsd.numel()), device="cuda", dtype=td)
+    g_n = torch.zeros((b, k), device="cuda", dtype=td)
+    g_t = torch.zeros_like(yd)
+    info = torch.zeros(1, device="cuda", dtype=torch.int32)
+    bid, nid, gmd, gvd = to_dev(bi), to_dev(ni), to_dev(gm, td), to_dev(gv, td)
+    rc = _lib.fn("posterior_backward", td)(_lib.ptr(Xd), _lib.ptr(Xd), d, _lib.ptr(bid), _lib.ptr(nid), b, k, _lib.ptr(yd), 1, 0, 2e-2, None,
+                                           kid, 0 if metric == "l2" else 1, _lib.ptr(lsd), lsd.numel(), _lib.ptr(gmd), _lib.ptr(gvd), None, None,
+                                           _lib.ptr(g_t), _lib.ptr(g_l), _lib.ptr(g_n), _lib.ptr(info), _lib.stream_ptr())
+    assert rc == 0 and int(info.item()) == 0
+    name = _lib.last_kernel()
+    assert "backward" in name and f",32,{k},1,{d}," in name, name
+    rtol = 1e-5 if dtype == "float64" else 3e-3
+    assert_close(g_l.double().sum(0).cpu().numpy(), np.atleast_1d(ref["length_scale"]), rtol, "g_length_scale")
+    assert_close(g_n.double().sum().cpu().numpy().reshape(()), ref["noise"], rtol, "g_noise")
+    assert_close(g_t.double().cpu().numpy(), ref["targets"], rtol, "g_targets")

@@ -250,8 +250,10 @@ def test_knn_finish_kernel_orders_and_maps(m, k, d):
     train = torch.randn((n, d), device="cuda", generator=g)
     q = torch.randn((m, d), device="cuda", generator=g)
     cand = torch.stack([torch.randperm(n, device="cuda", generator=g)[:k] for _ in range(m)]).to(torch.int32)
-    if k > 2:
-        train[cand[:, 1].long()] = train[cand[:, 0].long()]  # an exact tie per query
+    if k > 2:  # an exact tie per query: list position 1 points at a COPY of the row at position 0
+        train = torch.cat([train, train[cand[:, 0].long()]]).contiguous()
+        cand[:, 1] = n + torch.arange(m, device="cuda", dtype=torch.int32)
+        n = n + m
     perm = torch.randperm(n, device="cuda", generator=g)
     idx = torch.empty((m, k), device="cuda", dtype=torch.int64)
     dist = torch.empty((m, k), device="cuda")
@@ -267,8 +269,11 @@ def test_knn_finish_kernel_orders_and_maps(m, k, d):
         want = cand.long() if row_map is None else perm[cand.long()]
         assert torch.equal(idx.sort(dim=1).values, want.sort(dim=1).values)
         order = dd.argsort(dim=1, stable=True)
-        clear = (dd.gather(1, order)[:, 1:] - dd.gather(1, order)[:, :-1]).abs().min(dim=1).values > 1e-4
-        assert torch.equal(idx[clear], want.gather(1, order)[clear])
+        if k > 1:
+            clear = (dd.gather(1, order)[:, 1:] - dd.gather(1, order)[:, :-1]).abs().min(dim=1).values > 1e-4
+            assert torch.equal(idx[clear], want.gather(1, order)[clear])
+        else:
+            assert torch.equal(idx, want)
         if k > 2:  # the planted tie: list positions 0 and 1 carry the same row -> position 0 first (a stable order)
             p0 = (idx == want[:, :1]).float().argmax(dim=1)
             p1 = (idx == want[:, 1:2]).float().argmax(dim=1)
