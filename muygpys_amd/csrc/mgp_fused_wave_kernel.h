@@ -1582,7 +1582,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
                     on = on && wrap(i + own_offset(jj)) < wrap(i + pp + 1);
                   const T gK = ar[jj] * Pc[pp] - ur[jj] * Qc[pp];
                   const T qv = on ? gK * dv[u] : T(0);
-                  liso = fma_t(qv, acc[sidx], liso);
+                  liso = fma_t(qv, acc[sidx], liso);  // (difference form: every kept distance is finite, 0 x finite = 0)
                   if constexpr (SWEEP_LATE) acc[sidx] = qv;
                   if constexpr (!SWEEP_LATE)
                   if (sweep) {
@@ -1876,7 +1876,8 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
             if ((HALFM >> sidx) & 1ull) on = on && wrap(i + own_offset(jj)) < wrap(i + pp + 1);
             const T gK = ar[jj] * Pc[pp] - ur[jj] * Qc[pp];
             const T qv = on ? gK * dk : T(0);
-            liso = fma_t(qv, sq, liso);
+            // (a pair with a slot that has no features carries an infinite / NaN Gram-form distance: 0 x inf)
+            liso = on ? fma_t(qv, sq, liso) : liso;
             if (sweep) {
               const T* xa_ = Xh + wrap(i + own_offset(jj)) * xs;
               const T* xb_ = Xh + wrap(i + pp + 1) * xs;

@@ -64,9 +64,13 @@ def test_headline_kernels_hold_their_register_budget():
     # kept through the covariance phase) at two waves per SIMD with at most a handful of loop-invariant spills
     c4b = [k for k in res if re.search(r"fused_wave_kernelIdLi64ELi50ELi1ELi8ELb1ELb0ELb0ELb0ELb0ELb1EEE", k)]
     assert len(c4b) == 1, sorted(res)
-    # (the count is the union over the ten covariance-function variants of the pair phase; few per executed path --
-    # bounded here, timed on the GPU by tools/gradbench.py)
-    assert res[c4b[0]]["Occupancy [waves/SIMD]"] >= 2 and res[c4b[0]]["VGPRs Spill"] <= 200, res[c4b[0]]
+    # (its register allocation is fragile and it matters: 8 spill slots = 27.0 ms per 2 M neighbourhoods, 41 = 30.8, 93 =
+    # 36.1 -- a change that pushes it over fails here, not on the GPU)
+    assert res[c4b[0]]["Occupancy [waves/SIMD]"] >= 2 and res[c4b[0]]["VGPRs Spill"] <= 16, res[c4b[0]]
+    # ... and the row-per-lane backward of the headline shape (fp32, Gram form): no spill at two waves per SIMD
+    c2b = [k for k in res if re.search(r"fused_wave_kernelIfLi32ELi30ELi1ELi40ELb1ELb0ELb0ELb1ELb0ELb1EEE", k)]
+    assert len(c2b) == 1, sorted(res)
+    assert res[c2b[0]]["Occupancy [waves/SIMD]"] >= 2 and res[c2b[0]]["VGPRs Spill"] == 0, res[c2b[0]]
     # BASELINE config 5 (fused_rhs_mf_kernel<16>: Gram matrix on the matrix cores' layout): three waves per SIMD and --
     # round 6 -- no spilled register (13 until the pair distances stopped being kept between guard and covariances:
     # 0.68 GB of scratch writes per launch)
