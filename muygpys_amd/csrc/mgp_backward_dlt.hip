@@ -127,11 +127,18 @@ static int launch_bwd_dlt_jit(const BackwardArgs& b, hipStream_t stream) {
 }
 
 // ---- row-per-lane form: 32-slot static shapes of either element type (BASELINE config 3's k = 30, d = 40 built in) ----
+// slots of the row-per-lane instantiation that serves a shape (0: none): 32 for up to 32 rows (smaller neighbourhoods
+// ride in the 32-slot kernel: lanes idle, nothing else changes), 64 for fp32 beyond; rows of whole 16-byte groups, one
+// feature stage
 template <typename T>
-static bool row_shape(int k, int d) {  // 17 .. 32 slots, rows of whole 16-byte groups, one feature stage
+static int row_slots(int k, int d) {
   constexpr int E = 16 / (int)sizeof(T), CH = 2 * E;
-  return k + 2 >= 17 && k + 2 <= 32 && d >= E && d % E == 0 && (d + CH - 1) / CH * CH <= 64;
+  if (k < 3 || d < E || d % E != 0 || (d + CH - 1) / CH * CH > 64) return 0;
+  if (k + 2 <= 32) return 32;
+  return (sizeof(T) == 4 && k + 2 <= 64) ? 64 : 0;
 }
+template <typename T>
+static bool row_shape(int k, int d) { return row_slots<T>(k, d) != 0; }
 template <typename T>
 static bool row_gram(const FusedArgs& f) {  // (the forward kernels' rule: fp32, not the Matern-1/2 kernel)
   return sizeof(T) == 4 && MGP_GRAM && f.kernel_id != MGP_KERNEL_MATERN_05;
@@ -150,7 +157,8 @@ static void row_geometry(const FusedArgs& a, const WaveDims& WD, int NP, WaveGeo
   // (behind tile and exchange images: the column buffers / norm array / row addresses, and -- BWD -- the two solved
   // vectors of both neighbourhoods: 128 entries)
   const size_t tail = wave_colbuf_bytes(sizeof(T), NP, false) > 128 * sizeof(T) ? wave_colbuf_bytes(sizeof(T), NP, false) : 128 * sizeof(T);
-  *lds = ((tile_feat + (size_t)WD.NH * WD.KMAT) * sizeof(T) + tail + 15) & ~(size_t)15;
+  const size_t kmat = (size_t)NP * (NP + WD.E);  // (whole rows: the packed triangle of the 64-slot forward does not apply)
+  *lds = ((tile_feat + (size_t)WD.NH * kmat) * sizeof(T) + tail + 15) & ~(size_t)15;
 }
 static int64_t row_grid(int cus, int per_cu, int64_t ntasks) {
   int64_t grid = (int64_t)cus * per_cu / 8 * 8;
@@ -184,10 +192,10 @@ static int launch_bwd_row_impl(const BackwardArgs& b, hipStream_t stream) {
 }
 template <typename T>
 static int launch_bwd_row_jit(const BackwardArgs& b, hipStream_t stream) {
-  constexpr int NP = 32;
   FusedArgs a;
   bwd_args(b, &a);
-  if (!row_shape<T>(a.k, a.d) || jit_mode() == 0) return MGP_EUNSUPPORTED;
+  const int NP = row_slots<T>(a.k, a.d);
+  if (NP == 0 || jit_mode() == 0) return MGP_EUNSUPPORTED;
   const bool gram = row_gram<T>(a);
   const WaveDims WD = wave_dims(sizeof(T), NP, a.k, 1, a.d, false, gram);
   if (WD.DLT || !WD.STAT) return MGP_EUNSUPPORTED;
@@ -220,7 +228,8 @@ int prepare_backward_fwd(int elem_size, int k, int d, int kernel_id) {
   if (!ok) return MGP_EUNSUPPORTED;
   const bool gram = elem_size == 4 && MGP_GRAM && kernel_id != MGP_KERNEL_MATERN_05;
   if (elem_size == 4 && k == 30 && d == 40 && gram) return MGP_OK;  // built in
-  return jit_wave_prepare(elem_size, 32, k, 1, d, false, gram, false, true);
+  const int np = elem_size == 4 ? row_slots<float>(k, d) : row_slots<double>(k, d);
+  return jit_wave_prepare(elem_size, np, k, 1, d, false, gram, false, true);
 }
 
 // hyper-parameter gradients of one response; plain tables, 16-byte aligned rows

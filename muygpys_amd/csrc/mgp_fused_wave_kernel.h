@@ -396,7 +396,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   // 17 KB instead of 34 KB in fp64, so LDS no longer holds these shapes at one wave per SIMD.  A lane
   // reads NP entries from the start of its row; what lies beyond its diagonal belongs to later rows
   // (upper-triangle garbage the elimination never uses).
-  constexpr bool TRI = NP == 64 && !COEFF;
+  constexpr bool TRI = NP == 64 && !COEFF && !(BWD && !WD.DLT);  // (the row-per-lane backward keeps whole rows of multipliers)
   auto rowoff = [](int r) {
     if constexpr (TRI) {
       const int a = r / E;
@@ -406,7 +406,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     }
   };
   constexpr int NG = WD.NG;      // 16-byte groups of a lane's row
-  constexpr int KMAT = WD.KMAT;  // elements per exchange matrix
+  constexpr int KMAT = (BWD && !WD.DLT) ? NP * KS : WD.KMAT;  // elements per exchange matrix
   // Dealt lower triangle (phase 4D): entry (i, c), i >= c, lives in pair cs2(c) + i/2 - c/2, element i & 1; lane l holds
   // pairs 64 s + l, s = 0 .. NSL-1.  The exchange matrix is stored in exactly that order, so the read-back is NSL
   // lane-linear ds_read_b128.
@@ -416,7 +416,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   // as the COEFF variant keeps them, two neighbourhoods per wave)
   constexpr bool BWD_ROW = BWD && !DLT;
   static_assert(!BWD || (RFIX == 1 && PIPED && !PACKED && !GEN64 && !COEFF && WD.STAT), "BWD: static shapes on plain tables, one response");
-  static_assert(!BWD || DLT || NP == 32, "BWD: the dealt-triangle shapes or the 32-slot ones");
+  static_assert(!BWD || DLT || NP == 32 || (NP == 64 && sizeof(T) == 4), "BWD: the dealt-triangle shapes, the 32-slot ones, fp32 with 64 slots");
   static_assert(!(BWD && DLT && GRAM), "BWD on the dealt triangle: difference form");
   constexpr int NR2 = WD.NR2, NPAIR = WD.NPAIR, NSL = WD.NSL;
   auto cs2 = [](int c) { return dlt_col_start(c, NR2); };

@@ -578,6 +578,9 @@ ROW_CASES = [
     ("float32", "matern05", "l2", True, 30, 40, 200),    # (difference form: no Gram for the Matern-1/2 kernel)
     ("float32", "maternInf", "l2", True, 20, 16, 333), ("float32", "matern15", "l2", False, 25, 8, 129),
     ("float64", "matern15", "l2", True, 30, 40, 400), ("float64", "matern25", "l2", False, 16, 6, 90),
+    # small neighbourhoods ride in the 32-slot kernel; fp32 with 33 .. 64 slots: the 64-slot one, whole rows of multipliers
+    ("float32", "matern15", "l2", True, 5, 4, 500), ("float64", "rbf", "F2", False, 3, 2, 77), ("float64", "matern15", "l2", True, 10, 8, 301),
+    ("float32", "matern15", "l2", True, 50, 8, 300), ("float32", "matern25", "l2", False, 62, 40, 70), ("float32", "matern05", "l2", True, 40, 16, 129),
 ]
 
 
@@ -617,7 +620,7 @@ def test_hyper_parameter_backward_row_per_lane_form(case):
                                            _lib.ptr(g_t), _lib.ptr(g_l), _lib.ptr(g_n), _lib.ptr(info), _lib.stream_ptr())
     assert rc == 0 and int(info.item()) == 0
     name = _lib.last_kernel()
-    assert "backward" in name and f",32,{k},1,{d}," in name, name
+    assert "backward" in name and f",{32 if k + 2 <= 32 else 64},{k},1,{d}," in name, name
     rtol = 1e-5 if dtype == "float64" else 3e-3
     assert_close(g_l.double().sum(0).cpu().numpy(), np.atleast_1d(ref["length_scale"]), rtol, "g_length_scale")
     assert_close(g_n.double().sum().cpu().numpy().reshape(()), ref["noise"], rtol, "g_noise")
