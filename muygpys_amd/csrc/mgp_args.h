@@ -46,6 +46,8 @@ struct FusedArgs {
   void* bwd_gls = nullptr;
   void* bwd_gnz = nullptr;
   void* bwd_gtg = nullptr;
+  void* bwd_gnn = nullptr;  // (n_nn, d) += feature cotangents of the neighbour rows (row-per-lane form only)
+  void* bwd_gq = nullptr;   // (n_q, d)  += ... of the query rows
 };
 
 #ifndef __HIPCC_RTC__  // the rest is host side: other argument blocks and the launcher declarations

@@ -1,7 +1,8 @@
 // Backward (vector-Jacobian product) of one response's posterior mean / variance / y^T K^-1 y with respect to the
-// HYPER-PARAMETERS -- length scale(s), the noise diagonal, the neighbours' responses; no feature cotangents -- for the
-// fp64 static shapes of the dealt-triangle forward kernels (BASELINE config 4: anisotropic Matern, k = 50, d = 8: the
-// gradient of the LOOCV objective that L-BFGS-B and the torch layer ask for; round 6).
+// HYPER-PARAMETERS -- length scale(s), the noise diagonal, the neighbours' responses -- for the fp64 static shapes of the
+// dealt-triangle forward kernels (BASELINE config 4: anisotropic Matern, k = 50, d = 8: the gradient of the LOOCV
+// objective that L-BFGS-B and the torch layer ask for; round 6), and, further down, for the row-per-lane static shapes
+// of either element type (config 3: k = 30, d = 40) -- those with the FEATURE cotangents as well.
 //
 // Reference: torch autograd over src/MuyGPyS/torch/muygps_layer.py:129-164 (the reference's way to these gradients);
 // the numpy chassis has only finite differences (src/MuyGPyS/_src/optimize/chassis/numpy.py:57-81).  The maths is
@@ -87,6 +88,8 @@ static void bwd_args(const BackwardArgs& b, FusedArgs* a) {
   a->bwd_gls = b.grad_ls;
   a->bwd_gnz = b.grad_noise;
   a->bwd_gtg = b.grad_targets;
+  a->bwd_gnn = b.grad_feat_nn;
+  a->bwd_gq = b.grad_feat_q;
 }
 static int launch_bwd_dlt_jit(const BackwardArgs& b, hipStream_t stream) {
   using T = double;
@@ -232,17 +235,19 @@ int prepare_backward_fwd(int elem_size, int k, int d, int kernel_id) {
   return jit_wave_prepare(elem_size, np, k, 1, d, false, gram, false, true);
 }
 
-// hyper-parameter gradients of one response; plain tables, 16-byte aligned rows
+// gradients of one response; plain tables, 16-byte aligned rows (feature cotangents: the row-per-lane shapes only)
 template <typename T>
 int launch_backward_fwd(const BackwardArgs& b, hipStream_t stream) {
   const FusedArgs& f = b.f;
-  if (f.R != 1 || b.grad_feat_q || b.grad_feat_nn || f.targets_batch || f.kernel_id == MGP_KERNEL_MATERN_GEN) return MGP_EUNSUPPORTED;
+  if (f.R != 1 || f.targets_batch || f.kernel_id == MGP_KERNEL_MATERN_GEN) return MGP_EUNSUPPORTED;
+  const bool feat = b.grad_feat_q != nullptr || b.grad_feat_nn != nullptr;  // feature cotangents: the row-per-lane form has them
   if (f.ls_count != 1 && f.ls_count != f.d) return MGP_EUNSUPPORTED;
   const uintptr_t align = (uintptr_t)f.feat_q | (uintptr_t)f.feat_nn;
   if (align % 16 != 0 || f.b >= ((int64_t)1 << 31)) return MGP_EUNSUPPORTED;
   static const bool off = getenv("MGP_BACKWARD_DLT") != nullptr && atoi(getenv("MGP_BACKWARD_DLT")) == 0;  // A/B switch (timing only)
   if (off) return MGP_EUNSUPPORTED;
   if constexpr (sizeof(T) == 8) {
+    if (feat && !row_shape<T>(f.k, f.d)) return MGP_EUNSUPPORTED;
     if (f.k == 50 && f.d == 8) return launch_bwd_dlt_impl<50, 8>(b, stream);
     if (dlt_shape(f.k, f.d)) return launch_bwd_dlt_jit(b, stream);
   } else {

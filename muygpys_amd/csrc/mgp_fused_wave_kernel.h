@@ -138,6 +138,9 @@
 #ifndef MGP_BWD_EXP
 #define MGP_BWD_EXP 0  // (experiments: bits switch parts of the BWD instantiation off -- 1 length-scale partials, 2 pair cotangents, 4 back-substitution, 8 factor write-back)
 #endif
+#ifndef MGP_FEAT_EXP
+#define MGP_FEAT_EXP 0  // (experiments on the feature-cotangent phase: 1 no sweep, 2 no pair stores, 4 no output, 8 plain stores for the atomic adds)
+#endif
 
 namespace mgp {
 
@@ -1831,9 +1834,18 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       }
       T* avec = colbuf;       // 64 + 64 entries: the norm array's space (dead since the distance phase)
       T* uvec = colbuf + 64;
+      // feature cotangents asked for (uniform): the pair cotangents q_rc are also laid out as a symmetric NP x NP image
+      // per neighbourhood where the multipliers were (dead from here on) -- phase 8B below
+      const bool feat = a.bwd_gnn != nullptr || a.bwd_gq != nullptr;
       __syncthreads();
       avec[lane] = i < KFIX ? xa : (i == KFIX ? T(-1) : T(0));
       uvec[lane] = i < KFIX ? xu : T(0);
+      if (feat) {
+        T* Q0 = tile + kmat_base;  // (both neighbourhoods' images are contiguous)
+#pragma unroll
+        for (int e = 0; e < NH * KMAT; e += 64 * E)
+          if (e + lane * E < NH * KMAT) *reinterpret_cast<V*>(Q0 + e + lane * E) = V(0);
+      }
       __syncthreads();
       const int64_t nbw = nb0 + h;
       const T gmv = (live && a.bwd_gmean) ? static_cast<const T*>(a.bwd_gmean)[nbw] : T(0);
@@ -1865,6 +1877,8 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         constexpr unsigned long long FIRSTM = wave_pair_first_mask(NS, BP, M), HALFM = wave_pair_half_mask(NS, BP, M);
         kernel_dispatch(a.kernel_id, a.metric_id, [&](auto kid, auto mid) {
           constexpr int KID = decltype(kid)::value, MID = decltype(mid)::value;
+          auto pairs = [&](auto featc) {
+          constexpr bool FEAT = decltype(featc)::value != 0;
 #pragma unroll
           for (int sidx = 0; sidx < NS; ++sidx) {
             const int jj = sidx / BP, pp = sidx % BP;
@@ -1878,6 +1892,14 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
             const T qv = on ? gK * dk : T(0);
             // (a pair with a slot that has no features carries an infinite / NaN Gram-form distance: 0 x inf)
             liso = on ? fma_t(qv, sq, liso) : liso;
+            if constexpr (FEAT && !(MGP_FEAT_EXP & 2)) {
+              // both mirror entries of the image; a pair that is not counted here (its twin is, or it has no
+              // features) goes to a padding element -- branch-free, as in the dealt form's write-back
+              const int r_ = wrap(i + own_offset(jj)), c_ = wrap(i + pp + 1);
+              constexpr int QDUMP = (NP - 1) * KS + NP;
+              Kh[on ? r_ * KS + c_ : QDUMP] = qv;
+              Kh[on ? c_ * KS + r_ : QDUMP] = qv;
+            }
             if (sweep) {
               const T* xa_ = Xh + wrap(i + own_offset(jj)) * xs;
               const T* xb_ = Xh + wrap(i + pp + 1) * xs;
@@ -1889,12 +1911,24 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
               }
             }
           }
+          };
+          if (feat) pairs(ic<1>{});
+          else pairs(ic<0>{});
         });
       }
       if (!skip && i < KFIX) {
         if (a.bwd_gnz) static_cast<T*>(a.bwd_gnz)[nbw * KFIX + i] = gvv * xa * xa - gmv * xa * xu - gyv * xu * xu;
         if (a.bwd_gtg)
           __hip_atomic_fetch_add(static_cast<T*>(a.bwd_gtg) + myidx, gmv * xa + T(2) * gyv * xu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // (feature cotangents, phase 8B below: row i of the pair-cotangent image into registers now -- the length-scale
+      // reduction that follows reuses the image, and its partial sums are out of the registers before the sweep starts)
+      constexpr int QG = (KFIX + 1 + E - 1) / E;  // 16-byte groups of the image row that hold q_i,0 .. q_i,KFIX
+      V qrow[QG];
+      if (feat) {
+        __syncthreads();
+#pragma unroll
+        for (int c4 = 0; c4 < QG; ++c4) qrow[c4] = *reinterpret_cast<const V*>(Kh + i * KS + c4 * E);
       }
       if (a.bwd_gls) {  // (uniform)
         T* gls = static_cast<T*>(a.bwd_gls);
@@ -1932,6 +1966,90 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
                   if (!skip && fg < d) gls[nbw * (int64_t)d + fg] = T(-2) * ilbuf[fg] * ((t0 + t1) + (t2 + t3));
                 }
               }
+            }
+          }
+        }
+      }
+      if (feat) {
+        // ---- phase 8B: feature cotangents  x-bar_i,f = 2 / l_f  sum_j q_ij (z_i,f - z_j,f)  on the (scaled, GRAM: centred)
+        // rows the tile still holds.  Lane i takes row i of the image into registers and walks the rows j of the tile
+        // (every lane of a neighbourhood reads the same 16 bytes: broadcast reads); the sums then go back into row i of
+        // the tile -- dead by then -- from where they leave as atomic adds with the lanes along the FEATURES of a row
+        // (one instruction covers 32 / 64 consecutive elements of the gradient table instead of as many rows).
+        // Reference: autograd through torch/muygps_layer.py:129-164 (crosswise / pairwise differences of the embedded
+        // features); the same sums as mgp_backward.hip's last stage.
+        __syncthreads();  // (the reduction's passes through the image are over)
+        // GRAM: the rows are centred on the query (|z| is of the size of the differences), so the sum is taken as
+        //   z_i sum_j q_ij - sum_j q_ij z_j  -- one packed FMA per two features and row instead of a subtraction and an FMA;
+        // difference form otherwise (raw rows: the products would cancel)
+        const T* xi_ = Xh + i * xs;
+        V gxv[DGF];
+#pragma unroll
+        for (int c4 = 0; c4 < DGF; ++c4) gxv[c4] = V(0);
+        if constexpr (GRAM) {
+          T qs = T(0);
+#pragma unroll
+          for (int j = 0; j <= ((MGP_FEAT_EXP & 1) ? -1 : KFIX); ++j) {
+            const T qj = qrow[j / E][j % E];
+            qs += qj;
+            const V qq = V(-qj);
+            const T* xj_ = Xh + j * xs;
+#pragma unroll
+            for (int c4 = 0; c4 < DGF; ++c4) gxv[c4] = *reinterpret_cast<const V*>(xj_ + c4 * E) * qq + gxv[c4];
+            if (j % 2 == 1) __builtin_amdgcn_sched_barrier(0);  // (two rows in flight; all of them hoisted is what spills)
+          }
+          const V qsv = V(qs);
+#pragma unroll
+          for (int c4 = 0; c4 < DGF; ++c4) gxv[c4] = *reinterpret_cast<const V*>(xi_ + c4 * E) * qsv + gxv[c4];
+        } else {
+          constexpr int FCH = DGF <= 10 ? DGF : 10;  // groups of the own row in registers at a time
+#pragma unroll
+          for (int c0 = 0; c0 < DGF; c0 += FCH) {
+            V xi[FCH];
+#pragma unroll
+            for (int u = 0; u < FCH; ++u)
+              if (c0 + u < DGF) xi[u] = *reinterpret_cast<const V*>(xi_ + (c0 + u) * E);
+#pragma unroll
+            for (int j = 0; j <= ((MGP_FEAT_EXP & 1) ? -1 : KFIX); ++j) {
+              const V qq = V(qrow[j / E][j % E]);
+              const T* xj_ = Xh + j * xs;
+#pragma unroll
+              for (int u = 0; u < FCH; ++u)
+                if (c0 + u < DGF) gxv[c0 + u] = (xi[u] - *reinterpret_cast<const V*>(xj_ + (c0 + u) * E)) * qq + gxv[c0 + u];
+              if (j % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+        // (the sums are pinned HERE: left to itself the compiler sinks each group's chain of FMAs to its use -- into
+        // the branches behind the barrier, which the loads cannot cross -- and keeps all 310 loaded groups alive in
+        // between: 1 150 spilled registers)
+#pragma unroll
+        for (int c4 = 0; c4 < DGF; ++c4) {
+          const V ilv = *reinterpret_cast<const V*>(ilbuf + c4 * E);  // (Isotropy: whatever the row holds; not used)
+          gxv[c4] = gxv[c4] * (aniso ? ilv * V(T(2)) : V(T(2)));
+          asm volatile("" : "+v"(gxv[c4]));
+        }
+        __syncthreads();  // every lane is done with the rows
+        {
+          T* gdst = i <= KFIX ? Xh + i * xs : Kh;  // (lanes without a row: into the dead image -- no branch)
+#pragma unroll
+          for (int c4 = 0; c4 < DGF; ++c4) *reinterpret_cast<V*>(gdst + c4 * E) = gxv[c4];
+        }
+        int64_t* roff = reinterpret_cast<int64_t*>(colbuf);  // element offset of every slot's row (the two vectors are dead)
+        roff[lane] = myidx * (int64_t)d;
+        __syncthreads();
+        T* gnn_ = static_cast<T*>(a.bwd_gnn);
+        T* gq_ = static_cast<T*>(a.bwd_gq);
+        constexpr int NOUT = (KFIX + 1) * DFIX;  // elements of a neighbourhood's cotangent block, row-major
+#pragma unroll 4
+        for (int t0 = 0; t0 < NOUT; t0 += NP) {
+          const int t = t0 + i;
+          const int r = t / DFIX, f = t - r * DFIX;
+          if (t < NOUT && !skip && !(MGP_FEAT_EXP & 4)) {
+            T* base = r < KFIX ? gnn_ : gq_;
+            if (base) {
+              if constexpr ((MGP_FEAT_EXP & 8) != 0) base[roff[h * NP + r] + f] = Xh[r * xs + f];  // (timing: plain stores)
+              else unsafeAtomicAdd(base + roff[h * NP + r] + f, Xh[r * xs + f]);
             }
           }
         }

@@ -625,3 +625,70 @@ def test_hyper_parameter_backward_row_per_lane_form(case):
     assert_close(g_l.double().sum(0).cpu().numpy(), np.atleast_1d(ref["length_scale"]), rtol, "g_length_scale")
     assert_close(g_n.double().sum().cpu().numpy().reshape(()), ref["noise"], rtol, "g_noise")
     assert_close(g_t.double().cpu().numpy(), ref["targets"], rtol, "g_targets")
+
+
+@pytest.mark.parametrize("case", ROW_CASES, ids=[f"{c[0]}-{c[1]}-{c[2]}-{'aniso' if c[3] else 'iso'}-k{c[4]}-d{c[5]}" for c in ROW_CASES])
+def test_feature_cotangents_row_per_lane_form(case):
+    """Round 6, last part: the same instantiations also emit the FEATURE cotangents (the gradient an embedding network in
+    front of the model asks for: reference torch/muygps_layer.py:129-164 under autograd) -- the pair cotangents laid out
+    as a symmetric image, one sweep over the tile's rows, atomic adds along the features of a row.  Separate query and
+    neighbour tables (two gradient buffers) and one shared table (one buffer, both kinds of row accumulate in it), with
+    every other gradient in the same launch, against the oracle's vector-Jacobian product."""
+    from muygpys_amd import _lib
+
+    dtype, kernel, metric, aniso, k, d, b = case
+    kid = {"rbf": 0, "matern05": 1, "matern15": 2, "matern25": 3, "maternInf": 4}[kernel]
+    es = 4 if dtype == "float32" else 8
+    rc = _lib.load().mgp_jit_prepare_backward(es, k, d, kid)
+    if rc == -2 and not (es == 4 and k == 30 and d == 40):
+        pytest.skip("no hiprtc on this machine: the older kernels serve the shape")
+    rng = np.random.default_rng(2500 + ROW_CASES.index(case))
+    n, nq = 3000, b + 17
+    X = rng.normal(size=(n, d))
+    Xq = rng.normal(size=(nq, d))
+    Y = np.sin(X @ rng.normal(size=(d, 1)) / np.sqrt(d)) + 0.1 * rng.normal(size=(n, 1))
+    ls = np.sqrt(d) * rng.uniform(0.7, 1.5, size=d) if aniso else float(np.sqrt(d))
+    spec_o = orc.Spec(kernel, metric, ls, 2e-2)
+    gm, gv = rng.normal(size=(b, 1)), rng.normal(size=b)
+    td = getattr(torch, dtype)
+    rtol = 1e-5 if dtype == "float64" else 3e-3
+    for shared in (False, True):
+        if shared:
+            bi = rng.choice(n, size=b, replace=False)
+            ni = np.stack([rng.choice(np.setdiff1d(np.arange(n), [i]), size=k, replace=False) for i in bi])
+            xq_np = X
+        else:
+            bi = rng.choice(nq, size=b, replace=False)
+            ni = np.stack([rng.choice(n, size=k, replace=False) for _ in bi])
+            xq_np = Xq
+        ref = orc.posterior_vjp(spec_o, xq_np, X, bi, ni, Y, gm, gv)
+        Xd, Xqd, yd, lsd = to_dev(X, td), to_dev(xq_np, td), to_dev(Y, td), to_dev(np.atleast_1d(ls), td)
+        g_l = torch.zeros((b, lsd.numel()), device="cuda", dtype=td)
+        g_n = torch.zeros((b, k), device="cuda", dtype=td)
+        g_t = torch.zeros_like(yd)
+        g_x = torch.zeros_like(Xd)
+        g_q = g_x if shared else torch.zeros_like(Xqd)
+        info = torch.zeros(1, device="cuda", dtype=torch.int32)
+        bid, nid, gmd, gvd = to_dev(bi), to_dev(ni), to_dev(gm, td), to_dev(gv, td)
+        rc = _lib.fn("posterior_backward", td)(_lib.ptr(Xd if shared else Xqd), _lib.ptr(Xd), d, _lib.ptr(bid), _lib.ptr(nid), b, k,
+                                               _lib.ptr(yd), 1, 0, 2e-2, None, kid, 0 if metric == "l2" else 1, _lib.ptr(lsd), lsd.numel(),
+                                               _lib.ptr(gmd), _lib.ptr(gvd), _lib.ptr(g_q), _lib.ptr(g_x), _lib.ptr(g_t), _lib.ptr(g_l),
+                                               _lib.ptr(g_n), _lib.ptr(info), _lib.stream_ptr())
+        assert rc == 0 and int(info.item()) == 0
+        name = _lib.last_kernel()
+        assert "backward" in name and f",{32 if k + 2 <= 32 else 64},{k},1,{d}," in name, name
+        if shared:
+            assert_close(g_x.double().cpu().numpy(), ref["train_features"] + ref["test_features"], rtol, "g_features (one table)")
+        else:
+            assert_close(g_x.double().cpu().numpy(), ref["train_features"], rtol, "g_train_features")
+            assert_close(g_q.double().cpu().numpy(), ref["test_features"], rtol, "g_test_features")
+        assert_close(g_l.double().sum(0).cpu().numpy(), np.atleast_1d(ref["length_scale"]), rtol, "g_length_scale")
+        assert_close(g_n.double().sum().cpu().numpy().reshape(()), ref["noise"], rtol, "g_noise")
+        assert_close(g_t.double().cpu().numpy(), ref["targets"], rtol, "g_targets")
+    # only the neighbour rows' cotangents asked for: the query rows' stay out (and nothing else is written)
+    g_x2 = torch.zeros_like(Xd)
+    rc = _lib.fn("posterior_backward", td)(_lib.ptr(Xd), _lib.ptr(Xd), d, _lib.ptr(bid), _lib.ptr(nid), b, k, _lib.ptr(yd), 1, 0, 2e-2, None,
+                                           kid, 0 if metric == "l2" else 1, _lib.ptr(lsd), lsd.numel(), _lib.ptr(gmd), _lib.ptr(gvd), None,
+                                           _lib.ptr(g_x2), None, None, None, _lib.ptr(info), _lib.stream_ptr())
+    assert rc == 0 and "backward" in _lib.last_kernel()
+    assert_close(g_x2.double().cpu().numpy(), ref["train_features"], rtol, "g_train_features alone")
