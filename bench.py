@@ -548,6 +548,37 @@ def secondary_line(name: str, cfg_id: int, route: str, args, dev, steps: int = 5
         def step():  # noqa: F811
             grad["value"], grad["g_ls"], grad["g_noise"] = loocv_value_and_grad(gspec, w["X"], w["y"], w["bi"], w["ni"], loss="lool")
             return {"lool": grad["value"], "sigma_sq": 1.0}
+    bwd = None
+    if cfg.get("bwd"):
+        # the full backward of one prediction batch (what the torch layer's .backward() launches: reference
+        # torch/muygps_layer.py:129-164 under autograd): cotangents of the features (scatter-add into the table's
+        # gradient), the length scale, the noise diagonal and the responses, from random upstream cotangents
+        from muygpys_amd.fused import _length_scale_tensor
+
+        g_ = torch.Generator(device=dev)
+        g_.manual_seed(11)
+        P = _lib.ptr
+        tg = w["y"].reshape(w["n"], -1).contiguous()
+        lst = _length_scale_tensor(w["ls"], w["d"], w["X"])
+        bwd = dict(gm=torch.randn((w["b"], 1), device=dev, dtype=w["td"], generator=g_),
+                   gv=torch.randn((w["b"],), device=dev, dtype=w["td"], generator=g_),
+                   gx=torch.zeros_like(w["X"]), gy=torch.zeros_like(tg), lst=lst, tg=tg,
+                   gl=torch.empty((w["b"], lst.numel()), device=dev, dtype=w["td"]),
+                   gn=torch.empty((w["b"], w["k"]), device=dev, dtype=w["td"]))
+        kid = {"rbf": 0, "matern05": 1, "matern15": 2, "matern25": 3, "maternInf": 4}[cfg["kernel"]]
+        mid = 0 if cfg["metric"] == "l2" else 1
+
+        def run_backward(X, tgt, bi, ni, lst_, gm, gv, gx, gy, gl, gn, info):
+            td_ = X.dtype
+            rc = _lib.fn("posterior_backward", td_)(P(X), P(X), w["d"], P(bi), P(ni), bi.shape[0], w["k"], P(tgt), 1, 0,
+                                                    float(cfg["noise"]), None, kid, mid, P(lst_), lst_.numel(), P(gm), P(gv),
+                                                    P(gx), P(gx), P(gy), P(gl), P(gn), P(info), _lib.stream_ptr())
+            _lib.check(rc, "mgp_posterior_backward")
+
+        def step():  # noqa: F811
+            run_backward(w["X"], bwd["tg"], w["bi"], w["ni"], bwd["lst"], bwd["gm"], bwd["gv"], bwd["gx"], bwd["gy"], bwd["gl"],
+                         bwd["gn"], w["info"])
+            return None
     acquire = None
     if cfg.get("acquire"):
         # one trial of the Bayes loop = one evaluation + one acquisition step (surrogate fit on the trials so far,
@@ -597,7 +628,43 @@ def secondary_line(name: str, cfg_id: int, route: str, args, dev, steps: int = 5
         print(f"[debug] {name}: est {est * 1e3:.3f} ms, steps {steps}, plans {[(p.b, p.host_result) for p in D_._PLANS.values()]}, "
               f"mean {np.mean(kern_ms):.3f} kern_ms {[round(v, 3) for v in kern_ms][:12]}", file=sys.stderr)
     roof = roofline_of(cfg, w, avg_ms, _lib.last_kernel(), cfg["objective"])  # the instantiation actually launched
-    if grad is not None:
+    if bwd is not None:
+        # bytes of the backward: the forward's, the gradient rows of the k + 1 gathered rows read and written back, the
+        # noise and length-scale partials
+        es = 4 if cfg["dtype"] == "f32" else 8
+        Bb = (algorithmic_bytes(w["k"], w["d"], w["R"], es) + 2 * (w["k"] + 1) * w["d"] * es + w["k"] * es
+              + bwd["lst"].numel() * es)
+        roof["achieved"] = Bb * w["b"] / (avg_ms * 1e-3) / 1e9
+        roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+        roof["traffic"], roof["traffic_source"] = None, None
+        # the same cotangents of the first 2 000 neighbourhoods in fp64 (another instantiation, or the LDS workgroup
+        # kernel): feature-gradient table and the summed length-scale / noise partials
+        m = min(2000, w["b"])
+        f64 = torch.float64
+        X64, tg64 = w["X"].to(f64), bwd["tg"].to(f64)
+        bi_s, ni_s = w["bi"][:m].contiguous(), w["ni"][:m].contiguous()
+
+        def subset(td_, X, tgt):
+            gx, gy = torch.zeros_like(X), torch.zeros_like(tgt)
+            gl = torch.zeros((m, bwd["lst"].numel()), device=dev, dtype=td_)
+            gn = torch.zeros((m, w["k"]), device=dev, dtype=td_)
+            info = torch.zeros(1, dtype=torch.int32, device=dev)
+            run_backward(X, tgt, bi_s, ni_s, bwd["lst"].to(td_), bwd["gm"][:m].to(td_).contiguous(),
+                         bwd["gv"][:m].to(td_).contiguous(), gx, gy, gl, gn, info)
+            torch.cuda.synchronize()
+            return gx.double(), gy.double(), gl.double().sum(0), gn.double().sum()
+
+        got, ref = subset(w["td"], w["X"], bwd["tg"]), subset(f64, X64, tg64)
+        step()  # (`kernel` below: the timed instantiation again)
+
+        def rel(a_, b_):
+            return float((a_ - b_).abs().max() / (b_.abs().max() + 1e-300))
+
+        err = max(rel(a_, b_) for a_, b_ in zip(got, ref))
+        tol = 2e-2 if cfg["dtype"] == "f32" else 1e-8
+        check = {"rows": int(m), "max_rel_err": err, "tol": tol, "ok": bool(err <= tol),
+                 "against": "the same cotangents of the first neighbourhoods computed in fp64 (max-norm relative)"}
+    elif grad is not None:
         # the gradient against central differences of the objective itself along the first length scale
         from muygpys_amd import distributed as D_
         from muygpys_amd.fused import KernelSpec as KS_
@@ -625,6 +692,11 @@ def secondary_line(name: str, cfg_id: int, route: str, args, dev, steps: int = 5
         "valu": {"frac": roof["valu"]["frac"], "achieved": roof["valu"]["achieved"], "unit": "TFLOP/s"},
         "kernel": roof["kernel"], "check": check,
     }
+    if bwd is not None:
+        out["kernel"] = _lib.last_kernel()
+        out["note"] = ("the full backward of one prediction batch: feature (scatter-add), length-scale, noise and "
+                       "response cotangents in one launch; roofline bytes = the forward's + the gathered rows' gradient "
+                       "read and written back")
     if grad is not None:
         out["note"] = ("one LOOCV objective evaluation AND its analytic gradient with respect to the length scales "
                        "(fused.loocv_value_and_grad); `kernel` names the backward launch")
@@ -843,7 +915,7 @@ def main():
             # and its empty_cache(), it read 0.219 ms per step in some runs and 0.26 in others -- tools/c3bench.py in a
             # fresh process is stable at 0.222-0.227 --, i.e. it measured where the allocator had put its table)
             plan = [("dropin", 2, "dropin", {}), ("dropin_plain", 2, "dropin_plain", {}), ("c3", 3, "fused", {}),
-                    ("c3_shard8", 3, "fused", {"batch": 125_000}),
+                    ("c3_shard8", 3, "fused", {"batch": 125_000}), ("c2_bwd", 2, "fused", {"bwd": True}),
                     ("c4", 4, "fused", {}), ("c4_shard8", 4, "fused", {"batch": 1_250_000, "acquire": True}),
                     ("c4_grad", 4, "fused", {"batch": 2_000_000, "grad": True}),
                     ("c5", 5, "fused", {}), ("knn", 2, "fused", {"knn": True}),

@@ -1836,11 +1836,19 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       T* uvec = colbuf + 64;
       // feature cotangents asked for (uniform): the pair cotangents q_rc are also laid out as a symmetric NP x NP image
       // per neighbourhood where the multipliers were (dead from here on) -- phase 8B below
+      // With them the per-feature length-scale sums come out of the same sweep: sum over pairs of q_rc (z_rf - z_cf)^2
+      //   = sum_i z_if g_if  with g_i = sum_j q_ij (z_i - z_j), the unscaled feature cotangent (the g_i add up to zero, so
+      // any common offset of the rows drops out) -- one product per row and feature instead of 40 subtractions and FMAs
+      // per PAIR inside the pair loop: every cotangent with 40 length scales 9.4 -> 8.0 ms per 1 M.  Without feature
+      // cotangents the pair loop keeps its own sweep (the image would cost as much at d = 40 and more at d = 8).
       const bool feat = a.bwd_gnn != nullptr || a.bwd_gq != nullptr;
+      const bool lsweep = a.bwd_gls != nullptr && aniso;  // (uniform)
+      const bool img = feat;
+      const bool sweep = lsweep && !feat;
       __syncthreads();
       avec[lane] = i < KFIX ? xa : (i == KFIX ? T(-1) : T(0));
       uvec[lane] = i < KFIX ? xu : T(0);
-      if (feat) {
+      if (img) {
         T* Q0 = tile + kmat_base;  // (both neighbourhoods' images are contiguous)
 #pragma unroll
         for (int e = 0; e < NH * KMAT; e += 64 * E)
@@ -1854,10 +1862,9 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       const bool skip = bad || !live;
       T liso = T(0);
       constexpr int DGF = DSTFIX / E;
-      V s2h[DGF];
+      V s2p[DGF];  // (pair-loop sweep only)
 #pragma unroll
-      for (int c4 = 0; c4 < DGF; ++c4) s2h[c4] = V(0);
-      const bool sweep = a.bwd_gls != nullptr && aniso;  // (uniform)
+      for (int c4 = 0; c4 < DGF; ++c4) s2p[c4] = V(0);
       {
         T ar[BA], ur[BA], Pc[BP], Qc[BP];
 #pragma unroll
@@ -1900,19 +1907,21 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
               Kh[on ? r_ * KS + c_ : QDUMP] = qv;
               Kh[on ? c_ * KS + r_ : QDUMP] = qv;
             }
-            if (sweep) {
-              const T* xa_ = Xh + wrap(i + own_offset(jj)) * xs;
-              const T* xb_ = Xh + wrap(i + pp + 1) * xs;
-              const V qq = V(qv);
+            if constexpr (!FEAT) {
+              if (sweep) {
+                const T* xa_ = Xh + wrap(i + own_offset(jj)) * xs;
+                const T* xb_ = Xh + wrap(i + pp + 1) * xs;
+                const V qq = V(qv);
 #pragma unroll
-              for (int c4 = 0; c4 < DGF; ++c4) {
-                const V dz = vsub(*reinterpret_cast<const V*>(xa_ + c4 * E), *reinterpret_cast<const V*>(xb_ + c4 * E));
-                s2h[c4] = (dz * qq) * dz + s2h[c4];
+                for (int c4 = 0; c4 < DGF; ++c4) {
+                  const V dz = vsub(*reinterpret_cast<const V*>(xa_ + c4 * E), *reinterpret_cast<const V*>(xb_ + c4 * E));
+                  s2p[c4] = (dz * qq) * dz + s2p[c4];
+                }
               }
             }
           }
           };
-          if (feat) pairs(ic<1>{});
+          if (img) pairs(ic<1>{});
           else pairs(ic<0>{});
         });
       }
@@ -1921,22 +1930,9 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         if (a.bwd_gtg)
           __hip_atomic_fetch_add(static_cast<T*>(a.bwd_gtg) + myidx, gmv * xa + T(2) * gyv * xu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      // (feature cotangents, phase 8B below: row i of the pair-cotangent image into registers now -- the length-scale
-      // reduction that follows reuses the image, and its partial sums are out of the registers before the sweep starts)
-      constexpr int QG = (KFIX + 1 + E - 1) / E;  // 16-byte groups of the image row that hold q_i,0 .. q_i,KFIX
-      V qrow[QG];
-      if (feat) {
-        __syncthreads();
-#pragma unroll
-        for (int c4 = 0; c4 < QG; ++c4) qrow[c4] = *reinterpret_cast<const V*>(Kh + i * KS + c4 * E);
-      }
-      if (a.bwd_gls) {  // (uniform)
-        T* gls = static_cast<T*>(a.bwd_gls);
-        if (!aniso) {
-          T sum = liso;
-          for (int off = NP / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-          if (!skip && i == 0) gls[nbw] = T(-2) / ls[0] * sum;
-        } else {
+      // per-feature length-scale sums -> gradient partials of the neighbourhood
+      auto ls_reduce = [&](const V (&s2h)[DGF]) {
+          T* gls = static_cast<T*>(a.bwd_gls);
           // per-feature sums over the neighbourhood's lanes, through its (dead) exchange image, FPP features per pass:
           // lane i writes its sums of the pass, lane f adds the NP rows of feature f
           constexpr int FPP = (KMAT / NP) / E * E;  // features of a pass (whole 16-byte groups)
@@ -1968,9 +1964,10 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
               }
             }
           }
-        }
-      }
-      if (feat) {
+      };
+      if (sweep) ls_reduce(s2p);  // (before the registers of the feature sweep are needed)
+      V gxv[DGF];
+      if (img) {
         // ---- phase 8B: feature cotangents  x-bar_i,f = 2 / l_f  sum_j q_ij (z_i,f - z_j,f)  on the (scaled, GRAM: centred)
         // rows the tile still holds.  Lane i takes row i of the image into registers and walks the rows j of the tile
         // (every lane of a neighbourhood reads the same 16 bytes: broadcast reads); the sums then go back into row i of
@@ -1978,12 +1975,15 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         // (one instruction covers 32 / 64 consecutive elements of the gradient table instead of as many rows).
         // Reference: autograd through torch/muygps_layer.py:129-164 (crosswise / pairwise differences of the embedded
         // features); the same sums as mgp_backward.hip's last stage.
-        __syncthreads();  // (the reduction's passes through the image are over)
+        __syncthreads();
+        constexpr int QG = (KFIX + 1 + E - 1) / E;  // 16-byte groups of the image row that hold q_i,0 .. q_i,KFIX
+        V qrow[QG];
+#pragma unroll
+        for (int c4 = 0; c4 < QG; ++c4) qrow[c4] = *reinterpret_cast<const V*>(Kh + i * KS + c4 * E);
         // GRAM: the rows are centred on the query (|z| is of the size of the differences), so the sum is taken as
         //   z_i sum_j q_ij - sum_j q_ij z_j  -- one packed FMA per two features and row instead of a subtraction and an FMA;
         // difference form otherwise (raw rows: the products would cancel)
         const T* xi_ = Xh + i * xs;
-        V gxv[DGF];
 #pragma unroll
         for (int c4 = 0; c4 < DGF; ++c4) gxv[c4] = V(0);
         if constexpr (GRAM) {
@@ -2021,25 +2021,46 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
           }
         }
         // (the sums are pinned HERE: left to itself the compiler sinks each group's chain of FMAs to its use -- into
-        // the branches behind the barrier, which the loads cannot cross -- and keeps all 310 loaded groups alive in
+        // the branches behind the next barrier, which the loads cannot cross -- and keeps all 310 loaded groups alive in
         // between: 1 150 spilled registers)
+#pragma unroll
+        for (int c4 = 0; c4 < DGF; ++c4) asm volatile("" : "+v"(gxv[c4]));
+      }
+      if (a.bwd_gls) {  // (uniform)
+        T* gls = static_cast<T*>(a.bwd_gls);
+        if (!aniso) {
+          T sum = liso;
+          for (int off = NP / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+          if (!skip && i == 0) gls[nbw] = T(-2) / ls[0] * sum;
+        } else if (feat) {
+          V s2h[DGF];
+#pragma unroll
+          for (int c4 = 0; c4 < DGF; ++c4) {
+            const V zi = *reinterpret_cast<const V*>(Xh + i * xs + c4 * E);
+            s2h[c4] = i <= KFIX ? zi * gxv[c4] : V(0);
+          }
+          ls_reduce(s2h);
+        }
+      }
+      if (feat) {
 #pragma unroll
         for (int c4 = 0; c4 < DGF; ++c4) {
           const V ilv = *reinterpret_cast<const V*>(ilbuf + c4 * E);  // (Isotropy: whatever the row holds; not used)
           gxv[c4] = gxv[c4] * (aniso ? ilv * V(T(2)) : V(T(2)));
-          asm volatile("" : "+v"(gxv[c4]));
         }
         __syncthreads();  // every lane is done with the rows
+        T* gnn_ = static_cast<T*>(a.bwd_gnn);
+        T* gq_ = static_cast<T*>(a.bwd_gq);
+        int64_t* roff = reinterpret_cast<int64_t*>(colbuf);  // element offset of every slot's row (the two vectors are dead)
+        // (Measured out: requesting the NEXT task's rows here, ahead of the scatter -- the sums then staged through the
+        // dead image in two passes instead of the tile: 9.2 against 7.3 ms per 1 M at the headline shape.)
         {
           T* gdst = i <= KFIX ? Xh + i * xs : Kh;  // (lanes without a row: into the dead image -- no branch)
 #pragma unroll
           for (int c4 = 0; c4 < DGF; ++c4) *reinterpret_cast<V*>(gdst + c4 * E) = gxv[c4];
         }
-        int64_t* roff = reinterpret_cast<int64_t*>(colbuf);  // element offset of every slot's row (the two vectors are dead)
         roff[lane] = myidx * (int64_t)d;
         __syncthreads();
-        T* gnn_ = static_cast<T*>(a.bwd_gnn);
-        T* gq_ = static_cast<T*>(a.bwd_gq);
         constexpr int NOUT = (KFIX + 1) * DFIX;  // elements of a neighbourhood's cotangent block, row-major
 #pragma unroll 4
         for (int t0 = 0; t0 < NOUT; t0 += NP) {

@@ -90,10 +90,10 @@ def test_every_kernel_the_default_bench_line_times_is_oracle_checked():
     checked |= {_oracle_checked_kernel(2, "dropin"), _oracle_checked_kernel(2, "dropin_plain")}
     assert out["check"]["ok"], out["check"]
     assert out["roofline"]["kernel"] in checked, (out["roofline"]["kernel"], checked)
-    assert set(out["secondary"]) >= {"dropin", "dropin_plain", "c3", "c4", "c5", "knn", "points8M", "c3_shard8", "c4_shard8", "c4_grad"}
+    assert set(out["secondary"]) >= {"dropin", "dropin_plain", "c3", "c4", "c5", "knn", "points8M", "c3_shard8", "c4_shard8", "c4_grad", "c2_bwd"}
     for name, sec in out["secondary"].items():
         assert "error" not in sec, (name, sec)
-        if name != "c4_grad":  # (its kernel is the backward instantiation: checked against finite differences in the line)
+        if name not in ("c4_grad", "c2_bwd"):  # (backward instantiations: checked in the line -- finite differences / fp64)
             assert sec["kernel"] in checked, (name, sec["kernel"], checked)
         assert sec["check"]["ok"], (name, sec["check"])
         assert np.isfinite(sec["value"]) and sec["value"] > 0
@@ -102,6 +102,8 @@ def test_every_kernel_the_default_bench_line_times_is_oracle_checked():
     assert out["secondary"]["c4"]["batch"] == 10_000_000 and out["secondary"]["c4_shard8"]["batch"] == 1_250_000
     # ... and one evaluation WITH its analytic gradient (round 6: the backward on the dealt-triangle forward kernel)
     assert "backward" in out["secondary"]["c4_grad"]["kernel"], out["secondary"]["c4_grad"]["kernel"]
+    # ... and the full backward at the headline shape (feature cotangents included) on the forward kernel
+    assert "backward" in out["secondary"]["c2_bwd"]["kernel"], out["secondary"]["c2_bwd"]["kernel"]
     assert 0.0 < out["secondary"]["c4_shard8"]["acquisition_ms"] < 60.0
     # the record the driver keeps (`roofline` survives its parser, unknown top-level keys do not) holds all of it
     compact = out["roofline"]["secondaries"]
