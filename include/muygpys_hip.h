@@ -223,10 +223,11 @@ int mgp_posterior_gen_f64(const double* feat_q, const double* feat_nn, const voi
  * on which kernel served a call beyond the rounding of a different summation order.
  *   mgp_jit_prepare: compile one shape into the disk cache ahead of time (no GPU needed);
  *                    MGP_OK, or MGP_EUNSUPPORTED (shape outside the static kernels, or no hiprtc).
- *   mgp_jit_prepare_backward: the same for the hyper-parameter backward of one response (mgp_posterior_backward_* /
- *                    mgp_loocv_backward_* without feature cotangents): the backward instantiation of the forward
- *                    kernel (round 6) -- fp64 with 33 <= nn_count + 2 <= 64 (dealt triangle), either type with
- *                    17 <= nn_count + 2 <= 32 (row per lane); rows of whole 16-byte groups.
+ *   mgp_jit_prepare_backward: the same for the backward instantiation of the forward kernel (round 6) that serves
+ *                    mgp_posterior_backward_* / mgp_loocv_backward_*: row per lane -- either type with
+ *                    5 <= nn_count + 2 <= 32, fp32 up to 64; every cotangent, feature cotangents included, any response
+ *                    count; rows of whole 16-byte groups, up to 64 features (fp32: 128) -- or, fp64 with
+ *                    33 <= nn_count + 2 <= 64, on the dealt triangle (no feature cotangents).
  *   mgp_jit_mode:    0 off, 1 automatic, 2 forced.
  *   mgp_jit_loaded_count: run-time compiled kernels loaded in this process so far.
  *   mgp_jit_source_hash:  the 16 hex digits every cache file name of THIS build ends in (kernel sources, compile

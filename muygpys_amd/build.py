@@ -164,7 +164,7 @@ def _parse_resource_remarks(text: str) -> dict:
 PREWARM_K = (10, 20, 25, 30, 40, 50)
 PREWARM_D = (8, 16, 32, 40, 64)
 # ... and the fp64 hyper-parameter backward of a few shapes next to BASELINE config 4's built-in (50, 8) (round 6)
-PREWARM_BWD = ((8, 40, 8), (8, 40, 16), (8, 50, 16), (8, 32, 8), (4, 30, 16), (4, 20, 40), (4, 25, 8), (8, 30, 40), (4, 50, 8), (4, 40, 16), (4, 10, 8))
+PREWARM_BWD = ((8, 40, 8), (8, 40, 16), (8, 50, 16), (8, 32, 8), (4, 30, 16), (4, 20, 40), (4, 25, 8), (8, 30, 40), (4, 50, 8), (4, 40, 16), (4, 10, 8), (4, 30, 100))
 
 
 def _prewarm_one(job):

@@ -136,7 +136,8 @@ static int launch_bwd_dlt_jit(const BackwardArgs& b, hipStream_t stream) {
 template <typename T>
 static int row_slots(int k, int d) {
   constexpr int E = 16 / (int)sizeof(T), CH = 2 * E;
-  if (k < 3 || d < E || d % E != 0 || (d + CH - 1) / CH * CH > 64) return 0;
+  constexpr int DCAP = sizeof(T) == 4 ? 128 : 64;  // (fp32: rows of up to 128 features in one stage)
+  if (k < 3 || d < E || d % E != 0 || (d + CH - 1) / CH * CH > DCAP) return 0;
   if (k + 2 <= 32) return 32;
   return (sizeof(T) == 4 && k + 2 <= 64) ? 64 : 0;
 }
@@ -239,7 +240,9 @@ int prepare_backward_fwd(int elem_size, int k, int d, int kernel_id) {
 template <typename T>
 int launch_backward_fwd(const BackwardArgs& b, hipStream_t stream) {
   const FusedArgs& f = b.f;
-  if (f.R != 1 || f.targets_batch || f.kernel_id == MGP_KERNEL_MATERN_GEN) return MGP_EUNSUPPORTED;
+  // (several responses: one combined right-hand side Y g_mean, formed as the rows' responses are fetched; the LOOCV form
+  // with its y^T K^-1 y is one response by definition)
+  if (f.R < 1 || (f.R != 1 && b.grad_yk) || f.targets_batch || f.kernel_id == MGP_KERNEL_MATERN_GEN) return MGP_EUNSUPPORTED;
   const bool feat = b.grad_feat_q != nullptr || b.grad_feat_nn != nullptr;  // feature cotangents: the row-per-lane form has them
   if (f.ls_count != 1 && f.ls_count != f.d) return MGP_EUNSUPPORTED;
   const uintptr_t align = (uintptr_t)f.feat_q | (uintptr_t)f.feat_nn;

@@ -428,7 +428,10 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     else return rowoff(hi) + lo;
   };
   constexpr int DPADFIX = (DFIX + CH - 1) / CH * CH;
-  constexpr int DSTFIX = DFIX > 0 ? (DPADFIX < 64 ? DPADFIX : 64) : CH;
+  // (one feature stage of up to 64 columns; the row-per-lane backward takes rows of up to 128 -- the reference's torch
+  // tutorial embeds into 100 dimensions -- at 37 KB of LDS per wave)
+  constexpr int DCAP = (BWD && !WD.DLT && sizeof(T) == 4) ? 128 : 64;
+  constexpr int DSTFIX = DFIX > 0 ? (DPADFIX < DCAP ? DPADFIX : DCAP) : CH;
   using V = typename v16<T>::type;
   using ACC = typename v16<T>::acc;
 
@@ -534,7 +537,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   // costs no registers and its latency hides behind the Cholesky.  One load instruction fills
   // 64 consecutive 16-byte slots of the tile (SPR slots per row, the last one padding).
   constexpr bool PIPE = PIPED;
-  static_assert(!PIPED || DFIX <= 64, "the pipelined gather stages all features at once");
+  static_assert(!PIPED || DFIX <= DCAP, "the pipelined gather stages all features at once");
   const int SPR = xs / E;                                   // 16-byte slots per staged row (NH * NP = 64 rows
   const int C16V = d / E;                                   //  -> SPR loads per task); C16V of them hold data
   constexpr int GB = 11;                                    // loads issued per batch (= SPR at d = 40, fp32)
@@ -593,6 +596,17 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     }
     // (prepared tables: the responses arrive in the tile, unless the caller hands them over gathered)
     if (!PACKED || a.targets_batch) pre_y = targets[pre_tg * (int64_t)R];
+    if constexpr (BWD) {
+      // several responses (a.R > 1; the system itself has one right-hand side): the combined column Y g_mean of the
+      // row -- mean-bar . mean = a^T K^-1 (Y g_mean), so one solve serves any response count (mgp_backward.hip)
+      if (a.R > 1) {  // (uniform)
+        const T* gmp = static_cast<const T*>(a.bwd_gmean);
+        const int64_t nbq = (int64_t)task_n * NH + ((NH > 1 && (int64_t)task_n * NH + h >= a.b) ? 0 : h);
+        T ys = T(0);
+        for (int r = 0; r < a.R; ++r) ys = fma_t(gmp ? gmp[nbq * a.R + r] : T(0), targets[pre_tg * (int64_t)a.R + r], ys);
+        pre_y = ys;
+      }
+    }
     pre_eps = (T)a.noise_scalar;
     if (a.noise_mode != MGP_NOISE_SCALAR) {
       const int64_t nb0 = (int64_t)task_n * NH;
@@ -829,7 +843,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
           const bool has = i < k || i == q;
           T* xrow = Xh + (MODM ? wrap(i) : i) * xs;  // (modulo scheme: idle lanes repeat a live one; they store nothing)
           const T* qrow = Xh + q * xs;
-          if constexpr (DFIX > 0 && FOLD && NCF > 10 && !OWNREG) {
+          if constexpr (DFIX > 0 && (FOLD || (BWD && NCF > 16)) && NCF > 10 && !OWNREG) {
             // (FOLD, long rows: the parked rows of the pair's first task leave no room for a whole row and a
             // whole query row in registers -- four groups at a time; a chunk of the query row is overwritten
             // (by lane q) only after every lane has read it)
@@ -1526,7 +1540,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         avec[lane] = i < KFIX ? xa : (i == KFIX ? T(-1) : T(0));
         uvec[lane] = i < KFIX ? xu : T(0);
         __syncthreads();
-        const T gmv = (live && a.bwd_gmean) ? static_cast<const T*>(a.bwd_gmean)[nb0] : T(0);
+        const T gmv = (live && a.bwd_gmean) ? (a.R > 1 ? T(1) : static_cast<const T*>(a.bwd_gmean)[nb0]) : T(0);  // (R > 1: folded into the column)
         const T gvv = (live && a.bwd_gvar) ? static_cast<const T*>(a.bwd_gvar)[nb0] : T(0);
         const T gyv = (live && a.bwd_gyk) ? static_cast<const T*>(a.bwd_gyk)[nb0] : T(0);
         const bool skip = bad || !live;  // (cotangents of a neighbourhood that did not factorise are left untouched)
@@ -1607,8 +1621,15 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         // per-neighbourhood outputs that need a and u only
         if (!skip && i < KFIX) {
           if (a.bwd_gnz) static_cast<T*>(a.bwd_gnz)[nb0 * KFIX + i] = gvv * xa * xa - gmv * xa * xu - gyv * xu * xu;
-          if (a.bwd_gtg)
-            __hip_atomic_fetch_add(static_cast<T*>(a.bwd_gtg) + myidx, gmv * xa + T(2) * gyv * xu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (a.bwd_gtg) {
+            if (a.R > 1) {  // (uniform) y-bar_j,r = g_mean,r a_j
+              const T* gmp = static_cast<const T*>(a.bwd_gmean);
+              for (int r = 0; gmp && r < a.R; ++r)
+                __hip_atomic_fetch_add(static_cast<T*>(a.bwd_gtg) + myidx * a.R + r, gmp[nb0 * a.R + r] * xa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+              __hip_atomic_fetch_add(static_cast<T*>(a.bwd_gtg) + myidx, gmv * xa + T(2) * gyv * xu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
         }
         // ---- phase 7B: length-scale partials ------------------------------------------------------------------
         if (a.bwd_gls && !(MGP_BWD_EXP & 1)) {  // (uniform)
@@ -1856,7 +1877,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       }
       __syncthreads();
       const int64_t nbw = nb0 + h;
-      const T gmv = (live && a.bwd_gmean) ? static_cast<const T*>(a.bwd_gmean)[nbw] : T(0);
+      const T gmv = (live && a.bwd_gmean) ? (a.R > 1 ? T(1) : static_cast<const T*>(a.bwd_gmean)[nbw]) : T(0);  // (R > 1: folded into the column)
       const T gvv = (live && a.bwd_gvar) ? static_cast<const T*>(a.bwd_gvar)[nbw] : T(0);
       const T gyv = (live && a.bwd_gyk) ? static_cast<const T*>(a.bwd_gyk)[nbw] : T(0);
       const bool skip = bad || !live;
@@ -1927,8 +1948,22 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       }
       if (!skip && i < KFIX) {
         if (a.bwd_gnz) static_cast<T*>(a.bwd_gnz)[nbw * KFIX + i] = gvv * xa * xa - gmv * xa * xu - gyv * xu * xu;
-        if (a.bwd_gtg)
+        if (a.bwd_gtg && a.R == 1)
           __hip_atomic_fetch_add(static_cast<T*>(a.bwd_gtg) + myidx, gmv * xa + T(2) * gyv * xu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (a.bwd_gtg && a.R > 1 && a.bwd_gmean) {  // (uniform)
+        // several responses: y-bar_j,r = g_mean,r a_j, the lanes along (row, response) -- R consecutive elements per row
+        // (a lane per row and a loop over r: 5 of 10.9 ms per 500 k neighbourhoods at k = 30, R = 10)
+        const T* gmp = static_cast<const T*>(a.bwd_gmean) + nbw * a.R;
+        const int RR = a.R, nel = KFIX * RR;
+        for (int t0 = 0; t0 < nel; t0 += NP) {
+          const int t = t0 + i;
+          const int tt = t < nel ? t : 0;
+          const int j = tt / RR, r = tt - j * RR;
+          const int64_t rowj = __shfl(myidx, h * NP + j, 64);  // (slot j's table row)
+          if (t < nel && !skip)
+            __hip_atomic_fetch_add(static_cast<T*>(a.bwd_gtg) + rowj * RR + r, gmp[r] * avec[hoff + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
       // per-feature length-scale sums -> gradient partials of the neighbourhood
       auto ls_reduce = [&](const V (&s2h)[DGF]) {

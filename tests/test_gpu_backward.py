@@ -581,6 +581,9 @@ ROW_CASES = [
     # small neighbourhoods ride in the 32-slot kernel; fp32 with 33 .. 64 slots: the 64-slot one, whole rows of multipliers
     ("float32", "matern15", "l2", True, 5, 4, 500), ("float64", "rbf", "F2", False, 3, 2, 77), ("float64", "matern15", "l2", True, 10, 8, 301),
     ("float32", "matern15", "l2", True, 50, 8, 300), ("float32", "matern25", "l2", False, 62, 40, 70), ("float32", "matern05", "l2", True, 40, 16, 129),
+    # fp32 rows of up to 128 features in one stage (the reference's torch tutorial: k = 30 on a 100-dimensional embedding)
+    ("float32", "matern15", "l2", False, 30, 100, 300), ("float32", "rbf", "F2", True, 30, 100, 129), ("float32", "matern05", "l2", True, 20, 72, 200),
+    ("float32", "matern25", "l2", True, 50, 128, 65),
 ]
 
 
@@ -692,3 +695,59 @@ def test_feature_cotangents_row_per_lane_form(case):
                                            _lib.ptr(g_x2), None, None, None, _lib.ptr(info), _lib.stream_ptr())
     assert rc == 0 and "backward" in _lib.last_kernel()
     assert_close(g_x2.double().cpu().numpy(), ref["train_features"], rtol, "g_train_features alone")
+
+
+@pytest.mark.parametrize("dtype,kernel,aniso,k,d,R,b", [("float32", "matern15", False, 30, 40, 10, 401), ("float32", "rbf", True, 30, 40, 3, 300),
+                                                       ("float64", "matern25", True, 10, 8, 2, 257), ("float32", "matern15", True, 50, 8, 4, 130)])
+def test_backward_on_the_forward_kernel_with_several_responses(dtype, kernel, aniso, k, d, R, b):
+    """Several responses (the reference's torch tutorial trains on ten one-hot columns, docs/examples/torch_tutorial.ipynb)
+    on the row-per-lane backward instantiations: the system still has ONE right-hand side, the combined column
+    Y g_mean formed as the rows' responses are fetched; the responses' cotangents are g_mean,r a_j.  Everything against
+    the oracle's vector-Jacobian product."""
+    from muygpys_amd import _lib
+
+    kid = {"rbf": 0, "matern05": 1, "matern15": 2, "matern25": 3, "maternInf": 4}[kernel]
+    es = 4 if dtype == "float32" else 8
+    rc = _lib.load().mgp_jit_prepare_backward(es, k, d, kid)
+    if rc == -2 and not (es == 4 and k == 30 and d == 40):
+        pytest.skip("no hiprtc on this machine: the older kernels serve the shape")
+    rng = np.random.default_rng(77 + R)
+    n = 2500
+    X = rng.normal(size=(n, d))
+    Y = np.sin(X @ rng.normal(size=(d, R)) / np.sqrt(d)) + 0.1 * rng.normal(size=(n, R))
+    bi = rng.choice(n, size=b, replace=False)
+    ni = np.stack([rng.choice(np.setdiff1d(np.arange(n), [i]), size=k, replace=False) for i in bi])
+    ls = np.sqrt(d) * rng.uniform(0.7, 1.5, size=d) if aniso else float(np.sqrt(d))
+    metric = "F2" if kernel == "rbf" else "l2"
+    spec_o = orc.Spec(kernel, metric, ls, 2e-2)
+    gm, gv = rng.normal(size=(b, R)), rng.normal(size=b)
+    ref = orc.posterior_vjp(spec_o, X, X, bi, ni, Y, gm, gv)
+    td = getattr(torch, dtype)
+    Xd, yd, lsd = to_dev(X, td), to_dev(Y, td), to_dev(np.atleast_1d(ls), td)
+    g_l = torch.zeros((b, lsd.numel()), device="cuda", dtype=td)
+    g_n = torch.zeros((b, k), device="cuda", dtype=td)
+    g_t, g_x = torch.zeros_like(yd), torch.zeros_like(Xd)
+    info = torch.zeros(1, device="cuda", dtype=torch.int32)
+    bid, nid, gmd, gvd = to_dev(bi), to_dev(ni), to_dev(gm, td), to_dev(gv, td)
+    rc = _lib.fn("posterior_backward", td)(_lib.ptr(Xd), _lib.ptr(Xd), d, _lib.ptr(bid), _lib.ptr(nid), b, k, _lib.ptr(yd), R, 0, 2e-2, None,
+                                           kid, 0 if metric == "l2" else 1, _lib.ptr(lsd), lsd.numel(), _lib.ptr(gmd), _lib.ptr(gvd),
+                                           _lib.ptr(g_x), _lib.ptr(g_x), _lib.ptr(g_t), _lib.ptr(g_l), _lib.ptr(g_n), _lib.ptr(info),
+                                           _lib.stream_ptr())
+    assert rc == 0 and int(info.item()) == 0
+    name = _lib.last_kernel()
+    assert "backward" in name and f",{32 if k + 2 <= 32 else 64},{k},1,{d}," in name, name
+    rtol = 1e-5 if dtype == "float64" else 3e-3
+    assert_close(g_x.double().cpu().numpy(), ref["train_features"] + ref["test_features"], rtol, "g_features")
+    assert_close(g_t.double().cpu().numpy(), ref["targets"], rtol, "g_targets")
+    assert_close(g_l.double().sum(0).cpu().numpy(), np.atleast_1d(ref["length_scale"]), rtol, "g_length_scale")
+    assert_close(g_n.double().sum().cpu().numpy().reshape(()), ref["noise"], rtol, "g_noise")
+    # only the variance's cotangent (no g_mean): the combined column is zero
+    g_x.zero_(); g_t.zero_()
+    rc = _lib.fn("posterior_backward", td)(_lib.ptr(Xd), _lib.ptr(Xd), d, _lib.ptr(bid), _lib.ptr(nid), b, k, _lib.ptr(yd), R, 0, 2e-2, None,
+                                           kid, 0 if metric == "l2" else 1, _lib.ptr(lsd), lsd.numel(), None, _lib.ptr(gvd),
+                                           _lib.ptr(g_x), _lib.ptr(g_x), _lib.ptr(g_t), _lib.ptr(g_l), _lib.ptr(g_n), _lib.ptr(info),
+                                           _lib.stream_ptr())
+    assert rc == 0
+    ref0 = orc.posterior_vjp(spec_o, X, X, bi, ni, Y, np.zeros_like(gm), gv)
+    assert_close(g_x.double().cpu().numpy(), ref0["train_features"] + ref0["test_features"], rtol, "g_features (variance only)")
+    assert float(g_t.abs().max()) == 0.0
