@@ -36,7 +36,7 @@ struct FusedArgs {
   // ones (mgp_loocv_tree.h).  Only launch_fused_wave serves it (and fills in tree.grid / tree.nh); behind every other
   // kernel family the caller walks the same tree with launch_loocv_tree (mgp_tensor_ops.hip).
   LoocvTree tree;
-  // Backward of one response's outputs on the dealt-triangle kernels (BWD instantiations of fused_wave_kernel,
+  // Backward on the forward kernels (BWD instantiations of fused_wave_kernel,
   // mgp_backward_dlt.hip; nullptr everywhere else): upstream cotangents of mean / variance / y^T K^-1 y, (b) each (any
   // may be null = zero), and the per-neighbourhood partials they produce -- d/d length scale(s) (b, ls_count), the
   // diagonal (noise) cotangent (b, k), and the cotangent of the neighbours' responses (n, 1; atomic adds)
@@ -83,9 +83,10 @@ struct BackwardArgs {
 };
 template <typename T> int launch_backward(const BackwardArgs&, hipStream_t);
 template <typename T> int launch_backward_wave(const BackwardArgs&, hipStream_t);  // Isotropy, k + 2 <= 64: on the wave kernel's phases
-// hyper-parameter gradients of one response (no feature cotangents) on the forward kernel's own phases + the saved
-// factor (mgp_backward_dlt.hip): fp64 dealt-triangle shapes (BASELINE config 4: k = 50, d = 8) and the 32-slot static
-// shapes of either type (config 3: k = 30, d = 40); MGP_EUNSUPPORTED for everything else
+// the backward on the forward kernel's own phases + the saved factor (mgp_backward_dlt.hip): the row-per-lane static
+// shapes of either type (config 3: k = 30, d = 40; every cotangent, the feature cotangents included, any response
+// count) and the fp64 dealt-triangle shapes (BASELINE config 4: k = 50, d = 8; hyper-parameter gradients of one
+// response); MGP_EUNSUPPORTED for everything else
 template <typename T> int launch_backward_fwd(const BackwardArgs&, hipStream_t);
 int max_nn_count_backward(int elem_size);
 
