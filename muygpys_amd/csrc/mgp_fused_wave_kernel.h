@@ -1458,7 +1458,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
           // round trip per slot) ...
           // (MGP_DLT_CHUNK slots at a time: the whole step in flight needs 6 registers per slot)
 #ifndef MGP_DLT_CHUNK
-#define MGP_DLT_CHUNK 4  // (config 4 at three waves per SIMD: 4 / 6 slots per chunk 158.0 / 155.8 M/s; two waves, whole step: 153.1)
+#define MGP_DLT_CHUNK 2  // (config 4 at three waves per SIMD, slots per chunk -- 2: 157.0, 4: 153.5, 6: 154, whole step: 149 M/s (tools/jit_sweep.py, k = 49; profiles/r06_c4_param_sweep.txt))
 #endif
           constexpr int CHK = MGP_DLT_CHUNK;
           const int n1 = j + 1 < KFIX ? (cs2(j + 2) - 1) >> 6 : sl - 1;  // last slot of column j + 1
@@ -1554,9 +1554,12 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         constexpr int DGF = DSTFIX / E;
         V s2h[DGF];  // (unused under SWEEP_LATE)
         const bool sweep_any = a.bwd_gls != nullptr && aniso && !(MGP_BWD_EXP & 1);  // (uniform)
-        // ... except at BASELINE config 4's own shape, where keeping the q values and sweeping afterwards -- the partner
-        // rows of a lane read once for all its own rows -- fits with 8 spill slots: 27.0 against 30.8 ms per 2 M
-        constexpr bool SWEEP_LATE = MGP_BWD_SWEEP_LATE < 0 ? (KFIX == 50 && DFIX == 8) : MGP_BWD_SWEEP_LATE != 0;
+        // ... except where keeping the q values and sweeping afterwards -- the partner rows of a lane read once for all
+        // its own rows -- fits the registers: BASELINE config 4's own shape 27.0 against 30.8 ms per 2 M; by shape
+        // (tools/jit_sweep.py, 1 M neighbourhoods, late / in the loop): k = 40, d = 8: 10.5 / 10.9 ms, k = 40, d = 16:
+        // 13.2 / 15.1, k = 50, d = 16: 19.0 / 22.6 -- but k = 62, d = 8: 36.7 / 30.6, and from d = 24 on ten times slower
+        // (the q values and 2 d sums: scratch)
+        constexpr bool SWEEP_LATE = MGP_BWD_SWEEP_LATE < 0 ? (KFIX <= 52 && DFIX <= 16) : MGP_BWD_SWEEP_LATE != 0;
         const bool sweep = sweep_any && !SWEEP_LATE;
         if constexpr (!SWEEP_LATE) {
 #pragma unroll
