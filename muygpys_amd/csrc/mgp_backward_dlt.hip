@@ -165,6 +165,8 @@ static void row_geometry(const FusedArgs& a, const WaveDims& WD, int NP, WaveGeo
   *lds = ((tile_feat + (size_t)WD.NH * kmat) * sizeof(T) + tail + 15) & ~(size_t)15;
 }
 static int64_t row_grid(int cus, int per_cu, int64_t ntasks) {
+  static const int env_per_cu = getenv("MGP_BWD_ROW_PER_CU") ? atoi(getenv("MGP_BWD_ROW_PER_CU")) : 0;  // occupancy experiments
+  if (env_per_cu > 0 && env_per_cu < per_cu) per_cu = env_per_cu;
   int64_t grid = (int64_t)cus * per_cu / 8 * 8;
   if (grid < 8) grid = 8;
   if (grid > ntasks) grid = (ntasks + 7) / 8 * 8;
