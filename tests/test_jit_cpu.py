@@ -116,3 +116,30 @@ def test_prewarmed_instantiations_do_not_spill():
         assert spills == 0 and scratch == 0, (name, spills, scratch)
         seen += 1
     assert seen >= 60
+
+
+def test_jit_sweep_variants_rewrite_the_defaults(tmp_path):
+    """tools/jit_sweep.py builds its variants by rewriting `#define MGP_X default` in a copy of the kernel headers: the
+    copy must hold every header the run-time compiler hashes, the rewrite must hit exactly the named macro, and an
+    unknown name must stop the sweep."""
+    import importlib.util
+    import re
+
+    import pytest
+
+    from muygpys_amd import build
+
+    spec = importlib.util.spec_from_file_location("jit_sweep", os.path.join(os.path.dirname(build.CSRC), "..", "tools", "jit_sweep.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    base = mod.make_variant("base", str(tmp_path))
+    var = mod.make_variant("MGP_DLT_CHUNK=6,MGP_CHOL_PRIO=3", str(tmp_path))
+    for name in ("mgp_fused_wave_kernel.h", "mgp_wave_common.h", "mgp_args.h", "mgp_device.h", "mgp_loocv_tree.h"):
+        assert os.path.exists(os.path.join(base, "csrc", name))
+    a = open(os.path.join(base, "csrc", "mgp_fused_wave_kernel.h")).read()
+    b = open(os.path.join(var, "csrc", "mgp_fused_wave_kernel.h")).read()
+    assert a == open(os.path.join(build.CSRC, "mgp_fused_wave_kernel.h")).read()
+    changed = [(x, y) for x, y in zip(a.splitlines(), b.splitlines()) if x != y]
+    assert len(changed) == 2 and all(re.match(r"#define MGP_(DLT_CHUNK|CHOL_PRIO) ", y) for _, y in changed), changed
+    with pytest.raises(SystemExit):
+        mod.make_variant("MGP_NO_SUCH_KNOB=1", str(tmp_path))
