@@ -1458,9 +1458,12 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
           // round trip per slot) ...
           // (MGP_DLT_CHUNK slots at a time: the whole step in flight needs 6 registers per slot)
 #ifndef MGP_DLT_CHUNK
-#define MGP_DLT_CHUNK 2  // (config 4 at three waves per SIMD, slots per chunk -- 2: 157.0, 4: 153.5, 6: 154, whole step: 149 M/s (tools/jit_sweep.py, k = 49; profiles/r06_c4_param_sweep.txt))
+#define MGP_DLT_CHUNK 0  // slots per chunk; 0 = by shape
 #endif
-          constexpr int CHK = MGP_DLT_CHUNK;
+          // (tools/jit_sweep.py at three waves per SIMD, 2 / 4 slots per chunk: k = 49, d = 8: 157.0 / 153.5 M/s -- BASELINE
+          // config 4's neighbourhood --, k = 32 and 40: the same, k = 50, d = 16: 124.0 / 125.0, k = 62, d = 16: 84.4 /
+          // 87.4; 6: 154, the whole step: 149; profiles/r06_c4_param_sweep.txt)
+          constexpr int CHK = MGP_DLT_CHUNK > 0 ? MGP_DLT_CHUNK : (DFIX <= 8 && KFIX <= 52 ? 2 : 4);
           const int n1 = j + 1 < KFIX ? (cs2(j + 2) - 1) >> 6 : sl - 1;  // last slot of column j + 1
 #pragma unroll
           for (int sc = sl; sc < NSL; sc += CHK) {
