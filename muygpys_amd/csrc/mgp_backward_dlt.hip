@@ -160,7 +160,8 @@ static void row_geometry(const FusedArgs& a, const WaveDims& WD, int NP, WaveGeo
   const size_t tile_feat = (size_t)wave_tile_rows(WD, NP, a.k, g->xs) * g->xs + wave_stage_elems(WD);
   // (behind tile and exchange images: the column buffers / norm array / row addresses, and -- BWD -- the two solved
   // vectors of both neighbourhoods: 128 entries)
-  const size_t tail = wave_colbuf_bytes(sizeof(T), NP, false) > 128 * sizeof(T) ? wave_colbuf_bytes(sizeof(T), NP, false) : 128 * sizeof(T);
+  size_t tail = wave_colbuf_bytes(sizeof(T), NP, false) > 128 * sizeof(T) ? wave_colbuf_bytes(sizeof(T), NP, false) : 128 * sizeof(T);
+  if (wave_bwd_tailfree((int)sizeof(T), NP, row_gram<T>(a), g->dst)) tail = 0;  // (everything that lived there has another home)
   const size_t kmat = (size_t)NP * (NP + WD.E);  // (whole rows: the packed triangle of the 64-slot forward does not apply)
   *lds = ((tile_feat + (size_t)WD.NH * kmat) * sizeof(T) + tail + 15) & ~(size_t)15;
 }

@@ -174,6 +174,13 @@ constexpr int dlt_col_start(int c, int NR2) {
   const int m = c >> 1, b = c & 1;
   return 2 * m * NR2 - m * (m - 1) + b * (NR2 - m);
 }
+// The row-per-lane backward at the headline shape (fp32, 32 slots, Gram form, 33 .. 40 padded features) without the
+// 512 bytes behind tile and image -- 20 480 instead of 20 992 bytes of LDS per wave: the eighth wave of a CU, and the
+// kernel's rate follows the waves in flight.  What lived there moves into space that is dead at the time: row pointers
+// of the gather and the norms into the image (not yet / no longer in use), the elimination's pivot buffer into the
+// tile's query row (all zeros in the Gram form: re-zeroed afterwards), the two solved vectors into the padding columns
+// of the image, the rows' element offsets of the scatter into the image's last rows.
+constexpr bool wave_bwd_tailfree(int es, int NP, bool gram, int dst) { return es == 4 && NP == 32 && gram && dst > 32 && dst <= 40; }
 constexpr WaveDims wave_dims(int es, int NP, int KFIX, int RFIX, int DFIX, bool COEFF, bool GRAM) {
   WaveDims w{};
   w.E = 16 / es;
@@ -461,7 +468,8 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
   T* colbuf = tile + tile_elems;                      // 64 entries
   T* ilbuf = PIPE_ ? tile + (NPL - 1) * xs : colbuf + 64;  // dst entries (Anisotropy)
   int64_t* idxbuf = reinterpret_cast<int64_t*>(ilbuf + dst + (dst & 1));  // 64 entries (plain kernels)
-  const T** rowaddr = reinterpret_cast<const T**>(colbuf);  // 64 row pointers (pipelined; overlays colbuf + 256 B)
+  constexpr bool TF = BWD && !WD.DLT && wave_bwd_tailfree(sizeof(T), NP, GRAM, DSTFIX);  // (no space behind tile and image)
+  const T** rowaddr = reinterpret_cast<const T**>(TF ? tile + kmat_base : colbuf);  // 64 row pointers (pipelined; overlays colbuf + 256 B)
 
   const float* gtab = reinterpret_cast<const float*>(smem + g.gen_tab);
   if (a.kernel_id == MGP_KERNEL_MATERN_GEN) {  // node table of the launch's smoothness, once per workgroup
@@ -688,7 +696,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     const int i = lane & (NP - 1);
     T* Xh = tile + h * NP * xs;
     T* Kh = tile + kmat_base + h * KMAT;
-    T* colh = colbuf + h * NP;
+    T* colh = TF ? Xh + KFIX * xs : colbuf + h * NP;  // (TF: the query row of the neighbourhood's tile)
     int64_t* idxh = idxbuf + h * NP;
     const int64_t nb0 = (int64_t)task * NH;
     const bool live = nb0 + h < a.b;
@@ -828,7 +836,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         // cost the headline kernel five spilled registers).
         constexpr bool NDUP = sizeof(T) == 4;
         constexpr int NCYC = MODM ? M : NP;
-        T* nrmh = colbuf + h * (NDUP ? 2 * NP : NP);
+        T* nrmh = (TF ? tile + kmat_base : colbuf) + h * (NDUP ? 2 * NP : NP);
         const int iw = MODM ? wrap(i) : i;
         auto put_norm = [&](bool has, T n2) {
           if (MODM && !has) return;  // (modulo scheme: idle lanes repeat a live one; they store nothing)
@@ -1830,6 +1838,9 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       // ---- phases 5B-7B, row-per-lane form (32-slot static shapes, NH neighbourhoods per wave): the multipliers
       // l_m,j sit in the exchange image (Kh[m * KS + j], written step by step above); see the dealt-triangle form of
       // these phases for the algebra.  Reference: torch autograd over torch/muygps_layer.py:129-164. ----------------
+      if constexpr (TF) {  // the query row held the pivot buffer: zeros again, as the Gram form left it
+        if (i < DSTFIX / E) *reinterpret_cast<V*>(Xh + KFIX * xs + i * E) = V(0);
+      }
       __syncthreads();
       const int hoff = NH == 1 ? 0 : h * NP;
       T xa = i < KFIX ? Kh[KFIX * KS + i] : T(0);        // l_q,i = (D^-1 L^-1 c)_i
@@ -1859,8 +1870,11 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
           }
         }
       }
-      T* avec = colbuf;       // 64 + 64 entries: the norm array's space (dead since the distance phase)
-      T* uvec = colbuf + 64;
+      // the two solved vectors by slot: 64 + 64 entries in the norm array's space (dead since the distance phase), or
+      // (TF) in the padding columns NP, NP + 1 of the slot's image row
+      T* avec = TF ? tile + kmat_base + NP : colbuf;
+      T* uvec = TF ? tile + kmat_base + NP + 1 : colbuf + 64;
+      auto vslot = [&](int s64) { return TF ? (s64 / NP) * KMAT + (s64 % NP) * KS : s64; };  // (entry of slot s64 = h NP + r)
       // feature cotangents asked for (uniform): the pair cotangents q_rc are also laid out as a symmetric NP x NP image
       // per neighbourhood where the multipliers were (dead from here on) -- phase 8B below
       // With them the per-feature length-scale sums come out of the same sweep: sum over pairs of q_rc (z_rf - z_cf)^2
@@ -1873,14 +1887,14 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
       const bool img = feat;
       const bool sweep = lsweep && !feat;
       __syncthreads();
-      avec[lane] = i < KFIX ? xa : (i == KFIX ? T(-1) : T(0));
-      uvec[lane] = i < KFIX ? xu : T(0);
-      if (img) {
+      if (img) {  // (before the vectors: TF keeps them in the image's padding)
         T* Q0 = tile + kmat_base;  // (both neighbourhoods' images are contiguous)
 #pragma unroll
         for (int e = 0; e < NH * KMAT; e += 64 * E)
           if (e + lane * E < NH * KMAT) *reinterpret_cast<V*>(Q0 + e + lane * E) = V(0);
       }
+      avec[vslot(lane)] = i < KFIX ? xa : (i == KFIX ? T(-1) : T(0));
+      uvec[vslot(lane)] = i < KFIX ? xu : T(0);
       __syncthreads();
       const int64_t nbw = nb0 + h;
       const T gmv = (live && a.bwd_gmean) ? (a.R > 1 ? T(1) : static_cast<const T*>(a.bwd_gmean)[nbw]) : T(0);  // (R > 1: folded into the column)
@@ -1897,13 +1911,13 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 #pragma unroll
         for (int j = 0; j < BA; ++j) {
           const int r = wrap(i + own_offset(j));
-          ar[j] = avec[hoff + r];
-          ur[j] = uvec[hoff + r];
+          ar[j] = avec[vslot(hoff + r)];
+          ur[j] = uvec[vslot(hoff + r)];
         }
 #pragma unroll
         for (int p = 0; p < BP; ++p) {
           const int c = wrap(i + p + 1);
-          const T ac = avec[hoff + c], uc = uvec[hoff + c];
+          const T ac = avec[vslot(hoff + c)], uc = uvec[vslot(hoff + c)];
           Pc[p] = T(2) * gvv * ac - gmv * uc;
           Qc[p] = gmv * ac + T(2) * gyv * uc;
         }
@@ -1968,7 +1982,7 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
           const int j = tt / RR, r = tt - j * RR;
           const int64_t rowj = __shfl(myidx, h * NP + j, 64);  // (slot j's table row)
           if (t < nel && !skip)
-            __hip_atomic_fetch_add(static_cast<T*>(a.bwd_gtg) + rowj * RR + r, gmp[r] * avec[hoff + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(static_cast<T*>(a.bwd_gtg) + rowj * RR + r, gmp[r] * avec[vslot(hoff + j)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       // per-feature length-scale sums -> gradient partials of the neighbourhood
@@ -2092,7 +2106,8 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         __syncthreads();  // every lane is done with the rows
         T* gnn_ = static_cast<T*>(a.bwd_gnn);
         T* gq_ = static_cast<T*>(a.bwd_gq);
-        int64_t* roff = reinterpret_cast<int64_t*>(colbuf);  // element offset of every slot's row (the two vectors are dead)
+        // element offset of every slot's row: where the two vectors were, or (TF) in the last 512 bytes of the images
+        int64_t* roff = reinterpret_cast<int64_t*>(TF ? tile + kmat_base + NH * KMAT - 128 : colbuf);
         // (Measured out: requesting the NEXT task's rows here, ahead of the scatter -- the sums then staged through the
         // dead image in two passes instead of the tile: 9.2 against 7.3 ms per 1 M at the headline shape.)
         {
