@@ -747,6 +747,18 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
     for (int d0 = 0; d0 < d; d0 += dst) {
       const int w = min(dst, d - d0);
       const int wp = (w + CH - 1) / CH * CH;
+      // (Anisotropy, pipelined kernels: the inverse length scales are REQUESTED before the wait for the tile -- they go
+      // into a tile row the gather has just overwritten, every task; loaded where they are stored, behind the barrier,
+      // the round trip to L2 is exposed once per task: 5 % of the headline kernel, 10 % of its backward)
+      constexpr int ILN = PIPED ? (DSTFIX + 63) / 64 : 1;
+      T il_pre[ILN];
+      if constexpr (PIPED) {
+#pragma unroll
+        for (int u = 0; u < ILN; ++u) {
+          const int c = u * 64 + lane;
+          il_pre[u] = (aniso && c < w) ? T(1) / ls[d0 + c] : T(0);
+        }
+      }
 #if MGP_DMA_ASM
       if (PIPE) lds_dma_wait();  // this task's tile (requested during the previous task's elimination) has landed
 #endif
@@ -812,8 +824,15 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
           Xh[row * xs + c] = v;
         }
       }
-      if (aniso)
-        for (int c = lane; c < wp; c += 64) ilbuf[c] = c < w ? T(1) / ls[d0 + c] : T(0);
+      if (aniso) {
+        if constexpr (PIPED) {
+#pragma unroll
+          for (int u = 0; u < ILN; ++u)
+            if (u * 64 + lane < wp) ilbuf[u * 64 + lane] = il_pre[u];
+        } else {
+          for (int c = lane; c < wp; c += 64) ilbuf[c] = c < w ? T(1) / ls[d0 + c] : T(0);
+        }
+      }
       __syncthreads();
 
       if constexpr (GRAM) {
