@@ -2125,9 +2125,8 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
         __syncthreads();  // every lane is done with the rows
         T* gnn_ = static_cast<T*>(a.bwd_gnn);
         T* gq_ = static_cast<T*>(a.bwd_gq);
-        // where every slot's row of the gradient table starts (null: not asked for, or a neighbourhood that is skipped):
-        // where the two vectors were, or (TF) in the last 512 bytes of the images
-        T** rptr = reinterpret_cast<T**>(TF ? tile + kmat_base + NH * KMAT - 128 : colbuf);
+        // element offset of every slot's row: where the two vectors were, or (TF) in the last 512 bytes of the images
+        int64_t* roff = reinterpret_cast<int64_t*>(TF ? tile + kmat_base + NH * KMAT - 128 : colbuf);
         // (Measured out: requesting the NEXT task's rows here, ahead of the scatter -- the sums then staged through the
         // dead image in two passes instead of the tile: 9.2 against 7.3 ms per 1 M at the headline shape.)
         {
@@ -2135,28 +2134,19 @@ void fused_wave_kernel(FusedArgs a, WaveGeom g) {
 #pragma unroll
           for (int c4 = 0; c4 < DGF; ++c4) *reinterpret_cast<V*>(gdst + c4 * E) = gxv[c4];
         }
-        {
-          T* base = i < KFIX ? gnn_ : (i == KFIX ? gq_ : nullptr);
-          rptr[lane] = (base != nullptr && !skip && !(MGP_FEAT_EXP & 4)) ? base + myidx * (int64_t)d : nullptr;
-        }
+        roff[lane] = myidx * (int64_t)d;
         __syncthreads();
-        // element t = r DFIX + f of the neighbourhood's block, t = i, i + NP, ...: (r, f) and the tile address stepped along
-        // (NP <= DFIX + ...: a step crosses at most ceil(NP / DFIX) row ends)
         constexpr int NOUT = (KFIX + 1) * DFIX;  // elements of a neighbourhood's cotangent block, row-major
-        int r = i / DFIX, f = i - r * DFIX;
 #pragma unroll 4
         for (int t0 = 0; t0 < NOUT; t0 += NP) {
-          T* rp = rptr[h * NP + (r <= KFIX ? r : KFIX)];
-          if (r <= KFIX && rp != nullptr) {
-            if constexpr ((MGP_FEAT_EXP & 8) != 0) rp[f] = Xh[r * xs + f];  // (timing: plain stores)
-            else unsafeAtomicAdd(rp + f, Xh[r * xs + f]);
-          }
-          f += NP;
-#pragma unroll
-          for (int w_ = 0; w_ < (NP + DFIX - 1) / DFIX; ++w_) {
-            const bool over = f >= DFIX;
-            f = over ? f - DFIX : f;
-            r = over ? r + 1 : r;
+          const int t = t0 + i;
+          const int r = t / DFIX, f = t - r * DFIX;
+          if (t < NOUT && !skip && !(MGP_FEAT_EXP & 4)) {
+            T* base = r < KFIX ? gnn_ : gq_;
+            if (base) {
+              if constexpr ((MGP_FEAT_EXP & 8) != 0) base[roff[h * NP + r] + f] = Xh[r * xs + f];  // (timing: plain stores)
+              else unsafeAtomicAdd(base + roff[h * NP + r] + f, Xh[r * xs + f]);
+            }
           }
         }
       }
